@@ -1,0 +1,221 @@
+/* skg.h - C ABI of libskg.so: MI355X (gfx950) kernels for the sketch-guided diffusion
+ * sampler hot path (Mikubill/sketch2img).
+ *
+ * The reference is 100 % Python and has no FFI of its own; every "kernel" on its hot path is
+ * reached through third-party Python packages (diffusers -> torch/cuDNN/cuBLAS, xformers).  Each
+ * entry point below therefore cites the reference CALL SITE (file:line under the reference
+ * repo root) whose third-party kernels it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless noted; the caller owns every buffer (the library
+ *     never allocates or frees), `stream` is a hipStream_t passed as void* (0 = null stream);
+ *   - activations are fp16, token-major / NHWC: a tensor of `rows` images of H x W pixels and C
+ *     channels is the row-major matrix [rows*H*W][C] with an explicit leading dimension (in
+ *     elements) where a slice of a wider buffer may be passed;
+ *   - weights are fp16 [N][K] row-major ("out x in", K contiguous), see each function;
+ *   - return value: 0 = launched, negative = SKG_E_* (nothing launched).  No exceptions.
+ */
+#ifndef SKG_H_
+#define SKG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SKG_OK 0
+#define SKG_E_BADARG (-1)    /* shape/alignment precondition violated */
+#define SKG_E_UNSUPPORTED (-2)
+#define SKG_E_LAUNCH (-3)    /* hipGetLastError() != hipSuccess after the launch */
+
+#define SKG_ABI_VERSION 1
+int skg_abi_version(void);
+/* Human-readable text of the last SKG_E_LAUNCH on this thread ("" if none). */
+const char* skg_last_error(void);
+
+/* ---- epilogue flags shared by skg_gemm_f16 / skg_conv3x3_f16 ---------------------------------- */
+#define SKG_EPI_RELU 1u      /* max(.,0) applied last */
+#define SKG_EPI_OUT_F32 2u   /* C is float* instead of fp16 */
+
+/* C[m][n] = epi( alpha * (sum_k A[m][k] * B[n][k] + bias[n]) + residual[m][n] )
+ * A fp16 [M][K] (lda), B fp16 [N][K] (ldb), C fp16|fp32 [M][N] (ldc), bias fp16 [N] or NULL,
+ * residual fp16 [M][N] (ldr) or NULL.  Requires K % 32 == 0, N % 8 == 0, lda/ldb % 8 == 0,
+ * ldc/ldr % 4 == 0, 16-byte aligned A/B, 8-byte aligned C/residual/bias.
+ * Replaces: every nn.Linear / 1x1 Conv2d the UNet evaluates at modules/pipeline.py:96
+ * (diffusers proj_in/proj_out, to_q/k/v, to_out, ff.net, conv_shortcut -> cuBLAS/cuDNN), their
+ * backward-to-input GEMMs triggered at modules/pipeline.py:159, the LGP's Linear layers at
+ * modules/latent_predictor.py:45 and Conv1d(k=1) at modules/clip_guided_attn.py:124. */
+int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc,
+                 int M, int N, int K, const void* bias, const void* residual, int ldr,
+                 float alpha, unsigned flags, void* stream);
+
+/* 3x3 convolution, padding 1, as implicit GEMM over NHWC fp16.
+ *   mode SKG_CONV_S1      stride 1                         out (OH,OW) = in (IH,IW)
+ *   mode SKG_CONV_S2      stride 2                         out = in / 2
+ *   mode SKG_CONV_UP2     nearest 2x upsample then stride 1  out = 2 * in
+ *   mode SKG_CONV_S2T     transpose of S2 (its dgrad)      out = 2 * in
+ * X fp16 [rows*IH*IW][Cin] (ldx), Wp fp16 [Cout][3][3][Cin] (tap-major, Cin contiguous),
+ * Y [rows*OH*OW][Cout] (ldy).  IH, IW are the INPUT sizes.  Requires Cin % 32 == 0, Cout % 8 == 0.
+ * bias / residual / alpha / flags as skg_gemm_f16.  For a dgrad pass Wp is the flipped,
+ * in/out-swapped pack (see sketch2img_amd/weights.py).
+ * Replaces: ResnetBlock2D conv1/conv2, Downsample2D, Upsample2D, conv_in/conv_out (cuDNN) at
+ * modules/pipeline.py:96 and their dgrad at modules/pipeline.py:159. */
+#define SKG_CONV_S1 0
+#define SKG_CONV_S2 1
+#define SKG_CONV_UP2 2
+#define SKG_CONV_S2T 3
+int skg_conv3x3_f16(const void* X, int ldx, const void* Wp, void* Y, int ldy,
+                    int rows, int IH, int IW, int Cin, int Cout, int mode,
+                    const void* bias, const void* residual, int ldr, float alpha,
+                    unsigned flags, void* stream);
+
+/* ---- GroupNorm (+SiLU), NHWC fp16 -------------------------------------------------------------
+ * stats: per (row, group) mean and rstd (float2 [rows][groups]) over HW x (C/groups) values.
+ *   `partial` is scratch of skg_groupnorm_scratch_floats(rows, groups) floats.
+ * apply: y = act((x-mean)*rstd*gamma+beta), act = SiLU if silu != 0.
+ * bwd:   dx = GN'(SiLU'(dy)) + residual (residual may be NULL); needs x and the saved stats.
+ * Replaces: torch group_norm + silu (ResnetBlock2D.norm1/2 + nonlinearity, Transformer2DModel.norm,
+ * conv_norm_out) at modules/pipeline.py:96; backward at :159. */
+size_t skg_groupnorm_scratch_floats(int rows, int groups);
+int skg_groupnorm_stats(const void* X, int ldx, int rows, int HW, int C, int groups, float eps,
+                        float* stats, float* partial, void* stream);
+int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C,
+                        int groups, const float* stats, const void* gamma, const void* beta,
+                        int silu, void* stream);
+int skg_groupnorm_bwd(const void* X, int ldx, const void* dY, int lddy, void* dX, int lddx,
+                      const void* residual, int ldr, int rows, int HW, int C, int groups,
+                      const float* stats, const void* gamma, const void* beta, int silu,
+                      float* partial, void* stream);
+
+/* ---- LayerNorm over the last dim, fp16 [M][C] ------------------------------------------------
+ * fwd also writes float2 (mean, rstd) per row to `stats` if non-NULL.
+ * bwd: dX = LN'(dY) + residual.  Requires C % 8 == 0, C <= 2048.
+ * Replaces: BasicTransformerBlock.norm1/2/3 and sketch_norm (modules/clip_guided_attn.py:113). */
+int skg_layernorm_fwd(const void* X, int ldx, void* Y, int ldy, int M, int C, const void* gamma,
+                      const void* beta, float eps, float* stats, void* stream);
+int skg_layernorm_bwd(const void* X, int ldx, const void* dY, int lddy, void* dX, int lddx,
+                      const void* residual, int ldr, int M, int C, const void* gamma,
+                      const float* stats, void* stream);
+
+/* ---- GEGLU: Y[m][j] = H[m][j] * gelu(H[m][F + j]),  H fp16 [M][2F] ------------------------------
+ * bwd writes dH [M][2F] from dY [M][F] and the saved H.  F % 8 == 0.
+ * Replaces: diffusers GEGLU (ff.net.0) inside BasicTransformerBlock. */
+int skg_geglu_fwd(const void* H, int ldh, void* Y, int ldy, int M, int F, void* stream);
+int skg_geglu_bwd(const void* H, int ldh, const void* dY, int lddy, void* dH, int lddh, int M,
+                  int F, void* stream);
+
+/* ---- fused multi-head attention (flash style), fp16 --------------------------------------------
+ * Q [batch*Nq][..] (ldq), K [batch*kv_stride][..] (ldk), head h occupies columns
+ * [h*dh, (h+1)*dh).  Vt is V transposed: Vt[h*dh + d][b*kv_stride + j] (ldvt).  Only the first
+ * Nkv of each batch row's kv_stride key slots are valid.  O [batch*Nq][..] (ldo).
+ * lse (float [batch][heads][Nq], natural-log-sum-exp of the scaled scores) may be NULL.
+ * dh in {16, 32, 40, 64, 80, 160}; kv_stride % 8 == 0.
+ * Replaces: xformers memory_efficient_attention (enabled at app.py:43) / diffusers
+ * CrossAttention baddbmm+softmax+bmm for attn1, attn2 and the injected sketch_attn
+ * (modules/clip_guided_attn.py:114, modules/sketch_guided_attn.py:127). */
+int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt,
+                 void* O, int ldo, float* lse, int batch, int heads, int Nq, int Nkv,
+                 int kv_stride, int dh, float scale, void* stream);
+/* backward.  delta[b][h][q] = sum_d dO*O (skg_attn_bwd_delta).  dQ kernel needs K, V row-major
+ * (V [batch*kv_stride][..] ldv) and Kt (K transposed like Vt); dKV kernel needs Q, dO row-major
+ * and their transposes Qt, dOt ([h*dh+d][b*Nq + q]).  Outputs row-major like their primals. */
+int skg_attn_bwd_delta(const void* O, int ldo, const void* dO, int lddo, float* delta, int batch,
+                       int heads, int Nq, int dh, void* stream);
+int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                    const void* Kt, int ldkt, const void* dO, int lddo, const float* lse,
+                    const float* delta, void* dQ, int lddq, int batch, int heads, int Nq, int Nkv,
+                    int kv_stride, int dh, float scale, void* stream);
+int skg_attn_bwd_dkv(const void* Q, int ldq, const void* Qt, int ldqt, const void* K, int ldk,
+                     const void* V, int ldv, const void* dO, int lddo, const void* dOt, int lddot,
+                     const float* lse, const float* delta, void* dK, int lddk, void* dV, int lddv,
+                     int batch, int heads, int Nq, int Nkv, int dh, float scale, void* stream);
+
+/* ---- data movement -----------------------------------------------------------------------------*/
+/* Out[c][m] = In[m][c], fp16, In [M][C] (ldi), Out [C][M] (ldo).  C % 8 == 0, M % 8 == 0. */
+int skg_transpose_f16(const void* In, int ldi, void* Out, int ldo, int M, int C, void* stream);
+/* Y[m][c] = alpha*A[m][c] + beta*B[m][c] (B may be NULL); fp16, C % 8 == 0.  Used for channel
+ * concat (copy into a slice), skip-gradient accumulation and slicing. */
+int skg_axpby_f16(const void* A, int lda, const void* B, int ldb, void* Y, int ldy, int M, int C,
+                  float alpha, float beta, void* stream);
+/* Y = silu(X), fp16 [M][C], C % 8 == 0.  Used once per timestep for the time-embedding MLP
+ * (diffusers TimestepEmbedding / ResnetBlock2D.time_emb_proj input), off the per-step path. */
+int skg_silu_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, void* stream);
+/* adjoint of nearest 2x upsample: Y[b][y][x][c] = sum of the 2x2 block of X.  X [rows*2H*2W][C]. */
+int skg_sumpool2x2_f16(const void* X, int ldx, void* Y, int ldy, int rows, int H, int W, int C,
+                       void* stream);
+/* NCHW float [rows][C][HW]  ->  NHWC fp16 [rows*HW][Cpad] (channels >= C zero-filled) and back
+ * (the inverse reads the first C channels of fp16 [rows*HW][ldx] into float NCHW). */
+int skg_nchw_f32_to_nhwc_f16(const float* X, void* Y, int rows, int C, int HW, int Cpad, void* stream);
+int skg_nhwc_f16_to_nchw_f32(const void* X, int ldx, float* Y, int rows, int C, int HW, void* stream);
+
+/* ---- LGP (Latent Gradient/Edge Predictor) pieces ------------------------------------------------
+ * Layer 0 is re-associated with the bilinear resize: per tap i the caller runs
+ * skg_gemm_f16(F_i, W0[:, off_i:off_i+C_i]) -> P_i fp32 [rows*s_i*s_i][H0] at the tap's NATIVE
+ * size; skg_lgp_layer0_gather then forms, for every output pixel of the h x h grid,
+ *   z = relu( fp16( sum_i bilinear_i(P_i) + W0[:, E:E+40] . fp16(e) + b0 ) )
+ * with e = [nl(4), sin(2 pi nl 2^-l) l=0..8 (36)], nl = sigma * noise  (fp32, then fp16 cast, as
+ * modules/latent_predictor.py:39-43).  Output Z fp16 [rows*h*h][H0], pixel order (y, x).
+ * `taps` is a HOST array of ntaps (<= 12) SkgLgpTap; rows = 2*samples in the row layout
+ * [uncond rows of all samples; cond rows of all samples]; noise float NCHW [samples][4][h][h].  Replaces F.interpolate x9 + cat + cast + layer 0 of
+ * modules/pipeline.py:146-153 / modules/latent_predictor.py:42-45. */
+typedef struct {
+  const float* P;   /* fp32 [rows*s*s][H0] */
+  int s;            /* native side */
+  int pad_;
+} SkgLgpTap;
+int skg_lgp_layer0_gather(const SkgLgpTap* taps, int ntaps, const void* Wextra, int ldw,
+                          const void* bias0, const float* noise, float sigma, int samples,
+                          void* Z, int rows, int h, int H0, void* stream);
+/* adjoint of the bilinear part for ONE tap: dP [rows*s*s][H0] fp16 from dZ [rows*h*h][H0] fp16. */
+int skg_lgp_layer0_scatter(const void* dZ, int lddz, void* dP, int rows, int h, int s, int H0,
+                           void* stream);
+/* train-mode BatchNorm1d whose "batch" is ONE sample's LGP rows (the reference only runs B = 1:
+ * SURVEY Q1/Q3).  Row layout of X: row = (j*samples + s)*seg_rows + i, j = 0..segs-1 (segs = 2 CFG
+ * halves, seg_rows = h*h).  X is the post-ReLU activation fp16 [samples*segs*seg_rows][C].
+ * stats float [samples][C][2] = (mean, rstd), biased variance.  If running_mean/var != NULL
+ * (float [C]) they receive the momentum-0.1 / unbiased-variance update once per sample, in sample
+ * order (= the side effect of `samples` consecutive reference calls).
+ * apply:    Y = fp16((x-mean)*rstd*gamma+beta).
+ * relu_bwd: dX = [x>0] * gamma*rstd*(dY - mean_s(dY) - xhat*mean_s(dY*xhat))  - BatchNorm backward
+ *           including the statistic terms, then the ReLU that precedes the BN in
+ *           modules/latent_predictor.py:15-27 (x is post-ReLU so relu'(.) = [x>0]).  With
+ *           train_mode == 0 the statistic terms are dropped (eval-mode BN: stats from running).
+ * scratch: skg_bn_scratch_floats(samples, C) floats. */
+size_t skg_bn_scratch_floats(int samples, int C);
+int skg_bn_stats(const void* X, int ldx, int samples, int segs, int seg_rows, int C, float eps,
+                 float* stats, float* scratch, float* running_mean, float* running_var,
+                 void* stream);
+int skg_bn_stats_from_running(const float* running_mean, const float* running_var, int samples,
+                              int C, float eps, float* stats, void* stream);
+int skg_bn_apply(const void* X, int ldx, void* Y, int ldy, int samples, int segs, int seg_rows,
+                 int C, const float* stats, const void* gamma, const void* beta, void* stream);
+int skg_bn_relu_bwd(const void* X, int ldx, const void* dY, int lddy, void* dX, int lddx,
+                    int samples, int segs, int seg_rows, int C, const float* stats,
+                    const void* gamma, int train_mode, float* scratch, void* stream);
+/* MSE seed: for the cond rows, dOut = loss_scale * 2*(out - target)/(n) with n = 4*h*h, zero for the
+ * uncond rows; also writes loss (float[samples]).  out fp16 [2*samples*h*h][ldo] (uncond block then
+ * cond block, (y,x) pixel order), first 4 columns valid; target float NCHW [samples][4][h][h].  dOut fp16 [..][ldd],
+ * columns >= 4 zeroed up to ldd.  Mirrors modules/pipeline.py:155-157. */
+int skg_lgp_mse_seed(const void* out, int ldo, const float* target, void* dOut, int ldd,
+                     float* loss, int samples, int h, float loss_scale, void* stream);
+
+/* ---- sampler elementwise -------------------------------------------------------------------------
+ * CFG combine + DDIM step (eta = 0) on float NCHW latents:
+ *   eps = eps_u + g*(eps_c - eps_u);  x0 = (x - c1*eps)/c0;  x_prev = c2*x0 + c3*eps
+ * eps_u / eps_c are fp16 NHWC [HW][ld] rows of the UNet output (first 4 channels).
+ * Replaces modules/pipeline.py:99-104 (CFG + scheduler.step). */
+int skg_cfg_ddim_step(const void* eps_u, const void* eps_c, int ld, const float* x, float* x_prev,
+                      float* eps_out, int samples, int HW, float g, float c0, float c1, float c2,
+                      float c3, void* stream);
+/* guidance update, modules/pipeline.py:159-161, per sample s:
+ *   g = -grad[s] (fp16 NHWC [HW][ld], first 4 ch);  alpha = sqrt(2)*||x_in - x_prev|| / ||g|| * beta
+ *   x_prev += alpha * g.   aux float [samples][4] receives (alpha, ||g||, ||x_in-x_prev||*sqrt2, 0). */
+int skg_guidance_update(const void* grad, int ld, const float* x_in, float* x_prev, float* aux,
+                        int samples, int HW, float beta, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SKG_H_ */

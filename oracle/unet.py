@@ -48,7 +48,7 @@ SD21 = UNetConfig(cross_attention_dim=1024, num_heads=(5, 10, 20, 20), use_linea
                   sample_size=96)
 # small config used by fast parity tests (same topology, narrow channels)
 TINY = UNetConfig(block_out_channels=(32, 64, 128, 128), cross_attention_dim=64,
-                  num_heads=(2, 2, 4, 4), sample_size=16)
+                  num_heads=(2, 2, 4, 4), norm_groups=8, sample_size=32)
 
 
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,89 @@
+"""ctypes binding of libskg.so (the C ABI declared in include/skg.h).
+
+The library is the product's only compute path.  If it is missing or does not export a declared
+symbol this module raises at import time: there is no CPU / PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libskg.so")
+
+# spec letters: p = device/host pointer, i = int, f = float, u = unsigned, z = size_t (return only)
+SIGNATURES = {
+    "skg_abi_version": ("i", ""),
+    "skg_last_error": ("s", ""),
+    "skg_gemm_f16": ("i", "pipipiiiippifup"),
+    "skg_conv3x3_f16": ("i", "pippiiiiiiippifup"),
+    "skg_groupnorm_scratch_floats": ("z", "ii"),
+    "skg_groupnorm_stats": ("i", "piiiiifppp"),
+    "skg_groupnorm_apply": ("i", "pipiiiiipppip"),
+    "skg_groupnorm_bwd": ("i", "pipipipiiiiipppipp"),
+    "skg_layernorm_fwd": ("i", "pipiiippfpp"),
+    "skg_layernorm_bwd": ("i", "pipipipiiippp"),
+    "skg_geglu_fwd": ("i", "pipiiip"),
+    "skg_geglu_bwd": ("i", "pipipiiip"),
+    "skg_attn_fwd": ("i", "pipipipipiiiiiifp"),
+    "skg_attn_bwd_delta": ("i", "pipipiiiip"),
+    "skg_attn_bwd_dq": ("i", "pipipipipipppiiiiiiifp"),
+    "skg_attn_bwd_dkv": ("i", "pipipipipipipppipiiiiiifp"),
+    "skg_transpose_f16": ("i", "pipiiip"),
+    "skg_axpby_f16": ("i", "pipipiiiffp"),
+    "skg_silu_f16": ("i", "pipiiip"),
+    "skg_sumpool2x2_f16": ("i", "pipiiiiip"),
+    "skg_nchw_f32_to_nhwc_f16": ("i", "ppiiiip"),
+    "skg_nhwc_f16_to_nchw_f32": ("i", "pipiiip"),
+    "skg_lgp_layer0_gather": ("i", "pipippfipiiip"),
+    "skg_lgp_layer0_scatter": ("i", "pipiiiip"),
+    "skg_bn_scratch_floats": ("z", "ii"),
+    "skg_bn_stats": ("i", "piiiiifppppp"),
+    "skg_bn_stats_from_running": ("i", "ppiifpp"),
+    "skg_bn_apply": ("i", "pipiiiiipppp"),
+    "skg_bn_relu_bwd": ("i", "pipipiiiiippipp"),
+    "skg_lgp_mse_seed": ("i", "pippipiifp"),
+    "skg_cfg_ddim_step": ("i", "ppipppiifffffp"),
+    "skg_guidance_update": ("i", "pipppiifp"),
+}
+
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "u": ctypes.c_uint,
+       "z": ctypes.c_size_t, "s": ctypes.c_char_p}
+
+
+class SkgTap(ctypes.Structure):
+    _fields_ = [("P", ctypes.c_void_p), ("s", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+class SkgError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C sketch2img_amd/csrc`.  sketch2img_amd has no fallback compute path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (ret, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise ImportError(f"libskg.so does not export {name}") from e
+        fn.restype = _CT[ret]
+        fn.argtypes = [_CT[a] for a in args]
+    if lib.skg_abi_version() != 1:
+        raise ImportError("libskg.so ABI version mismatch")
+    return lib
+
+
+lib = _load()
+
+_ERR = {-1: "SKG_E_BADARG (shape/alignment precondition violated)", -2: "SKG_E_UNSUPPORTED",
+        -3: "SKG_E_LAUNCH"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        detail = lib.skg_last_error().decode() if rc == -3 else ""
+        raise SkgError(f"{what}: {_ERR.get(rc, rc)} {detail}")

@@ -1,0 +1,58 @@
+"""Architecture description of the SD-style UNet the sampler drives (host-side data only).
+
+Field meanings follow the diffusers ``UNet2DConditionModel`` config the reference loads through
+``AntiGradientPipeline.from_pretrained`` (app.py:32-37); SD1.5 / SD2.1 values are the public model
+configs (validated by exact parameter counts in tests/test_oracle.py).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Tuple
+
+
+@dataclass(frozen=True)
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    layers_per_block: int = 2
+    cross_attention_dim: int = 768
+    num_heads: Tuple[int, ...] = (8, 8, 8, 8)      # SD1.5: 8 heads per block; SD2.1: (5, 10, 20, 20)
+    use_linear_projection: bool = False
+    norm_groups: int = 32
+    sample_size: int = 64
+
+    @property
+    def time_embed_dim(self) -> int:
+        return self.block_out_channels[0] * 4
+
+
+SD15 = UNetConfig()
+SD21 = UNetConfig(cross_attention_dim=1024, num_heads=(5, 10, 20, 20), use_linear_projection=True,
+                  sample_size=96)
+TINY = UNetConfig(block_out_channels=(32, 64, 128, 128), cross_attention_dim=64, num_heads=(2, 2, 4, 4),
+                  norm_groups=8, sample_size=32)
+
+
+def up_block_plan(cfg: UNetConfig) -> List[List[Tuple[int, int, int]]]:
+    """Per up block, per resnet: (channels of h, channels of the skip, output channels)."""
+    rev = tuple(reversed(cfg.block_out_channels))
+    nb = len(rev)
+    plan = []
+    for i in range(nb):
+        out_c = rev[i]
+        prev = rev[i - 1] if i > 0 else rev[0]
+        inp = rev[min(i + 1, nb - 1)]
+        plan.append([(prev if j == 0 else out_c, inp if j == cfg.layers_per_block else out_c, out_c)
+                     for j in range(cfg.layers_per_block + 1)])
+    return plan
+
+
+def tap_channels(cfg: UNetConfig) -> List[int]:
+    b = cfg.block_out_channels
+    rev = tuple(reversed(b))
+    return [b[0], b[1], b[2], b[-1], b[-1], b[-1], rev[0], rev[1], rev[2]]
+
+
+def tap_sizes(h: int) -> List[int]:
+    return [h // 2, h // 4, h // 8, h // 8, h // 8, h // 8, h // 4, h // 2, h]

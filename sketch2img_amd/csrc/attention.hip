@@ -1,0 +1,480 @@
+// Flash-style fused attention for gfx950, fp16 in / fp32 accumulate: forward, dQ and dK/dV.
+//
+// Formulation ("swapped" products, so every softmax statistic is lane-local or a 2-step shuffle):
+// a wave owns 16 query rows and computes S^T = K Q^T with 16x16x32 f16 MFMAs, K rows as the A
+// operand (from LDS) and the wave's Q rows as the B operand (registers, loaded once).  In the MFMA
+// C layout lane (q = lane & 15, g = lane >> 4) then holds S^T[kv = 16 t + 4 g + r][q] in register r of
+// tile t: all 16 scores a lane holds belong to ONE query, so max / sum are in-lane plus two xor
+// shuffles (16, 32), and the online-softmax rescale factor is a per-lane scalar.
+// For the second product O^T = V^T P^T the probabilities are used straight from those registers as
+// the B operand: element i of lane (q, g) is declared to be k-slot (g, i) <-> key
+// 32 s + 16 (i >> 2) + 4 g + (i & 3); the MFMA only needs A and B to agree on the k <-> key map, so
+// the A operand (V^T rows = head-dim index, from an LDS tile that is stored transposed) is read with
+// the same map as two 8-byte LDS reads.  No P round trip through LDS, no cross-lane transposes.
+// V^T (and K^T, Q^T, dO^T for the backward kernels) are produced by skg_transpose_f16.
+//
+// Block = 4 waves = 64 query rows (forward, dQ) or 64 key rows (dK/dV); KV / Q tiles of 64 rows are
+// staged in LDS (padded pitches: conflict-free ds_read_b128 / b64 fragment reads).
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+  const half_t* Q; int ldq;
+  const half_t* K; int ldk;
+  const half_t* V; int ldv;       // row-major V (backward)
+  const half_t* Vt; int ldvt;     // forward: V^T; dq: K^T
+  const half_t* Qt; int ldqt;     // dkv: Q^T
+  const half_t* dO; int lddo;
+  const half_t* dOt; int lddot;   // dkv: dO^T
+  half_t* O; int ldo;             // fwd: O; dq: dQ; dkv: dK
+  half_t* O2; int ldo2;           // dkv: dV
+  float* lse;                     // [batch][heads][Nq]
+  const float* delta;             // [batch][heads][Nq]
+  int batch, heads, Nq, Nkv, kv_stride, dh;
+  float scale;
+};
+
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+constexpr int TP = 72;   // pitch (halves) of the transposed tiles [d][64 + 8]
+
+// stage a [64][dh] row-major tile (rows r0.., zero rows >= rlim, zero cols >= dh) into LDS [64][KP]
+template <int KS>
+__device__ __forceinline__ void stage_rows(half_t* __restrict__ dst, const half_t* __restrict__ src, int ld,
+                                           int r0, int rlim, int dh) {
+  constexpr int KP = KS * 32 + 8;
+  constexpr int PPR = KS * 4;
+  for (int pi = threadIdx.x; pi < 64 * PPR; pi += 256) {
+    const int r = pi / PPR, pc = (pi - r * PPR) * 8;
+    half8_t v = zero_half8();
+    if (r0 + r < rlim && pc < dh) v = ld_half8(src + (size_t)(r0 + r) * ld + pc);
+    st_half8(dst + r * KP + pc, v);
+  }
+}
+// stage a transposed tile: rows d (0..dh-1 valid, up to ND*16 zero), cols c0..c0+63 (valid < clim)
+template <int ND>
+__device__ __forceinline__ void stage_cols(half_t* __restrict__ dst, const half_t* __restrict__ src, int ld,
+                                           int c0, int clim, int dh) {
+  for (int pi = threadIdx.x; pi < ND * 16 * 8; pi += 256) {
+    const int d = pi >> 3, pc = (pi & 7) * 8;
+    half8_t v = zero_half8();
+    if (d < dh && c0 + pc < clim) v = ld_half8(src + (size_t)d * ld + c0 + pc);
+    st_half8(dst + d * TP + pc, v);
+  }
+}
+
+// A-operand fragment of a transposed tile for k-step s: head-dim row (16 u + l16), keys by the map above
+__device__ __forceinline__ half8_t tfrag(const half_t* tile, int u, int s, int l16, int g) {
+  const half_t* p = tile + (u * 16 + l16) * TP + 32 * s + 4 * g;
+  const half4_t lo = ld_half4(p), hi = ld_half4(p + 16);
+  half8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return f;
+}
+// pack score-layout registers (4 tiles x 4) into the two B-operand fragments
+__device__ __forceinline__ void pack_p(const float4_t (&s)[4], half8_t (&pb)[2]) {
+#pragma unroll
+  for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pb[k2][i] = (half_t)s[2 * k2 + (i >> 2)][i & 3];
+}
+
+// -------------------------------------------------------------------------------------------------
+template <int KS, int ND>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+  constexpr int KP = KS * 32 + 8;
+  __shared__ __attribute__((aligned(16))) half_t Ks[64 * KP];
+  __shared__ __attribute__((aligned(16))) half_t Vs[ND * 16 * TP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * 64 + wave * 16 + l16;
+  const bool qok = q < p.Nq;
+  const int dh = p.dh;
+
+  half8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = 32 * ks + 8 * g;
+    qf[ks] = (qok && c < dh) ? ld_half8(p.Q + (size_t)(b * p.Nq + q) * p.ldq + h * dh + c) : zero_half8();
+  }
+  float4_t o[ND];
+#pragma unroll
+  for (int u = 0; u < ND; ++u) o[u] = float4_t{0.f, 0.f, 0.f, 0.f};
+  float m = NEG_BIG, l = 0.f;
+  const float sc = p.scale * LOG2E;
+
+  const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
+  const half_t* Vb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
+  const int nt = (p.Nkv + 63) / 64;
+  for (int t0 = 0; t0 < nt; ++t0) {
+    const int kv0 = t0 * 64;
+    __syncthreads();
+    stage_rows<KS>(Ks, Kb, p.ldk, kv0, p.kv_stride, dh);
+    stage_cols<ND>(Vs, Vb, p.ldvt, kv0, p.kv_stride, dh);
+    __syncthreads();
+
+    float4_t s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const half8_t kf = ld_half8(Ks + (16 * t + l16) * KP + 32 * ks + 8 * g);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[t], 0, 0, 0);
+      }
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kv = kv0 + 16 * t + 4 * g + r;
+        s[t][r] = kv < p.Nkv ? s[t][r] * sc : NEG_BIG;
+        mx = fmaxf(mx, s[t][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = exp2f(m - mn);
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = exp2f(s[t][r] - mn);
+        s[t][r] = e;
+        ps += e;
+      }
+    l = l * alpha + ps;
+    half8_t pb[2];
+    pack_p(s, pb);
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      o[u] *= alpha;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+        o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag(Vs, u, k2, l16, g), pb[k2], o[u], 0, 0, 0);
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.f / l;
+  if (qok) {
+    half_t* orow = p.O + (size_t)(b * p.Nq + q) * p.ldo + h * dh;
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int d = 16 * u + 4 * g;
+      if (d < dh) {
+        half4_t v = {(half_t)(o[u][0] * inv), (half_t)(o[u][1] * inv), (half_t)(o[u][2] * inv),
+                     (half_t)(o[u][3] * inv)};
+        st_half4(orow + d, v);
+      }
+    }
+    if (p.lse && g == 0) p.lse[((size_t)b * p.heads + h) * p.Nq + q] = (m + log2f(l)) * LN2;
+  }
+}
+
+// dQ: per 64-query block, loop over key tiles.  dS^T = P^T o (dP^T - delta);  dQ^T += K^T dS^T.
+template <int KS, int ND>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+  constexpr int KP = KS * 32 + 8;
+  __shared__ __attribute__((aligned(16))) half_t Ks[64 * KP];
+  __shared__ __attribute__((aligned(16))) half_t Vr[64 * KP];
+  __shared__ __attribute__((aligned(16))) half_t Kt[ND * 16 * TP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * 64 + wave * 16 + l16;
+  const bool qok = q < p.Nq;
+  const int dh = p.dh;
+
+  half8_t qf[KS], dof[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = 32 * ks + 8 * g;
+    const bool ok = qok && c < dh;
+    qf[ks] = ok ? ld_half8(p.Q + (size_t)(b * p.Nq + q) * p.ldq + h * dh + c) : zero_half8();
+    dof[ks] = ok ? ld_half8(p.dO + (size_t)(b * p.Nq + q) * p.lddo + h * dh + c) : zero_half8();
+  }
+  const size_t sidx = ((size_t)b * p.heads + h) * p.Nq + (qok ? q : 0);
+  const float lse2 = qok ? p.lse[sidx] * LOG2E : -NEG_BIG;
+  const float dl = qok ? p.delta[sidx] : 0.f;
+  const float sc = p.scale * LOG2E;
+  float4_t dq[ND];
+#pragma unroll
+  for (int u = 0; u < ND; ++u) dq[u] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
+  const half_t* Vb = p.V + (size_t)b * p.kv_stride * p.ldv + h * dh;
+  const half_t* Ktb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
+  const int nt = (p.Nkv + 63) / 64;
+  for (int t0 = 0; t0 < nt; ++t0) {
+    const int kv0 = t0 * 64;
+    __syncthreads();
+    stage_rows<KS>(Ks, Kb, p.ldk, kv0, p.kv_stride, dh);
+    stage_rows<KS>(Vr, Vb, p.ldv, kv0, p.kv_stride, dh);
+    stage_cols<ND>(Kt, Ktb, p.ldvt, kv0, p.kv_stride, dh);
+    __syncthreads();
+    float4_t s[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+      dp[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = (16 * t + l16) * KP + 32 * ks + 8 * g;
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(Ks + off), qf[ks], s[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(Vr + off), dof[ks], dp[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kv = kv0 + 16 * t + 4 * g + r;
+        const float pr = kv < p.Nkv ? exp2f(s[t][r] * sc - lse2) : 0.f;
+        s[t][r] = pr * (dp[t][r] - dl);
+      }
+    half8_t sb[2];
+    pack_p(s, sb);
+#pragma unroll
+    for (int u = 0; u < ND; ++u)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2)
+        dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag(Kt, u, k2, l16, g), sb[k2], dq[u], 0, 0, 0);
+  }
+  if (qok) {
+    half_t* orow = p.O + (size_t)(b * p.Nq + q) * p.ldo + h * dh;
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int d = 16 * u + 4 * g;
+      if (d < dh) {
+        half4_t v = {(half_t)(dq[u][0] * p.scale), (half_t)(dq[u][1] * p.scale), (half_t)(dq[u][2] * p.scale),
+                     (half_t)(dq[u][3] * p.scale)};
+        st_half4(orow + d, v);
+      }
+    }
+  }
+}
+
+// dK/dV: per 64-key block (lane column = key), loop over query tiles.
+//   S = Q K^T (rows q), P = exp(S*scale - lse[q]), dP = dO V^T, dS = P o (dP - delta[q])
+//   dV^T += dO^T P,   dK^T += Q^T dS      (A operands = transposed tiles, B = registers)
+template <int KS, int ND>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+  constexpr int KP = KS * 32 + 8;
+  __shared__ __attribute__((aligned(16))) half_t Qs[64 * KP];
+  __shared__ __attribute__((aligned(16))) half_t Ds[64 * KP];
+  __shared__ __attribute__((aligned(16))) half_t Qt[ND * 16 * TP];
+  __shared__ __attribute__((aligned(16))) half_t Dt[ND * 16 * TP];
+  __shared__ float lse_s[64], del_s[64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int kv = blockIdx.x * 64 + wave * 16 + l16;
+  const bool kok = kv < p.Nkv;
+  const int dh = p.dh;
+
+  half8_t kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int c = 32 * ks + 8 * g;
+    const bool ok = kok && c < dh;
+    kf[ks] = ok ? ld_half8(p.K + (size_t)(b * p.kv_stride + kv) * p.ldk + h * dh + c) : zero_half8();
+    vf[ks] = ok ? ld_half8(p.V + (size_t)(b * p.kv_stride + kv) * p.ldv + h * dh + c) : zero_half8();
+  }
+  const float sc = p.scale * LOG2E;
+  float4_t dk[ND], dv[ND];
+#pragma unroll
+  for (int u = 0; u < ND; ++u) {
+    dk[u] = float4_t{0.f, 0.f, 0.f, 0.f};
+    dv[u] = float4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  const half_t* Qb = p.Q + (size_t)b * p.Nq * p.ldq + h * dh;
+  const half_t* Db = p.dO + (size_t)b * p.Nq * p.lddo + h * dh;
+  const half_t* Qtb = p.Qt + (size_t)h * dh * p.ldqt + (size_t)b * p.Nq;
+  const half_t* Dtb = p.dOt + (size_t)h * dh * p.lddot + (size_t)b * p.Nq;
+  const size_t sbase = ((size_t)b * p.heads + h) * p.Nq;
+  const int nt = (p.Nq + 63) / 64;
+  for (int t0 = 0; t0 < nt; ++t0) {
+    const int q0 = t0 * 64;
+    __syncthreads();
+    stage_rows<KS>(Qs, Qb, p.ldq, q0, p.Nq, dh);
+    stage_rows<KS>(Ds, Db, p.lddo, q0, p.Nq, dh);
+    stage_cols<ND>(Qt, Qtb, p.ldqt, q0, p.Nq, dh);
+    stage_cols<ND>(Dt, Dtb, p.lddot, q0, p.Nq, dh);
+    if (threadIdx.x < 64) {
+      const int qq = q0 + threadIdx.x;
+      lse_s[threadIdx.x] = qq < p.Nq ? p.lse[sbase + qq] * LOG2E : -NEG_BIG;
+      del_s[threadIdx.x] = qq < p.Nq ? p.delta[sbase + qq] : 0.f;
+    }
+    __syncthreads();
+    float4_t s[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+      dp[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = (16 * t + l16) * KP + 32 * ks + 8 * g;
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(Qs + off), kf[ks], s[t], 0, 0, 0);
+        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(Ds + off), vf[ks], dp[t], 0, 0, 0);
+      }
+    }
+    float4_t ds[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * t + 4 * g + r;
+        const float pr = exp2f(s[t][r] * sc - lse_s[ql]);
+        s[t][r] = pr;
+        ds[t][r] = pr * (dp[t][r] - del_s[ql]);
+      }
+    half8_t pb[2], sb[2];
+    pack_p(s, pb);
+    pack_p(ds, sb);
+#pragma unroll
+    for (int u = 0; u < ND; ++u)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        dv[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag(Dt, u, k2, l16, g), pb[k2], dv[u], 0, 0, 0);
+        dk[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag(Qt, u, k2, l16, g), sb[k2], dk[u], 0, 0, 0);
+      }
+  }
+  if (kok) {
+    half_t* krow = p.O + (size_t)(b * p.kv_stride + kv) * p.ldo + h * dh;
+    half_t* vrow = p.O2 + (size_t)(b * p.kv_stride + kv) * p.ldo2 + h * dh;
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      const int d = 16 * u + 4 * g;
+      if (d < dh) {
+        half4_t a = {(half_t)(dk[u][0] * p.scale), (half_t)(dk[u][1] * p.scale), (half_t)(dk[u][2] * p.scale),
+                     (half_t)(dk[u][3] * p.scale)};
+        half4_t c = {(half_t)dv[u][0], (half_t)dv[u][1], (half_t)dv[u][2], (half_t)dv[u][3]};
+        st_half4(krow + d, a);
+        st_half4(vrow + d, c);
+      }
+    }
+  }
+}
+
+// delta[b][h][q] = sum_d dO[q][h*dh+d] * O[q][h*dh+d]; one 16-lane group per (row, head)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restrict__ O, int ldo,
+                                                         const half_t* __restrict__ dO, int lddo,
+                                                         float* __restrict__ delta, int batch, int heads, int Nq,
+                                                         int dh) {
+  const size_t total = (size_t)batch * Nq * heads;
+  const size_t item = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  float s = 0.f;
+  if (item < total) {
+    const int h = (int)(item % heads);
+    const size_t row = item / heads;   // b*Nq + q
+    for (int c = sub * 8; c < dh; c += 128) {
+      const half8_t a = ld_half8(O + row * ldo + h * dh + c);
+      const half8_t d = ld_half8(dO + row * lddo + h * dh + c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)a[j] * (float)d[j];
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (item < total && sub == 0) {
+    const int h = (int)(item % heads);
+    const size_t row = item / heads;
+    const size_t b = row / Nq, q = row - b * Nq;
+    delta[(b * heads + h) * Nq + q] = s;
+  }
+}
+
+#define SKG_ATTN_DISPATCH(KERNEL, grid)                                                          \
+  switch (p.dh) {                                                                                \
+    case 16: hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(256), 0, st, p); break;               \
+    case 32: hipLaunchKernelGGL((KERNEL<1, 2>), grid, dim3(256), 0, st, p); break;               \
+    case 40: hipLaunchKernelGGL((KERNEL<2, 3>), grid, dim3(256), 0, st, p); break;               \
+    case 64: hipLaunchKernelGGL((KERNEL<2, 4>), grid, dim3(256), 0, st, p); break;               \
+    case 80: hipLaunchKernelGGL((KERNEL<3, 5>), grid, dim3(256), 0, st, p); break;               \
+    case 160: hipLaunchKernelGGL((KERNEL<5, 10>), grid, dim3(256), 0, st, p); break;             \
+    default: return SKG_E_UNSUPPORTED;                                                           \
+  }
+
+inline bool common_ok(int batch, int heads, int Nq, int Nkv, int kv_stride, int dh) {
+  return batch > 0 && heads > 0 && Nq > 0 && Nkv > 0 && kv_stride >= Nkv && kv_stride % 8 == 0 && dh % 8 == 0;
+}
+
+}  // namespace
+
+extern "C" int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O,
+                            int ldo, float* lse, int batch, int heads, int Nq, int Nkv, int kv_stride, int dh,
+                            float scale, void* stream) {
+  SKG_REQUIRE(Q && K && Vt && O && common_ok(batch, heads, Nq, Nkv, kv_stride, dh));
+  SKG_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0);
+  SKG_REQUIRE(skg_aligned(Q, 16) && skg_aligned(K, 16) && skg_aligned(Vt, 16) && skg_aligned(O, 8));
+  AttnParams p{};
+  p.Q = (const half_t*)Q; p.ldq = ldq; p.K = (const half_t*)K; p.ldk = ldk; p.Vt = (const half_t*)Vt; p.ldvt = ldvt;
+  p.O = (half_t*)O; p.ldo = ldo; p.lse = lse;
+  p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(skg_cdiv(Nq, 64), heads, batch);
+  SKG_ATTN_DISPATCH(attn_fwd_kernel, grid);
+  SKG_CHECK_LAUNCH("skg_attn_fwd");
+  return SKG_OK;
+}
+
+extern "C" int skg_attn_bwd_delta(const void* O, int ldo, const void* dO, int lddo, float* delta, int batch,
+                                  int heads, int Nq, int dh, void* stream) {
+  SKG_REQUIRE(O && dO && delta && batch > 0 && heads > 0 && Nq > 0 && dh % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0);
+  SKG_REQUIRE(skg_aligned(O, 16) && skg_aligned(dO, 16));
+  const size_t total = (size_t)batch * Nq * heads;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total * 16 + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const half_t*)O, ldo, (const half_t*)dO, lddo, delta, batch, heads, Nq, dh);
+  SKG_CHECK_LAUNCH("skg_attn_bwd_delta");
+  return SKG_OK;
+}
+
+extern "C" int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                               const void* Kt, int ldkt, const void* dO, int lddo, const float* lse,
+                               const float* delta, void* dQ, int lddq, int batch, int heads, int Nq, int Nkv,
+                               int kv_stride, int dh, float scale, void* stream) {
+  SKG_REQUIRE(Q && K && V && Kt && dO && lse && delta && dQ && common_ok(batch, heads, Nq, Nkv, kv_stride, dh));
+  SKG_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldkt % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0);
+  SKG_REQUIRE(skg_aligned(Q, 16) && skg_aligned(K, 16) && skg_aligned(V, 16) && skg_aligned(Kt, 16) &&
+              skg_aligned(dO, 16) && skg_aligned(dQ, 8));
+  AttnParams p{};
+  p.Q = (const half_t*)Q; p.ldq = ldq; p.K = (const half_t*)K; p.ldk = ldk; p.V = (const half_t*)V; p.ldv = ldv;
+  p.Vt = (const half_t*)Kt; p.ldvt = ldkt; p.dO = (const half_t*)dO; p.lddo = lddo;
+  p.lse = const_cast<float*>(lse); p.delta = delta; p.O = (half_t*)dQ; p.ldo = lddq;
+  p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(skg_cdiv(Nq, 64), heads, batch);
+  SKG_ATTN_DISPATCH(attn_bwd_dq_kernel, grid);
+  SKG_CHECK_LAUNCH("skg_attn_bwd_dq");
+  return SKG_OK;
+}
+
+extern "C" int skg_attn_bwd_dkv(const void* Q, int ldq, const void* Qt, int ldqt, const void* K, int ldk,
+                                const void* V, int ldv, const void* dO, int lddo, const void* dOt, int lddot,
+                                const float* lse, const float* delta, void* dK, int lddk, void* dV, int lddv,
+                                int batch, int heads, int Nq, int Nkv, int dh, float scale, void* stream) {
+  SKG_REQUIRE(Q && Qt && K && V && dO && dOt && lse && delta && dK && dV && common_ok(batch, heads, Nq, Nkv, Nkv, dh));
+  SKG_REQUIRE(Nq % 8 == 0);   // transposed tiles are read in 16-byte pieces along q (self-attention: Nkv == kv_stride)
+  SKG_REQUIRE(ldq % 8 == 0 && ldqt % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddot % 8 == 0 &&
+              lddk % 4 == 0 && lddv % 4 == 0);
+  SKG_REQUIRE(skg_aligned(Q, 16) && skg_aligned(Qt, 16) && skg_aligned(K, 16) && skg_aligned(V, 16) &&
+              skg_aligned(dO, 16) && skg_aligned(dOt, 16) && skg_aligned(dK, 8) && skg_aligned(dV, 8));
+  AttnParams p{};
+  p.Q = (const half_t*)Q; p.ldq = ldq; p.Qt = (const half_t*)Qt; p.ldqt = ldqt; p.K = (const half_t*)K; p.ldk = ldk;
+  p.V = (const half_t*)V; p.ldv = ldv; p.dO = (const half_t*)dO; p.lddo = lddo; p.dOt = (const half_t*)dOt;
+  p.lddot = lddot; p.lse = const_cast<float*>(lse); p.delta = delta; p.O = (half_t*)dK; p.ldo = lddk;
+  p.O2 = (half_t*)dV; p.ldo2 = lddv;
+  p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = Nkv; p.dh = dh; p.scale = scale;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(skg_cdiv(Nkv, 64), heads, batch);
+  SKG_ATTN_DISPATCH(attn_bwd_dkv_kernel, grid);
+  SKG_CHECK_LAUNCH("skg_attn_bwd_dkv");
+  return SKG_OK;
+}

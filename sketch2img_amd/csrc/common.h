@@ -1,0 +1,80 @@
+// Shared device helpers for the skg kernels (gfx950 / CDNA4 only: 64-lane wavefronts).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/skg.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+#define SKG_WAVE 64
+
+// host side ------------------------------------------------------------------------------------
+void skg_set_error(const char* what, hipError_t e);
+#define SKG_CHECK_LAUNCH(name)                                  \
+  do {                                                          \
+    hipError_t e__ = hipGetLastError();                         \
+    if (e__ != hipSuccess) {                                    \
+      skg_set_error(name, e__);                                 \
+      return SKG_E_LAUNCH;                                      \
+    }                                                           \
+  } while (0)
+#define SKG_REQUIRE(cond)               \
+  do {                                  \
+    if (!(cond)) return SKG_E_BADARG;   \
+  } while (0)
+
+static inline bool skg_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+static inline int skg_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// device side ----------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum of `v` for blocks of NT threads (NT multiple of 64); result valid on all threads.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* smem /* >= NT/64 floats */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) smem[w] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) r += smem[i];
+  return r;
+}
+
+__device__ __forceinline__ half8_t ld_half8(const half_t* p) { return *reinterpret_cast<const half8_t*>(p); }
+__device__ __forceinline__ void st_half8(half_t* p, half8_t v) { *reinterpret_cast<half8_t*>(p) = v; }
+__device__ __forceinline__ half4_t ld_half4(const half_t* p) { return *reinterpret_cast<const half4_t*>(p); }
+__device__ __forceinline__ void st_half4(half_t* p, half4_t v) { *reinterpret_cast<half4_t*>(p) = v; }
+
+__device__ __forceinline__ half8_t zero_half8() {
+  half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return z;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+  const float s = 1.f / (1.f + __expf(-x));
+  return s * (1.f + x * (1.f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}

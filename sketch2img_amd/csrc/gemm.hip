@@ -1,0 +1,257 @@
+// fp16 MFMA GEMM and 3x3 implicit-GEMM convolution for gfx950.
+//
+//   C[m][n] = epi(alpha * (sum_k A[m][k] * B[n][k] + bias[n]) + residual[m][n])
+//
+// One kernel template serves the dense GEMM and the four conv gather modes: only the A-operand
+// address generator differs (the K axis of a conv is (ky, kx, cin) with cin contiguous, so a
+// BK = 32 slice always lies inside one filter tap because Cin % 32 == 0).
+//
+// Tiling (v1): 128 x BN x 32 block tile, 4 waves as 2(M) x 2(N), each wave 64 x BN/2 out of
+// 16x16x32 f16 MFMAs.  Operands are staged global -> VGPR -> LDS (padded pitch, conflict-free
+// ds_read_b128) with a register prefetch of the next K slice and ONE barrier per slice.
+// The MFMA is issued "swapped" (weights as the A operand, activations as B) so that each lane's
+// four accumulator registers are four CONSECUTIVE output channels of one pixel: the epilogue
+// then does 8-byte bias/residual loads and 8-byte stores instead of 2-byte ones.
+#include "common.h"
+
+namespace {
+
+enum { MODE_DIRECT = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_UP2 = 3, MODE_S2T = 4 };
+
+struct GemmParams {
+  const half_t* A; int lda;
+  const half_t* B; int ldb;
+  void* C; int ldc;
+  const half_t* bias;
+  const half_t* res; int ldr;
+  int M, N, K;
+  float alpha; unsigned flags;
+  int IH, IW, OH, OW, Cin;   // conv only
+};
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int PITCH = 40;   // halves; 80-byte rows keep ds_read_b128 of 16 rows conflict-free
+
+template <int BN, int MODE>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+  constexpr int WN = BN / 2;
+  constexpr int NT = WN / 16;
+  constexpr int MT = 4;
+  constexpr int BPT = BN / 64;   // B 16-byte pieces per thread
+  __shared__ __attribute__((aligned(16))) half_t As[2][BM * PITCH];
+  __shared__ __attribute__((aligned(16))) half_t Bs[2][BN * PITCH];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int m0 = blockIdx.y * BM;
+  const int n0 = blockIdx.x * BN;
+
+  // ---- per-thread loader coordinates ------------------------------------------------------
+  const int lrow = tid >> 2;          // 0..63
+  const int lkc = (tid & 3) * 8;      // k offset of this thread's 16-byte piece
+  // A rows lrow and lrow + 64
+  bool a_ok[2];
+  const half_t* a_base[2];
+  int a_oy[2], a_ox[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int m = m0 + lrow + 64 * q;
+    a_ok[q] = m < p.M;
+    if (MODE == MODE_DIRECT) {
+      a_base[q] = p.A + (size_t)(a_ok[q] ? m : 0) * p.lda + lkc;
+      a_oy[q] = a_ox[q] = 0;
+    } else {
+      const int mm = a_ok[q] ? m : 0;
+      const int ohw = p.OH * p.OW;
+      const int b = mm / ohw;
+      const int r = mm - b * ohw;
+      a_oy[q] = r / p.OW;
+      a_ox[q] = r - a_oy[q] * p.OW;
+      a_base[q] = p.A + (size_t)b * p.IH * p.IW * p.lda + lkc;
+    }
+  }
+  bool b_ok[BPT];
+  const half_t* b_base[BPT];
+#pragma unroll
+  for (int q = 0; q < BPT; ++q) {
+    const int n = n0 + lrow + 64 * q;
+    b_ok[q] = n < p.N;
+    b_base[q] = p.B + (size_t)(b_ok[q] ? n : 0) * p.ldb + lkc;
+  }
+
+  half8_t ra[2], rb[BPT];
+  auto load_tiles = [&](int kt) {
+    const int k0 = kt * BK;
+    if (MODE == MODE_DIRECT) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) ra[q] = a_ok[q] ? ld_half8(a_base[q] + k0) : zero_half8();
+    } else {
+      const int tap = k0 / p.Cin;
+      const int c0 = k0 - tap * p.Cin;
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        int ty = a_oy[q] + ky - 1, tx = a_ox[q] + kx - 1;
+        bool ok = a_ok[q];
+        int iy, ix;
+        if (MODE == MODE_S1) {
+          iy = ty; ix = tx;
+          ok = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        } else if (MODE == MODE_S2) {
+          iy = ty + a_oy[q]; ix = tx + a_ox[q];     // 2*o + k - 1
+          ok = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        } else if (MODE == MODE_UP2) {
+          ok = ok && ty >= 0 && ty < p.OH && tx >= 0 && tx < p.OW;
+          iy = ty >> 1; ix = tx >> 1;
+        } else {   // MODE_S2T
+          ok = ok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1);
+          iy = ty >> 1; ix = tx >> 1;
+          ok = ok && iy < p.IH && ix < p.IW;
+        }
+        ra[q] = ok ? ld_half8(a_base[q] + ((size_t)iy * p.IW + ix) * p.lda + c0) : zero_half8();
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) rb[q] = b_ok[q] ? ld_half8(b_base[q] + k0) : zero_half8();
+  };
+  auto store_tiles = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) st_half8(&As[buf][(lrow + 64 * q) * PITCH + lkc], ra[q]);
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) st_half8(&Bs[buf][(lrow + 64 * q) * PITCH + lkc], rb[q]);
+  };
+
+  float4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int KT = p.K / BK;
+  load_tiles(0);
+  store_tiles(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < KT;
+    if (more) load_tiles(kt + 1);
+    half8_t xf[MT], wf[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) xf[i] = ld_half8(&As[cur][(wm * 64 + i * 16 + l16) * PITCH + g * 8]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wf[j] = ld_half8(&Bs[cur][(wn * WN + j * 16 + l16) * PITCH + g * 8]);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds C[m = .. + l16][n = .. + 4g .. 4g+3] ---------------------------
+  const bool relu = p.flags & SKG_EPI_RELU;
+  const bool f32out = p.flags & SKG_EPI_OUT_F32;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + l16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * WN + j * 16 + g * 4;
+      if (n >= p.N) continue;
+      float4_t v = acc[i][j];
+      if (p.bias) {
+        const half4_t b = ld_half4(p.bias + n);
+        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+      }
+      v *= p.alpha;
+      if (p.res) {
+        const half4_t r = ld_half4(p.res + (size_t)m * p.ldr + n);
+        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+      }
+      if (relu) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      }
+      if (f32out) {
+        *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+      } else {
+        half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        st_half4(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n, o);
+      }
+    }
+  }
+}
+
+template <int MODE>
+int launch(const GemmParams& p, hipStream_t st) {
+  const int tm = skg_cdiv(p.M, BM);
+  // wide tiles when N fills them and there are enough blocks to cover the 256 CUs
+  const bool wide = (p.N % 128 == 0) && ((long)tm * (p.N / 128) >= 256);
+  if (wide) {
+    dim3 grid(p.N / 128, tm);
+    hipLaunchKernelGGL((gemm_kernel<128, MODE>), grid, dim3(256), 0, st, p);
+  } else {
+    dim3 grid(skg_cdiv(p.N, 64), tm);
+    hipLaunchKernelGGL((gemm_kernel<64, MODE>), grid, dim3(256), 0, st, p);
+  }
+  SKG_CHECK_LAUNCH("skg_gemm");
+  return SKG_OK;
+}
+
+}  // namespace
+
+extern "C" int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M,
+                            int N, int K, const void* bias, const void* residual, int ldr,
+                            float alpha, unsigned flags, void* stream) {
+  SKG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
+  SKG_REQUIRE(K % 32 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0);
+  SKG_REQUIRE(skg_aligned(A, 16) && skg_aligned(B, 16) && skg_aligned(C, 8));
+  SKG_REQUIRE(!bias || skg_aligned(bias, 8));
+  SKG_REQUIRE(!residual || (skg_aligned(residual, 8) && ldr % 4 == 0));
+  SKG_REQUIRE(lda >= K && ldb >= K && ldc >= N);
+  GemmParams p{};
+  p.A = (const half_t*)A; p.lda = lda; p.B = (const half_t*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.bias = (const half_t*)bias; p.res = (const half_t*)residual; p.ldr = ldr;
+  p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.flags = flags;
+  return launch<MODE_DIRECT>(p, (hipStream_t)stream);
+}
+
+extern "C" int skg_conv3x3_f16(const void* X, int ldx, const void* Wp, void* Y, int ldy, int rows,
+                               int IH, int IW, int Cin, int Cout, int mode, const void* bias,
+                               const void* residual, int ldr, float alpha, unsigned flags,
+                               void* stream) {
+  SKG_REQUIRE(X && Wp && Y && rows > 0 && IH > 0 && IW > 0);
+  SKG_REQUIRE(Cin % 32 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldx >= Cin && ldy % 4 == 0 && ldy >= Cout);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Wp, 16) && skg_aligned(Y, 8));
+  SKG_REQUIRE(!bias || skg_aligned(bias, 8));
+  SKG_REQUIRE(!residual || (skg_aligned(residual, 8) && ldr % 4 == 0));
+  GemmParams p{};
+  p.A = (const half_t*)X; p.lda = ldx; p.B = (const half_t*)Wp; p.ldb = 9 * Cin; p.C = Y; p.ldc = ldy;
+  p.bias = (const half_t*)bias; p.res = (const half_t*)residual; p.ldr = ldr;
+  p.N = Cout; p.K = 9 * Cin; p.alpha = alpha; p.flags = flags;
+  p.IH = IH; p.IW = IW; p.Cin = Cin;
+  hipStream_t st = (hipStream_t)stream;
+  switch (mode) {
+    case SKG_CONV_S1:
+      p.OH = IH; p.OW = IW; p.M = rows * p.OH * p.OW;
+      return launch<MODE_S1>(p, st);
+    case SKG_CONV_S2:
+      SKG_REQUIRE(IH % 2 == 0 && IW % 2 == 0);
+      p.OH = IH / 2; p.OW = IW / 2; p.M = rows * p.OH * p.OW;
+      return launch<MODE_S2>(p, st);
+    case SKG_CONV_UP2:
+      p.OH = IH * 2; p.OW = IW * 2; p.M = rows * p.OH * p.OW;
+      return launch<MODE_UP2>(p, st);
+    case SKG_CONV_S2T:
+      p.OH = IH * 2; p.OW = IW * 2; p.M = rows * p.OH * p.OW;
+      return launch<MODE_S2T>(p, st);
+    default:
+      return SKG_E_UNSUPPORTED;
+  }
+}

@@ -1,0 +1,380 @@
+// LGP (Latent Gradient/Edge Predictor) kernels: re-associated layer 0 (bilinear gather of per-tap
+// partial products + noise-level / sinusoid channels), its adjoint, per-sample train-mode
+// BatchNorm1d (stats / apply / backward through the preceding ReLU) and the MSE seed gradient.
+//
+// Row layout of every LGP activation: row = (j * S + s) * hw + pixel with j = CFG half (0 = uncond,
+// 1 = cond), s = sample, pixel = y * h + x.  One BatchNorm "batch" is one sample's two CFG rows
+// (2*hw LGP rows): the reference only runs B = 1, so statistics are per sample.
+#include "common.h"
+
+namespace {
+
+constexpr int BN_CHUNKS = 64;
+constexpr int MAX_TAPS = 12;
+constexpr int NEXTRA = 40;   // 4 noise-level channels + 9 * 4 sinusoid channels
+
+struct TapArgs {
+  const float* P[MAX_TAPS];
+  int s[MAX_TAPS];
+  int n;
+};
+
+__device__ __forceinline__ void bil_coord(int d, int s, int h, int& i0, int& i1, float& w1) {
+  const float scale = (float)s / (float)h;
+  float src = ((float)d + 0.5f) * scale - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > s - 1) i0 = s - 1;
+  i1 = i0 + (i0 < s - 1 ? 1 : 0);
+  w1 = src - (float)i0;
+}
+
+// one 128-thread half-block per output pixel, 4 channels per thread (H0 == 512)
+__global__ __launch_bounds__(256) void lgp_gather_kernel(const TapArgs taps, const half_t* __restrict__ Wx, int ldw,
+                                                         const half_t* __restrict__ bias0,
+                                                         const float* __restrict__ noise, float sigma, int S,
+                                                         half_t* __restrict__ Z, int rows, int h, int H0) {
+  __shared__ float e_s[2][NEXTRA];
+  const int hw = h * h;
+  const int half_id = threadIdx.x >> 7;
+  const int tl = threadIdx.x & 127;
+  const size_t pix = (size_t)blockIdx.x * 2 + half_id;   // over rows*hw
+  const bool ok = pix < (size_t)rows * hw;
+  const int row = ok ? (int)(pix / hw) : 0;
+  const int pp = ok ? (int)(pix - (size_t)row * hw) : 0;
+  const int y = pp / h, x = pp - y * h;
+  const int smp = row % S;
+  if (tl < NEXTRA) {
+    const int c = tl < 4 ? tl : (tl - 4) & 3;
+    const float nl = sigma * noise[((size_t)smp * 4 + c) * hw + pp];
+    float v = nl;
+    if (tl >= 4) {
+      const int l = (tl - 4) >> 2;
+      v = sinf((6.283185307179586f * nl) * exp2f(-(float)l));
+    }
+    e_s[half_id][tl] = (float)(half_t)v;    // the reference casts the concatenated input to fp16
+  }
+  __syncthreads();
+  if (!ok) return;
+  for (int c0 = tl * 4; c0 < H0; c0 += 512) {
+    float4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < taps.n; ++i) {
+      const int s = taps.s[i];
+      const float* P = taps.P[i] + (size_t)row * s * s * H0 + c0;
+      if (s == h) {
+        acc += *reinterpret_cast<const float4_t*>(P + (size_t)pp * H0);
+      } else {
+        int y0, y1, x0, x1;
+        float wy, wx;
+        bil_coord(y, s, h, y0, y1, wy);
+        bil_coord(x, s, h, x0, x1, wx);
+        const float4_t v00 = *reinterpret_cast<const float4_t*>(P + (size_t)(y0 * s + x0) * H0);
+        const float4_t v01 = *reinterpret_cast<const float4_t*>(P + (size_t)(y0 * s + x1) * H0);
+        const float4_t v10 = *reinterpret_cast<const float4_t*>(P + (size_t)(y1 * s + x0) * H0);
+        const float4_t v11 = *reinterpret_cast<const float4_t*>(P + (size_t)(y1 * s + x1) * H0);
+        acc += (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const half_t* w = Wx + (size_t)(c0 + j) * ldw;
+      float d = 0.f;
+#pragma unroll
+      for (int k = 0; k < NEXTRA; k += 8) {
+        const half8_t wv = ld_half8(w + k);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d += (float)wv[q] * e_s[half_id][k + q];
+      }
+      acc[j] += d + (float)bias0[c0 + j];
+    }
+    half4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (half_t)fmaxf((float)(half_t)acc[j], 0.f);
+    st_half4(Z + pix * H0 + c0, o);
+  }
+}
+
+// adjoint of the bilinear resize for one tap: one block per native pixel
+__global__ __launch_bounds__(256) void lgp_scatter_kernel(const half_t* __restrict__ dZ, int lddz,
+                                                          half_t* __restrict__ dP, int rows, int h, int s, int H0) {
+  const int ss = s * s;
+  const int row = blockIdx.x / ss;
+  const int np = blockIdx.x - row * ss;
+  const int py = np / s, px = np - py * s;
+  const int f = h / s;
+  const int ylo = max(0, f * py - f), yhi = min(h - 1, f * py + 2 * f - 1);
+  const int xlo = max(0, f * px - f), xhi = min(h - 1, f * px + 2 * f - 1);
+  for (int c0 = threadIdx.x * 2; c0 < H0; c0 += 512) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int y = ylo; y <= yhi; ++y) {
+      int y0, y1;
+      float wy;
+      bil_coord(y, s, h, y0, y1, wy);
+      const float cy = (y0 == py ? 1.f - wy : 0.f) + (y1 == py ? wy : 0.f);
+      if (cy == 0.f) continue;
+      for (int x = xlo; x <= xhi; ++x) {
+        int x0, x1;
+        float wx;
+        bil_coord(x, s, h, x0, x1, wx);
+        const float cx = (x0 == px ? 1.f - wx : 0.f) + (x1 == px ? wx : 0.f);
+        if (cx == 0.f) continue;
+        const half2_t v = *reinterpret_cast<const half2_t*>(dZ + ((size_t)row * h * h + y * h + x) * lddz + c0);
+        a0 += cy * cx * (float)v[0];
+        a1 += cy * cx * (float)v[1];
+      }
+    }
+    half2_t o = {(half_t)a0, (half_t)a1};
+    *reinterpret_cast<half2_t*>(dP + ((size_t)row * ss + np) * H0 + c0) = o;
+  }
+}
+
+// ---- BatchNorm1d, statistics over one sample's rows -------------------------------------------
+// KIND 0: (sum x, sum x^2);  KIND 1: (sum dy, sum dy*xhat)
+template <int KIND>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const half_t* __restrict__ X, int ldx,
+                                                         const half_t* __restrict__ dY, int lddy, int S, int segs,
+                                                         int seg_rows, int C, const float* __restrict__ stats,
+                                                         float* __restrict__ partial) {
+  const int g = blockIdx.y, chunk = blockIdx.x;
+  const int n = segs * seg_rows;
+  const int per = (n + BN_CHUNKS - 1) / BN_CHUNKS;
+  const int i0 = chunk * per, i1 = min(n, i0 + per);
+  for (int cp = threadIdx.x; cp < (C >> 1); cp += 256) {
+    const int c = cp * 2;
+    float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
+    float ma = 0.f, mb = 0.f, ra = 0.f, rb = 0.f;
+    if (KIND == 1) {
+      ma = stats[((size_t)g * C + c) * 2]; ra = stats[((size_t)g * C + c) * 2 + 1];
+      mb = stats[((size_t)g * C + c + 1) * 2]; rb = stats[((size_t)g * C + c + 1) * 2 + 1];
+    }
+    for (int i = i0; i < i1; ++i) {
+      const int j = i / seg_rows, ii = i - j * seg_rows;
+      const size_t row = ((size_t)j * S + g) * seg_rows + ii;
+      const half2_t xv = *reinterpret_cast<const half2_t*>(X + row * ldx + c);
+      if (KIND == 0) {
+        const float a = (float)xv[0], b = (float)xv[1];
+        s1a += a; s1b += b; s2a += a * a; s2b += b * b;
+      } else {
+        const half2_t dv = *reinterpret_cast<const half2_t*>(dY + row * lddy + c);
+        const float da = (float)dv[0], db = (float)dv[1];
+        s1a += da; s1b += db;
+        s2a += da * ((float)xv[0] - ma) * ra;
+        s2b += db * ((float)xv[1] - mb) * rb;
+      }
+    }
+    float* o = partial + (((size_t)g * BN_CHUNKS + chunk) * C + c) * 2;
+    o[0] = s1a; o[1] = s2a; o[2] = s1b; o[3] = s2b;
+  }
+}
+
+// fold chunks; KIND 0 -> (mean, rstd) + running-stat side effects, groups visited in order
+template <int KIND>
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int S, int C, int n, float eps,
+                                   float* __restrict__ out, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = 0.f, rv = 0.f;
+  if (KIND == 0 && running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+  for (int g = 0; g < S; ++g) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < BN_CHUNKS; ++k) {
+      const float* q = partial + (((size_t)g * BN_CHUNKS + k) * C + c) * 2;
+      s1 += q[0]; s2 += q[1];
+    }
+    if (KIND == 0) {
+      const float mean = s1 / n;
+      const float var = fmaxf(s2 / n - mean * mean, 0.f);
+      out[((size_t)g * C + c) * 2] = mean;
+      out[((size_t)g * C + c) * 2 + 1] = rsqrtf(var + eps);
+      rm = 0.9f * rm + 0.1f * mean;
+      rv = 0.9f * rv + 0.1f * var * ((float)n / (float)(n - 1));
+    } else {
+      out[((size_t)g * C + c) * 2] = s1 / n;
+      out[((size_t)g * C + c) * 2 + 1] = s2 / n;
+    }
+  }
+  if (KIND == 0 && running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+}
+
+__global__ void bn_from_running_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int S, int C,
+                                       float eps, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * C) return;
+  const int c = i % C;
+  out[(size_t)i * 2] = rm[c];
+  out[(size_t)i * 2 + 1] = rsqrtf(rv[c] + eps);
+}
+
+// MODE 0: y = (x-mean)*rstd*gamma+beta.   MODE 1: dx = [x>0] * gamma*rstd*(dy - m1 - xhat*m2)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const half_t* __restrict__ X, int ldx,
+                                                       const half_t* __restrict__ dY, int lddy,
+                                                       half_t* __restrict__ Y, int ldy, int S, int seg_rows,
+                                                       size_t nrows, int C, const float* __restrict__ stats,
+                                                       const float* __restrict__ sums,
+                                                       const half_t* __restrict__ gamma,
+                                                       const half_t* __restrict__ beta, int train) {
+  const int C8 = C >> 3;
+  const size_t total = nrows * C8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t row = i / C8;
+    const int c0 = (int)(i - row * C8) * 8;
+    const int g = (int)((row / seg_rows) % S);
+    const half8_t xv = ld_half8(X + row * ldx + c0);
+    const half8_t gv = ld_half8(gamma + c0);
+    const float* st = stats + ((size_t)g * C + c0) * 2;
+    half8_t o;
+    if (MODE == 0) {
+      const half8_t bv = ld_half8(beta + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        o[j] = (half_t)(((float)xv[j] - st[2 * j]) * st[2 * j + 1] * (float)gv[j] + (float)bv[j]);
+    } else {
+      const half8_t dv = ld_half8(dY + row * lddy + c0);
+      const float* sm = sums + ((size_t)g * C + c0) * 2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = (float)xv[j];
+        const float rstd = st[2 * j + 1];
+        float d = (float)dv[j];
+        if (train) d = d - sm[2 * j] - (x - st[2 * j]) * rstd * sm[2 * j + 1];
+        o[j] = x > 0.f ? (half_t)((float)gv[j] * rstd * d) : (half_t)0.f;
+      }
+    }
+    st_half8(Y + row * ldy + c0, o);
+  }
+}
+
+// one block per sample: loss, and the seed gradient for the cond row (zeros for the uncond row)
+__global__ __launch_bounds__(256) void mse_seed_kernel(const half_t* __restrict__ out, int ldo,
+                                                       const float* __restrict__ target, half_t* __restrict__ dOut,
+                                                       int ldd, float* __restrict__ loss, int S, int h,
+                                                       float loss_scale) {
+  __shared__ float red[8];
+  const int s = blockIdx.x;
+  const int hw = h * h;
+  const float k = loss_scale * 2.f / (4.f * hw);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < hw * ldd; i += 256) {
+    const int p = i / ldd, c = i - p * ldd;
+    const size_t urow = (size_t)s * hw + p, crow = ((size_t)S + s) * hw + p;
+    dOut[urow * ldd + c] = (half_t)0.f;
+    float gval = 0.f;
+    if (c < 4) {
+      const float d = (float)out[crow * ldo + c] - target[((size_t)s * 4 + c) * hw + p];
+      acc += d * d;
+      gval = k * d;
+    }
+    dOut[crow * ldd + c] = (half_t)gval;
+  }
+  acc = block_sum<256>(acc, red);
+  if (threadIdx.x == 0 && loss) loss[s] = acc / (4.f * hw);
+}
+
+inline int ew_grid(size_t total_items) {
+  size_t b = (total_items + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int skg_lgp_layer0_gather(const SkgLgpTap* taps, int ntaps, const void* Wextra, int ldw,
+                                     const void* bias0, const float* noise, float sigma, int samples, void* Z,
+                                     int rows, int h, int H0, void* stream) {
+  SKG_REQUIRE(taps && ntaps > 0 && ntaps <= MAX_TAPS && Wextra && bias0 && noise && Z && rows > 0 && h > 0);
+  SKG_REQUIRE(H0 % 4 == 0 && ldw % 8 == 0 && skg_aligned(Wextra, 16) && skg_aligned(Z, 8) && samples > 0 &&
+              rows % samples == 0);
+  TapArgs a{};
+  a.n = ntaps;
+  for (int i = 0; i < ntaps; ++i) {
+    SKG_REQUIRE(taps[i].P && taps[i].s > 0 && h % taps[i].s == 0 && skg_aligned(taps[i].P, 16));
+    a.P[i] = taps[i].P;
+    a.s[i] = taps[i].s;
+  }
+  const size_t pixels = (size_t)rows * h * h;
+  hipLaunchKernelGGL(lgp_gather_kernel, dim3((unsigned)((pixels + 1) / 2)), dim3(256), 0, (hipStream_t)stream, a,
+                     (const half_t*)Wextra, ldw, (const half_t*)bias0, noise, sigma, samples, (half_t*)Z, rows, h, H0);
+  SKG_CHECK_LAUNCH("skg_lgp_layer0_gather");
+  return SKG_OK;
+}
+
+extern "C" int skg_lgp_layer0_scatter(const void* dZ, int lddz, void* dP, int rows, int h, int s, int H0,
+                                      void* stream) {
+  SKG_REQUIRE(dZ && dP && rows > 0 && h > 0 && s > 0 && h % s == 0 && H0 % 2 == 0 && lddz % 2 == 0);
+  hipLaunchKernelGGL(lgp_scatter_kernel, dim3(rows * s * s), dim3(256), 0, (hipStream_t)stream, (const half_t*)dZ,
+                     lddz, (half_t*)dP, rows, h, s, H0);
+  SKG_CHECK_LAUNCH("skg_lgp_layer0_scatter");
+  return SKG_OK;
+}
+
+extern "C" size_t skg_bn_scratch_floats(int samples, int C) {
+  return (size_t)samples * BN_CHUNKS * C * 2 + (size_t)samples * C * 2;
+}
+
+extern "C" int skg_bn_stats(const void* X, int ldx, int samples, int segs, int seg_rows, int C, float eps,
+                            float* stats, float* scratch, float* running_mean, float* running_var, void* stream) {
+  SKG_REQUIRE(X && stats && scratch && samples > 0 && segs > 0 && seg_rows > 0 && C % 2 == 0 && ldx % 2 == 0);
+  SKG_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(BN_CHUNKS, samples), dim3(256), 0, st, (const half_t*)X, ldx,
+                     (const half_t*)nullptr, 0, samples, segs, seg_rows, C, (const float*)nullptr, scratch);
+  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(skg_cdiv(C, 128)), dim3(128), 0, st, scratch, samples, C,
+                     segs * seg_rows, eps, stats, running_mean, running_var);
+  SKG_CHECK_LAUNCH("skg_bn_stats");
+  return SKG_OK;
+}
+
+extern "C" int skg_bn_stats_from_running(const float* running_mean, const float* running_var, int samples, int C,
+                                         float eps, float* stats, void* stream) {
+  SKG_REQUIRE(running_mean && running_var && stats && samples > 0 && C > 0);
+  hipLaunchKernelGGL(bn_from_running_kernel, dim3(skg_cdiv(samples * C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     running_mean, running_var, samples, C, eps, stats);
+  SKG_CHECK_LAUNCH("skg_bn_stats_from_running");
+  return SKG_OK;
+}
+
+extern "C" int skg_bn_apply(const void* X, int ldx, void* Y, int ldy, int samples, int segs, int seg_rows, int C,
+                            const float* stats, const void* gamma, const void* beta, void* stream) {
+  SKG_REQUIRE(X && Y && stats && gamma && beta && samples > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
+  const size_t nrows = (size_t)samples * segs * seg_rows;
+  hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(ew_grid(nrows * C / 8)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)X, ldx, (const half_t*)nullptr, 0, (half_t*)Y, ldy, samples, seg_rows, nrows, C,
+                     stats, (const float*)nullptr, (const half_t*)gamma, (const half_t*)beta, 1);
+  SKG_CHECK_LAUNCH("skg_bn_apply");
+  return SKG_OK;
+}
+
+extern "C" int skg_bn_relu_bwd(const void* X, int ldx, const void* dY, int lddy, void* dX, int lddx, int samples,
+                               int segs, int seg_rows, int C, const float* stats, const void* gamma,
+                               int train_mode, float* scratch, void* stream) {
+  SKG_REQUIRE(X && dY && dX && stats && gamma && scratch && samples > 0 && C % 8 == 0);
+  SKG_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && skg_aligned(X, 16) && skg_aligned(dY, 16) &&
+              skg_aligned(dX, 16) && skg_aligned(gamma, 16));
+  hipStream_t st = (hipStream_t)stream;
+  float* sums = scratch + (size_t)samples * BN_CHUNKS * C * 2;
+  if (train_mode) {
+    hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(BN_CHUNKS, samples), dim3(256), 0, st, (const half_t*)X, ldx,
+                       (const half_t*)dY, lddy, samples, segs, seg_rows, C, stats, scratch);
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(skg_cdiv(C, 128)), dim3(128), 0, st, scratch, samples, C,
+                       segs * seg_rows, 0.f, sums, (float*)nullptr, (float*)nullptr);
+  }
+  const size_t nrows = (size_t)samples * segs * seg_rows;
+  hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(ew_grid(nrows * C / 8)), dim3(256), 0, st, (const half_t*)X, ldx,
+                     (const half_t*)dY, lddy, (half_t*)dX, lddx, samples, seg_rows, nrows, C, stats, sums,
+                     (const half_t*)gamma, (const half_t*)nullptr, train_mode);
+  SKG_CHECK_LAUNCH("skg_bn_relu_bwd");
+  return SKG_OK;
+}
+
+extern "C" int skg_lgp_mse_seed(const void* out, int ldo, const float* target, void* dOut, int ldd, float* loss,
+                                int samples, int h, float loss_scale, void* stream) {
+  SKG_REQUIRE(out && target && dOut && samples > 0 && h > 0 && ldo >= 4 && ldd >= 4);
+  hipLaunchKernelGGL(mse_seed_kernel, dim3(samples), dim3(256), 0, (hipStream_t)stream, (const half_t*)out, ldo,
+                     target, (half_t*)dOut, ldd, loss, samples, h, loss_scale);
+  SKG_CHECK_LAUNCH("skg_lgp_mse_seed");
+  return SKG_OK;
+}

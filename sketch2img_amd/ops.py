@@ -1,0 +1,363 @@
+"""Thin tensor-level wrappers over the C ABI (include/skg.h).
+
+Every function takes torch CUDA tensors only to get at device pointers, strides and the current HIP
+stream; all arithmetic happens inside libskg.so.  A 2-D "matrix view" is any tensor with
+``stride(1) == 1`` - column slices of wider buffers are passed as (pointer, leading dimension).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import SkgTap, check, lib
+
+EPI_RELU, EPI_OUT_F32 = 1, 2
+CONV_S1, CONV_S2, CONV_UP2, CONV_S2T = 0, 1, 2, 3
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), "matrix view must be row-major"
+    return t.stride(0)
+
+
+def _f16(*ts):
+    for t in ts:
+        assert t is None or (t.is_cuda and t.dtype == torch.float16), "fp16 CUDA tensor expected"
+
+
+def gemm(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *,
+         bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         alpha: float = 1.0, relu: bool = False, out_f32: bool = False) -> torch.Tensor:
+    """out[m][n] = epi(alpha*(A[m,:] . B[n,:] + bias[n]) + residual[m][n]);  A [M,K], B [N,K]."""
+    _f16(A, B, bias, residual)
+    M, K = A.shape
+    N = B.shape[0]
+    assert B.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else torch.float16)
+    flags = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0)
+    check(lib.skg_gemm_f16(_p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out), M, N, K, _p(bias),
+                           _p(residual), _ld(residual) if residual is not None else 0, alpha, flags,
+                           _stream()), "skg_gemm_f16")
+    return out
+
+
+def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode: int = CONV_S1,
+            out: Optional[torch.Tensor] = None, *, bias=None, residual=None, alpha: float = 1.0,
+            relu: bool = False) -> torch.Tensor:
+    """X [rows*IH*IW, Cin] (view), Wp [Cout, 9*Cin] tap-major.  Returns [rows*OH*OW, Cout]."""
+    _f16(X, Wp, bias, residual)
+    Cin = X.shape[1]
+    Cout = Wp.shape[0]
+    assert Wp.shape[1] == 9 * Cin and Wp.is_contiguous() and X.shape[0] == rows * IH * IW
+    if mode == CONV_S1:
+        OH, OW = IH, IW
+    elif mode == CONV_S2:
+        OH, OW = IH // 2, IW // 2
+    else:
+        OH, OW = IH * 2, IW * 2
+    if out is None:
+        out = torch.empty(rows * OH * OW, Cout, device=X.device, dtype=torch.float16)
+    check(lib.skg_conv3x3_f16(_p(X), _ld(X), _p(Wp), _p(out), _ld(out), rows, IH, IW, Cin, Cout, mode,
+                              _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
+                              alpha, EPI_RELU if relu else 0, _stream()), "skg_conv3x3_f16")
+    return out
+
+
+_scratch = {}
+
+
+def _gn_scratch(rows: int, groups: int, dev) -> torch.Tensor:
+    n = lib.skg_groupnorm_scratch_floats(rows, groups)
+    key = ("gn", dev, n)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(n, device=dev, dtype=torch.float32)
+    return _scratch[key]
+
+
+def groupnorm_stats(X, rows, HW, groups, eps, stats=None):
+    _f16(X)
+    C = X.shape[1]
+    if stats is None:
+        stats = torch.empty(rows, groups, 2, device=X.device, dtype=torch.float32)
+    check(lib.skg_groupnorm_stats(_p(X), _ld(X), rows, HW, C, groups, eps, _p(stats),
+                                  _p(_gn_scratch(rows, groups, X.device)), _stream()), "skg_groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply(X, rows, HW, groups, stats, gamma, beta, silu: bool, out=None):
+    _f16(X, gamma, beta)
+    C = X.shape[1]
+    if out is None:
+        out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
+    check(lib.skg_groupnorm_apply(_p(X), _ld(X), _p(out), _ld(out), rows, HW, C, groups, _p(stats), _p(gamma),
+                                  _p(beta), int(silu), _stream()), "skg_groupnorm_apply")
+    return out
+
+
+def groupnorm(X, rows, HW, groups, eps, gamma, beta, silu: bool, out=None):
+    st = groupnorm_stats(X, rows, HW, groups, eps)
+    return groupnorm_apply(X, rows, HW, groups, st, gamma, beta, silu, out), st
+
+
+def groupnorm_bwd(X, dY, rows, HW, groups, stats, gamma, beta, silu: bool, residual=None, out=None):
+    _f16(X, dY, gamma, beta, residual)
+    C = X.shape[1]
+    if out is None:
+        out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
+    check(lib.skg_groupnorm_bwd(_p(X), _ld(X), _p(dY), _ld(dY), _p(out), _ld(out), _p(residual),
+                                _ld(residual) if residual is not None else 0, rows, HW, C, groups, _p(stats),
+                                _p(gamma), _p(beta), int(silu), _p(_gn_scratch(rows, groups, X.device)),
+                                _stream()), "skg_groupnorm_bwd")
+    return out
+
+
+def layernorm(X, gamma, beta, eps=1e-5, out=None, want_stats=False):
+    _f16(X, gamma, beta)
+    M, C = X.shape
+    if out is None:
+        out = torch.empty(M, C, device=X.device, dtype=torch.float16)
+    stats = torch.empty(M, 2, device=X.device, dtype=torch.float32) if want_stats else None
+    check(lib.skg_layernorm_fwd(_p(X), _ld(X), _p(out), _ld(out), M, C, _p(gamma), _p(beta), eps, _p(stats),
+                                _stream()), "skg_layernorm_fwd")
+    return (out, stats) if want_stats else out
+
+
+def layernorm_bwd(X, dY, gamma, stats, residual=None, out=None):
+    _f16(X, dY, gamma, residual)
+    M, C = X.shape
+    if out is None:
+        out = torch.empty(M, C, device=X.device, dtype=torch.float16)
+    check(lib.skg_layernorm_bwd(_p(X), _ld(X), _p(dY), _ld(dY), _p(out), _ld(out), _p(residual),
+                                _ld(residual) if residual is not None else 0, M, C, _p(gamma), _p(stats),
+                                _stream()), "skg_layernorm_bwd")
+    return out
+
+
+def geglu(H, out=None):
+    _f16(H)
+    M, F2 = H.shape
+    F = F2 // 2
+    if out is None:
+        out = torch.empty(M, F, device=H.device, dtype=torch.float16)
+    check(lib.skg_geglu_fwd(_p(H), _ld(H), _p(out), _ld(out), M, F, _stream()), "skg_geglu_fwd")
+    return out
+
+
+def geglu_bwd(H, dY, out=None):
+    _f16(H, dY)
+    M, F2 = H.shape
+    if out is None:
+        out = torch.empty(M, F2, device=H.device, dtype=torch.float16)
+    check(lib.skg_geglu_bwd(_p(H), _ld(H), _p(dY), _ld(dY), _p(out), _ld(out), M, F2 // 2, _stream()),
+          "skg_geglu_bwd")
+    return out
+
+
+def transpose(X, out=None):
+    _f16(X)
+    M, C = X.shape
+    if out is None:
+        out = torch.empty(C, M, device=X.device, dtype=torch.float16)
+    check(lib.skg_transpose_f16(_p(X), _ld(X), _p(out), _ld(out), M, C, _stream()), "skg_transpose_f16")
+    return out
+
+
+def axpby(A, B=None, out=None, alpha=1.0, beta=1.0):
+    _f16(A, B)
+    M, C = A.shape
+    if out is None:
+        out = torch.empty(M, C, device=A.device, dtype=torch.float16)
+    check(lib.skg_axpby_f16(_p(A), _ld(A), _p(B), _ld(B) if B is not None else 0, _p(out), _ld(out), M, C,
+                            alpha, beta, _stream()), "skg_axpby_f16")
+    return out
+
+
+def silu(X, out=None):
+    _f16(X)
+    M, C = X.shape
+    if out is None:
+        out = torch.empty(M, C, device=X.device, dtype=torch.float16)
+    check(lib.skg_silu_f16(_p(X), _ld(X), _p(out), _ld(out), M, C, _stream()), "skg_silu_f16")
+    return out
+
+
+def sumpool2x2(X, rows, H, W, out=None):
+    """X [rows*2H*2W, C] -> [rows*H*W, C]."""
+    _f16(X)
+    C = X.shape[1]
+    if out is None:
+        out = torch.empty(rows * H * W, C, device=X.device, dtype=torch.float16)
+    check(lib.skg_sumpool2x2_f16(_p(X), _ld(X), _p(out), _ld(out), rows, H, W, C, _stream()),
+          "skg_sumpool2x2_f16")
+    return out
+
+
+def nchw_to_nhwc(X: torch.Tensor, Cpad: int, out=None):
+    """float32 [rows, C, H, W] -> fp16 [rows*H*W, Cpad]."""
+    assert X.is_cuda and X.dtype == torch.float32 and X.is_contiguous()
+    rows, C, H, W = X.shape
+    if out is None:
+        out = torch.empty(rows * H * W, Cpad, device=X.device, dtype=torch.float16)
+    check(lib.skg_nchw_f32_to_nhwc_f16(_p(X), _p(out), rows, C, H * W, Cpad, _stream()),
+          "skg_nchw_f32_to_nhwc_f16")
+    return out
+
+
+def nhwc_to_nchw(X: torch.Tensor, rows: int, C: int, H: int, W: int):
+    _f16(X)
+    out = torch.empty(rows, C, H, W, device=X.device, dtype=torch.float32)
+    check(lib.skg_nhwc_f16_to_nchw_f32(_p(X), _ld(X), _p(out), rows, C, H * W, _stream()),
+          "skg_nhwc_f16_to_nchw_f32")
+    return out
+
+
+def attn_fwd(Q, K, Vt, batch, heads, Nq, Nkv, kv_stride, dh, scale, out=None, want_lse=False):
+    _f16(Q, K, Vt)
+    if out is None:
+        out = torch.empty(batch * Nq, heads * dh, device=Q.device, dtype=torch.float16)
+    lse = torch.empty(batch, heads, Nq, device=Q.device, dtype=torch.float32) if want_lse else None
+    check(lib.skg_attn_fwd(_p(Q), _ld(Q), _p(K), _ld(K), _p(Vt), _ld(Vt), _p(out), _ld(out), _p(lse), batch,
+                           heads, Nq, Nkv, kv_stride, dh, scale, _stream()), "skg_attn_fwd")
+    return (out, lse) if want_lse else out
+
+
+def attn_bwd_delta(O, dO, batch, heads, Nq, dh):
+    _f16(O, dO)
+    delta = torch.empty(batch, heads, Nq, device=O.device, dtype=torch.float32)
+    check(lib.skg_attn_bwd_delta(_p(O), _ld(O), _p(dO), _ld(dO), _p(delta), batch, heads, Nq, dh, _stream()),
+          "skg_attn_bwd_delta")
+    return delta
+
+
+def attn_bwd_dq(Q, K, V, Kt, dO, lse, delta, batch, heads, Nq, Nkv, kv_stride, dh, scale, out=None):
+    _f16(Q, K, V, Kt, dO)
+    if out is None:
+        out = torch.empty(batch * Nq, heads * dh, device=Q.device, dtype=torch.float16)
+    check(lib.skg_attn_bwd_dq(_p(Q), _ld(Q), _p(K), _ld(K), _p(V), _ld(V), _p(Kt), _ld(Kt), _p(dO), _ld(dO),
+                              _p(lse), _p(delta), _p(out), _ld(out), batch, heads, Nq, Nkv, kv_stride, dh,
+                              scale, _stream()), "skg_attn_bwd_dq")
+    return out
+
+
+def attn_bwd_dkv(Q, Qt, K, V, dO, dOt, lse, delta, batch, heads, Nq, Nkv, dh, scale, dK=None, dV=None):
+    _f16(Q, Qt, K, V, dO, dOt)
+    if dK is None:
+        dK = torch.empty(batch * Nkv, heads * dh, device=Q.device, dtype=torch.float16)
+    if dV is None:
+        dV = torch.empty(batch * Nkv, heads * dh, device=Q.device, dtype=torch.float16)
+    check(lib.skg_attn_bwd_dkv(_p(Q), _ld(Q), _p(Qt), _ld(Qt), _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO),
+                               _p(dOt), _ld(dOt), _p(lse), _p(delta), _p(dK), _ld(dK), _p(dV), _ld(dV), batch,
+                               heads, Nq, Nkv, dh, scale, _stream()), "skg_attn_bwd_dkv")
+    return dK, dV
+
+
+# ---- LGP --------------------------------------------------------------------------------------------
+def lgp_layer0_gather(P: Sequence[torch.Tensor], sizes: Sequence[int], Wextra, bias0, noise, sigma: float,
+                      samples: int, h: int, H0: int, out=None):
+    rows = 2 * samples
+    arr = (SkgTap * len(P))()
+    for i, (t, s) in enumerate(zip(P, sizes)):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (rows * s * s, H0)
+        arr[i].P, arr[i].s = t.data_ptr(), s
+    if out is None:
+        out = torch.empty(rows * h * h, H0, device=noise.device, dtype=torch.float16)
+    check(lib.skg_lgp_layer0_gather(ctypes.addressof(arr), len(P), _p(Wextra), _ld(Wextra), _p(bias0),
+                                    _p(noise), sigma, samples, _p(out), rows, h, H0, _stream()),
+          "skg_lgp_layer0_gather")
+    return out
+
+
+def lgp_layer0_scatter(dZ, rows, h, s, H0):
+    _f16(dZ)
+    out = torch.empty(rows * s * s, H0, device=dZ.device, dtype=torch.float16)
+    check(lib.skg_lgp_layer0_scatter(_p(dZ), _ld(dZ), _p(out), rows, h, s, H0, _stream()),
+          "skg_lgp_layer0_scatter")
+    return out
+
+
+def _bn_scratch(samples, C, dev):
+    n = lib.skg_bn_scratch_floats(samples, C)
+    key = ("bn", dev, n)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(n, device=dev, dtype=torch.float32)
+    return _scratch[key]
+
+
+def bn_stats(X, samples, segs, seg_rows, eps=1e-5, running_mean=None, running_var=None):
+    _f16(X)
+    C = X.shape[1]
+    stats = torch.empty(samples, C, 2, device=X.device, dtype=torch.float32)
+    check(lib.skg_bn_stats(_p(X), _ld(X), samples, segs, seg_rows, C, eps, _p(stats),
+                           _p(_bn_scratch(samples, C, X.device)), _p(running_mean), _p(running_var), _stream()),
+          "skg_bn_stats")
+    return stats
+
+
+def bn_stats_from_running(running_mean, running_var, samples, eps=1e-5):
+    C = running_mean.numel()
+    stats = torch.empty(samples, C, 2, device=running_mean.device, dtype=torch.float32)
+    check(lib.skg_bn_stats_from_running(_p(running_mean), _p(running_var), samples, C, eps, _p(stats), _stream()),
+          "skg_bn_stats_from_running")
+    return stats
+
+
+def bn_apply(X, samples, segs, seg_rows, stats, gamma, beta, out=None):
+    _f16(X, gamma, beta)
+    C = X.shape[1]
+    if out is None:
+        out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
+    check(lib.skg_bn_apply(_p(X), _ld(X), _p(out), _ld(out), samples, segs, seg_rows, C, _p(stats), _p(gamma),
+                           _p(beta), _stream()), "skg_bn_apply")
+    return out
+
+
+def bn_relu_bwd(X, dY, samples, segs, seg_rows, stats, gamma, train: bool, out=None):
+    _f16(X, dY, gamma)
+    C = X.shape[1]
+    if out is None:
+        out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
+    check(lib.skg_bn_relu_bwd(_p(X), _ld(X), _p(dY), _ld(dY), _p(out), _ld(out), samples, segs, seg_rows, C,
+                              _p(stats), _p(gamma), int(train), _p(_bn_scratch(samples, C, X.device)), _stream()),
+          "skg_bn_relu_bwd")
+    return out
+
+
+def lgp_mse_seed(out16, target, samples, h, ldd, loss_scale):
+    _f16(out16)
+    dOut = torch.empty(2 * samples * h * h, ldd, device=out16.device, dtype=torch.float16)
+    loss = torch.empty(samples, device=out16.device, dtype=torch.float32)
+    check(lib.skg_lgp_mse_seed(_p(out16), _ld(out16), _p(target), _p(dOut), ldd, _p(loss), samples, h,
+                               loss_scale, _stream()), "skg_lgp_mse_seed")
+    return dOut, loss
+
+
+# ---- sampler ------------------------------------------------------------------------------------------
+def cfg_ddim_step(eps_u, eps_c, x, samples, HW, g, coeffs: Tuple[float, float, float, float],
+                  want_eps=False):
+    _f16(eps_u, eps_c)
+    x_prev = torch.empty_like(x)
+    eps_out = torch.empty_like(x) if want_eps else None
+    c0, c1, c2, c3 = coeffs
+    check(lib.skg_cfg_ddim_step(_p(eps_u), _p(eps_c), _ld(eps_u), _p(x), _p(x_prev), _p(eps_out), samples, HW,
+                                g, c0, c1, c2, c3, _stream()), "skg_cfg_ddim_step")
+    return (x_prev, eps_out) if want_eps else x_prev
+
+
+def guidance_update(grad, x_in, x_prev, samples, HW, beta):
+    """In place: x_prev += alpha * (-grad).  Returns aux [samples,4] = (alpha, ||g||, sqrt2*||dx||, 0)."""
+    _f16(grad)
+    aux = torch.empty(samples, 4, device=grad.device, dtype=torch.float32)
+    check(lib.skg_guidance_update(_p(grad), _ld(grad), _p(x_in), _p(x_prev), _p(aux), samples, HW, beta,
+                                  _stream()), "skg_guidance_update")
+    return aux

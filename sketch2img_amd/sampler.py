@@ -1,0 +1,106 @@
+"""The sketch-guided DDIM sampling loop on the libskg.so kernels.
+
+Mirrors the reference's hot loop, modules/pipeline.py:83-115 and apply_anti_gradient :141-161:
+  per step  CFG-doubled UNet eval (:85-96) -> CFG combine (:99-101) -> scheduler.step (:104) ->
+            on guided steps (i <= 0.5*T, :89-92,:108) the LGP loss gradient w.r.t. the UNet input
+            and the alpha-scaled update of x_{t-1} (:157-161).
+Scheduler tables and per-step coefficients are host-side integer / scalar work (bit-exact timestep
+indexing); everything that touches a latent runs in HIP kernels.
+
+A batch of S samples is S independent B = 1 trajectories of the reference (which crashes for B > 1:
+SURVEY Q1): alpha, the BatchNorm statistics and the loss are per sample.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from .lgp import HipLGP
+from .unet import CIN_PAD, HipUNet, Stash
+
+
+@dataclass
+class DDIMTables:
+    alphas_cumprod: torch.Tensor      # (num_train,) fp32 CPU
+    final_alpha_cumprod: float
+    timesteps: np.ndarray             # (T,) int64 descending
+    ratio: int
+
+    @staticmethod
+    def make(num_inference_steps: int, num_train_timesteps: int = 1000, beta_start: float = 0.00085,
+             beta_end: float = 0.012, steps_offset: int = 1, set_alpha_to_one: bool = False) -> "DDIMTables":
+        """diffusers DDIMScheduler(scaled_linear) as configured for SD1.5 (app.py:15-19 betas;
+        steps_offset=1, set_alpha_to_one=False from the model repo's scheduler config)."""
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        acp = torch.cumprod(1.0 - betas, dim=0)
+        ratio = num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + steps_offset
+        return DDIMTables(acp, 1.0 if set_alpha_to_one else float(acp[0]), ts, ratio)
+
+    def coeffs(self, t: int):
+        """(sqrt(a_t), sqrt(1-a_t), sqrt(a_prev), sqrt(1-a_prev)) - fp32 table arithmetic, eta = 0."""
+        prev = t - self.ratio
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else torch.tensor(self.final_alpha_cumprod)
+        return float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_p ** 0.5), float((1 - a_p) ** 0.5)
+
+    def sigma(self, t: int) -> float:
+        """get_noise_level's factor sqrt(1 - alphas_cumprod[t]) (modules/pipeline.py:133)."""
+        return float((1 - self.alphas_cumprod[t]) ** 0.5)
+
+
+def guided_step(i: int, T: int) -> bool:
+    return not (i > 0.5 * T)            # modules/pipeline.py:89-92,108
+
+
+class HipSampler:
+    def __init__(self, unet: HipUNet, lgp: Optional[HipLGP] = None):
+        self.unet, self.lgp = unet, lgp
+        self.last_aux: List[Optional[torch.Tensor]] = []
+
+    @torch.no_grad()
+    def step(self, x: torch.Tensor, noise: torch.Tensor, target: Optional[torch.Tensor], tab: DDIMTables,
+             i: int, guidance_scale: float, beta: float, want_eps: bool = False):
+        """One iteration of the loop for S samples.  x fp32 [S,4,h,h] on the device -> x_{t-1}."""
+        S, _, h, _ = x.shape
+        hw = h * h
+        T = len(tab.timesteps)
+        t = int(tab.timesteps[i])
+        guided = guided_step(i, T) and target is not None and self.lgp is not None
+        x32 = ops.nchw_to_nhwc(torch.cat([x, x]).contiguous(), CIN_PAD)
+        stash = Stash() if guided else None
+        eps, taps = self.unet.forward(x32, t, 2 * S, h, stash, want_taps=guided)
+        res = ops.cfg_ddim_step(eps[:S * hw], eps[S * hw:], x, S, hw, guidance_scale, tab.coeffs(t), want_eps)
+        x_prev, eps_cfg = res if want_eps else (res, None)
+        aux = None
+        if guided:
+            keep = {}
+            out = self.lgp.forward(taps, noise, tab.sigma(t), S, h, keep)
+            tap_grads, loss = self.lgp.backward(out, target, keep)
+            grad = self.unet.backward(stash, tap_grads)
+            aux = ops.guidance_update(grad, x, x_prev, S, hw, beta)
+            aux[:, 3] = loss
+        return x_prev, eps_cfg, aux
+
+    @torch.no_grad()
+    def sample(self, latents0: torch.Tensor, target: Optional[torch.Tensor], num_inference_steps: int = 50,
+               guidance_scale: float = 7.5, beta: float = 1.6,
+               callback: Optional[Callable[[int, int, torch.Tensor], None]] = None,
+               tables: Optional[DDIMTables] = None) -> torch.Tensor:
+        dev = self.unet.dev
+        tab = tables or DDIMTables.make(num_inference_steps)
+        x = latents0.to(dev, torch.float32).contiguous()
+        noise = x.clone()                                     # modules/pipeline.py:75
+        tgt = None if target is None else target.to(dev, torch.float32).expand_as(x).contiguous()
+        self.unet.prepare_timesteps(tab.timesteps.tolist())
+        self.last_aux = []
+        for i, t in enumerate(tab.timesteps.tolist()):
+            x, _, aux = self.step(x, noise, tgt, tab, i, guidance_scale, beta)
+            self.last_aux.append(aux)
+            if callback is not None:
+                callback(i, t, x)
+        return x

@@ -1,0 +1,434 @@
+"""SD-style UNet evaluated with the libskg.so kernels: forward (with feature taps) and
+backward-to-input.
+
+Replaces what the reference reaches through ``self.unet(...)`` at modules/pipeline.py:96
+(diffusers UNet2DConditionModel -> cuDNN / cuBLAS / xformers kernels), the forward hooks of
+modules/latent_predictor.py:47-81 (the nine taps) and the autograd pass triggered at
+modules/pipeline.py:159.  Weights use the diffusers state_dict key names.
+
+Data layout in HBM: every activation is fp16, token-major [rows*H*W, C]; rows are
+ordered [uncond rows of all samples ; cond rows of all samples] so the backward pass (cond rows
+only - the uncond gradient is discarded at modules/pipeline.py:159) works on the contiguous second
+half of every stashed buffer.  Weight packs: Linear / 1x1 conv [N][K]; conv3x3
+[Cout][ky][kx][Cin]; each has a second "dgrad" pack (transposed / tap-flipped) for backward.
+
+Work hoisted out of the per-step loop because it does not depend on the latent:
+  * the time-embedding MLP and every ResnetBlock2D.time_emb_proj(silu(temb)) -> one fused bias
+    vector per (timestep, resnet), folded into conv1's bias;
+  * cross-attention K / V projections of the text embeddings (per prompt).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .config import UNetConfig, up_block_plan
+
+CIN_PAD = 32      # latent channels padded to one BK slice of the implicit-GEMM conv
+COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
+CTX_PAD = 8       # text tokens padded to a multiple of 8 (77 -> 80)
+
+
+def _h(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.detach().to(device=dev, dtype=torch.float16).contiguous()
+
+
+def pack_conv(w: torch.Tensor, dev, cin_pad: int = 0, cout_pad: int = 0) -> torch.Tensor:
+    """[Cout,Cin,3,3] -> [Cout(+pad)][ky][kx][Cin(+pad)] flattened to [Cout, 9*Cin]."""
+    co, ci = w.shape[:2]
+    p = w.permute(0, 2, 3, 1)
+    if cin_pad > ci:
+        p = torch.nn.functional.pad(p, (0, cin_pad - ci))
+    if cout_pad > co:
+        p = torch.nn.functional.pad(p, (0, 0, 0, 0, 0, 0, 0, cout_pad - co))
+    return _h(p.reshape(p.shape[0], -1), dev)
+
+
+def pack_conv_dgrad(w: torch.Tensor, dev, cin_pad: int = 0, cout_pad: int = 0) -> torch.Tensor:
+    """dgrad pack: Wd[ci][ky'][kx'][co] = W[co][ci][2-ky'][2-kx'] -> [Cin, 9*Cout].
+    ``cin_pad`` pads the OUTPUT rows (the conv's input channels), ``cout_pad`` the contraction."""
+    co, ci = w.shape[:2]
+    p = w.flip(2, 3).permute(1, 2, 3, 0)
+    if cout_pad > co:
+        p = torch.nn.functional.pad(p, (0, cout_pad - co))
+    if cin_pad > ci:
+        p = torch.nn.functional.pad(p, (0, 0, 0, 0, 0, 0, 0, cin_pad - ci))
+    return _h(p.reshape(p.shape[0], -1), dev)
+
+
+def _pad_vec(v: torch.Tensor, n: int) -> torch.Tensor:
+    return torch.nn.functional.pad(v, (0, n - v.shape[0])) if n > v.shape[0] else v
+
+
+@dataclass
+class Stash:
+    """Activations kept by a grad-enabled forward for the backward pass."""
+    res: Dict[str, dict] = field(default_factory=dict)
+    tr: Dict[str, dict] = field(default_factory=dict)
+    misc: dict = field(default_factory=dict)
+
+
+class HipUNet:
+    def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda",
+                 need_backward: bool = True):
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.need_backward = need_backward
+        self.W: Dict[str, torch.Tensor] = {}
+        self._pack(state_dict)
+        self._sd_time = {k: v for k, v in state_dict.items()
+                         if k.startswith("time_embedding.") or ".time_emb_proj." in k or k.endswith("conv1.bias")}
+        self.tbias: Dict[int, Dict[str, torch.Tensor]] = {}
+        self.ctx: Optional[dict] = None
+        self.inject: Optional[Callable] = None      # set by modules.*_guided_attn.SatMixin
+
+    # ------------------------------------------------------------------ packing
+    def _pack(self, sd):
+        W, dev, bw = self.W, self.dev, self.need_backward
+        for k, v in sd.items():
+            if v.dim() == 4 and v.shape[2] == 3:
+                if k == "conv_in.weight":
+                    W[k] = pack_conv(v, dev, cin_pad=CIN_PAD)
+                    if bw:
+                        W[k + ":T"] = pack_conv_dgrad(v, dev, cin_pad=COUT_PAD)
+                elif k == "conv_out.weight":
+                    W[k] = pack_conv(v, dev, cout_pad=COUT_PAD)
+                else:
+                    W[k] = pack_conv(v, dev)
+                    if bw:
+                        W[k + ":T"] = pack_conv_dgrad(v, dev)
+            elif v.dim() == 4:                                  # 1x1 conv
+                W[k] = _h(v.reshape(v.shape[0], v.shape[1]), dev)
+                if bw:
+                    W[k + ":T"] = _h(v.reshape(v.shape[0], v.shape[1]).t(), dev)
+            elif v.dim() == 2:
+                if ".attn1.to_" in k and not k.endswith("to_out.0.weight"):
+                    continue                                    # fused below
+                if ".attn2.to_k." in k or ".attn2.to_v." in k:
+                    W[k] = _h(v, dev)                            # used once per prompt
+                    continue
+                if ".time_emb" in k:
+                    W[k] = _h(v, dev)
+                    continue
+                W[k] = _h(v, dev)
+                if bw:
+                    W[k + ":T"] = _h(v.t(), dev)
+            else:
+                W[k] = _h(_pad_vec(v, COUT_PAD) if k == "conv_out.bias" else v, dev)
+        for k in list(sd.keys()):
+            if k.endswith(".attn1.to_q.weight"):
+                p = k[: -len(".to_q.weight")]
+                qkv = torch.cat([sd[p + ".to_q.weight"], sd[p + ".to_k.weight"], sd[p + ".to_v.weight"]], 0)
+                W[p + ".qkv"] = _h(qkv, dev)
+                if bw:
+                    W[p + ".qkv:T"] = _h(qkv.t(), dev)
+
+    # ------------------------------------------------------------------ hoisted precompute
+    def prepare_timesteps(self, timesteps: Sequence[int]):
+        """Time-embedding MLP and the per-resnet time projections for every timestep of the schedule
+        (diffusers get_timestep_embedding(flip_sin_to_cos=True, shift 0) -> TimestepEmbedding ->
+        ResnetBlock2D.time_emb_proj(silu(.))), folded with conv1.bias."""
+        cfg, W = self.cfg, self.W
+        ts = [int(t) for t in timesteps if int(t) not in self.tbias]
+        if not ts:
+            return
+        c0 = cfg.block_out_channels[0]
+        half = c0 // 2
+        expo = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+        emb = torch.tensor(ts, dtype=torch.float32)[:, None] * torch.exp(expo)[None, :]
+        emb = torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)              # host table, fp32
+        e = emb.to(self.dev, torch.float16).contiguous()
+        e = ops.gemm(e, W["time_embedding.linear_1.weight"], bias=W["time_embedding.linear_1.bias"])
+        e = ops.silu(e)
+        e = ops.gemm(e, W["time_embedding.linear_2.weight"], bias=W["time_embedding.linear_2.bias"])
+        e = ops.silu(e)                                                          # silu(temb), [T, 4*c0]
+        out = {t: {} for t in ts}
+        for k in W:
+            if k.endswith(".time_emb_proj.weight"):
+                p = k[: -len(".time_emb_proj.weight")]
+                proj = ops.gemm(e, W[k], bias=W[p + ".time_emb_proj.bias"])       # [T, Cout]
+                fused = ops.axpby(proj, W[p + ".conv1.bias"].expand(len(ts), -1).contiguous())
+                for i, t in enumerate(ts):
+                    out[t][p] = fused[i].contiguous()
+        self.tbias.update(out)
+
+    def prepare_context(self, ehs: torch.Tensor):
+        """Cross-attention K / V of the text embeddings, per transformer block.  ehs [rows, L, D] in the
+        row order [uncond rows; cond rows]."""
+        cfg, W = self.cfg, self.W
+        rows, L, D = ehs.shape
+        Lp = (L + CTX_PAD - 1) // CTX_PAD * CTX_PAD
+        Dp = (D + 31) // 32 * 32
+        x = torch.zeros(rows, Lp, Dp, device=self.dev, dtype=torch.float16)
+        x[:, :L, :D] = ehs.to(self.dev, torch.float16)
+        x = x.reshape(rows * Lp, Dp)
+        S = rows // 2
+        ctx = dict(L=L, Lp=Lp, rows=rows, blocks={})
+        for k in W:
+            if k.endswith(".attn2.to_k.weight"):
+                p = k[: -len(".to_k.weight")]
+                wk, wv = W[k], W[p + ".to_v.weight"]
+                if Dp != D:
+                    wk = torch.nn.functional.pad(wk, (0, Dp - D)).contiguous()
+                    wv = torch.nn.functional.pad(wv, (0, Dp - D)).contiguous()
+                Kc = ops.gemm(x, wk)                     # padded token rows are exactly zero (zero input, no bias)
+                Vc = ops.gemm(x, wv)
+                blk = dict(K=Kc, V=Vc, Vt=ops.transpose(Vc))
+                if self.need_backward:
+                    blk["Kt_c"] = ops.transpose(Kc[S * Lp:])
+                ctx["blocks"][p] = blk
+        self.ctx = ctx
+
+    # ------------------------------------------------------------------ modules, forward
+    def _res_fwd(self, p, x, rows, H, tb, stash: Optional[Stash]):
+        cfg, W = self.cfg, self.W
+        G, HW = cfg.norm_groups, H * H
+        n1, st1 = ops.groupnorm(x, rows, HW, G, 1e-5, W[p + ".norm1.weight"], W[p + ".norm1.bias"], True)
+        h1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, bias=tb[p])
+        n2, st2 = ops.groupnorm(h1, rows, HW, G, 1e-5, W[p + ".norm2.weight"], W[p + ".norm2.bias"], True)
+        if (p + ".conv_shortcut.weight") in W:
+            sc = ops.gemm(x, W[p + ".conv_shortcut.weight"], bias=W[p + ".conv_shortcut.bias"])
+        else:
+            sc = x
+        out = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, bias=W[p + ".conv2.bias"], residual=sc)
+        if stash is not None:
+            stash.res[p] = dict(x=x, st1=st1, h1=h1, st2=st2, H=H)
+        return out
+
+    def _tr_fwd(self, p, x, rows, H, heads, stash: Optional[Stash]):
+        cfg, W = self.cfg, self.W
+        HW = H * H
+        C = x.shape[1]
+        dh = C // heads
+        scale = dh ** -0.5
+        t = p + ".transformer_blocks.0"
+        keep = stash is not None
+        g, gst = ops.groupnorm(x, rows, HW, cfg.norm_groups, 1e-6, W[p + ".norm.weight"], W[p + ".norm.bias"], False)
+        pin = ops.gemm(g, W[p + ".proj_in.weight"], bias=W[p + ".proj_in.bias"])
+        a1, st1 = ops.layernorm(pin, W[t + ".norm1.weight"], W[t + ".norm1.bias"], want_stats=True)
+        qkv = ops.gemm(a1, W[t + ".attn1.qkv"])
+        vt = ops.transpose(qkv[:, 2 * C:])
+        o1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], vt, rows, heads, HW, HW, HW, dh, scale, want_lse=True)
+        p1 = ops.gemm(o1, W[t + ".attn1.to_out.0.weight"], bias=W[t + ".attn1.to_out.0.bias"], residual=pin)
+        if self.inject is not None:
+            p1 = self.inject(t, p1, rows, HW, heads)
+        a2, st2 = ops.layernorm(p1, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
+        q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"])
+        cb = self.ctx["blocks"][t + ".attn2"]
+        o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["Vt"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
+                                want_lse=True)
+        p2 = ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], bias=W[t + ".attn2.to_out.0.bias"], residual=p1)
+        a3, st3 = ops.layernorm(p2, W[t + ".norm3.weight"], W[t + ".norm3.bias"], want_stats=True)
+        f = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"])
+        gg = ops.geglu(f)
+        p3 = ops.gemm(gg, W[t + ".ff.net.2.weight"], bias=W[t + ".ff.net.2.bias"], residual=p2)
+        out = ops.gemm(p3, W[p + ".proj_out.weight"], bias=W[p + ".proj_out.bias"], residual=x)
+        if keep:
+            stash.tr[p] = dict(x=x, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1, st2=st2, q2=q2,
+                               o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads)
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x32: torch.Tensor, t: int, rows: int, H: int, stash: Optional[Stash] = None,
+                want_taps: bool = True, want_eps: bool = True):
+        """x32: fp16 [rows*H*H, 32] (latent channels zero-padded).  Returns (eps [rows*H*H, 8] or None,
+        taps: list of 9 (tensor [rows*s*s, C], s))."""
+        cfg, W = self.cfg, self.W
+        assert self.ctx is not None and self.ctx["rows"] == rows, "call prepare_context first"
+        self.prepare_timesteps([t])
+        tb = self.tbias[int(t)]
+        boc = cfg.block_out_channels
+        nb = len(boc)
+        h = ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, bias=W["conv_in.bias"])
+        skips = [h]
+        taps_down = []
+        cur = H
+        for i in range(nb):
+            for j in range(cfg.layers_per_block):
+                h = self._res_fwd(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, stash)
+                if i < nb - 1:
+                    h = self._tr_fwd(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i], stash)
+                skips.append(h)
+            if i < nb - 1:
+                p = f"down_blocks.{i}.downsamplers.0.conv"
+                h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_S2, bias=W[p + ".bias"])
+                cur //= 2
+                skips.append(h)
+            if i < 3:
+                taps_down.append((h, cur))
+        h = self._res_fwd("mid_block.resnets.0", h, rows, cur, tb, stash)
+        tap_r0 = (h, cur)
+        h = self._tr_fwd("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash)
+        tap_at = (h, cur)
+        h = self._res_fwd("mid_block.resnets.1", h, rows, cur, tb, stash)
+        tap_r1 = (h, cur)
+        taps_up = []
+        rev_heads = tuple(reversed(cfg.num_heads))
+        last_needed = 2 if not want_eps else nb - 1
+        for i in range(nb):
+            if i > last_needed:
+                break
+            for j in range(cfg.layers_per_block + 1):
+                sk = skips.pop()
+                ch, cs = h.shape[1], sk.shape[1]
+                cat = torch.empty(h.shape[0], ch + cs, device=self.dev, dtype=torch.float16)
+                ops.axpby(h, out=cat[:, :ch])
+                ops.axpby(sk, out=cat[:, ch:])
+                h = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash)
+                if i > 0:
+                    h = self._tr_fwd(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], stash)
+            if i < nb - 1:
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, bias=W[p + ".bias"])
+                cur *= 2
+            if i < 3:
+                taps_up.append((h, cur))
+        eps = None
+        if want_eps:
+            n, _ = ops.groupnorm(h, rows, cur * cur, cfg.norm_groups, 1e-5, W["conv_norm_out.weight"],
+                                 W["conv_norm_out.bias"], True)
+            eps = ops.conv3x3(n, W["conv_out.weight"], rows, cur, cur, bias=W["conv_out.bias"])
+        taps = taps_down + [tap_at, tap_r0, tap_r1] + taps_up
+        if stash is not None:
+            stash.misc.update(rows=rows, H=H)
+        return eps, (taps if want_taps else None)
+
+    # ------------------------------------------------------------------ modules, backward (cond rows)
+    def _res_bwd(self, p, dout, S, st: dict):
+        cfg, W = self.cfg, self.W
+        H = st["H"]
+        HW, G = H * H, cfg.norm_groups
+        x, h1 = st["x"][S * HW:], st["h1"][S * HW:]
+        st1, st2 = st["st1"][S:], st["st2"][S:]
+        dn2 = ops.conv3x3(dout, W[p + ".conv2.weight:T"], S, H, H)
+        dh1 = ops.groupnorm_bwd(h1, dn2, S, HW, G, st2, W[p + ".norm2.weight"], W[p + ".norm2.bias"], True)
+        dn1 = ops.conv3x3(dh1, W[p + ".conv1.weight:T"], S, H, H)
+        if (p + ".conv_shortcut.weight") in W:
+            sc = ops.gemm(dout, W[p + ".conv_shortcut.weight:T"])
+        else:
+            sc = dout
+        return ops.groupnorm_bwd(x, dn1, S, HW, G, st1, W[p + ".norm1.weight"], W[p + ".norm1.bias"], True,
+                                 residual=sc)
+
+    def _tr_bwd(self, p, dout, S, st: dict):
+        cfg, W = self.cfg, self.W
+        H, heads = st["H"], st["heads"]
+        HW = H * H
+        M0 = S * HW
+        C = dout.shape[1]
+        dh = C // heads
+        scale = dh ** -0.5
+        t = p + ".transformer_blocks.0"
+        c = lambda a: a[M0:]
+        dp3 = ops.gemm(dout, W[p + ".proj_out.weight:T"])
+        dgg = ops.gemm(dp3, W[t + ".ff.net.2.weight:T"])
+        df = ops.geglu_bwd(c(st["f"]), dgg)
+        da3 = ops.gemm(df, W[t + ".ff.net.0.proj.weight:T"])
+        dp2 = ops.layernorm_bwd(c(st["p2"]), da3, W[t + ".norm3.weight"], c(st["st3"]), residual=dp3)
+        # cross-attention: only dQ (K/V come from the constant text embeddings)
+        do2 = ops.gemm(dp2, W[t + ".attn2.to_out.0.weight:T"])
+        cb = self.ctx["blocks"][t + ".attn2"]
+        L, Lp = self.ctx["L"], self.ctx["Lp"]
+        delta2 = ops.attn_bwd_delta(c(st["o2"]), do2, S, heads, HW, dh)
+        dq2 = ops.attn_bwd_dq(c(st["q2"]), cb["K"][S * Lp:], cb["V"][S * Lp:], cb["Kt_c"], do2, st["lse2"][S:],
+                              delta2, S, heads, HW, L, Lp, dh, scale)
+        da2 = ops.gemm(dq2, W[t + ".attn2.to_q.weight:T"])
+        dp1 = ops.layernorm_bwd(c(st["p1"]), da2, W[t + ".norm2.weight"], c(st["st2"]), residual=dp2)
+        # self-attention
+        do1 = ops.gemm(dp1, W[t + ".attn1.to_out.0.weight:T"])
+        qkv = c(st["qkv"])
+        Q, K, V = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        delta1 = ops.attn_bwd_delta(c(st["o1"]), do1, S, heads, HW, dh)
+        lse1 = st["lse1"][S:]
+        dqkv = torch.empty(M0, 3 * C, device=self.dev, dtype=torch.float16)
+        ops.attn_bwd_dq(Q, K, V, ops.transpose(K), do1, lse1, delta1, S, heads, HW, HW, HW, dh, scale,
+                        out=dqkv[:, :C])
+        ops.attn_bwd_dkv(Q, ops.transpose(Q), K, V, do1, ops.transpose(do1), lse1, delta1, S, heads, HW, HW, dh,
+                         scale, dK=dqkv[:, C:2 * C], dV=dqkv[:, 2 * C:])
+        da1 = ops.gemm(dqkv, W[t + ".attn1.qkv:T"])
+        dpin = ops.layernorm_bwd(c(st["pin"]), da1, W[t + ".norm1.weight"], c(st["st1"]), residual=dp1)
+        dg = ops.gemm(dpin, W[p + ".proj_in.weight:T"])
+        return ops.groupnorm_bwd(c(st["x"]), dg, S, HW, cfg.norm_groups, st["gst"][S:], W[p + ".norm.weight"],
+                                 W[p + ".norm.bias"], False, residual=dout)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, stash: Stash, tap_grads: Sequence[Optional[torch.Tensor]]) -> torch.Tensor:
+        """tap_grads: 9 fp16 tensors [S*s*s, C] (cond rows) in tap order.  Returns d loss / d x for the
+        cond rows, fp16 [S*H*H, 8] (first 4 channels valid)."""
+        assert self.need_backward and self.inject is None, "backward with injected attention is not supported"
+        cfg, W = self.cfg, self.W
+        rows, H = stash.misc["rows"], stash.misc["H"]
+        S = rows // 2
+        nb = len(cfg.block_out_channels)
+        lpb = cfg.layers_per_block
+
+        def add(a, b):
+            if a is None:
+                return b
+            if b is None:
+                return a
+            return ops.axpby(a, b)
+
+        # skip index bookkeeping: skips = [conv_in] + per down block (lpb resnet outs [+ downsample out])
+        n_skips = 1 + sum(lpb + (1 if i < nb - 1 else 0) for i in range(nb))
+        gskip: List[Optional[torch.Tensor]] = [None] * n_skips
+        # ---- up path, reversed (blocks 2, 1, 0; block 3 does not feed any tap)
+        cur = H                                  # spatial size of up block 2's output (after its upsampler)
+        for _ in range(nb - 1 - 3):              # generic: taps end at up block 2
+            pass
+        # index of the skip consumed first by up block i: pops from the end
+        pop_idx = n_skips
+        consumed = {}
+        for i in range(nb):
+            for j in range(lpb + 1):
+                pop_idx -= 1
+                consumed[(i, j)] = pop_idx
+        dh = tap_grads[8]
+        cur = H
+        plan = up_block_plan(cfg)
+        for i in (2, 1, 0):
+            if i < nb - 1:
+                # upsampler backward: dgrad at the upsampled size, then 2x2 sum-pool
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                du = ops.conv3x3(dh, W[p + ".weight:T"], S, cur, cur)
+                cur //= 2
+                dh = ops.sumpool2x2(du, S, cur, cur)
+            for j in range(lpb, -1, -1):
+                if i > 0:
+                    dh = self._tr_bwd(f"up_blocks.{i}.attentions.{j}", dh, S, stash.tr[f"up_blocks.{i}.attentions.{j}"])
+                dcat = self._res_bwd(f"up_blocks.{i}.resnets.{j}", dh, S, stash.res[f"up_blocks.{i}.resnets.{j}"])
+                ch = plan[i][j][0]
+                k = consumed[(i, j)]
+                gskip[k] = add(gskip[k], dcat[:, ch:])
+                dh = dcat[:, :ch]
+            if i > 0:
+                dh = add(dh, tap_grads[6 + i - 1])      # output of up block i-1 (after its upsampler)
+        # ---- mid
+        dh = add(dh, tap_grads[5])
+        dh = self._res_bwd("mid_block.resnets.1", dh, S, stash.res["mid_block.resnets.1"])
+        dh = add(dh, tap_grads[3])
+        dh = self._tr_bwd("mid_block.attentions.0", dh, S, stash.tr["mid_block.attentions.0"])
+        dh = add(dh, tap_grads[4])
+        dh = self._res_bwd("mid_block.resnets.0", dh, S, stash.res["mid_block.resnets.0"])
+        # ---- down path, reversed
+        k = n_skips - 1
+        for i in range(nb - 1, -1, -1):
+            if i < nb - 1:
+                dh = add(dh, gskip[k]); k -= 1
+                if i < 3:
+                    dh = add(dh, tap_grads[i])
+                p = f"down_blocks.{i}.downsamplers.0.conv"
+                dh = ops.conv3x3(dh, W[p + ".weight:T"], S, cur, cur, ops.CONV_S2T)
+                cur *= 2
+            for j in range(lpb - 1, -1, -1):
+                dh = add(dh, gskip[k]); k -= 1
+                if i < nb - 1:
+                    dh = self._tr_bwd(f"down_blocks.{i}.attentions.{j}", dh, S,
+                                      stash.tr[f"down_blocks.{i}.attentions.{j}"])
+                dh = self._res_bwd(f"down_blocks.{i}.resnets.{j}", dh, S, stash.res[f"down_blocks.{i}.resnets.{j}"])
+        dh = add(dh, gskip[0])
+        return ops.conv3x3(dh, W["conv_in.weight:T"], S, H, H)

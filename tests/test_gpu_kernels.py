@@ -1,0 +1,325 @@
+"""GPU parity tests (-m gpu): every libskg.so kernel, called through the C ABI, against plain PyTorch
+fp32 math on the same fp16-rounded inputs.  Tolerances are stated per test; "rel" is the relative
+Frobenius error ||got - ref|| / ||ref|| and is dominated by the final fp16 rounding of the output
+(2^-11 = 4.9e-4 per element) unless noted."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import report
+
+pytestmark = pytest.mark.gpu
+
+FP16_RND = 6e-4      # one fp16 output rounding, relative Frobenius
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sketch2img_amd import ops as o
+    return o
+
+
+# ---------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 320, 64), (1024, 1280, 320), (4099, 64, 512), (65, 8, 32),
+                                   (33000, 256, 128), (16384, 640, 640)])
+def test_gemm_plain(ops, M, N, K):
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5)
+    C = ops.gemm(A.to(dev()), B.to(dev()))
+    ref = A.float() @ B.float().t()
+    r, _ = report(f"gemm {M}x{N}x{K}", C.float(), ref)
+    assert r < FP16_RND
+
+
+def test_gemm_epilogue_and_views(ops):
+    M, N, K = 777, 320, 96
+    Abig, Bbig = rnd(M, K + 40, seed=3), rnd(N, K + 64, seed=4, scale=0.1)
+    bias, res = rnd(N, seed=5), rnd(M, N + 8, seed=6)
+    A, B = Abig[:, 8:8 + K], Bbig[:, 32:32 + K]                # column-slice views: lda/ldb > K
+    out = torch.zeros(M, N + 16, device=dev(), dtype=torch.float16)
+    ops.gemm(Abig.to(dev())[:, 8:8 + K], Bbig.to(dev())[:, 32:32 + K], out=out[:, 8:8 + N],
+             bias=bias.to(dev()), residual=res.to(dev())[:, :N], alpha=0.5, relu=True)
+    ref = torch.relu(0.5 * (A.float() @ B.float().t() + bias.float()) + res[:, :N].float())
+    r, _ = report("gemm epilogue", out[:, 8:8 + N].float(), ref)
+    assert r < FP16_RND
+    assert out[:, :8].abs().max() == 0 and out[:, 8 + N:].abs().max() == 0      # no stray writes
+    o32 = ops.gemm(A.contiguous().to(dev()), B.contiguous().to(dev()), out_f32=True)
+    r, _ = report("gemm f32 out", o32, A.float() @ B.float().t())
+    assert o32.dtype == torch.float32 and r < 2e-6 * math.sqrt(K) + 1e-6
+
+
+def test_gemm_rejects_bad_args(ops):
+    from sketch2img_amd._lib import SkgError
+    A, B = rnd(16, 24).to(dev()), rnd(8, 24).to(dev())        # K % 32 != 0
+    with pytest.raises(SkgError):
+        ops.gemm(A, B)
+
+
+# ---------------------------------------------------------------------------------------------- conv
+def nhwc(x):   # [B,C,H,W] -> [B*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def from_nhwc(y, B, H, W):
+    return y.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(2, 32, 64, 16), (3, 320, 320, 8), (1, 64, 40, 33), (2, 960, 640, 16)])
+def test_conv3x3_s1(ops, B, Cin, Cout, H):
+    from sketch2img_amd.unet import pack_conv
+    x, w, b = rnd(B, Cin, H, H, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5), rnd(Cout, seed=3)
+    res = rnd(B * H * H, Cout, seed=4)
+    y = ops.conv3x3(nhwc(x).to(dev()), pack_conv(w, dev()), B, H, H, bias=b.to(dev()), residual=res.to(dev()))
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + from_nhwc(res.float(), B, H, H)
+    r, _ = report(f"conv s1 {Cin}->{Cout}@{H}", from_nhwc(y.float().cpu(), B, H, H), ref)
+    assert r < FP16_RND
+
+
+def test_conv3x3_stride2_up2_and_dgrads(ops):
+    from sketch2img_amd.unet import pack_conv, pack_conv_dgrad
+    B, Ci, Co, H = 2, 64, 96, 16
+    x, w = rnd(B, Ci, H, H, seed=1), rnd(Co, Ci, 3, 3, seed=2, scale=(9 * Ci) ** -0.5)
+    d = dev()
+    # stride 2
+    y = ops.conv3x3(nhwc(x).to(d), pack_conv(w, d), B, H, H, ops.CONV_S2)
+    ref = F.conv2d(x.float(), w.float(), stride=2, padding=1)
+    assert report("conv s2", from_nhwc(y.float().cpu(), B, H // 2, H // 2), ref)[0] < FP16_RND
+    # nearest-2x upsample fused into the gather
+    y = ops.conv3x3(nhwc(x).to(d), pack_conv(w, d), B, H, H, ops.CONV_UP2)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), padding=1)
+    assert report("conv up2", from_nhwc(y.float().cpu(), B, 2 * H, 2 * H), ref)[0] < FP16_RND
+    # dgrad of stride 1: conv with the flipped / swapped pack
+    gy = rnd(B, Co, H, H, seed=7)
+    xg = x.float().requires_grad_(True)
+    F.conv2d(xg, w.float(), padding=1).backward(gy.float())
+    gx = ops.conv3x3(nhwc(gy).to(d), pack_conv_dgrad(w, d), B, H, H, ops.CONV_S1)
+    assert report("conv s1 dgrad", from_nhwc(gx.float().cpu(), B, H, H), xg.grad)[0] < FP16_RND
+    # dgrad of stride 2 (transposed conv gather)
+    gy2 = rnd(B, Co, H // 2, H // 2, seed=8)
+    xg = x.float().requires_grad_(True)
+    F.conv2d(xg, w.float(), stride=2, padding=1).backward(gy2.float())
+    gx = ops.conv3x3(nhwc(gy2).to(d), pack_conv_dgrad(w, d), B, H // 2, H // 2, ops.CONV_S2T)
+    assert report("conv s2 dgrad", from_nhwc(gx.float().cpu(), B, H, H), xg.grad)[0] < FP16_RND
+    # dgrad of upsample+conv: stride-1 dgrad at 2H then 2x2 sum-pool
+    gy3 = rnd(B, Co, 2 * H, 2 * H, seed=9)
+    xg = x.float().requires_grad_(True)
+    F.conv2d(F.interpolate(xg, scale_factor=2.0, mode="nearest"), w.float(), padding=1).backward(gy3.float())
+    gu = ops.conv3x3(nhwc(gy3).to(d), pack_conv_dgrad(w, d), B, 2 * H, 2 * H, ops.CONV_S1)
+    gx = ops.sumpool2x2(gu, B, H, H)
+    # two fp16 roundings (dgrad output, pooled sum)
+    assert report("conv up2 dgrad", from_nhwc(gx.float().cpu(), B, H, H), xg.grad)[0] < 2 * FP16_RND
+
+
+def test_conv_in_out_padding_paths(ops):
+    """conv_in (4 -> C, latent padded to 32 ch) and conv_out (C -> 4, padded to 8) as the UNet uses them."""
+    from sketch2img_amd.unet import CIN_PAD, COUT_PAD, pack_conv, pack_conv_dgrad
+    B, C, H = 2, 64, 16
+    x, w_in, w_out = rnd(B, 4, H, H, seed=1), rnd(C, 4, 3, 3, seed=2, scale=1 / 6), rnd(4, C, 3, 3, seed=3, scale=0.04)
+    d = dev()
+    x32 = ops.nchw_to_nhwc(x.float().to(d), CIN_PAD)
+    h = ops.conv3x3(x32, pack_conv(w_in, d, cin_pad=CIN_PAD), B, H, H)
+    ref = F.conv2d(x.float(), w_in.float(), padding=1)
+    assert report("conv_in", from_nhwc(h.float().cpu(), B, H, H), ref)[0] < FP16_RND
+    e = ops.conv3x3(h, pack_conv(w_out, d, cout_pad=COUT_PAD), B, H, H)
+    ref2 = F.conv2d(from_nhwc(h.float().cpu(), B, H, H), w_out.float(), padding=1)
+    got = ops.nhwc_to_nchw(e, B, 4, H, H).cpu()
+    assert report("conv_out", got, ref2)[0] < FP16_RND
+    assert e[:, 4:].abs().max() == 0
+    gy = rnd(B, C, H, H, seed=5)
+    xg = x.float().requires_grad_(True)
+    F.conv2d(xg, w_in.float(), padding=1).backward(gy.float())
+    gx = ops.conv3x3(nhwc(gy).to(d), pack_conv_dgrad(w_in, d, cin_pad=COUT_PAD), B, H, H)
+    assert report("conv_in dgrad", ops.nhwc_to_nchw(gx, B, 4, H, H).cpu(), xg.grad)[0] < FP16_RND
+
+
+# ---------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,C,H,G,silu", [(2, 320, 8, 32, True), (3, 960, 16, 32, True), (2, 64, 64, 8, False),
+                                          (1, 2560, 8, 32, True)])
+def test_groupnorm_fwd_bwd(ops, B, C, H, G, silu):
+    x = rnd(B, C, H, H, seed=1) + 0.3
+    ga, be = (1 + 0.2 * rnd(C, seed=2).float()).half(), (0.2 * rnd(C, seed=3).float()).half()
+    d = dev()
+    xh = nhwc(x).to(d)
+    y, st = ops.groupnorm(xh, B, H * H, G, 1e-5, ga.to(d), be.to(d), silu)
+    xr = x.float().requires_grad_(True)
+    ref = F.group_norm(xr, G, ga.float(), be.float(), 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    assert report(f"gn fwd C{C}", from_nhwc(y.float().cpu(), B, H, H), ref)[0] < FP16_RND
+    dy, res = rnd(B, C, H, H, seed=4), rnd(B, C, H, H, seed=5)
+    ref.backward(dy.float())
+    dx = ops.groupnorm_bwd(xh, nhwc(dy).to(d), B, H * H, G, st, ga.to(d), be.to(d), silu, residual=nhwc(res).to(d))
+    assert report(f"gn bwd C{C}", from_nhwc(dx.float().cpu(), B, H, H), xr.grad + res.float())[0] < 2 * FP16_RND
+
+
+@pytest.mark.parametrize("M,C", [(77, 320), (1024, 1280), (5, 32), (4096, 640)])
+def test_layernorm_fwd_bwd(ops, M, C):
+    x = rnd(M, C, seed=1) * 2 + 0.5
+    ga, be = (1 + 0.2 * rnd(C, seed=2).float()).half(), (0.2 * rnd(C, seed=3).float()).half()
+    d = dev()
+    y, st = ops.layernorm(x.to(d), ga.to(d), be.to(d), want_stats=True)
+    xr = x.float().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), ga.float(), be.float(), 1e-5)
+    assert report(f"ln fwd {M}x{C}", y.float().cpu(), ref)[0] < FP16_RND
+    dy, res = rnd(M, C, seed=4), rnd(M, C, seed=5)
+    ref.backward(dy.float())
+    dx = ops.layernorm_bwd(x.to(d), dy.to(d), ga.to(d), st, residual=res.to(d))
+    assert report(f"ln bwd {M}x{C}", dx.float().cpu(), xr.grad + res.float())[0] < 2 * FP16_RND
+
+
+def test_geglu_fwd_bwd(ops):
+    M, Fd = 300, 1280
+    h = rnd(M, 2 * Fd, seed=1)
+    d = dev()
+    y = ops.geglu(h.to(d))
+    hr = h.float().requires_grad_(True)
+    a, g = hr.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    assert report("geglu fwd", y.float().cpu(), ref)[0] < FP16_RND
+    dy = rnd(M, Fd, seed=2)
+    ref.backward(dy.float())
+    dh = ops.geglu_bwd(h.to(d), dy.to(d))
+    assert report("geglu bwd", dh.float().cpu(), hr.grad)[0] < FP16_RND
+
+
+def test_data_movement(ops):
+    d = dev()
+    x = rnd(200, 72, seed=1)
+    assert torch.equal(ops.transpose(x.to(d)).cpu(), x.t().contiguous())
+    big = rnd(4096 + 64, 320, seed=2)
+    assert torch.equal(ops.transpose(big.to(d)).cpu(), big.t().contiguous())
+    a, b = rnd(100, 64, seed=3), rnd(100, 96, seed=4)
+    out = ops.axpby(a.to(d), b.to(d)[:, 16:80], alpha=1.0, beta=1.0)
+    assert report("axpby", out.float().cpu(), a.float() + b[:, 16:80].float())[0] < FP16_RND
+    cat = torch.zeros(100, 160, device=d, dtype=torch.float16)
+    ops.axpby(a.to(d), out=cat[:, :64]); ops.axpby(b.to(d), out=cat[:, 64:])
+    assert torch.equal(cat.cpu(), torch.cat([a, b], 1))
+    x4 = rnd(2, 24, 8, 8, seed=5)
+    p = ops.sumpool2x2(nhwc(x4).to(d), 2, 4, 4)
+    ref = F.avg_pool2d(x4.float(), 2) * 4
+    assert report("sumpool", from_nhwc(p.float().cpu(), 2, 4, 4), ref)[0] < FP16_RND
+    s = ops.silu(a.to(d))
+    assert report("silu", s.float().cpu(), F.silu(a.float()))[0] < FP16_RND
+    lat = torch.randn(3, 4, 8, 8)
+    n = ops.nchw_to_nhwc(lat.to(d), 32)
+    assert n.shape == (3 * 64, 32) and n[:, 4:].abs().max() == 0
+    assert torch.equal(ops.nhwc_to_nchw(n, 3, 4, 8, 8).cpu(), lat.half().float())
+
+
+# ---------------------------------------------------------------------------------------------- attention
+def ref_attention(q, k, v, heads, scale):
+    B, N, C = q.shape
+    dh = C // heads
+    qh = q.view(B, N, heads, dh).transpose(1, 2)
+    kh = k.view(B, -1, heads, dh).transpose(1, 2)
+    vh = v.view(B, -1, heads, dh).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    lse = torch.logsumexp(s, dim=-1)
+    o = torch.softmax(s, dim=-1) @ vh
+    return o.transpose(1, 2).reshape(B, N, C), lse
+
+
+@pytest.mark.parametrize("dh,heads,Nq,Nkv", [(40, 8, 256, 256), (80, 8, 128, 128), (160, 8, 64, 64), (64, 5, 200, 200),
+                                            (16, 2, 72, 72), (32, 2, 1024, 1024), (40, 8, 4096, 4096),
+                                            (40, 8, 256, 77), (160, 8, 64, 77), (64, 5, 144, 401)])
+def test_attention_forward(ops, dh, heads, Nq, Nkv):
+    B, C = 2, heads * dh
+    kvs = (Nkv + 7) // 8 * 8
+    q, k, v = rnd(B, Nq, C, seed=1), rnd(B, Nkv, C, seed=2), rnd(B, Nkv, C, seed=3)
+    scale = dh ** -0.5
+    d = dev()
+    kp = torch.zeros(B, kvs, C, dtype=torch.float16); kp[:, :Nkv] = k
+    vp = torch.zeros(B, kvs, C, dtype=torch.float16); vp[:, :Nkv] = v
+    Q, K, V = q.reshape(B * Nq, C).to(d), kp.reshape(B * kvs, C).to(d), vp.reshape(B * kvs, C).to(d)
+    o, lse = ops.attn_fwd(Q, K, ops.transpose(V), B, heads, Nq, Nkv, kvs, dh, scale, want_lse=True)
+    ro, rl = ref_attention(q.float(), k.float(), v.float(), heads, scale)
+    r, _ = report(f"attn fwd dh{dh} {Nq}x{Nkv}", o.float().cpu().view(B, Nq, C), ro)
+    # P is rounded to fp16 before the PV product (like every fp16 flash kernel): ~1e-3 relative
+    assert r < 2e-3
+    assert report("attn lse", lse.cpu(), rl)[1] < 2e-3
+
+
+def test_attention_forward_strided_qkv_and_online_rescale(ops):
+    """Q/K read as column slices of a fused [M, 3C] buffer; spiked keys force the running max to jump at a
+    late tile (the online-softmax rescale branch)."""
+    B, heads, dh, N = 2, 8, 40, 320
+    C = heads * dh
+    qkv = rnd(B * N, 3 * C, seed=1)
+    qkv[B * N // 2 + 200, C:2 * C] *= 12.0          # one key with a huge norm, in the 4th kv tile
+    qkv[200, C:2 * C] *= -9.0
+    d = dev()
+    t = qkv.to(d)
+    o = ops.attn_fwd(t[:, :C], t[:, C:2 * C], ops.transpose(t[:, 2 * C:]), B, heads, N, N, N, dh, dh ** -0.5)
+    q, k, v = (qkv[:, i * C:(i + 1) * C].float().view(B, N, C) for i in range(3))
+    ro, _ = ref_attention(q, k, v, heads, dh ** -0.5)
+    assert report("attn fwd strided+spike", o.float().cpu().view(B, N, C), ro)[0] < 2e-3
+
+
+@pytest.mark.parametrize("dh,heads,Nq,Nkv,cross", [(40, 8, 256, 256, False), (80, 8, 64, 64, False),
+                                                  (160, 8, 64, 64, False), (16, 2, 16, 16, False),
+                                                  (64, 5, 200, 200, False), (32, 2, 1024, 1024, False),
+                                                  (40, 8, 128, 77, True), (160, 8, 64, 77, True)])
+def test_attention_backward(ops, dh, heads, Nq, Nkv, cross):
+    B, C = 2, heads * dh
+    kvs = (Nkv + 7) // 8 * 8
+    scale = dh ** -0.5
+    q, k, v = rnd(B, Nq, C, seed=1), rnd(B, Nkv, C, seed=2), rnd(B, Nkv, C, seed=3)
+    do = rnd(B, Nq, C, seed=4)
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    ro, _ = ref_attention(qf, kf, vf, heads, scale)
+    ro.backward(do.float())
+    d = dev()
+    kp = torch.zeros(B, kvs, C, dtype=torch.float16); kp[:, :Nkv] = k
+    vp = torch.zeros(B, kvs, C, dtype=torch.float16); vp[:, :Nkv] = v
+    Q, K, V = q.reshape(B * Nq, C).to(d), kp.reshape(B * kvs, C).to(d), vp.reshape(B * kvs, C).to(d)
+    dO = do.reshape(B * Nq, C).to(d)
+    o, lse = ops.attn_fwd(Q, K, ops.transpose(V), B, heads, Nq, Nkv, kvs, dh, scale, want_lse=True)
+    delta = ops.attn_bwd_delta(o, dO, B, heads, Nq, dh)
+    dq = ops.attn_bwd_dq(Q, K, V, ops.transpose(K), dO, lse, delta, B, heads, Nq, Nkv, kvs, dh, scale)
+    # tolerance: P and dS are rounded to fp16 before their MFMA products, delta uses the fp16 O
+    assert report(f"attn dq dh{dh}", dq.float().cpu().view(B, Nq, C), qf.grad)[0] < 4e-3
+    if not cross:
+        dk, dv = ops.attn_bwd_dkv(Q, ops.transpose(Q), K, V, dO, ops.transpose(dO), lse, delta, B, heads, Nq, Nkv,
+                                  dh, scale)
+        assert report(f"attn dk dh{dh}", dk.float().cpu().view(B, Nkv, C), kf.grad)[0] < 4e-3
+        assert report(f"attn dv dh{dh}", dv.float().cpu().view(B, Nkv, C), vf.grad)[0] < 4e-3
+
+
+# ---------------------------------------------------------------------------------------------- sampler pointwise
+def test_cfg_ddim_and_guidance_update(ops):
+    from sketch2img_amd.sampler import DDIMTables
+    from oracle import ddim as oddim
+    S, h = 3, 16
+    hw = h * h
+    d = dev()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(S, 4, h, h, generator=g)
+    eps = rnd(2 * S * hw, 8, seed=1)
+    tab, otab = DDIMTables.make(50), oddim.make_tables(50)
+    assert tab.timesteps.tolist() == otab.timesteps.tolist()
+    t = int(tab.timesteps[7])
+    xp, e = ops.cfg_ddim_step(eps.to(d)[:S * hw], eps.to(d)[S * hw:], x.to(d), S, hw, 7.5, tab.coeffs(t), want_eps=True)
+    eu = eps[:S * hw, :4].float().view(S, hw, 4).permute(0, 2, 1).reshape(S, 4, h, h)
+    ec = eps[S * hw:, :4].float().view(S, hw, 4).permute(0, 2, 1).reshape(S, 4, h, h)
+    er = eu + 7.5 * (ec - eu)
+    assert report("cfg eps", e.cpu(), er)[1] < 1e-5
+    assert report("ddim step", xp.cpu(), oddim.ddim_step(otab, er, t, x))[1] < 2e-5
+    grad = rnd(S * hw, 8, seed=2, scale=3.0)
+    xprev = xp.clone()
+    aux = ops.guidance_update(grad.to(d), x.to(d), xprev, S, hw, 1.6)
+    gref = -grad[:, :4].float().view(S, hw, 4).permute(0, 2, 1).reshape(S, 4, h, h)
+    for s in range(S):
+        num = math.sqrt(2.0) * float((x[s] - xp[s].cpu()).norm())
+        alpha = num / float(gref[s].norm()) * 1.6
+        assert abs(float(aux[s, 0]) - alpha) / alpha < 1e-5
+        assert report(f"guidance update s{s}", xprev[s].cpu(), xp[s].cpu() + alpha * gref[s])[1] < 1e-4

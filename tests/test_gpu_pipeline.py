@@ -1,0 +1,252 @@
+"""GPU parity tests (-m gpu) of the assembled hot path - LGP, UNet forward, UNet backward-to-input, the
+guidance step and the sampling loop - against (a) the golden vectors made from the reference's own code
+and (b) the CPU oracle on identical seeded inputs.  Everything goes through the C ABI (libskg.so)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.util import load_npz, report, sd_from_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc16(x):
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous().half().to(DEV)
+
+
+def from_nhwc(y, B, H, W):
+    return y.float().cpu().reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def tap_sizes(h):
+    return [h // 2, h // 4, h // 8, h // 8, h // 8, h // 8, h // 4, h // 2, h]
+
+
+# ------------------------------------------------------------------------------------------------------ LGP
+@pytest.mark.parametrize("h", [8, 16])
+@pytest.mark.parametrize("training", [True, False])
+def test_lgp_forward_matches_reference_golden(h, training):
+    """HIP LGP vs outputs of the reference's LatentEdgePredictor (fp16 module, CPU)."""
+    from sketch2img_amd.lgp import HipLGP
+    d = load_npz(f"lgp_fwd_h{h}.npz")
+    sd = sd_from_npz(d)
+    x, t = torch.from_numpy(d["x"]), torch.from_numpy(d["t"])
+    lgp = HipLGP(sd, [x.shape[1]], DEV, training=training)
+    out = lgp.forward([(nhwc16(x), h)], t[:1].contiguous().to(DEV), 1.0, 1, h)
+    ref = torch.from_numpy(d["y_train" if training else "y_eval"]).reshape(2, h, h, 4).permute(0, 2, 1, 3)  # (b w h)->(b y x)
+    got = out[:, :4].float().cpu().reshape(2, h, h, 4)
+    _, m = report(f"lgp fwd golden h{h} train={training}", got, ref)
+    assert m <= 4 * 2 ** -8                      # a few fp16 ulps at |y| <= 8 (same bound as the oracle's)
+    assert out[:, 4:].abs().max() == 0
+    if training:
+        for l, i in enumerate((2, 5, 8, 11)):
+            for nm, got_r in (("running_mean", lgp.running_mean[l]), ("running_var", lgp.running_var[l])):
+                ref_r = torch.from_numpy(d[f"sd_after.layers.{i}.{nm}"]).float()
+                assert (got_r.cpu() - ref_r).abs().max() <= 1e-3 * max(1.0, float(ref_r.abs().max()))
+        assert lgp.num_batches_tracked == [1, 1, 1, 1]
+
+
+@pytest.mark.parametrize("h", [8, 16])
+def test_guidance_step_matches_reference_golden(h):
+    """Reference apply_anti_gradient (toy differentiable feature extractor on the CPU side) vs HIP LGP
+    forward + backward-to-features + guidance update."""
+    from sketch2img_amd import ops
+    from sketch2img_amd.lgp import HipLGP
+    from sketch2img_amd.sampler import DDIMTables
+    d = load_npz(f"guidance_h{h}.npz")
+    sd = sd_from_npz(d)
+    x = torch.from_numpy(d["x"])
+    x_in = torch.cat([x] * 2).requires_grad_(True)
+    sizes = tap_sizes(h)
+    taps = [F.adaptive_avg_pool2d(torch.tanh(F.conv2d(x_in, torch.from_numpy(d[f"conv{i}"]))), s)
+            for i, s in enumerate(sizes)]
+    lgp = HipLGP(sd, [t.shape[1] for t in taps], DEV)
+    tab = DDIMTables.make(50)
+    assert np.array_equal(tab.alphas_cumprod.numpy(), d["alphas_cumprod"])      # bit-exact fp32 table
+    keep = {}
+    noise = torch.from_numpy(d["noise"]).to(DEV)
+    out = lgp.forward([(nhwc16(t.detach()), s) for t, s in zip(taps, sizes)], noise, tab.sigma(int(d["t"])), 1, h, keep)
+    grads, loss = lgp.backward(out, torch.from_numpy(d["target"]).to(DEV), keep)
+    # push the HIP feature gradients (cond row) back through the toy extractor on the CPU
+    tot = 0
+    for t, s, g in zip(taps, sizes, grads):
+        gc = from_nhwc(g, 1, s, s)
+        tot = tot + (t[1:2] * gc).sum()
+    grad_x = torch.autograd.grad(tot, x_in)[0][1:2]                # d loss / d x_in, cond row (x LOSS_SCALE)
+    gn = torch.zeros(h * h, 8, dtype=torch.float16)
+    gn[:, :4] = grad_x.permute(0, 2, 3, 1).reshape(h * h, 4).half()
+    lat = torch.from_numpy(d["latents"])
+    xp = lat.clone().to(DEV)
+    aux = ops.guidance_update(gn.to(DEV), x.to(DEV), xp, 1, h * h, float(d["beta"]))
+    ref = torch.from_numpy(d["out"])
+    upd, upd_ref = xp.cpu() - lat, ref - lat
+    r, _ = report(f"guidance update vs reference h{h}", upd, upd_ref)
+    expect = math.sqrt(2.0) * float((x - lat).norm()) * 1.6
+    assert abs(float(upd.norm()) - expect) / expect < 2e-3
+    # same bound as the oracle-vs-reference test: ReLU-gate sensitivity to 1-ulp forward differences
+    assert r < 0.06
+    assert float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm())) > 0.998
+
+
+def test_lgp_forward_backward_vs_oracle_two_samples():
+    """S = 2 independent samples (per-sample BatchNorm statistics) at the TINY tap widths, h = 32."""
+    from oracle import guidance as og, lgp as olgp, unet as ounet
+    from sketch2img_amd.lgp import HipLGP, LOSS_SCALE
+    cfg = ounet.TINY
+    chans, h, S = ounet.tap_channels(cfg), 32, 2
+    sizes = tap_sizes(h)
+    sd = olgp.init_state_dict(sum(chans) + 40, seed=11)
+    g = torch.Generator().manual_seed(4)
+    feats = [[torch.randn(2, c, s, s, generator=g).half().float() for c, s in zip(chans, sizes)] for _ in range(S)]
+    noise = torch.randn(S, 4, h, h, generator=g)
+    target = 0.2 * torch.randn(S, 4, h, h, generator=g)
+    sigma = 0.8
+    # HIP: rows = [uncond s0, uncond s1, cond s0, cond s1]
+    lgp = HipLGP(sd, chans, DEV)
+    taps = []
+    for i, s in enumerate(sizes):
+        rows = torch.cat([feats[0][i][:1], feats[1][i][:1], feats[0][i][1:], feats[1][i][1:]])
+        taps.append((nhwc16(rows), s))
+    keep = {}
+    out = lgp.forward(taps, noise.to(DEV), sigma, S, h, keep)
+    grads, loss = lgp.backward(out, target.to(DEV), keep)
+    for smp in range(S):
+        fs = [f.clone().requires_grad_(True) for f in feats[smp]]
+        x = torch.cat([F.interpolate(f, size=h, mode="bilinear") for f in fs], 1)
+        nl = (sigma * noise[smp:smp + 1])
+        o = olgp.lgp_forward(sd, x, torch.cat([nl] * 2), training=True)
+        oc = o.reshape(2, h, h, 4).permute(0, 3, 2, 1)              # "(b w h) c -> b c h w"
+        got = out[:, :4].float().cpu().reshape(2 * S, h, h, 4).permute(0, 3, 1, 2)
+        for j in range(2):
+            _, m = report(f"lgp out s{smp} row{j}", got[j * S + smp], oc[j])
+            assert m <= 6 * 2 ** -8
+        ls = F.mse_loss(target[smp:smp + 1], oc[1:2])
+        assert abs(float(loss[smp]) - float(ls)) < 2e-3 * max(1.0, float(ls))
+        gs = torch.autograd.grad(ls, fs)
+        # feature gradients: per-tap relative error.  Bound 8 %: fp16 gate flips of the 4 ReLU layers
+        # (see test_guidance_step_matches_reference) + fp16 storage of every backward activation.
+        num = den = 0.0
+        for i, s in enumerate(sizes):
+            gg = from_nhwc(grads[i], S, s, s)[smp] / LOSS_SCALE
+            num += float((gg - gs[i][1]).norm() ** 2)
+            den += float(gs[i][1].norm() ** 2)
+        r = math.sqrt(num / den)
+        print(f"[parity] lgp feature-grad s{smp}: rel={r:.3e}")
+        assert r < 0.08
+
+
+# ------------------------------------------------------------------------------------------------------ UNet
+@pytest.fixture(scope="module")
+def tiny():
+    from oracle import unet as ounet
+    from sketch2img_amd.config import TINY
+    from sketch2img_amd.unet import HipUNet
+    cfg = ounet.TINY
+    assert vars(cfg) == vars(TINY)
+    W = ounet.init_weights(cfg)
+    S, h = 2, 32
+    g = torch.Generator().manual_seed(21)
+    ehs = torch.randn(2 * S, 77, cfg.cross_attention_dim, generator=g).half().float()
+    net = HipUNet(TINY, W, DEV)
+    net.prepare_context(ehs)
+    x = torch.randn(S, 4, h, h, generator=g)
+    return dict(cfg=cfg, W=W, net=net, ehs=ehs, x=x, S=S, h=h)
+
+
+def test_unet_tiny_forward_vs_oracle(tiny):
+    from oracle import unet as ounet
+    from sketch2img_amd import ops
+    from sketch2img_amd.unet import CIN_PAD
+    S, h, net = tiny["S"], tiny["h"], tiny["net"]
+    xx = torch.cat([tiny["x"], tiny["x"]]).half().float()
+    eps, taps = net.forward(ops.nchw_to_nhwc(xx.to(DEV), CIN_PAD), 501, 2 * S, h)
+    with torch.no_grad():
+        re, rt = ounet.unet_forward(tiny["cfg"], tiny["W"], xx, 501, tiny["ehs"])
+    # fp16 storage of ~150 intermediate tensors vs fp32 oracle: measured ~2e-3, bound 1e-2
+    assert report("unet tiny eps", ops.nhwc_to_nchw(eps, 2 * S, 4, h, h).cpu(), re)[0] < 1e-2
+    for i, ((tp, s), r) in enumerate(zip(taps, rt)):
+        assert s == r.shape[2]
+        assert report(f"unet tiny tap{i}", from_nhwc(tp, 2 * S, s, s), r)[0] < 1e-2
+
+
+def test_unet_tiny_backward_vs_oracle(tiny):
+    from oracle import unet as ounet
+    from sketch2img_amd import ops
+    from sketch2img_amd.unet import CIN_PAD, Stash
+    S, h, net, cfg = tiny["S"], tiny["h"], tiny["net"], tiny["cfg"]
+    xx = torch.cat([tiny["x"], tiny["x"]]).half().float()
+    stash = Stash()
+    eps, taps = net.forward(ops.nchw_to_nhwc(xx.to(DEV), CIN_PAD), 501, 2 * S, h, stash)
+    g = torch.Generator().manual_seed(33)
+    tg = [torch.randn(S, t.shape[1], s, s, generator=g).half().float() for t, s in taps]
+    dx = net.backward(stash, [nhwc16(t) for t in tg])
+    xr = xx.clone().requires_grad_(True)
+    _, rt = ounet.unet_forward(cfg, tiny["W"], xr, 501, tiny["ehs"])
+    tot = sum((r[S:] * t).sum() for r, t in zip(rt, tg))
+    gr = torch.autograd.grad(tot, xr)[0][S:]
+    got = ops.nhwc_to_nchw(dx, S, 4, h, h).cpu()
+    # every backward activation is stored in fp16 and P / dS are fp16 MFMA operands: measured ~5e-3
+    assert report("unet tiny d/dx", got, gr)[0] < 2e-2
+    assert dx[:, 4:].abs().max() == 0
+    # each tap on its own (catches a mis-routed skip / tap gradient that a sum could hide)
+    for i in (0, 2, 3, 4, 5, 6, 8):
+        one = [nhwc16(t if j == i else torch.zeros_like(t)) for j, t in enumerate(tg)]
+        dxi = ops.nhwc_to_nchw(net.backward(stash, one), S, 4, h, h).cpu()
+        gi = torch.autograd.grad((rt[i][S:] * tg[i]).sum(), xr, retain_graph=True)[0][S:]
+        assert report(f"unet tiny d/dx tap{i}", dxi, gi)[0] < 2e-2
+
+
+def test_sampler_tiny_vs_oracle(tiny):
+    """4-step guided trajectory (guided on i = 0, 1, 2), two independent samples, vs oracle.sample_one."""
+    from oracle import guidance as og, lgp as olgp, unet as ounet
+    from sketch2img_amd.lgp import HipLGP
+    from sketch2img_amd.sampler import HipSampler
+    cfg, S, h = tiny["cfg"], tiny["S"], tiny["h"]
+    sd = olgp.init_state_dict(sum(ounet.tap_channels(cfg)) + 40, seed=12)
+    g = torch.Generator().manual_seed(44)
+    target = 0.18215 * torch.randn(S, 4, h, h, generator=g)
+    x0 = tiny["x"]
+    sampler = HipSampler(tiny["net"], HipLGP(sd, ounet.tap_channels(cfg), DEV))
+    traj = []
+    out = sampler.sample(x0, target, 4, callback=lambda i, t, x: traj.append(x.cpu().clone()))
+    assert torch.isfinite(out).all()
+    for smp in range(S):
+        ehs = tiny["ehs"][[smp, S + smp]]
+        tr = []
+        ref = og.sample_one(cfg, tiny["W"], sd, ehs, x0[smp:smp + 1], target[smp:smp + 1], 4, trace=tr)
+        for i in range(4):
+            r, _ = report(f"sampler s{smp} step{i}", traj[i][smp:smp + 1], tr[i]["latents"])
+            # unguided arithmetic agrees to fp16-UNet accuracy; the guided update direction carries the
+            # few-% ReLU-gate sensitivity of the LGP gradient, scaled by |update|/|x| ~ 0.2
+            assert r < 3e-2
+        a_ref = float(tr[0]["aux"]["alpha"]) / 4096.0
+        print(f"[parity] alpha step0 s{smp}: hip={float(sampler.last_aux[0][smp, 0]):.4e} oracle*={a_ref:.4e}")
+    assert [a is not None for a in sampler.last_aux] == [True, True, True, False]
+
+
+def test_unet_sd15_forward_vs_oracle_full_size():
+    """One full-size SD1.5 evaluation (2 rows, 64x64 latent, 860 M parameters) vs the fp32 CPU oracle."""
+    from oracle import unet as ounet
+    from sketch2img_amd import ops
+    from sketch2img_amd.config import SD15
+    from sketch2img_amd.unet import CIN_PAD, HipUNet
+    cfg = ounet.SD15
+    W = ounet.init_weights(cfg)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 4, 64, 64, generator=g).half().float()
+    xx = torch.cat([x, x])
+    ehs = torch.randn(2, 77, 768, generator=g).half().float()
+    net = HipUNet(SD15, W, DEV, need_backward=False)
+    net.prepare_context(ehs)
+    eps, taps = net.forward(ops.nchw_to_nhwc(xx.to(DEV), CIN_PAD), 981, 2, 64)
+    with torch.no_grad():
+        re, rt = ounet.unet_forward(cfg, W, xx, 981, ehs)
+    assert report("unet sd15 eps", ops.nhwc_to_nchw(eps, 2, 4, 64, 64).cpu(), re)[0] < 1e-2
+    for i, ((tp, s), r) in enumerate(zip(taps, rt)):
+        assert report(f"unet sd15 tap{i}", from_nhwc(tp, 2, s, s), r)[0] < 1e-2
+    _, m = report("unet sd15 eps (abs)", ops.nhwc_to_nchw(eps, 2, 4, 64, 64).cpu(), re)
+    print(f"[parity] max |eps - eps_oracle| = {m:.3e} (north-star aspiration 1e-3 at fp16)")

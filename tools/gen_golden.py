@@ -37,7 +37,7 @@ def import_reference():
     return LatentEdgePredictor, hook_unet, AntiGradientPipeline
 
 
-TAP_C = [8, 12, 16, 16, 16, 16, 16, 12, 8]          # toy tap widths (sum 120)
+TAP_C = [32] * 9                                  # toy tap widths (multiples of the GEMM K slice)
 
 
 def tap_sizes(h):
@@ -74,12 +74,13 @@ def main():
 
     # 2. LGP forward, train-mode and eval-mode BN ----------------------------------------------
     for h in (8, 16):
-        C = 120
+        C = 128
         lgp = seeded_lgp(LatentEdgePredictor, C + 40, seed=100 + h)
         sd0 = sd_to_np(lgp.state_dict())
         g = torch.Generator().manual_seed(7 + h)
         x = torch.randn(2, C, h, h, generator=g)
-        t = 0.7 * torch.randn(2, 4, h, h, generator=g)
+        t0 = 0.7 * torch.randn(1, 4, h, h, generator=g)
+        t = torch.cat([t0] * 2)                     # as the pipeline passes it: cat([noise_level] * 2)
         lgp.train()
         with torch.no_grad():
             y_train = lgp(x, t)
