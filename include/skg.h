@@ -51,6 +51,10 @@ int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ld
                  int M, int N, int K, const void* bias, const void* residual, int ldr,
                  float alpha, unsigned flags, void* stream);
 
+/* Column width (128 or 64) of the block tile skg_gemm_f16 / skg_conv3x3_f16 pick for an M x N output;
+ * lets a profiler attribute a launch to the kernel instantiation that ran (bench.py roofline). */
+int skg_gemm_tile_n(int M, int N);
+
 /* 3x3 convolution, padding 1, as implicit GEMM over NHWC fp16.
  *   mode SKG_CONV_S1      stride 1                         out (OH,OW) = in (IH,IW)
  *   mode SKG_CONV_S2      stride 2                         out = in / 2

@@ -188,12 +188,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
   }
 }
 
+// wide (128-column) tiles when N fills them and there are enough blocks to cover the 256 CUs
+inline bool use_wide(int M, int N) { return (N % 128 == 0) && ((long)skg_cdiv(M, BM) * (N / 128) >= 256); }
+
 template <int MODE>
 int launch(const GemmParams& p, hipStream_t st) {
   const int tm = skg_cdiv(p.M, BM);
-  // wide tiles when N fills them and there are enough blocks to cover the 256 CUs
-  const bool wide = (p.N % 128 == 0) && ((long)tm * (p.N / 128) >= 256);
-  if (wide) {
+  if (use_wide(p.M, p.N)) {
     dim3 grid(p.N / 128, tm);
     hipLaunchKernelGGL((gemm_kernel<128, MODE>), grid, dim3(256), 0, st, p);
   } else {
@@ -205,6 +206,8 @@ int launch(const GemmParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int skg_gemm_tile_n(int M, int N) { return use_wide(M, N) ? 128 : 64; }
 
 extern "C" int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M,
                             int N, int K, const void* bias, const void* residual, int ldr,

@@ -1,0 +1,159 @@
+"""Seeded synthetic weights and inputs (there are no checkpoints or datasets on the build / GPU boxes).
+
+Recipe: SURVEY.md section 8(d).  UNet / LGP tensors in diffusers / reference state_dict key order from one
+``torch.Generator``; Linear / conv U(+-1/sqrt(fan_in)); LGP kaiming-uniform with zero bias as
+modules/latent_predictor.py:32-35; text embeddings, initial latents and sketch targets from fixed seeds.
+All values are rounded through fp16 so that an fp32 checker sees bit-identical parameters.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import torch
+
+from .config import UNetConfig, tap_channels, up_block_plan
+
+WEIGHT_SEED = 20260929
+
+
+def _resnet(p, cin, cout, temb, s):
+    s[p + ".norm1.weight"] = (cin,); s[p + ".norm1.bias"] = (cin,)
+    s[p + ".conv1.weight"] = (cout, cin, 3, 3); s[p + ".conv1.bias"] = (cout,)
+    s[p + ".time_emb_proj.weight"] = (cout, temb); s[p + ".time_emb_proj.bias"] = (cout,)
+    s[p + ".norm2.weight"] = (cout,); s[p + ".norm2.bias"] = (cout,)
+    s[p + ".conv2.weight"] = (cout, cout, 3, 3); s[p + ".conv2.bias"] = (cout,)
+    if cin != cout:
+        s[p + ".conv_shortcut.weight"] = (cout, cin, 1, 1); s[p + ".conv_shortcut.bias"] = (cout,)
+
+
+def _attn(p, c, ctx, linear, s):
+    s[p + ".norm.weight"] = (c,); s[p + ".norm.bias"] = (c,)
+    pw = (c, c) if linear else (c, c, 1, 1)
+    s[p + ".proj_in.weight"] = pw; s[p + ".proj_in.bias"] = (c,)
+    t = p + ".transformer_blocks.0"
+    for n in ("norm1", "norm2", "norm3"):
+        s[f"{t}.{n}.weight"] = (c,); s[f"{t}.{n}.bias"] = (c,)
+    for a, kd in (("attn1", c), ("attn2", ctx)):
+        s[f"{t}.{a}.to_q.weight"] = (c, c); s[f"{t}.{a}.to_k.weight"] = (c, kd); s[f"{t}.{a}.to_v.weight"] = (c, kd)
+        s[f"{t}.{a}.to_out.0.weight"] = (c, c); s[f"{t}.{a}.to_out.0.bias"] = (c,)
+    s[f"{t}.ff.net.0.proj.weight"] = (8 * c, c); s[f"{t}.ff.net.0.proj.bias"] = (8 * c,)
+    s[f"{t}.ff.net.2.weight"] = (c, 4 * c); s[f"{t}.ff.net.2.bias"] = (c,)
+    s[p + ".proj_out.weight"] = pw; s[p + ".proj_out.bias"] = (c,)
+
+
+def unet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, tuple]":
+    """diffusers UNet2DConditionModel state_dict keys -> shapes for an SD-layout config."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    boc, temb, nb = cfg.block_out_channels, cfg.time_embed_dim, len(cfg.block_out_channels)
+    s["conv_in.weight"] = (boc[0], cfg.in_channels, 3, 3); s["conv_in.bias"] = (boc[0],)
+    s["time_embedding.linear_1.weight"] = (temb, boc[0]); s["time_embedding.linear_1.bias"] = (temb,)
+    s["time_embedding.linear_2.weight"] = (temb, temb); s["time_embedding.linear_2.bias"] = (temb,)
+    cin = boc[0]
+    for i, cout in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            _resnet(f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, temb, s)
+            if i < nb - 1:
+                _attn(f"down_blocks.{i}.attentions.{j}", cout, cfg.cross_attention_dim, cfg.use_linear_projection, s)
+        if i < nb - 1:
+            s[f"down_blocks.{i}.downsamplers.0.conv.weight"] = (cout, cout, 3, 3)
+            s[f"down_blocks.{i}.downsamplers.0.conv.bias"] = (cout,)
+        cin = cout
+    for i, blk in enumerate(up_block_plan(cfg)):
+        for j, (hin, skip, cout) in enumerate(blk):
+            _resnet(f"up_blocks.{i}.resnets.{j}", hin + skip, cout, temb, s)
+            if i > 0:
+                _attn(f"up_blocks.{i}.attentions.{j}", cout, cfg.cross_attention_dim, cfg.use_linear_projection, s)
+        if i < nb - 1:
+            c = blk[0][2]
+            s[f"up_blocks.{i}.upsamplers.0.conv.weight"] = (c, c, 3, 3)
+            s[f"up_blocks.{i}.upsamplers.0.conv.bias"] = (c,)
+    cm = boc[-1]
+    _resnet("mid_block.resnets.0", cm, cm, temb, s)
+    _attn("mid_block.attentions.0", cm, cfg.cross_attention_dim, cfg.use_linear_projection, s)
+    _resnet("mid_block.resnets.1", cm, cm, temb, s)
+    s["conv_norm_out.weight"] = (boc[0],); s["conv_norm_out.bias"] = (boc[0],)
+    s["conv_out.weight"] = (cfg.out_channels, boc[0], 3, 3); s["conv_out.bias"] = (cfg.out_channels,)
+    return s
+
+
+def unet_state_dict(cfg: UNetConfig, seed: int = WEIGHT_SEED) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    shapes = unet_param_shapes(cfg)
+    sd: Dict[str, torch.Tensor] = {}
+    for k, shp in shapes.items():
+        leaf = k.split(".")[-2]
+        if leaf.startswith("norm") or leaf == "conv_norm_out":
+            w = (torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)) + 0.1 * (torch.rand(shp, generator=g) - 0.5)
+        else:
+            wk = k[: -len("bias")] + "weight" if k.endswith("bias") else k
+            bound = 1.0 / math.sqrt(math.prod(shapes[wk][1:]))
+            w = (torch.rand(shp, generator=g) * 2 - 1) * bound
+        sd[k] = w.half().float()
+    return sd
+
+
+LGP_LIN, LGP_BN, LGP_HIDDEN = (0, 3, 6, 9, 12), (2, 5, 8, 11), (512, 256, 128, 64)
+
+
+def lgp_state_dict(input_dim: int = 9320, output_dim: int = 4, seed: int = WEIGHT_SEED,
+                   perturb_bn: bool = True) -> Dict[str, torch.Tensor]:
+    """The reference's LatentEdgePredictor(input_dim, output_dim, 9).state_dict() layout (30 keys)."""
+    g = torch.Generator().manual_seed(seed)
+    dims = (input_dim,) + LGP_HIDDEN + (output_dim,)
+    sd: Dict[str, torch.Tensor] = {}
+    for i in range(5):
+        bound = math.sqrt(6.0 / dims[i])
+        sd[f"layers.{LGP_LIN[i]}.weight"] = ((torch.rand(dims[i + 1], dims[i], generator=g) * 2 - 1) * bound).half().float()
+        sd[f"layers.{LGP_LIN[i]}.bias"] = torch.zeros(dims[i + 1])
+        if i < 4:
+            b, n = LGP_BN[i], dims[i + 1]
+            pert = lambda: 0.2 * (torch.rand(n, generator=g) - 0.5) if perturb_bn else torch.zeros(n)
+            sd[f"layers.{b}.weight"] = (torch.ones(n) + pert()).half().float()
+            sd[f"layers.{b}.bias"] = pert().half().float()
+            sd[f"layers.{b}.running_mean"] = torch.zeros(n)
+            sd[f"layers.{b}.running_var"] = torch.ones(n)
+            sd[f"layers.{b}.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    return sd
+
+
+def text_embeddings(samples: int, dim: int = 768, tokens: int = 77) -> torch.Tensor:
+    """[uncond rows (seed 8); cond rows (seed 7)], every sample uses the same fixed 'prompt'."""
+    gu, gc = torch.Generator().manual_seed(8), torch.Generator().manual_seed(7)
+    u = torch.randn(1, tokens, dim, generator=gu).half().float()
+    c = torch.randn(1, tokens, dim, generator=gc).half().float()
+    return torch.cat([u.expand(samples, -1, -1), c.expand(samples, -1, -1)]).contiguous()
+
+
+def initial_latents(first: int, count: int, h: int) -> torch.Tensor:
+    """Per-sample CPU generators, seed 1000 + global sample index (placement independent)."""
+    return torch.cat([torch.randn(1, 4, h, h, generator=torch.Generator().manual_seed(1000 + i))
+                      for i in range(first, first + count)])
+
+
+def sketch_targets(first: int, count: int, h: int) -> torch.Tensor:
+    """Stand-in for vae.encode(sketch) * 0.18215 (app.py:109): 8 seeded random polylines on an 8h x 8h
+    canvas, average-pooled 8x, replicated to 4 channels, mapped to [-1, 1] * 0.18215."""
+    out = []
+    for i in range(first, first + count):
+        g = torch.Generator().manual_seed(2000 + i)
+        n = 8 * h
+        img = torch.zeros(n, n)
+        for _ in range(8):
+            pts = (torch.rand(4, 2, generator=g) * (n - 1))
+            for a, b in zip(pts[:-1], pts[1:]):
+                steps = int(max(abs(float(b[0] - a[0])), abs(float(b[1] - a[1])))) + 1
+                tt = torch.linspace(0, 1, steps)
+                ys = (a[0] + (b[0] - a[0]) * tt).round().long().clamp(0, n - 1)
+                xs = (a[1] + (b[1] - a[1]) * tt).round().long().clamp(0, n - 1)
+                for dy in (-1, 0, 1):
+                    for dx in (-1, 0, 1):
+                        img[(ys + dy).clamp(0, n - 1), (xs + dx).clamp(0, n - 1)] = 1.0
+        pooled = torch.nn.functional.avg_pool2d(img[None, None], 8)[0, 0]
+        out.append(((1.0 - pooled) * 2 - 1).expand(4, -1, -1) * 0.18215)     # white paper, dark strokes
+    return torch.stack(out).contiguous()
+
+
+def lgp_input_dim(cfg: UNetConfig) -> int:
+    return sum(tap_channels(cfg)) + 4 + 36

@@ -295,6 +295,96 @@ def test_attention_backward(ops, dh, heads, Nq, Nkv, cross):
         assert report(f"attn dv dh{dh}", dv.float().cpu().view(B, Nkv, C), vf.grad)[0] < 4e-3
 
 
+# ---------------------------------------------------------------------------------------------- LGP pieces
+def test_lgp_layer0_gather_and_scatter(ops):
+    """Re-associated layer 0: bilinear gather of fp32 partial products (+ extras, bias, fp16 round, ReLU)
+    vs F.interpolate, and the scatter kernel as its exact adjoint."""
+    S, h, H0 = 2, 16, 512
+    sizes = [8, 2, 16, 4]
+    g = torch.Generator().manual_seed(0)
+    d = dev()
+    P = [torch.randn(2 * S, H0, s, s, generator=g) for s in sizes]
+    Wx, b0 = rnd(H0, 40, seed=1, scale=0.3), rnd(H0, seed=2)
+    noise = torch.randn(S, 4, h, h, generator=g)
+    sigma = 0.7
+    Wfull = torch.zeros(H0, 48, dtype=torch.float16); Wfull[:, 8:] = Wx        # view with ldw > 40
+    Z = ops.lgp_layer0_gather([p.permute(0, 2, 3, 1).reshape(-1, H0).contiguous().to(d) for p in P], sizes,
+                              Wfull.to(d)[:, 8:], b0.to(d), noise.to(d), sigma, S, h, H0)
+    nl = sigma * noise
+    e = torch.cat([nl] + [torch.sin(2 * math.pi * nl * 2 ** -l) for l in range(9)], 1).half().float()   # [S,40,h,h]
+    e = torch.cat([e, e])                                                            # rows [uncond; cond]
+    ref = sum(F.interpolate(p, size=h, mode="bilinear") for p in P)
+    ref = ref + torch.einsum("oc,bchw->bohw", Wx.float(), e) + b0.float()[None, :, None, None]
+    ref = torch.relu(ref.half().float())
+    got = Z.float().cpu().reshape(2 * S, h, h, H0).permute(0, 3, 1, 2)
+    assert report("lgp gather", got, ref)[0] < FP16_RND
+    # adjoint: <gather_bilinear(P), dZ> == <P, scatter(dZ)>
+    dZ = rnd(S * h * h, H0, seed=5)
+    for s in (8, 2, 16, 1):
+        dP = ops.lgp_layer0_scatter(dZ.to(d), S, h, s, H0)
+        pr = torch.randn(S, H0, s, s, generator=g).requires_grad_(True)
+        up = F.interpolate(pr, size=h, mode="bilinear")
+        up.backward(dZ.float().reshape(S, h, h, H0).permute(0, 3, 1, 2))
+        assert report(f"lgp scatter s{s}", dP.float().cpu().reshape(S, s, s, H0).permute(0, 3, 1, 2), pr.grad)[0] < FP16_RND
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_batchnorm_per_sample_fwd_bwd(ops, train):
+    """BatchNorm1d with one sample's two CFG segments as the batch + backward through the preceding ReLU,
+    checked on the SAME post-ReLU activations (so no gate can flip between the two sides)."""
+    S, hw, C = 3, 64, 256
+    d = dev()
+    x = torch.relu(rnd(2 * S * hw, C, seed=1).float() + 0.2).half()                 # post-ReLU activations
+    ga, be = (1 + 0.2 * rnd(C, seed=2).float()).half(), (0.2 * rnd(C, seed=3).float()).half()
+    rm, rv = torch.zeros(C), torch.ones(C)
+    dy = rnd(2 * S * hw, C, seed=4)
+    if train:
+        rmd, rvd = rm.clone().to(d), rv.clone().to(d)
+        st = ops.bn_stats(x.to(d), S, 2, hw, 1e-5, rmd, rvd)
+    else:
+        rm, rv = 0.1 * torch.randn(C), 1 + 0.1 * torch.rand(C)
+        st = ops.bn_stats_from_running(rm.to(d), rv.to(d), S)
+    y = ops.bn_apply(x.to(d), S, 2, hw, st, ga.to(d), be.to(d))
+    dx = ops.bn_relu_bwd(x.to(d), dy.to(d), S, 2, hw, st, ga.to(d), train)
+    xs = x.float().reshape(2, S, hw, C)
+    rm_ref, rv_ref = torch.zeros(C), torch.ones(C)
+    for s in range(S):
+        pre = xs[:, s].reshape(2 * hw, C).clone().requires_grad_(True)          # treat as pre-activation > 0 or == 0
+        act = torch.relu(pre)
+        if train:
+            ref = F.batch_norm(act, None, None, ga.float(), be.float(), True, 0.1, 1e-5)
+            mean, var = act.mean(0), act.var(0, unbiased=True)
+            rm_ref = 0.9 * rm_ref + 0.1 * mean.detach(); rv_ref = 0.9 * rv_ref + 0.1 * var.detach()
+        else:
+            ref = F.batch_norm(act, rm, rv, ga.float(), be.float(), False, 0.1, 1e-5)
+        dys = dy.float().reshape(2, S, hw, C)[:, s].reshape(2 * hw, C)
+        ref.backward(dys)
+        ys = y.float().cpu().reshape(2, S, hw, C)[:, s].reshape(2 * hw, C)
+        dxs = dx.float().cpu().reshape(2, S, hw, C)[:, s].reshape(2 * hw, C)
+        assert report(f"bn fwd s{s}", ys, ref)[0] < FP16_RND
+        gref = pre.grad * (pre > 0)                                                 # relu'(0) = 0 on both sides
+        assert report(f"bn+relu bwd s{s}", dxs, gref)[0] < FP16_RND
+    if train:
+        assert report("bn running_mean", rmd.cpu(), rm_ref)[1] < 1e-5
+        assert report("bn running_var", rvd.cpu(), rv_ref)[1] < 1e-5
+
+
+def test_mse_seed(ops):
+    S, h = 2, 8
+    hw = h * h
+    d = dev()
+    out = rnd(2 * S * hw, 8, seed=1)
+    tgt = torch.randn(S, 4, h, h)
+    dO, loss = ops.lgp_mse_seed(out.to(d), tgt.to(d), S, h, 32, 4096.0)
+    oc = out[S * hw:, :4].float().reshape(S, hw, 4).permute(0, 2, 1).reshape(S, 4, h, h)
+    for s in range(S):
+        assert abs(float(loss[s]) - float(F.mse_loss(oc[s], tgt[s]))) < 1e-5
+    ref = 4096.0 * 2 * (oc - tgt) / (4 * hw)
+    got = dO[S * hw:, :4].float().cpu().reshape(S, hw, 4).permute(0, 2, 1).reshape(S, 4, h, h)
+    assert report("mse seed", got, ref)[0] < FP16_RND
+    assert dO[:S * hw].abs().max() == 0 and dO[:, 4:].abs().max() == 0
+
+
 # ---------------------------------------------------------------------------------------------- sampler pointwise
 def test_cfg_ddim_and_guidance_update(ops):
     from sketch2img_amd.sampler import DDIMTables

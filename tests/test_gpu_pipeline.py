@@ -187,7 +187,7 @@ def test_unet_tiny_backward_vs_oracle(tiny):
     xr = xx.clone().requires_grad_(True)
     _, rt = ounet.unet_forward(cfg, tiny["W"], xr, 501, tiny["ehs"])
     tot = sum((r[S:] * t).sum() for r, t in zip(rt, tg))
-    gr = torch.autograd.grad(tot, xr)[0][S:]
+    gr = torch.autograd.grad(tot, xr, retain_graph=True)[0][S:]
     got = ops.nhwc_to_nchw(dx, S, 4, h, h).cpu()
     # every backward activation is stored in fp16 and P / dS are fp16 MFMA operands: measured ~5e-3
     assert report("unet tiny d/dx", got, gr)[0] < 2e-2
@@ -201,31 +201,57 @@ def test_unet_tiny_backward_vs_oracle(tiny):
 
 
 def test_sampler_tiny_vs_oracle(tiny):
-    """4-step guided trajectory (guided on i = 0, 1, 2), two independent samples, vs oracle.sample_one."""
+    """4-step guided trajectory (guided on i = 0, 1, 2), two independent samples, vs oracle.sample_one.
+    Per step, teacher-forced from the oracle's state so that errors do not compound: the CFG epsilon,
+    the norm of the guidance update (pinned by alpha = sqrt(2)*||dx||/||g||*beta) and its direction."""
     from oracle import guidance as og, lgp as olgp, unet as ounet
     from sketch2img_amd.lgp import HipLGP
-    from sketch2img_amd.sampler import HipSampler
+    from sketch2img_amd.sampler import DDIMTables, HipSampler
     cfg, S, h = tiny["cfg"], tiny["S"], tiny["h"]
     sd = olgp.init_state_dict(sum(ounet.tap_channels(cfg)) + 40, seed=12)
     g = torch.Generator().manual_seed(44)
     target = 0.18215 * torch.randn(S, 4, h, h, generator=g)
     x0 = tiny["x"]
-    sampler = HipSampler(tiny["net"], HipLGP(sd, ounet.tap_channels(cfg), DEV))
-    traj = []
-    out = sampler.sample(x0, target, 4, callback=lambda i, t, x: traj.append(x.cpu().clone()))
-    assert torch.isfinite(out).all()
+    T = 4
+    traces = []
     for smp in range(S):
-        ehs = tiny["ehs"][[smp, S + smp]]
         tr = []
-        ref = og.sample_one(cfg, tiny["W"], sd, ehs, x0[smp:smp + 1], target[smp:smp + 1], 4, trace=tr)
-        for i in range(4):
-            r, _ = report(f"sampler s{smp} step{i}", traj[i][smp:smp + 1], tr[i]["latents"])
-            # unguided arithmetic agrees to fp16-UNet accuracy; the guided update direction carries the
-            # few-% ReLU-gate sensitivity of the LGP gradient, scaled by |update|/|x| ~ 0.2
-            assert r < 3e-2
-        a_ref = float(tr[0]["aux"]["alpha"]) / 4096.0
-        print(f"[parity] alpha step0 s{smp}: hip={float(sampler.last_aux[0][smp, 0]):.4e} oracle*={a_ref:.4e}")
+        og.sample_one(cfg, tiny["W"], sd, tiny["ehs"][[smp, S + smp]], x0[smp:smp + 1], target[smp:smp + 1], T, trace=tr)
+        traces.append(tr)
+    sampler = HipSampler(tiny["net"], HipLGP(sd, ounet.tap_channels(cfg), DEV))
+    tab = DDIMTables.make(T)
+    tiny["net"].prepare_timesteps(tab.timesteps.tolist())
+    noise = x0.to(DEV)
+    for i in range(T):
+        x_i = x0 if i == 0 else torch.cat([traces[s][i - 1]["latents"] for s in range(S)])
+        xp, eps, aux = sampler.step(x_i.to(DEV).contiguous(), noise, target.to(DEV), tab, i, 7.5, 1.6, want_eps=True)
+        for smp in range(S):
+            tr = traces[smp][i]
+            assert report(f"sampler step{i} s{smp} eps", eps[smp:smp + 1].cpu(), tr["eps"])[0] < 1e-2
+            if tr["aux"] is None:
+                assert aux is None
+                assert report(f"sampler step{i} s{smp} x_prev", xp[smp:smp + 1].cpu(), tr["latents"])[0] < 1e-2
+                continue
+            upd_ref = float(tr["aux"]["alpha"]) * tr["aux"]["cond_grad"]
+            x_unguided = tr["latents"] - upd_ref
+            upd = xp[smp:smp + 1].cpu() - x_unguided
+            nr = float(upd.norm() / upd_ref.norm())
+            cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm()))
+            print(f"[parity] sampler step{i} s{smp} update: |hip|/|oracle|={nr:.4f} cos={cos:.5f} "
+                  f"loss hip={float(aux[smp, 3]):.4e} oracle={float(tr['aux']['loss']):.4e}")
+            assert abs(nr - 1) < 2e-2
+            # direction: UNet backward (fp16, ~2e-3) + the LGP gradient's ReLU-gate sensitivity (2-3 %,
+            # same as reference-vs-oracle in tests/test_oracle.py): cos > 0.998 <=> < 6.3 % relative
+            assert cos > 0.998
+            assert abs(float(aux[smp, 3]) - float(tr["aux"]["loss"])) < 1e-2 * float(tr["aux"]["loss"])
+    # free-running loop: finite, guided on the first three steps only
+    out = sampler.sample(x0, target, T)
+    assert torch.isfinite(out).all()
     assert [a is not None for a in sampler.last_aux] == [True, True, True, False]
+    ref = torch.cat([traces[s][-1]["latents"] for s in range(S)])
+    # reported only: three guided updates of norm 2.3x the DDIM step each (T = 4) compound the few-%
+    # direction differences chaotically (measured 0.27); the per-step bounds above are the parity claim
+    report("sampler free-running final latents", out.cpu(), ref)
 
 
 def test_unet_sd15_forward_vs_oracle_full_size():
