@@ -54,6 +54,9 @@ class LaunchTimer:
         from sketch2img_amd._lib import lib
         ops = self.ops
 
+        def kname(variant, mode):
+            return f"{'gemm2_kernel' if variant >= 2000 else 'gemm_kernel'}<{variant % 1000},{mode}>"
+
         def gemm(A, B, *a, **k):
             M, K = A.shape
             N = B.shape[0]
@@ -61,7 +64,7 @@ class LaunchTimer:
             e0.record()
             out = self._gemm(A, B, *a, **k)
             e1.record()
-            self.rec.append((f"gemm_kernel<{lib.skg_gemm_tile_n(M, N)},DIRECT>", 2.0 * M * N * K, e0, e1))
+            self.rec.append((kname(lib.skg_gemm_variant(M, N, K, 0, 0), "DIRECT"), 2.0 * M * N * K, e0, e1))
             return out
 
         def conv(X, Wp, rows, IH, IW, mode=0, *a, **k):
@@ -73,7 +76,7 @@ class LaunchTimer:
             out = self._conv(X, Wp, rows, IH, IW, mode, *a, **k)
             e1.record()
             name = ("S1", "S2", "UP2", "S2T")[mode]
-            self.rec.append((f"gemm_kernel<{lib.skg_gemm_tile_n(M, Cout)},{name}>", 2.0 * M * Cout * 9 * Cin, e0, e1))
+            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, 9 * Cin, Cin, 1 + mode), name), 2.0 * M * Cout * 9 * Cin, e0, e1))
             return out
 
         ops.gemm, ops.conv3x3 = gemm, conv
@@ -96,7 +99,9 @@ def cpu_baseline(sd_unet, sd_lgp, ehs2, latent0, target0):
     materialised 9320-channel tensor) on a bounded sample of the same workload: ONE 512x512 sample, one
     guided and one unguided DDIM step, extrapolated to 26 guided + 24 unguided steps."""
     from oracle import ddim as oddim, guidance as og, unet as ounet
-    cores = os.cpu_count() or 1
+    # 32 threads is the fastest setting on the GPU box's 256-thread host for this eager fp32 graph (measured
+    # with tools/cpu_sweep.py: 5.3 s / UNet eval at 32 threads, 7.2 s at 64, 11.1 s at 128)
+    cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     cfg = ounet.SD15
     tab = oddim.make_tables(50)

@@ -51,9 +51,10 @@ int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ld
                  int M, int N, int K, const void* bias, const void* residual, int ldr,
                  float alpha, unsigned flags, void* stream);
 
-/* Column width (128 or 64) of the block tile skg_gemm_f16 / skg_conv3x3_f16 pick for an M x N output;
+/* Which kernel instantiation skg_gemm_f16 (mode 0, Cin ignored) / skg_conv3x3_f16 (mode = 1 + SKG_CONV_*)
+ * run for this shape: 2000 + BN for the LDS-DMA kernel (gemm2_kernel<BN,MODE>), 1000 + BN for the generic one;
  * lets a profiler attribute a launch to the kernel instantiation that ran (bench.py roofline). */
-int skg_gemm_tile_n(int M, int N);
+int skg_gemm_variant(int M, int N, int K, int Cin, int mode);
 
 /* 3x3 convolution, padding 1, as implicit GEMM over NHWC fp16.
  *   mode SKG_CONV_S1      stride 1                         out (OH,OW) = in (IH,IW)

@@ -12,22 +12,9 @@
 // The MFMA is issued "swapped" (weights as the A operand, activations as B) so that each lane's
 // four accumulator registers are four CONSECUTIVE output channels of one pixel: the epilogue
 // then does 8-byte bias/residual loads and 8-byte stores instead of 2-byte ones.
-#include "common.h"
+#include "gemm_params.h"
 
 namespace {
-
-enum { MODE_DIRECT = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_UP2 = 3, MODE_S2T = 4 };
-
-struct GemmParams {
-  const half_t* A; int lda;
-  const half_t* B; int ldb;
-  void* C; int ldc;
-  const half_t* bias;
-  const half_t* res; int ldr;
-  int M, N, K;
-  float alpha; unsigned flags;
-  int IH, IW, OH, OW, Cin;   // conv only
-};
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -193,6 +180,10 @@ inline bool use_wide(int M, int N) { return (N % 128 == 0) && ((long)skg_cdiv(M,
 
 template <int MODE>
 int launch(const GemmParams& p, hipStream_t st) {
+  if (skg_gemm2_try_launch(p, MODE, st)) {
+    SKG_CHECK_LAUNCH("skg_gemm (v2)");
+    return SKG_OK;
+  }
   const int tm = skg_cdiv(p.M, BM);
   if (use_wide(p.M, p.N)) {
     dim3 grid(p.N / 128, tm);
@@ -207,7 +198,10 @@ int launch(const GemmParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int skg_gemm_tile_n(int M, int N) { return use_wide(M, N) ? 128 : 64; }
+extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
+  const int v2 = skg_gemm2_tile_n(M, N, K, Cin, mode);
+  return v2 ? 2000 + v2 : 1000 + (use_wide(M, N) ? 128 : 64);
+}
 
 extern "C" int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M,
                             int N, int K, const void* bias, const void* residual, int ldr,

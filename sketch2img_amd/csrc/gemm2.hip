@@ -1,0 +1,326 @@
+// v2 fp16 MFMA GEMM / 3x3 implicit-GEMM convolution for gfx950: LDS-DMA staged, swizzled, double buffered.
+//
+//   C[m][n] = epi(alpha * (sum_k A[m][k] * B[n][k] + bias[n]) + residual[m][n])
+//
+// Block tile 128 x BN x 64 (BN = 160 | 128 | 64), 4 waves as 2(M) x 2(N), wave tile 64 x BN/2 out of
+// 16x16x32 f16 MFMAs (weights as the A operand so each lane owns 4 consecutive output channels).
+//
+// HBM/L2 -> LDS goes through `buffer_load_dwordx4 ... lds` (LDS-DMA, 16 B per lane, no VGPR round trip, no
+// ds_write pass).  The DMA writes the LDS image lane-linearly (wave-uniform base + lane * 16 B), so one
+// wave instruction fills 8 tile rows x 128 B and the LDS tile is an UNPADDED row-major [rows][64] image.
+// Read back row-major, the 16 rows of an MFMA fragment would sit on two 16-byte slots (8-way conflict);
+// instead piece p of row r is stored at slot p ^ ((r >> 1) & 7).  The permutation is applied to the
+// per-lane SOURCE offset (lanes of a row still cover the same 128-byte line, so coalescing is unchanged)
+// and to the ds_read_b128 address: the 16 rows of a fragment then land on 16 distinct slots of the
+// 256-byte bank row (SQ_LDS_BANK_CONFLICT = 0 measured).
+//
+// Address generation is kept off the VALU (the first version spent 3.5 VALU instructions per MFMA on it):
+// every operand row has ONE precomputed 32-bit byte offset (voffset) into a buffer descriptor; the K-tile
+// position - filter tap and channel offset for a conv - is a wave-uniform SGPR (soffset).  Padding, masked
+// rows and N/M edges use the descriptor's bounds check: an out-of-range voffset returns zeros, so a lane
+// "predicates" its load with one v_cndmask on a precomputed 9-bit tap-validity mask.  The conv descriptor's
+// base is shifted back by one row + one pixel so that tap offsets are non-negative.
+//
+// Pipeline: two LDS stages, ONE barrier per 64-deep K tile, loop unrolled by the stage parity so that every
+// LDS address is base + immediate.  The DMA for tile k+1 is issued right after the barrier and lands while
+// the 2 x (MT x NT) MFMAs of tile k run (and while the CU's second resident workgroup computes).
+// All LDS lives in ONE __shared__ object: with two, hipcc drains the in-flight DMA before every ds_read.
+//
+// Workgroup ids are remapped so that each XCD (private 4 MiB L2, workgroup b -> XCD b % 8) owns a
+// contiguous range of tiles, n fastest: the tiles that share an activation row panel hit the same L2.
+#include "gemm_params.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr unsigned OOB = 0x80000000u;     // voffset that fails the descriptor's range check -> zeros
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, half_t* lds_wave_base, unsigned voff,
+                                      unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+template <int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
+                                                       unsigned a_bytes, unsigned b_bytes, unsigned a_shift) {
+  constexpr int WN = BN / 2;
+  constexpr int NT = WN / 16;         // 5, 4 or 2
+  constexpr int MT = 4;
+  constexpr int ACH = BM / 8 / 4;     // A 8-row chunks per wave (4)
+  constexpr int BCH = BN / 8 / 4;     // B 8-row chunks per wave (5, 4, 2)
+  constexpr int STAGE = (BM + BN) * BK;               // halves per stage: A tile then B tile
+  constexpr bool AFFINE = (MODE == MODE_DIRECT || MODE == MODE_S1 || MODE == MODE_S2);
+  __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, l16 = lane & 15;
+
+  // ---- XCD-aware tile assignment (bijective) ------------------------------------------------------
+  int lid;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = lid / tiles_n;
+  const int tile_n = lid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // descriptors: A is based `a_shift` bytes BEFORE p.A (conv: one row + one pixel) so tap offsets are >= 0
+  const __amdgpu_buffer_rsrc_t rA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - a_shift), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, b_bytes, 0x00020000);
+
+  // ---- per-lane DMA source description ---------------------------------------------------------------
+  const int lr = lane >> 3;           // row within an 8-row chunk
+  const int lq = lane & 7;            // LDS slot this lane fills
+  unsigned a_voff[ACH];               // byte offset of (row, logical piece) at tap (0,0) / k = 0, or OOB
+  unsigned a_mask[ACH];               // S1/S2: bit t set <=> tap t reads a pixel inside the image
+  int a_oy[ACH], a_ox[ACH];           // UP2/S2T only
+  unsigned a_img[ACH];                // UP2/S2T: byte offset of the image + piece
+#pragma unroll
+  for (int j = 0; j < ACH; ++j) {
+    const int r = (j * 4 + wave) * 8 + lr;
+    const unsigned pk = (unsigned)(lq ^ ((r >> 1) & 7)) * 16u;      // byte offset of the logical piece
+    const int m = m0 + r;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    a_mask[j] = 0; a_oy[j] = a_ox[j] = 0; a_img[j] = 0;
+    if (MODE == MODE_DIRECT) {
+      a_voff[j] = ok ? (unsigned)mm * (unsigned)p.lda * 2u + pk : OOB;
+    } else {
+      const int ohw = p.OH * p.OW;
+      const int b = mm / ohw;
+      const int rr = mm - b * ohw;
+      const int oy = rr / p.OW, ox = rr - oy * p.OW;
+      const unsigned img = (unsigned)b * (unsigned)(p.IH * p.IW);
+      if (MODE == MODE_S1 || MODE == MODE_S2) {
+        const int cy = MODE == MODE_S2 ? 2 * oy : oy, cx = MODE == MODE_S2 ? 2 * ox : ox;
+        // with the shifted base, tap (ky,kx) of this row is at voff + ((ky*IW + kx)*lda + c0)*2
+        a_voff[j] = ok ? ((img + (unsigned)(cy * p.IW + cx)) * (unsigned)p.lda) * 2u + pk : OOB;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+          if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mk |= 1u << t;
+        }
+        a_mask[j] = mk;
+      } else {
+        a_voff[j] = ok ? 0u : OOB;
+        a_oy[j] = oy; a_ox[j] = ox;
+        a_img[j] = img * (unsigned)p.lda * 2u + pk + a_shift;
+      }
+    }
+  }
+  unsigned b_voff[BCH];
+#pragma unroll
+  for (int j = 0; j < BCH; ++j) {
+    const int r = (j * 4 + wave) * 8 + lr;
+    const unsigned pk = (unsigned)(lq ^ ((r >> 1) & 7)) * 16u;
+    const int n = n0 + r;
+    b_voff[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb * 2u + pk : OOB;
+  }
+
+  // issue the LDS-DMA of K tile kt into stage `buf` (buf is a compile-time constant at every call site)
+  auto issue = [&](int kt, int buf) {
+    const int k0 = kt * BK;
+    unsigned soff = (unsigned)k0 * 2u;
+    int tap = 0, ky = 0, kx = 0;
+    if (MODE != MODE_DIRECT) {
+      tap = k0 / p.Cin;
+      const int c0 = k0 - tap * p.Cin;
+      ky = tap / 3;
+      kx = tap - ky * 3;
+      soff = (unsigned)((ky * p.IW + kx) * p.lda + c0) * 2u;
+    }
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) {
+      unsigned v;
+      if (MODE == MODE_DIRECT) {
+        v = a_voff[j];
+      } else if (AFFINE) {
+        v = (a_mask[j] >> tap) & 1u ? a_voff[j] : OOB;
+      } else {
+        const int ty = a_oy[j] + ky - 1, tx = a_ox[j] + kx - 1;
+        bool ok = a_voff[j] != OOB;
+        int iy, ix;
+        if (MODE == MODE_UP2) {
+          ok = ok && ty >= 0 && ty < p.OH && tx >= 0 && tx < p.OW;
+          iy = ty >> 1; ix = tx >> 1;
+        } else {   // MODE_S2T
+          ok = ok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1);
+          iy = ty >> 1; ix = tx >> 1;
+          ok = ok && iy < p.IH && ix < p.IW;
+        }
+        v = ok ? a_img[j] + (unsigned)((iy * p.IW + ix) * p.lda) * 2u : OOB;
+      }
+      unsigned so = soff;
+      if (!AFFINE) so = (unsigned)(k0 - tap * p.Cin) * 2u;     // gather modes carry the pixel in voffset
+      dma16(rA, &smem[buf * STAGE + (j * 4 + wave) * 8 * BK], v, so);
+    }
+    const unsigned sb = (unsigned)k0 * 2u;
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) dma16(rB, &smem[buf * STAGE + BM * BK + (j * 4 + wave) * 8 * BK], b_voff[j], sb);
+  };
+
+  float4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read addresses (halves) inside a stage for k-step 0 / 1; slot = piece ^ ((row >> 1) & 7)
+  int a_ad[MT][2], b_ad[NT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wm * 64 + i * 16 + l16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a_ad[i][ks] = row * BK + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = wn * WN + j * 16 + l16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_ad[j][ks] = BM * BK + row * BK + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 3);
+  }
+
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8_t xf[MT], wf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = ld_half8(&smem[buf * STAGE + a_ad[i][ks]]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = ld_half8(&smem[buf * STAGE + b_ad[j][ks]]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int KT = p.K / BK;
+  issue(0, 0);
+  for (int kt = 0; kt < KT; kt += 2) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < KT) issue(kt + 1, 1);
+    compute(0);
+    if (kt + 1 < KT) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (kt + 2 < KT) issue(kt + 2, 0);
+      compute(1);
+    }
+  }
+
+  // ---- epilogue: lane holds C[m = .. + l16][n = .. + 4g .. 4g+3] -----------------------------------
+  const bool relu = p.flags & SKG_EPI_RELU;
+  const bool f32out = p.flags & SKG_EPI_OUT_F32;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + l16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * WN + j * 16 + g * 4;
+      if (n >= p.N) continue;
+      float4_t v = acc[i][j];
+      if (p.bias) {
+        const half4_t b = ld_half4(p.bias + n);
+        v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+      }
+      v *= p.alpha;
+      if (p.res) {
+        const half4_t r = ld_half4(p.res + (size_t)m * p.ldr + n);
+        v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+      }
+      if (relu) {
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+      }
+      if (f32out) {
+        *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = v;
+      } else {
+        half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        st_half4(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n, o);
+      }
+    }
+  }
+}
+
+// bytes of the A / B operands reachable through their descriptors (must stay below 2^31 for the OOB trick)
+inline bool operand_bytes(const GemmParams& p, int mode, unsigned long long& a, unsigned long long& b,
+                          unsigned long long& shift) {
+  b = ((unsigned long long)(p.N - 1) * p.ldb + p.K) * 2ull;
+  if (mode == MODE_DIRECT) {
+    shift = 0;
+    a = ((unsigned long long)(p.M - 1) * p.lda + p.K) * 2ull;
+  } else {
+    const unsigned long long rows = (unsigned long long)p.M / ((unsigned long long)p.OH * p.OW);
+    shift = (unsigned long long)(p.IW + 1) * p.lda * 2ull;
+    a = rows * p.IH * p.IW * p.lda * 2ull + shift + (unsigned long long)(2 * p.IW + 2) * p.lda * 2ull;
+  }
+  return a < 0x7fffffffull && b < 0x7fffffffull;
+}
+
+inline bool eligible(const GemmParams& p, int mode) {
+  if (p.K % BK != 0 || p.M < 1) return false;
+  if (mode != MODE_DIRECT && p.Cin % BK != 0) return false;
+  unsigned long long a, b, s;
+  return operand_bytes(p, mode, a, b, s);
+}
+
+// largest tile width that divides N and still gives >= ~0.8 workgroups per CU; else 64
+inline int pick_bn(int M, int N) {
+  const long tm = skg_cdiv(M, BM);
+  if (N % 160 == 0 && tm * (N / 160) >= 200) return 160;
+  if (N % 128 == 0 && tm * (N / 128) >= 200) return 128;
+  return 64;
+}
+
+template <int BN, int MODE>
+void launch_bn(const GemmParams& p, hipStream_t st) {
+  const int tiles_n = skg_cdiv(p.N, BN);
+  const int nwg = skg_cdiv(p.M, BM) * tiles_n;
+  unsigned long long a, b, s;
+  operand_bytes(p, MODE, a, b, s);
+  hipLaunchKernelGGL((gemm2_kernel<BN, MODE>), dim3(nwg), dim3(256), 0, st, p, tiles_n, nwg, (unsigned)a,
+                     (unsigned)b, (unsigned)s);
+}
+
+template <int MODE>
+void launch_mode(const GemmParams& p, hipStream_t st) {
+  switch (pick_bn(p.M, p.N)) {
+    case 160: launch_bn<160, MODE>(p, st); break;
+    case 128: launch_bn<128, MODE>(p, st); break;
+    default: launch_bn<64, MODE>(p, st); break;
+  }
+}
+
+}  // namespace
+
+int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode) {
+  if (K % BK != 0 || M < 1 || (mode != MODE_DIRECT && Cin % BK != 0)) return 0;
+  return pick_bn(M, N);
+}
+
+bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
+  if (!eligible(p, mode)) return false;
+  switch (mode) {
+    case MODE_DIRECT: launch_mode<MODE_DIRECT>(p, st); break;
+    case MODE_S1: launch_mode<MODE_S1>(p, st); break;
+    case MODE_S2: launch_mode<MODE_S2>(p, st); break;
+    case MODE_UP2: launch_mode<MODE_UP2>(p, st); break;
+    case MODE_S2T: launch_mode<MODE_S2T>(p, st); break;
+    default: return false;
+  }
+  return true;
+}

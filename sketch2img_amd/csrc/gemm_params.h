@@ -1,0 +1,21 @@
+// Parameter block shared by the GEMM / implicit-GEMM conv kernels (gemm.hip: generic v1, gemm2.hip: v2).
+#pragma once
+#include "common.h"
+
+enum { MODE_DIRECT = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_UP2 = 3, MODE_S2T = 4 };
+
+struct GemmParams {
+  const half_t* A; int lda;
+  const half_t* B; int ldb;
+  void* C; int ldc;
+  const half_t* bias;
+  const half_t* res; int ldr;
+  int M, N, K;
+  float alpha; unsigned flags;
+  int IH, IW, OH, OW, Cin;   // conv only
+};
+
+// v2 (gemm2.hip): returns true and launches if the shape is eligible, false otherwise (nothing launched).
+bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st);
+// column width of the tile v2 would use for an M x N output, or 0 if v2 does not take this shape
+int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode);
