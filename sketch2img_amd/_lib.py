@@ -17,6 +17,7 @@ SIGNATURES = {
     "skg_last_error": ("s", ""),
     "skg_gemm_f16": ("i", "pipipiiiippifup"),
     "skg_gemm_variant": ("i", "iiiii"),
+    "skg_set_workspace": ("i", "pz"),
     "skg_conv3x3_f16": ("i", "pippiiiiiiippifup"),
     "skg_groupnorm_scratch_floats": ("z", "ii"),
     "skg_groupnorm_stats": ("i", "piiiiifppp"),

@@ -198,6 +198,12 @@ int launch(const GemmParams& p, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int skg_set_workspace(void* ws, size_t bytes) {
+  SKG_REQUIRE(ws == nullptr || (skg_aligned(ws, 16) && bytes >= (1u << 20)));
+  skg_gemm2_set_workspace((float*)ws, ws ? bytes : 0);
+  return SKG_OK;
+}
+
 extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
   const int v2 = skg_gemm2_tile_n(M, N, K, Cin, mode);
   return v2 ? 2000 + v2 : 1000 + (use_wide(M, N) ? 128 : 64);

@@ -32,6 +32,9 @@
 
 namespace {
 
+float* g_ws = nullptr;          // caller-owned split-K workspace (skg_set_workspace)
+size_t g_ws_bytes = 0;
+
 constexpr int BM = 128;
 constexpr int BK = 64;
 constexpr unsigned OOB = 0x80000000u;     // voffset that fails the descriptor's range check -> zeros
@@ -45,7 +48,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, half_t* lds_w
 
 template <int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
-                                                       unsigned a_bytes, unsigned b_bytes, unsigned a_shift) {
+                                                       unsigned a_bytes, unsigned b_bytes, unsigned a_shift,
+                                                       int kt_per_split, float* __restrict__ ws) {
   constexpr int WN = BN / 2;
   constexpr int NT = WN / 16;         // 5, 4 or 2
   constexpr int MT = 4;
@@ -69,6 +73,10 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
     const int q = nwg >> 3, r = nwg & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // split-K: workgroups [s * ntiles, (s+1) * ntiles) own K tiles [s * kt_per_split, ...) and write fp32 slab s
+  const int ntiles = ws ? nwg / ((p.K / BK + kt_per_split - 1) / kt_per_split) : nwg;
+  const int split = lid / ntiles;
+  lid -= split * ntiles;
   const int tile_m = lid / tiles_n;
   const int tile_n = lid - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -207,9 +215,10 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
     }
   };
 
-  const int KT = p.K / BK;
-  issue(0, 0);
-  for (int kt = 0; kt < KT; kt += 2) {
+  const int kt_begin = split * kt_per_split;
+  const int KT = min(p.K / BK, kt_begin + kt_per_split);
+  issue(kt_begin, 0);
+  for (int kt = kt_begin; kt < KT; kt += 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (kt + 1 < KT) issue(kt + 1, 1);
@@ -225,6 +234,63 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
   // ---- epilogue: lane holds C[m = .. + l16][n = .. + 4g .. 4g+3] -----------------------------------
   const bool relu = p.flags & SKG_EPI_RELU;
   const bool f32out = p.flags & SKG_EPI_OUT_F32;
+  if (ws) {   // split-K partial: raw fp32 accumulators, epilogue happens in splitk_reduce_kernel
+    float* slab = ws + (size_t)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + l16;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WN + j * 16 + g * 4;
+        if (n < p.N) *reinterpret_cast<float4_t*>(slab + (size_t)m * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+  const bool staged = !f32out && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+  if (staged) {
+    // Final fp16 values go through LDS (the stages are dead now) so that the global stores are 16 bytes
+    // per lane over whole output rows, instead of 8-byte fragments of 16 different rows per instruction.
+    constexpr int OP = BN + 8;                 // staging pitch (halves)
+    __syncthreads();                           // every wave has finished reading the last stage
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int ml = wm * 64 + i * 16 + l16;
+      const int m = m0 + ml;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int nl = wn * WN + j * 16 + g * 4;
+        const int n = n0 + nl;
+        float4_t v = acc[i][j];
+        if (m < p.M && n < p.N) {
+          if (p.bias) {
+            const half4_t b = ld_half4(p.bias + n);
+            v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+          }
+          v *= p.alpha;
+          if (p.res) {
+            const half4_t r = ld_half4(p.res + (size_t)m * p.ldr + n);
+            v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+          }
+          if (relu) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          }
+        }
+        half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        st_half4(&smem[ml * OP + nl], o);
+      }
+    }
+    __syncthreads();
+    constexpr int PPR = BN / 8;                // 16-byte pieces per tile row
+    for (int pi = tid; pi < BM * PPR; pi += 256) {
+      const int r = pi / PPR, c = (pi - r * PPR) * 8;
+      const int m = m0 + r, n = n0 + c;
+      if (m < p.M && n < p.N)
+        st_half8(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n, ld_half8(&smem[r * OP + c]));
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + wm * 64 + i * 16 + l16;
@@ -254,6 +320,49 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
       }
     }
   }
+}
+
+// out = epi(sum_s slab[s]) for a split-K launch; 4 outputs per thread
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ ws,
+                                                            int splits) {
+  const int N4 = p.N >> 2;
+  const size_t total = (size_t)p.M * N4;
+  const size_t slab = (size_t)p.M * p.N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t m = i / N4;
+    const int n = (int)(i - m * N4) * 4;
+    float4_t v = *reinterpret_cast<const float4_t*>(ws + m * p.N + n);
+    for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const float4_t*>(ws + s * slab + m * p.N + n);
+    if (p.bias) {
+      const half4_t b = ld_half4(p.bias + n);
+      v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+    }
+    v *= p.alpha;
+    if (p.res) {
+      const half4_t r = ld_half4(p.res + m * p.ldr + n);
+      v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+    }
+    if (p.flags & SKG_EPI_RELU) {
+      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    }
+    if (p.flags & SKG_EPI_OUT_F32) {
+      *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
+    } else {
+      half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      st_half4(reinterpret_cast<half_t*>(p.C) + m * p.ldc + n, o);
+    }
+  }
+}
+
+
+// number of K splits for a launch of `nwg` 64-wide tiles over KT K-tiles (1 = no split)
+inline int pick_splits(long nwg, int KT, size_t slab_bytes) {
+  if (!g_ws || nwg >= 256 || KT < 16) return 1;
+  int s = (int)((512 + nwg - 1) / nwg);
+  if (s > 8) s = 8;
+  while (s > 1 && KT / s < 8) --s;
+  while (s > 1 && (size_t)s * slab_bytes > g_ws_bytes) --s;
+  return s;
 }
 
 // bytes of the A / B operands reachable through their descriptors (must stay below 2^31 for the OOB trick)
@@ -289,11 +398,23 @@ inline int pick_bn(int M, int N) {
 template <int BN, int MODE>
 void launch_bn(const GemmParams& p, hipStream_t st) {
   const int tiles_n = skg_cdiv(p.N, BN);
-  const int nwg = skg_cdiv(p.M, BM) * tiles_n;
+  const int ntiles = skg_cdiv(p.M, BM) * tiles_n;
   unsigned long long a, b, s;
   operand_bytes(p, MODE, a, b, s);
-  hipLaunchKernelGGL((gemm2_kernel<BN, MODE>), dim3(nwg), dim3(256), 0, st, p, tiles_n, nwg, (unsigned)a,
-                     (unsigned)b, (unsigned)s);
+  const int KT = p.K / BK;
+  const int splits = BN == 64 ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
+  if (splits > 1) {
+    const int per = skg_cdiv(KT, splits);
+    const int ns = skg_cdiv(KT, per);            // every split non-empty
+    hipLaunchKernelGGL((gemm2_kernel<BN, MODE>), dim3(ntiles * ns), dim3(256), 0, st, p, tiles_n, ntiles * ns,
+                       (unsigned)a, (unsigned)b, (unsigned)s, per, g_ws);
+    size_t blocks = ((size_t)p.M * (p.N / 4) + 255) / 256;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p,
+                       (const float*)g_ws, ns);
+    return;
+  }
+  hipLaunchKernelGGL((gemm2_kernel<BN, MODE>), dim3(ntiles), dim3(256), 0, st, p, tiles_n, ntiles, (unsigned)a,
+                     (unsigned)b, (unsigned)s, KT, (float*)nullptr);
 }
 
 template <int MODE>
@@ -306,6 +427,8 @@ void launch_mode(const GemmParams& p, hipStream_t st) {
 }
 
 }  // namespace
+
+void skg_gemm2_set_workspace(float* ws, size_t bytes) { g_ws = ws; g_ws_bytes = bytes; }
 
 int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode) {
   if (K % BK != 0 || M < 1 || (mode != MODE_DIRECT && Cin % BK != 0)) return 0;

@@ -17,7 +17,16 @@ EPI_RELU, EPI_OUT_F32 = 1, 2
 CONV_S1, CONV_S2, CONV_UP2, CONV_S2T = 0, 1, 2, 3
 
 
+_workspace = {}
+WORKSPACE_BYTES = 128 << 20
+
+
 def _stream() -> int:
+    """Current HIP stream; also hands libskg.so its split-K workspace the first time a device is used."""
+    dev = torch.cuda.current_device()
+    if dev not in _workspace:
+        _workspace[dev] = torch.empty(WORKSPACE_BYTES // 4, device=f"cuda:{dev}", dtype=torch.float32)
+        check(lib.skg_set_workspace(_workspace[dev].data_ptr(), WORKSPACE_BYTES), "skg_set_workspace")
     return torch.cuda.current_stream().cuda_stream
 
 
