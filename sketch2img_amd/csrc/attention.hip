@@ -81,6 +81,54 @@ __device__ __forceinline__ void pack_p(const float4_t (&s)[4], half8_t (&pb)[2])
 }
 
 // -------------------------------------------------------------------------------------------------
+// register staging of one K tile ([64][dh] rows) and one transposed V tile ([dh][64]) per workgroup
+template <int KS, int ND>
+struct KVRegs {
+  static constexpr int NK = KS;                 // 64 * KS*4 pieces / 256 threads
+  static constexpr int NV = (ND + 1) / 2;       // ND*16*8 pieces / 256 threads
+  half8_t k[NK], v[NV];
+};
+
+template <int KS, int ND>
+__device__ __forceinline__ void kv_load(KVRegs<KS, ND>& r, const half_t* __restrict__ Kb, int ldk,
+                                        const half_t* __restrict__ Vb, int ldvt, int kv0, int kvlim, int dh) {
+  constexpr int PPR = KS * 4;
+#pragma unroll
+  for (int q = 0; q < KVRegs<KS, ND>::NK; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    const int row = pi / PPR, pc = (pi - row * PPR) * 8;
+    r.k[q] = (kv0 + row < kvlim && pc < dh) ? ld_half8(Kb + (size_t)(kv0 + row) * ldk + pc) : zero_half8();
+  }
+#pragma unroll
+  for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    const int d = pi >> 3, pc = (pi & 7) * 8;
+    r.v[q] = (pi < ND * 128 && d < dh && kv0 + pc < kvlim) ? ld_half8(Vb + (size_t)d * ldvt + kv0 + pc) : zero_half8();
+  }
+}
+
+template <int KS, int ND>
+__device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __restrict__ Ks, half_t* __restrict__ Vs) {
+  constexpr int KP = KS * 32 + 8;
+  constexpr int PPR = KS * 4;
+#pragma unroll
+  for (int q = 0; q < KVRegs<KS, ND>::NK; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    const int row = pi / PPR, pc = (pi - row * PPR) * 8;
+    st_half8(Ks + row * KP + pc, r.k[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    if (pi < ND * 128) st_half8(Vs + (pi >> 3) * TP + (pi & 7) * 8, r.v[q]);
+  }
+}
+
+// Forward.  Per 64-key tile: issue the global loads of the NEXT tile into registers, run S^T = K Q^T,
+// online softmax and O^T += V^T P^T on the current LDS tile, then (barrier) spill the prefetched
+// registers into LDS: the HBM/L2 latency of tile t+1 hides under the MFMA + VALU work of tile t.
+// Softmax arithmetic is kept to ~6 VALU per score: raw v_exp_f32 (arguments are <= 0, no range fix-up),
+// scale folded into one FMA, masking only on a ragged last tile.
 template <int KS, int ND>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   constexpr int KP = KS * 32 + 8;
@@ -102,18 +150,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   float4_t o[ND];
 #pragma unroll
   for (int u = 0; u < ND; ++u) o[u] = float4_t{0.f, 0.f, 0.f, 0.f};
-  float m = NEG_BIG, l = 0.f;
+  float m = NEG_BIG, l = 0.f;       // m: running max of the RAW scores times sc (log2 domain)
   const float sc = p.scale * LOG2E;
 
   const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
   const half_t* Vb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
   const int nt = (p.Nkv + 63) / 64;
+  KVRegs<KS, ND> regs;
+  kv_load<KS, ND>(regs, Kb, p.ldk, Vb, p.ldvt, 0, p.kv_stride, dh);
+  kv_store<KS, ND>(regs, Ks, Vs);
+  __syncthreads();
   for (int t0 = 0; t0 < nt; ++t0) {
     const int kv0 = t0 * 64;
-    __syncthreads();
-    stage_rows<KS>(Ks, Kb, p.ldk, kv0, p.kv_stride, dh);
-    stage_cols<ND>(Vs, Vb, p.ldvt, kv0, p.kv_stride, dh);
-    __syncthreads();
+    const bool more = t0 + 1 < nt;
+    if (more) kv_load<KS, ND>(regs, Kb, p.ldk, Vb, p.ldvt, kv0 + 64, p.kv_stride, dh);
 
     float4_t s[4];
 #pragma unroll
@@ -125,26 +175,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[t], 0, 0, 0);
       }
     }
-    float mx = NEG_BIG;
+    if (kv0 + 64 > p.Nkv) {          // ragged last tile only (wave-uniform)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kv = kv0 + 16 * t + 4 * g + r;
-        s[t][r] = kv < p.Nkv ? s[t][r] * sc : NEG_BIG;
-        mx = fmaxf(mx, s[t][r]);
-      }
+        for (int r = 0; r < 4; ++r)
+          if (kv0 + 16 * t + 4 * g + r >= p.Nkv) s[t][r] = NEG_BIG;
+    }
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
+#pragma unroll
+    for (int t = 1; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    const float alpha = exp2f(m - mn);
+    const float mn = fmaxf(m, mx * sc);
+    const float alpha = __builtin_amdgcn_exp2f(m - mn);
     m = mn;
     float ps = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float e = exp2f(s[t][r] - mn);
+        const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -mn));
         s[t][r] = e;
         ps += e;
       }
@@ -157,6 +208,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2)
         o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag(Vs, u, k2, l16, g), pb[k2], o[u], 0, 0, 0);
+    }
+    if (more) {
+      __syncthreads();               // every wave is done reading tile t0
+      kv_store<KS, ND>(regs, Ks, Vs);
+      __syncthreads();
     }
   }
   l += __shfl_xor(l, 16, 64);
@@ -230,12 +286,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
         dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(Vr + off), dof[ks], dp[t], 0, 0, 0);
       }
     }
+    const bool ragged = kv0 + 64 > p.Nkv;      // wave-uniform
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int kv = kv0 + 16 * t + 4 * g + r;
-        const float pr = kv < p.Nkv ? exp2f(s[t][r] * sc - lse2) : 0.f;
+        float pr = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -lse2));
+        if (ragged && kv0 + 16 * t + 4 * g + r >= p.Nkv) pr = 0.f;
         s[t][r] = pr * (dp[t][r] - dl);
       }
     half8_t sb[2];
@@ -330,7 +387,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ql = 16 * t + 4 * g + r;
-        const float pr = exp2f(s[t][r] * sc - lse_s[ql]);
+        const float pr = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -lse_s[ql]));
         s[t][r] = pr;
         ds[t][r] = pr * (dp[t][r] - del_s[ql]);
       }
