@@ -6,74 +6,99 @@
 
 namespace {
 
-constexpr int GN_MAX_CHUNKS = 64;
+constexpr int GN_MAX_CHUNKS = 128;
 constexpr int GN_MAX_C = 4096;
 
+// pixels per workgroup ~32: enough workgroups (2048 at 64x64 x 16 rows) to cover the chip several times
 __host__ __device__ inline int gn_chunks(int HW) {
-  int c = (HW + 63) / 64;
+  int c = (HW + 31) / 32;
   return c > GN_MAX_CHUNKS ? GN_MAX_CHUNKS : (c < 1 ? 1 : c);
 }
 
 // ---- stage 1: per (row, pixel-chunk) partial sums of two per-element quantities, per group ----
 // KIND 0 (forward stats):   q1 = x,            q2 = x*x
 // KIND 1 (backward sums):   q1 = dyh*gamma,    q2 = dyh*gamma*xhat     (dyh = dy * silu'(y))
+// Each thread owns fixed 8-channel pieces (16-byte loads) for a strided subset of the chunk's pixels.  A piece
+// can straddle two groups (cpg = 10, 30 ...), so it keeps a (low group, high group) pair of partial sums; the
+// fold into groups runs in a fixed order from LDS -> bitwise deterministic results.
 template <int KIND>
 __global__ __launch_bounds__(256) void gn_partial_kernel(
     const half_t* __restrict__ X, int ldx, const half_t* __restrict__ dY, int lddy, int HW, int C,
     int groups, const float* __restrict__ stats, const half_t* __restrict__ gamma,
     const half_t* __restrict__ beta, int silu, float* __restrict__ partial) {
-  __shared__ float cs[2][GN_MAX_C / 2];   // per channel-pair sums, folded per group in a fixed order
+  constexpr int NP = GN_MAX_C / 8 / 256;       // pieces per thread when C/8 > 256 (2)
+  __shared__ float red[256 * NP][4];
   const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
   const int cpg = C / groups;
   const int per = (HW + nch - 1) / nch;
   const int p0 = chunk * per;
   const int p1 = min(HW, p0 + per);
-  const int C2 = C >> 1;
-  for (int cp = threadIdx.x; cp < C2; cp += 256) {
-    const int c = cp * 2;
-    const int grp = c / cpg;          // cpg is even, so both channels of the pair share a group
-    float s1 = 0.f, s2 = 0.f;
-    float mean = 0.f, rstd = 0.f, g0 = 0.f, g1 = 0.f, b0 = 0.f, b1 = 0.f;
-    if (KIND == 1) {
-      mean = stats[((size_t)b * groups + grp) * 2];
-      rstd = stats[((size_t)b * groups + grp) * 2 + 1];
-      g0 = (float)gamma[c]; g1 = (float)gamma[c + 1];
-      b0 = (float)beta[c]; b1 = (float)beta[c + 1];
-    }
-    const half_t* xp = X + ((size_t)b * HW + p0) * ldx + c;
-    const half_t* dp = KIND == 1 ? dY + ((size_t)b * HW + p0) * lddy + c : nullptr;
-    for (int p = p0; p < p1; ++p) {
-      const half2_t xv = *reinterpret_cast<const half2_t*>(xp);
-      const float x0 = (float)xv[0], x1 = (float)xv[1];
-      if (KIND == 0) {
-        s1 += x0 + x1;
-        s2 += x0 * x0 + x1 * x1;
-      } else {
-        const half2_t dv = *reinterpret_cast<const half2_t*>(dp);
-        const float xh0 = (x0 - mean) * rstd, xh1 = (x1 - mean) * rstd;
-        float d0 = (float)dv[0], d1 = (float)dv[1];
-        if (silu) {
-          d0 *= silu_grad_f(xh0 * g0 + b0);
-          d1 *= silu_grad_f(xh1 * g1 + b1);
-        }
-        d0 *= g0; d1 *= g1;
-        s1 += d0 + d1;
-        s2 += d0 * xh0 + d1 * xh1;
-        dp += lddy;
+  const int C8 = C >> 3;
+  const int P = C8 <= 256 ? 256 / C8 : 1;       // pixel lanes
+  const int T = C8 <= 256 ? P * C8 : 256;       // active threads
+  const int tid = threadIdx.x;
+  const int pl = C8 <= 256 ? tid / C8 : 0;
+  const int np = C8 <= 256 ? 1 : (C8 + 255) / 256;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    if (k >= np) break;
+    const int piece = C8 <= 256 ? tid - pl * C8 : tid + k * 256;
+    float s1lo = 0.f, s2lo = 0.f, s1hi = 0.f, s2hi = 0.f;
+    if (tid < T && piece < C8) {
+      const int c0 = piece * 8;
+      const int glo = c0 / cpg;
+      const int nlo = min(8, (glo + 1) * cpg - c0);        // channels [c0, c0+nlo) belong to glo, rest to glo+1
+      float mlo = 0.f, rlo = 0.f, mhi = 0.f, rhi = 0.f;
+      half8_t gv = zero_half8(), bv = zero_half8();
+      if (KIND == 1) {
+        mlo = stats[((size_t)b * groups + glo) * 2]; rlo = stats[((size_t)b * groups + glo) * 2 + 1];
+        if (nlo < 8) { mhi = stats[((size_t)b * groups + glo + 1) * 2]; rhi = stats[((size_t)b * groups + glo + 1) * 2 + 1]; }
+        gv = ld_half8(gamma + c0);
+        bv = ld_half8(beta + c0);
       }
-      xp += ldx;
+      for (int p = p0 + pl; p < p1; p += P) {
+        const half8_t xv = ld_half8(X + ((size_t)b * HW + p) * ldx + c0);
+        half8_t dv = zero_half8();
+        if (KIND == 1) dv = ld_half8(dY + ((size_t)b * HW + p) * lddy + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = (float)xv[j];
+          float q1, q2;
+          if (KIND == 0) {
+            q1 = x; q2 = x * x;
+          } else {
+            const bool lo = j < nlo;
+            const float xh = (x - (lo ? mlo : mhi)) * (lo ? rlo : rhi);
+            float d = (float)dv[j];
+            if (silu) d *= silu_grad_f(xh * (float)gv[j] + (float)bv[j]);
+            d *= (float)gv[j];
+            q1 = d; q2 = d * xh;
+          }
+          if (j < nlo) { s1lo += q1; s2lo += q2; } else { s1hi += q1; s2hi += q2; }
+        }
+      }
     }
-    cs[0][cp] = s1;
-    cs[1][cp] = s2;
+    red[tid + k * 256][0] = s1lo; red[tid + k * 256][1] = s2lo;
+    red[tid + k * 256][2] = s1hi; red[tid + k * 256][3] = s2hi;
   }
   __syncthreads();
-  if (threadIdx.x < groups) {
-    const int ppg = cpg >> 1;
+  if (tid < groups) {
+    // pieces overlapping group tid: [first, last]; for each, add the half that belongs to this group
+    const int first = (tid * cpg) >> 3, last = ((tid + 1) * cpg - 1) >> 3;
     float t1 = 0.f, t2 = 0.f;
-    for (int j = 0; j < ppg; ++j) { t1 += cs[0][threadIdx.x * ppg + j]; t2 += cs[1][threadIdx.x * ppg + j]; }
-    float* o = partial + (((size_t)b * nch + chunk) * groups + threadIdx.x) * 2;
-    o[0] = t1;
-    o[1] = t2;
+    for (int piece = first; piece <= last; ++piece) {
+      const bool is_lo = (piece * 8) / cpg == tid;          // this group is the piece's low group
+      const int o = is_lo ? 0 : 2;
+      if (C8 <= 256) {
+        for (int l = 0; l < P; ++l) { t1 += red[l * C8 + piece][o]; t2 += red[l * C8 + piece][o + 1]; }
+      } else {
+        const int slot = (piece & 255) + (piece >> 8) * 256;
+        t1 += red[slot][o]; t2 += red[slot][o + 1];
+      }
+    }
+    float* o2 = partial + (((size_t)b * nch + chunk) * groups + tid) * 2;
+    o2[0] = t1;
+    o2[1] = t2;
   }
 }
 
@@ -269,7 +294,8 @@ extern "C" size_t skg_groupnorm_scratch_floats(int rows, int groups) {
 extern "C" int skg_groupnorm_stats(const void* X, int ldx, int rows, int HW, int C, int groups, float eps,
                                    float* stats, float* partial, void* stream) {
   SKG_REQUIRE(X && stats && partial && rows > 0 && HW > 0 && groups > 0 && groups <= 64);
-  SKG_REQUIRE(C % groups == 0 && (C / groups) % 2 == 0 && ldx % 2 == 0 && ldx >= C && C <= GN_MAX_C);
+  SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && (C / groups) % 2 == 0 && (C / groups) >= 4 && ldx % 8 == 0 && ldx >= C &&
+              C <= GN_MAX_C && skg_aligned(X, 16));
   hipStream_t st = (hipStream_t)stream;
   const int nch = gn_chunks(HW);
   hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(nch, rows), dim3(256), 0, st, (const half_t*)X, ldx,
@@ -301,7 +327,7 @@ extern "C" int skg_groupnorm_bwd(const void* X, int ldx, const void* dY, int ldd
                                  const float* stats, const void* gamma, const void* beta, int silu,
                                  float* partial, void* stream) {
   SKG_REQUIRE(X && dY && dX && stats && gamma && beta && partial && rows > 0 && HW > 0 && groups <= 64);
-  SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && (C / groups) % 2 == 0 && C <= GN_MAX_C);
+  SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && (C / groups) % 2 == 0 && (C / groups) >= 4 && C <= GN_MAX_C);
   SKG_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && (!residual || ldr % 8 == 0));
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(dY, 16) && skg_aligned(dX, 16) && skg_aligned(gamma, 16) &&
               skg_aligned(beta, 16) && (!residual || skg_aligned(residual, 16)));
