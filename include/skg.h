@@ -150,6 +150,12 @@ int skg_transpose_f16(const void* In, int ldi, void* Out, int ldo, int M, int C,
  * concat (copy into a slice), skip-gradient accumulation and slicing. */
 int skg_axpby_f16(const void* A, int lda, const void* B, int ldb, void* Y, int ldy, int M, int C,
                   float alpha, float beta, void* stream);
+/* Out[b*out_batch_rows + r][:] = In[b*in_batch_rows + r][:] for b < batches, r < rows_per_batch (fp16, C % 8 == 0).
+ * Moves the N image tokens of every batch row into / out of the [N + 257 (+pad)]-token buffer of the
+ * injected self-attention, i.e. the torch.cat(..., dim=1) and [:, :N] slice of
+ * modules/clip_guided_attn.py:113,119. */
+int skg_batch_copy_f16(const void* In, int ldi, int in_batch_rows, void* Out, int ldo, int out_batch_rows,
+                       int batches, int rows_per_batch, int C, void* stream);
 /* Y = silu(X), fp16 [M][C], C % 8 == 0.  Used once per timestep for the time-embedding MLP
  * (diffusers TimestepEmbedding / ResnetBlock2D.time_emb_proj input), off the per-step path. */
 int skg_silu_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, void* stream);

@@ -33,6 +33,7 @@ SIGNATURES = {
     "skg_attn_bwd_dkv": ("i", "pipipipipipipppipiiiiiifp"),
     "skg_transpose_f16": ("i", "pipiiip"),
     "skg_axpby_f16": ("i", "pipipiiiffp"),
+    "skg_batch_copy_f16": ("i", "piipiiiiip"),
     "skg_silu_f16": ("i", "pipiiip"),
     "skg_sumpool2x2_f16": ("i", "pipiiiiip"),
     "skg_nchw_f32_to_nhwc_f16": ("i", "ppiiiip"),

@@ -100,6 +100,21 @@ __global__ __launch_bounds__(256) void axpby_kernel(const half_t* __restrict__ A
   }
 }
 
+// Out[b][r][:] = In[b][r][:] for r < rows_per_batch, with different batch strides on the two sides
+__global__ __launch_bounds__(256) void batch_copy_kernel(const half_t* __restrict__ In, int ldi, long in_bs,
+                                                         half_t* __restrict__ Out, int ldo, long out_bs,
+                                                         int batches, int rows_per_batch, int C) {
+  const int C8 = C >> 3;
+  const size_t total = (size_t)batches * rows_per_batch * C8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int c = (int)(i % C8) * 8;
+    const size_t t = i / C8;
+    const int r = (int)(t % rows_per_batch);
+    const size_t b = t / rows_per_batch;
+    st_half8(Out + (b * out_bs + r) * ldo + c, ld_half8(In + (b * in_bs + r) * ldi + c));
+  }
+}
+
 __global__ __launch_bounds__(256) void silu_kernel(const half_t* __restrict__ X, int ldx, half_t* __restrict__ Y,
                                                    int ldy, int M, int C) {
   const int C8 = C >> 3;
@@ -253,6 +268,18 @@ extern "C" int skg_axpby_f16(const void* A, int lda, const void* B, int ldb, voi
   hipLaunchKernelGGL(axpby_kernel, dim3(ew_grid((size_t)M * C / 8)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)A, lda, (const half_t*)B, ldb, (half_t*)Y, ldy, M, C, alpha, beta);
   SKG_CHECK_LAUNCH("skg_axpby_f16");
+  return SKG_OK;
+}
+
+extern "C" int skg_batch_copy_f16(const void* In, int ldi, int in_batch_rows, void* Out, int ldo,
+                                  int out_batch_rows, int batches, int rows_per_batch, int C, void* stream) {
+  SKG_REQUIRE(In && Out && batches > 0 && rows_per_batch > 0 && C > 0 && C % 8 == 0 && ldi % 8 == 0 && ldo % 8 == 0);
+  SKG_REQUIRE(in_batch_rows >= rows_per_batch && out_batch_rows >= rows_per_batch);
+  SKG_REQUIRE(skg_aligned(In, 16) && skg_aligned(Out, 16));
+  hipLaunchKernelGGL(batch_copy_kernel, dim3(ew_grid((size_t)batches * rows_per_batch * C / 8)), dim3(256), 0,
+                     (hipStream_t)stream, (const half_t*)In, ldi, (long)in_batch_rows, (half_t*)Out, ldo,
+                     (long)out_batch_rows, batches, rows_per_batch, C);
+  SKG_CHECK_LAUNCH("skg_batch_copy_f16");
   return SKG_OK;
 }
 

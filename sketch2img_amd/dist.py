@@ -59,7 +59,7 @@ def broadcast_state_dict(sd: Optional[Dict[str, torch.Tensor]], shapes: Optional
             t = sd[k].to(device, torch.int64).reshape(-1) if rank == src else torch.zeros(max(1, _numel(s)), device=device, dtype=torch.int64)
             dist.broadcast(t, src=src)
             out[k] = t.view(s)
-    return out
+    return OrderedDict((k, out[k]) for k, _, _ in manifest)       # the sender's key order
 
 
 def _numel(s) -> int:

@@ -1,0 +1,161 @@
+"""Injected attention (the reference's SatMixin / AttnModule step 1.5) on the libskg.so kernels.
+
+  * CLIP-token variant      modules/clip_guided_attn.py:111-125
+        s = sketch_proj(state); z = sketch_norm(cat([h, s], 1)); a = sketch_attn(z)[:, :N]; h += scale*conv1x1(a)
+  * UNet-feature variant    modules/sketch_guided_attn.py:120-132
+        z = sketch_norm(h); a = sketch_attn(z, encoder_hidden_states=res_sample); h += scale*conv1x1(a)
+
+What does not depend on the latent is hoisted to ``set_state`` / ``set_res_samples`` (once per image): the
+projected + normalised sketch tokens and, for the feature variant, the K / V projections of the residual
+samples.  LayerNorm is per token, so LayerNorm(cat([h, s])) == cat(LayerNorm(h), LayerNorm(s)): the sketch
+tokens are normalised once and copied into the tail of the per-step token buffer.
+
+Buffers, CLIP variant, per block: tokens [rows][N + T_pad][C] with T = 257 sketch tokens padded to a multiple
+of 8; the first N slots of every batch row are refreshed each step (skg_batch_copy_f16), the attention runs
+over all slots as queries (the T_pad sketch-query outputs are never read: 6 % extra work at N = 4096, no
+extra kernels) with the last padding keys masked by Nkv < kv_stride.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .config import UNetConfig
+
+SKETCH_TOKENS = 257
+CLIP_DIM = 1024
+
+
+def transformer_block_paths(cfg: UNetConfig) -> List[str]:
+    """BasicTransformerBlock paths in unet.named_modules() order: down, up, mid (SatMixin.blocks order)."""
+    nb = len(cfg.block_out_channels)
+    out = []
+    for i in range(nb - 1):
+        out += [f"down_blocks.{i}.attentions.{j}.transformer_blocks.0" for j in range(cfg.layers_per_block)]
+    for i in range(1, nb):
+        out += [f"up_blocks.{i}.attentions.{j}.transformer_blocks.0" for j in range(cfg.layers_per_block + 1)]
+    out.append("mid_block.attentions.0.transformer_blocks.0")
+    return out
+
+
+def block_dims(cfg: UNetConfig):
+    boc = cfg.block_out_channels
+    rev, rev_heads = tuple(reversed(boc)), tuple(reversed(cfg.num_heads))
+    out = []
+    for p in transformer_block_paths(cfg):
+        parts = p.split(".")
+        if parts[0] == "down_blocks":
+            out.append((p, boc[int(parts[1])], cfg.num_heads[int(parts[1])]))
+        elif parts[0] == "up_blocks":
+            out.append((p, rev[int(parts[1])], rev_heads[int(parts[1])]))
+        else:
+            out.append((p, boc[-1], cfg.num_heads[-1]))
+    return out
+
+
+def module_name(block_path: str) -> str:
+    """modules/clip_guided_attn.py:14-19: "sketch_attn." + path with '.' -> '_'."""
+    return ("sketch_attn." + block_path).replace(".", "_")
+
+
+def route_res_samples(res_samples: Sequence[Sequence[torch.Tensor]]) -> List[torch.Tensor]:
+    """modules/sketch_guided_attn.py:29-40."""
+    down, up = (), ()
+    mid = (res_samples[-1][-1],)
+    for layers in res_samples:
+        if len(layers) == 3:
+            down += (layers[0], layers[1])
+            up += (layers[0], layers[1], layers[1])
+    return list(down + up[::-1] + mid)
+
+
+class HipInjector:
+    """Callable installed as ``HipUNet.inject``; ``variant`` is 'clip' or 'sketch'."""
+
+    def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], variant: str, device):
+        assert variant in ("clip", "sketch")
+        self.cfg, self.variant, self.dev = cfg, variant, torch.device(device)
+        self.scale = 1.0
+        self.W: Dict[str, Dict[str, torch.Tensor]] = {}
+        self.per_image: Dict[str, dict] = {}
+        h16 = lambda t: t.detach().to(self.dev, torch.float16).contiguous()
+        for path, c, heads in block_dims(cfg):
+            n = module_name(path)
+            w = dict(C=c, heads=heads,
+                     ng=h16(state_dict[f"{n}.sketch_norm.weight"]), nb=h16(state_dict[f"{n}.sketch_norm.bias"]),
+                     wq=h16(state_dict[f"{n}.sketch_attn.to_q.weight"]),
+                     wkv=h16(torch.cat([state_dict[f"{n}.sketch_attn.to_k.weight"],
+                                        state_dict[f"{n}.sketch_attn.to_v.weight"]], 0)),
+                     wo=h16(state_dict[f"{n}.sketch_attn.to_out.0.weight"]),
+                     bo=h16(state_dict[f"{n}.sketch_attn.to_out.0.bias"]),
+                     wc=h16(state_dict[f"{n}.sketch_conv.weight"].reshape(c, c)),
+                     bc=h16(state_dict[f"{n}.sketch_conv.bias"]))
+            if variant == "clip":
+                w["wp"] = h16(state_dict[f"{n}.sketch_proj.weight"])
+                w["bp"] = h16(state_dict[f"{n}.sketch_proj.bias"])
+            self.W[path] = w
+
+    def set_scale(self, scale: float):
+        self.scale = float(scale)
+
+    # ---- once per image ---------------------------------------------------------------------------------
+    def set_state(self, sketch_state: Optional[torch.Tensor]):
+        """CLIP variant.  sketch_state [rows, 257, 1024] (uncond rows zero, modules/clip_guided_inf.py:107)."""
+        self.per_image = {}
+        if sketch_state is None:
+            return
+        rows, T, D = sketch_state.shape
+        st = sketch_state.to(self.dev, torch.float16).reshape(rows * T, D).contiguous()
+        for path, w in self.W.items():
+            s = ops.gemm(st, w["wp"], bias=w["bp"])
+            self.per_image[path] = dict(zs=ops.layernorm(s, w["ng"], w["nb"]), rows=rows, T=T, bufs={})
+
+    def set_res_samples(self, res_samples: Optional[Sequence[Sequence[torch.Tensor]]]):
+        """Feature variant.  res_samples: per down block a tuple of NCHW tensors [rows, C, h, w]."""
+        self.per_image = {}
+        if res_samples is None:
+            return
+        routed = route_res_samples(res_samples)
+        for (path, w), r in zip(self.W.items(), routed):
+            rows, C, hh, ww = r.shape
+            assert C == w["C"]
+            tok = r.to(self.dev, torch.float16).permute(0, 2, 3, 1).reshape(rows * hh * ww, C).contiguous()
+            kv = ops.gemm(tok, w["wkv"])                       # res_sample is used un-normalised (:127)
+            self.per_image[path] = dict(K=kv[:, :C], V=kv[:, C:], Vt=ops.transpose(kv[:, C:]), rows=rows, N=hh * ww)
+
+    # ---- per UNet evaluation ------------------------------------------------------------------------------
+    def __call__(self, path: str, h: torch.Tensor, rows: int, N: int, heads: int) -> torch.Tensor:
+        pi = self.per_image.get(path)
+        if pi is None:
+            return h
+        w = self.W[path]
+        C = w["C"]
+        dh = C // heads
+        scale = dh ** -0.5
+        if self.variant == "sketch":
+            assert pi["rows"] == rows and pi["N"] == N
+            z = ops.layernorm(h, w["ng"], w["nb"])
+            q = ops.gemm(z, w["wq"])
+            a = ops.attn_fwd(q, pi["K"], pi["Vt"], rows, heads, N, N, N, dh, scale)
+            o = ops.gemm(a, w["wo"], bias=w["bo"])
+            return ops.gemm(o, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)
+        # CLIP variant: self-attention over [N image tokens ; T sketch tokens]
+        assert pi["rows"] == rows
+        T = pi["T"]
+        L = (N + T + 7) // 8 * 8
+        buf = pi["bufs"].get(N)
+        if buf is None:
+            z = torch.zeros(rows * L, C, device=self.dev, dtype=torch.float16)
+            ops.batch_copy(pi["zs"], T, z[N:], L, rows, T)      # normalised sketch tokens, once per image
+            buf = pi["bufs"][N] = z
+        zh = ops.layernorm(h, w["ng"], w["nb"])
+        ops.batch_copy(zh, N, buf, L, rows, N)
+        q = ops.gemm(buf, w["wq"])
+        kv = ops.gemm(buf, w["wkv"])
+        a = ops.attn_fwd(q, kv[:, :C], ops.transpose(kv[:, C:]), rows, heads, L, N + T, L, dh, scale)
+        o = ops.gemm(a, w["wo"], bias=w["bo"])
+        on = torch.empty(rows * N, C, device=self.dev, dtype=torch.float16)
+        ops.batch_copy(o, L, on, N, rows, N)                    # [:, :N] (clip_guided_attn.py:119)
+        return ops.gemm(on, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)

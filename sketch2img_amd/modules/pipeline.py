@@ -1,0 +1,291 @@
+"""Drop-in for the reference's modules/pipeline.py: AntiGradientPipeline.
+
+Same public surface as the reference class: ``from_pretrained(path, vae=, torch_dtype=,
+scheduler=)``, ``.to(device)``, ``.unet`` / ``.vae`` / ``.scheduler`` / ``.vae_scale_factor``, ``.setup_lgp(lgp)``
+and ``__call__`` with the reference's keyword list (modules/pipeline.py:20-37) and return convention (:127-130:
+the bare list of PIL images when ``return_dict`` is true, ``(images, None)`` otherwise).  The sampling loop, the
+UNet, the LGP and the guidance gradient run in libskg.so; there is no diffusers dependency.
+
+Out of the hot path, handled by PyTorch modules the caller provides (next rows in SURVEY.md section 8f):
+  * ``vae``          any object with ``decode(latents) -> tensor | .sample`` (and ``encode`` for app.py:109);
+  * ``text_encoder`` a callable ``(list[str]) -> (B, 77, D) tensor``; without one, prompts map to seeded
+                     pseudo-embeddings (deterministic in the prompt text) so that the pipeline stays runnable
+                     on a box with no CLIP weights.
+Only the DDIM scheduler (the BASELINE metric) is implemented; DPM-Solver++ (what app.py configures) is a next row.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+from types import SimpleNamespace
+from typing import Callable, List, Optional, Union
+
+import numpy as np
+import torch
+
+from ..config import SD15, SD21, UNetConfig, tap_channels
+from ..sampler import DDIMTables, HipSampler
+from .latent_predictor import LatentEdgePredictor, hook_unet
+
+
+class UNetFacade:
+    """Stands where ``pipe.unet`` is: the attributes app.py / the reference pipeline touch, plus the engine."""
+
+    def __init__(self, cfg: UNetConfig, state_dict, device):
+        self.cfg = cfg
+        self.config = SimpleNamespace(sample_size=cfg.sample_size, in_channels=cfg.in_channels,
+                                      cross_attention_dim=cfg.cross_attention_dim)
+        self.in_channels = cfg.in_channels
+        self.dtype = torch.float16
+        self._state_dict = state_dict
+        self._device = torch.device(device)
+        self._hip = None
+        self._feature_taps = None
+
+    @property
+    def device(self):
+        return self._device
+
+    def to(self, device=None, dtype=None):
+        if device is not None and torch.device(device) != self._device:
+            self._device, self._hip = torch.device(device), None
+        return self
+
+    def enable_xformers_memory_efficient_attention(self):       # app.py:43 - fused attention is always on
+        return None
+
+    @property
+    def hip(self):
+        if self._hip is None:
+            if self._device.type != "cuda":
+                raise RuntimeError("sketch2img_amd computes on the GPU only: call pipe.to('cuda') first")
+            from ..unet import HipUNet
+            self._hip = HipUNet(self.cfg, self._state_dict, self._device)
+        return self._hip
+
+    def state_dict(self):
+        return self._state_dict
+
+    def __call__(self, sample, timestep, encoder_hidden_states, **kwargs):
+        """UNet2DConditionModel-style call (evaluation.py:94): sample (rows,4,h,w) in the row order
+        [uncond rows; cond rows], returns an object with ``.sample`` (fp32 NCHW epsilon).  Fills the hooked
+        feature taps (hook_unet) like the reference's forward hooks do."""
+        from .. import ops
+        from ..unet import CIN_PAD
+        rows, _, h, w = sample.shape
+        assert h == w
+        net = self.hip
+        if net.ctx is None or net.ctx.get("src") is not encoder_hidden_states:
+            net.prepare_context(encoder_hidden_states)
+            net.ctx["src"] = encoder_hidden_states
+        x32 = ops.nchw_to_nhwc(sample.to(self._device, torch.float32).contiguous(), CIN_PAD)
+        eps, taps = net.forward(x32, int(timestep), rows, h)
+        if self._feature_taps is not None:
+            for tp, (t, s) in zip(self._feature_taps, taps):
+                tp._nhwc = (t, rows, s)
+        return SimpleNamespace(sample=ops.nhwc_to_nchw(eps, rows, self.cfg.out_channels, h, w))
+
+
+def _load_unet_weights(path: Optional[str], cfg: UNetConfig):
+    """diffusers-layout folder (``<path>/unet/diffusion_pytorch_model.safetensors`` or ``.bin``) if present,
+    else seeded synthetic weights (no checkpoints exist on the build / GPU boxes)."""
+    if path and os.path.isdir(os.path.join(path, "unet")):
+        d = os.path.join(path, "unet")
+        st = os.path.join(d, "diffusion_pytorch_model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+            return load_file(st)
+        pt = os.path.join(d, "diffusion_pytorch_model.bin")
+        if os.path.exists(pt):
+            return torch.load(pt, map_location="cpu")
+    from .. import synthetic
+    return synthetic.unet_state_dict(cfg)
+
+
+def _config_from_folder(path: Optional[str]) -> UNetConfig:
+    if path:
+        cj = os.path.join(path, "unet", "config.json")
+        if os.path.exists(cj):
+            c = json.load(open(cj))
+            if c.get("cross_attention_dim") == 1024:
+                return SD21
+    return SD15
+
+
+class AntiGradientPipeline:
+    def __init__(self, unet: UNetFacade, vae=None, scheduler=None, text_encoder: Optional[Callable] = None):
+        self.unet, self.vae, self.scheduler, self.text_encoder = unet, vae, scheduler, text_encoder
+        self.vae_scale_factor = 8
+        self.lgp_model: Optional[LatentEdgePredictor] = None
+        self.feature_blocks = None
+        self.safety_checker = None
+
+    # ------------------------------------------------------------------ construction (app.py:32-46,67-70)
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, vae=None, torch_dtype=None, scheduler=None,
+                        text_encoder=None, unet_config: Optional[UNetConfig] = None, **kwargs):
+        cfg = unet_config or _config_from_folder(pretrained_model_name_or_path)
+        sd = _load_unet_weights(pretrained_model_name_or_path, cfg)
+        return cls(UNetFacade(cfg, sd, "cpu"), vae=vae, scheduler=scheduler, text_encoder=text_encoder)
+
+    def to(self, device):
+        self.unet.to(device)
+        if self.vae is not None and hasattr(self.vae, "to"):
+            self.vae.to(device)
+        return self
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    _execution_device = device
+
+    def setup_lgp(self, lgp):                                  # modules/pipeline.py:15-17
+        self.lgp_model = lgp
+        self.feature_blocks = hook_unet(self.unet)
+
+    # ------------------------------------------------------------------ helpers of the diffusers base class
+    def check_inputs(self, prompt, height, width, callback_steps):
+        if not isinstance(prompt, str) and not isinstance(prompt, list):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if (callback_steps is None) or (not isinstance(callback_steps, int) or callback_steps <= 0):
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps}")
+
+    def _encode_prompt(self, prompt, device, num_images_per_prompt, do_classifier_free_guidance, negative_prompt):
+        """[uncond rows; cond rows] like the diffusers helper (modules/pipeline.py:55-57)."""
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+        if negative_prompt is None:
+            negs = [""] * len(prompts)
+        elif isinstance(negative_prompt, str):
+            negs = [negative_prompt] * len(prompts)
+        else:
+            negs = list(negative_prompt)
+        if len(negs) != len(prompts):
+            raise ValueError("`negative_prompt` and `prompt` must have the same batch size")
+        enc = self.text_encoder or self._pseudo_text_encoder
+        cond = enc(prompts).repeat_interleave(num_images_per_prompt, 0)
+        if not do_classifier_free_guidance:
+            return cond
+        unc = enc(negs).repeat_interleave(num_images_per_prompt, 0)
+        return torch.cat([unc, cond])
+
+    def _pseudo_text_encoder(self, prompts: List[str]) -> torch.Tensor:
+        out = []
+        for p in prompts:
+            seed = int.from_bytes(hashlib.sha256(p.encode()).digest()[:4], "little")
+            g = torch.Generator().manual_seed(seed)
+            out.append(torch.randn(77, self.unet.cfg.cross_attention_dim, generator=g))
+        return torch.stack(out)
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if latents is None:
+            gdev = generator.device if isinstance(generator, torch.Generator) else "cpu"
+            latents = torch.randn(shape, generator=generator if isinstance(generator, torch.Generator) else None,
+                                  device=gdev, dtype=torch.float32)
+        elif tuple(latents.shape) != shape:
+            raise ValueError(f"Unexpected latents shape, got {tuple(latents.shape)}, expected {shape}")
+        return latents.to(device=device, dtype=torch.float32)       # init_noise_sigma = 1 for DDIM
+
+    def decode_latents(self, latents):
+        """diffusers decode_latents: /0.18215, VAE decode, /2 + 0.5, clamp, NHWC fp32 numpy."""
+        if self.vae is None:
+            # latent preview: no VAE weights on this box (VAE decoder is a "next" row)
+            m = torch.tensor([[0.298, 0.207, 0.208], [0.187, 0.286, 0.173], [-0.158, 0.189, 0.264],
+                              [-0.184, -0.271, -0.473]], device=latents.device)
+            img = torch.einsum("bchw,cr->brhw", latents.float(), m)
+            img = torch.nn.functional.interpolate(img, scale_factor=8.0, mode="nearest")
+        else:
+            img = self.vae.decode((latents / 0.18215).to(getattr(self.vae, "dtype", latents.dtype)))
+            img = getattr(img, "sample", img)
+        img = (img.float() / 2 + 0.5).clamp(0, 1)
+        return img.detach().cpu().permute(0, 2, 3, 1).numpy()
+
+    @staticmethod
+    def numpy_to_pil(images):
+        from PIL import Image
+        if images.ndim == 3:
+            images = images[None, ...]
+        images = (images * 255).round().astype("uint8")
+        return [Image.fromarray(im) for im in images]
+
+    def run_safety_checker(self, image, device, dtype):
+        return image, None
+
+    # ------------------------------------------------------------------ modules/pipeline.py:19-130
+    @torch.no_grad()
+    def __call__(self, prompt: Union[str, List[str]], height: Optional[int] = None, width: Optional[int] = None,
+                 num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 negative_prompt: Optional[Union[str, List[str]]] = None, num_images_per_prompt: Optional[int] = 1,
+                 eta: float = 0.0, generator=None, latents: Optional[torch.Tensor] = None,
+                 output_type: Optional[str] = "pil", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.Tensor], None]] = None,
+                 callback_steps: Optional[int] = 1, sketch_image=None):
+        height = height or self.unet.config.sample_size * self.vae_scale_factor
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, height, width, callback_steps)
+        if height != width:
+            raise RuntimeError("sketch guidance resizes with size=latents.shape[2] only: square images (SURVEY Q8)")
+        if eta != 0.0:
+            raise NotImplementedError("only eta = 0 (deterministic DDIM) is implemented")
+        batch_size = 1 if isinstance(prompt, str) else len(prompt)
+        device = self._execution_device
+        if guidance_scale <= 1.0:
+            raise NotImplementedError("classifier-free guidance is always on in the hot path (guidance_scale > 1)")
+        ehs = self._encode_prompt(prompt, device, num_images_per_prompt, True, negative_prompt)
+        S = batch_size * num_images_per_prompt
+        tab = self._tables(num_inference_steps)
+        lat = self.prepare_latents(S, self.unet.in_channels, height, width, torch.float32, device, generator, latents)
+
+        net = self.unet.hip
+        net.prepare_context(ehs)
+        lgp = None
+        target = None
+        if sketch_image is not None:
+            if self.lgp_model is None:
+                raise AttributeError("'AntiGradientPipeline' object has no attribute 'lgp_model' (call setup_lgp)")
+            lgp = self.lgp_model._engine(tap_channels(self.unet.cfg), device)
+            target = torch.as_tensor(sketch_image).to(device, torch.float32)
+            if target.shape[0] not in (1, S):
+                raise RuntimeError(f"The size of tensor a ({target.shape[0]}) must match the size of tensor b ({S})")
+        sampler = HipSampler(net, lgp)
+        cb = None
+        if callback is not None:
+            cb = lambda i, t, x: callback(i, t, x) if i % callback_steps == 0 else None
+        out = sampler.sample(lat, target, num_inference_steps, guidance_scale, 1.6, callback=cb, tables=tab)
+        self.last_aux = sampler.last_aux
+        if lgp is not None:
+            self.lgp_model._sync_running_stats()
+        if self.feature_blocks is not None:
+            for tp in self.feature_blocks:          # the reference deletes block.output after use (:149)
+                tp._nhwc = None
+        if output_type == "latent":
+            image = out
+        else:
+            image = self.decode_latents(out)
+            image, _ = self.run_safety_checker(image, device, torch.float16)
+            if output_type == "pil":
+                image = self.numpy_to_pil(image)
+        if not return_dict:
+            return (image, None)
+        return image                                # sic: the reference returns the bare list (:130, Q10)
+
+    def _tables(self, num_inference_steps: int) -> DDIMTables:
+        sch = self.scheduler
+        if sch is None:
+            return DDIMTables.make(num_inference_steps)
+        cfg = getattr(sch, "config", sch)
+        get = lambda k, d: (cfg.get(k, d) if isinstance(cfg, dict) else getattr(cfg, k, d))
+        if "DDIM" not in type(sch).__name__ and not isinstance(sch, (dict, SimpleNamespace)):
+            raise NotImplementedError(f"{type(sch).__name__}: only DDIM is implemented (DPM-Solver++ is a next row)")
+        return DDIMTables.make(num_inference_steps, get("num_train_timesteps", 1000), get("beta_start", 0.00085),
+                               get("beta_end", 0.012), get("steps_offset", 1), get("set_alpha_to_one", False))
+
+    # ------------------------------------------------------------------ modules/pipeline.py:132-161
+    def get_noise_level(self, noise, timesteps):
+        tab = self._tables(50)
+        s = (1 - tab.alphas_cumprod[int(timesteps)]) ** 0.5
+        return s.reshape(1, 1, 1, 1).to(noise.device) * noise

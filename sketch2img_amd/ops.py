@@ -192,6 +192,14 @@ def axpby(A, B=None, out=None, alpha=1.0, beta=1.0):
     return out
 
 
+def batch_copy(X, in_batch_rows, out, out_batch_rows, batches, rows_per_batch):
+    """out[b*out_batch_rows + r] = X[b*in_batch_rows + r] for r < rows_per_batch."""
+    _f16(X, out)
+    check(lib.skg_batch_copy_f16(_p(X), _ld(X), in_batch_rows, _p(out), _ld(out), out_batch_rows, batches,
+                                 rows_per_batch, X.shape[1], _stream()), "skg_batch_copy_f16")
+    return out
+
+
 def silu(X, out=None):
     _f16(X)
     M, C = X.shape

@@ -1,0 +1,194 @@
+"""GPU tests (-m gpu) of the drop-in boundary: the reference's ``modules.*`` callables backed by libskg.so, the
+injected-attention variants (BASELINE configs 4 and 5) and an SD2.1-style architecture."""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load_npz, report, sd_from_npz
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def test_latent_edge_predictor_module_matches_reference_golden():
+    """modules.latent_predictor.LatentEdgePredictor.forward (HIP) vs the reference module's outputs, in the
+    reference's own ``(b w h)`` row order, train-mode BN incl. the running-stat side effects."""
+    from modules.latent_predictor import LatentEdgePredictor
+    for h in (8, 16):
+        d = load_npz(f"lgp_fwd_h{h}.npz")
+        sd = sd_from_npz(d)
+        x, t = torch.from_numpy(d["x"]), torch.from_numpy(d["t"])
+        m = LatentEdgePredictor(x.shape[1] + 40, 4, 9)
+        m.load_state_dict(sd)
+        m.to(DEV)
+        assert m.training                                            # nobody calls .eval()
+        y = m(x.to(DEV), t.to(DEV))
+        assert y.dtype == torch.float16 and y.shape == (2 * h * h, 4)
+        _, mx = report(f"LatentEdgePredictor h{h} train", y.float().cpu(), torch.from_numpy(d["y_train"]))
+        assert mx <= 4 * 2 ** -8
+        assert int(m.layers[2].num_batches_tracked) == 1
+        ref_rm = torch.from_numpy(d["sd_after.layers.2.running_mean"]).float()
+        assert (m.layers[2].running_mean.cpu() - ref_rm).abs().max() < 1e-3
+        m.load_state_dict(sd)
+        m.eval()
+        ye = m(x.to(DEV), t.to(DEV))
+        _, mx = report(f"LatentEdgePredictor h{h} eval", ye.float().cpu(), torch.from_numpy(d["y_eval"]))
+        assert mx <= 4 * 2 ** -8
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    from modules.latent_predictor import LatentEdgePredictor
+    from modules.pipeline import AntiGradientPipeline
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import TINY
+    p = AntiGradientPipeline.from_pretrained(None, unet_config=TINY, torch_dtype=torch.float16)
+    p = p.to("cuda")
+    p.unet.enable_xformers_memory_efficient_attention()
+    lgp = LatentEdgePredictor(synthetic.lgp_input_dim(TINY), 4, 9)
+    lgp.load_state_dict(synthetic.lgp_state_dict(synthetic.lgp_input_dim(TINY)))
+    lgp.to(p.unet.device, dtype=p.unet.dtype)                         # app.py:69
+    p.setup_lgp(lgp)
+    return p
+
+
+def test_pipeline_call_matches_sampler_and_oracle(pipe):
+    from oracle import guidance as og, unet as ounet
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import TINY
+    h = 32
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(1, 4, h, h, generator=g)
+    target = synthetic.sketch_targets(0, 1, h)
+    out = pipe("a cat", negative_prompt="blurry", height=8 * h, width=8 * h, num_inference_steps=2, latents=lat,
+               sketch_image=target, output_type="latent")
+    assert out.shape == (1, 4, h, h) and torch.isfinite(out).all()
+    ehs = pipe._encode_prompt("a cat", "cpu", 1, True, "blurry").half().float()
+    lgp_sd = {k: (v.float().cpu() if v.dtype.is_floating_point else v.cpu()) for k, v in pipe.lgp_model.state_dict().items()}
+    ref = og.sample_one(ounet.TINY, pipe.unet.state_dict(), lgp_sd, ehs, lat, target, 2)
+    # two guided steps from the same start: per-step agreement is pinned in test_gpu_pipeline; here the
+    # end-to-end call must land on the same trajectory (bound: two compounded guided updates)
+    assert report("pipeline 2-step latents vs oracle", out.cpu(), ref)[0] < 6e-2
+    # unguided call: no LGP, tight agreement
+    out0 = pipe("a cat", negative_prompt="blurry", height=8 * h, width=8 * h, num_inference_steps=3, latents=lat,
+                output_type="latent")
+    ref0 = og.sample_one(ounet.TINY, pipe.unet.state_dict(), None, ehs, lat, None, 3)
+    assert report("pipeline unguided vs oracle", out0.cpu(), ref0)[0] < 1e-2
+
+
+def test_pipeline_return_conventions_and_errors(pipe):
+    from PIL import Image
+    h = 32
+    lat = torch.randn(2, 4, h, h, generator=torch.Generator().manual_seed(1))
+    imgs = pipe(["a", "b"], height=256, width=256, num_inference_steps=2, latents=lat)
+    assert isinstance(imgs, list) and len(imgs) == 2 and isinstance(imgs[0], Image.Image)      # Q10: bare list
+    assert imgs[0].size == (256, 256)
+    tup = pipe("a", height=256, width=256, num_inference_steps=1, return_dict=False, generator=torch.Generator().manual_seed(0))
+    assert isinstance(tup, tuple) and tup[1] is None and isinstance(tup[0][0], Image.Image)
+    with pytest.raises(ValueError):
+        pipe(3, height=256, width=256)
+    with pytest.raises(ValueError):
+        pipe("a", height=250, width=256)
+    with pytest.raises(ValueError):
+        pipe("a", height=256, width=256, callback_steps=0)
+    seen = []
+    pipe("a", height=256, width=256, num_inference_steps=4, output_type="latent", callback=lambda i, t, x: seen.append((i, t)),
+         callback_steps=2)
+    assert [i for i, _ in seen] == [0, 2]
+
+
+def test_unet_facade_call_and_hooks(pipe):
+    """evaluation.py-style use: unet(noisy, t, ehs) then read block.output of the hooked blocks."""
+    from modules.latent_predictor import hook_unet
+    from sketch2img_amd.config import TINY, tap_channels, tap_sizes
+    blocks = hook_unet(pipe.unet)
+    assert len(blocks) == 9
+    with pytest.raises(AttributeError):
+        blocks[0].output
+    h = 32
+    x = torch.randn(2, 4, h, h)
+    ehs = pipe._encode_prompt("p", "cpu", 1, True, None)
+    eps = pipe.unet(x.to(DEV), torch.tensor(100), ehs).sample
+    assert eps.shape == (2, 4, h, h) and eps.dtype == torch.float32
+    for b, c, s in zip(blocks, tap_channels(TINY), tap_sizes(h)):
+        assert b.output.shape == (2, c, s, s) and b.output.dtype == torch.float32
+    del blocks[3].output
+    with pytest.raises(AttributeError):
+        blocks[3].output
+    pipe.setup_lgp(pipe.lgp_model)
+
+
+@pytest.mark.parametrize("variant", ["clip", "sketch"])
+def test_injected_attention_vs_oracle(variant):
+    from modules.pipeline import AntiGradientPipeline
+    from oracle import attn_inject, unet as ounet
+    from sketch2img_amd import ops
+    from sketch2img_amd.config import TINY
+    from sketch2img_amd.unet import CIN_PAD
+    p = AntiGradientPipeline.from_pretrained(None, unet_config=TINY).to("cuda")
+    if variant == "clip":
+        from sketch2img.modules.clip_guided_attn import SatMixin
+    else:
+        from modules.sketch_guided_attn import SatMixin
+    sat = quiet(SatMixin, p.unet)
+    sd = attn_inject.init_state_dict(ounet.TINY, variant)
+    sat.load_state_dict(sd)
+    sat.to(torch.device("cuda"), dtype=p.unet.dtype)
+    g = torch.Generator().manual_seed(5)
+    h = 32
+    x = torch.randn(2, 4, h, h, generator=g).half().float()
+    ehs = torch.randn(2, 77, TINY.cross_attention_dim, generator=g).half().float()
+    W = p.unet.state_dict()
+    if variant == "clip":
+        hid = torch.randn(1, 257, 1024, generator=g).half().float()
+        state = torch.stack([torch.zeros_like(hid), hid]).squeeze(1)         # clip_guided_inf.py:107
+        sat.set_state(state.to(DEV))
+        oracle_inject = lambda s: attn_inject.make_clip_inject(sd, state, s)
+    else:
+        with torch.no_grad():
+            res = ounet.unet_forward(ounet.TINY, W, x, 301, ehs, down_only=True)
+        res = [tuple(r.half().float() for r in blk) for blk in res]
+        sat.set_res_samples([tuple(r.to(DEV) for r in blk) for blk in res])
+        oracle_inject = lambda s: attn_inject.make_sketch_inject(ounet.TINY, sd, res, s)
+    for scale in (1.0, 0.35):
+        sat.set_scale(scale)
+        eps = p.unet(x.to(DEV), 301, ehs).sample.cpu()
+        with torch.no_grad():
+            ref, _ = ounet.unet_forward(ounet.TINY, W, x, 301, ehs, inject=oracle_inject(scale))
+        assert report(f"inject {variant} scale {scale}", eps, ref)[0] < 1e-2
+    with torch.no_grad():
+        base, _ = ounet.unet_forward(ounet.TINY, W, x, 301, ehs)
+    assert (ref - base).abs().max() > 1e-3                 # the injection really changes the output
+
+
+def test_sd21_style_architecture_vs_oracle():
+    """use_linear_projection + head_dim 64 + 1024-wide context (the SD2.1 differences), narrow channels."""
+    from dataclasses import replace
+    from oracle import unet as ounet
+    from sketch2img_amd import ops, synthetic
+    from sketch2img_amd.config import SD21
+    from sketch2img_amd.unet import CIN_PAD, HipUNet
+    cfg = replace(SD21, block_out_channels=(64, 128, 256, 256), num_heads=(1, 2, 4, 4), norm_groups=8,
+                  sample_size=32)
+    ocfg = ounet.UNetConfig(**{k: getattr(cfg, k) for k in ("in_channels", "out_channels", "block_out_channels",
+                                                              "layers_per_block", "cross_attention_dim", "num_heads",
+                                                              "use_linear_projection", "norm_groups", "sample_size")})
+    W = synthetic.unet_state_dict(cfg)
+    assert W["down_blocks.0.attentions.0.proj_in.weight"].dim() == 2
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 4, 32, 32, generator=g).half().float()
+    ehs = torch.randn(2, 77, 1024, generator=g).half().float()
+    net = HipUNet(cfg, W, DEV, need_backward=False)
+    net.prepare_context(ehs)
+    eps, _ = net.forward(ops.nchw_to_nhwc(x.to(DEV), CIN_PAD), 501, 2, 32)
+    with torch.no_grad():
+        ref, _ = ounet.unet_forward(ocfg, W, x, 501, ehs)
+    assert report("sd21-style eps", ops.nhwc_to_nchw(eps, 2, 4, 32, 32).cpu(), ref)[0] < 1e-2

@@ -1,0 +1,213 @@
+"""CPU tests (-m "not gpu") of the host side: the C-ABI library loads and exports every symbol include/skg.h
+declares with the argument list the ctypes binding uses, scheduler / schedule host logic is bit-exact against
+the oracle, synthetic weights equal the oracle's, and the N > 1 plumbing works under gloo with world_size 2.
+No kernel is launched here."""
+import os
+import re
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def parse_header():
+    """name -> (return_letter, arg_letters) from include/skg.h using the binding's letter code."""
+    src = open(os.path.join(ROOT, "include", "skg.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    out = {}
+    for m in re.finditer(r"\b(int|size_t|const char\*)\s+(skg_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        letters = ""
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    letters += "p"
+                elif a.startswith("float"):
+                    letters += "f"
+                elif a.startswith("unsigned"):
+                    letters += "u"
+                elif a.startswith("size_t"):
+                    letters += "z"
+                elif a.startswith("int"):
+                    letters += "i"
+                else:
+                    raise AssertionError(f"unparsed argument {a!r} of {name}")
+        out[name] = ({"int": "i", "size_t": "z", "const char*": "s"}[ret], letters)
+    return out
+
+
+def test_library_exports_every_declared_symbol_with_matching_signature():
+    from sketch2img_amd import _lib
+    decl = parse_header()
+    assert len(decl) >= 35
+    assert set(decl) == set(_lib.SIGNATURES), (set(decl) ^ set(_lib.SIGNATURES))
+    for name, sig in decl.items():
+        assert _lib.SIGNATURES[name] == sig, (name, _lib.SIGNATURES[name], sig)
+        assert hasattr(_lib.lib, name)
+    assert _lib.lib.skg_abi_version() == 1
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (skg_\w+)", nm))
+    assert set(decl) <= exported
+
+
+def test_host_side_argument_checks_do_not_need_a_gpu():
+    """Precondition failures return SKG_E_BADARG before any HIP call."""
+    from sketch2img_amd._lib import lib
+    assert lib.skg_gemm_f16(None, 0, None, 0, None, 0, 1, 8, 32, None, None, 0, 1.0, 0, None) == -1
+    assert lib.skg_gemm_f16(16, 24, 16, 24, 16, 8, 4, 8, 24, None, None, 0, 1.0, 0, None) == -1      # K % 32
+    assert lib.skg_attn_fwd(16, 8, 16, 8, 16, 8, 16, 8, None, 1, 1, 8, 8, 8, 24, 1.0, None) == -2      # dh = 24
+    assert lib.skg_conv3x3_f16(16, 32, 16, 16, 8, 1, 4, 4, 32, 8, 9, None, None, 0, 1.0, 0, None) == -2  # mode 9
+    assert lib.skg_gemm_variant(65536, 320, 2880, 320, 2) == 2160
+    assert lib.skg_gemm_variant(4096, 64, 96, 32, 2) == 1064
+
+
+def test_ddim_tables_bit_exact_vs_oracle():
+    from oracle import ddim as oddim
+    from sketch2img_amd.sampler import DDIMTables, guided_step
+    for T in (4, 10, 50):
+        a, b = DDIMTables.make(T), oddim.make_tables(T)
+        assert a.timesteps.dtype == np.int64 and np.array_equal(a.timesteps, b.timesteps)
+        assert torch.equal(a.alphas_cumprod, b.alphas_cumprod) and a.final_alpha_cumprod == b.final_alpha_cumprod
+        for t in a.timesteps.tolist():
+            assert a.coeffs(t) == oddim.step_coeffs(b, t)
+    assert DDIMTables.make(50).timesteps.tolist() == list(range(981, 0, -20))
+    assert [i for i in range(50) if guided_step(i, 50)] == list(range(26))
+    assert [i for i in range(10) if guided_step(i, 10)] == list(range(6))
+
+
+def test_synthetic_weights_equal_oracle_init_and_configs_agree():
+    from oracle import lgp as olgp, unet as ounet
+    from sketch2img_amd import config, synthetic
+    for a, b in ((config.SD15, ounet.SD15), (config.SD21, ounet.SD21), (config.TINY, ounet.TINY)):
+        assert vars(a) == vars(b)
+        assert list(synthetic.unet_param_shapes(a).items()) == list(ounet.param_shapes(b).items())
+    assert sum(int(np.prod(s)) for s in synthetic.unet_param_shapes(config.SD15).values()) == 859_520_964
+    A, B = synthetic.unet_state_dict(config.TINY), ounet.init_weights(ounet.TINY)
+    assert list(A) == list(B) and all(torch.equal(A[k], B[k]) for k in A)
+    n = synthetic.lgp_input_dim(config.SD15)
+    assert n == 9320
+    la, lb = synthetic.lgp_state_dict(488), olgp.init_state_dict(488)
+    assert list(la) == list(lb) and all(torch.equal(la[k], lb[k]) for k in la)
+    assert config.tap_channels(config.SD15) == ounet.tap_channels(ounet.SD15)
+    assert config.up_block_plan(config.SD15) == ounet.up_block_plan(ounet.SD15)
+    # per-sample inputs depend only on the GLOBAL sample index (placement independent sharding)
+    assert torch.equal(synthetic.initial_latents(3, 2, 8)[1], synthetic.initial_latents(4, 1, 8)[0])
+    assert torch.equal(synthetic.sketch_targets(3, 2, 8)[1], synthetic.sketch_targets(4, 1, 8)[0])
+
+
+def test_weight_packs_match_conv_definitions():
+    """The implicit-GEMM weight packs (forward and dgrad) against F.conv2d / its autograd, on the CPU."""
+    import torch.nn.functional as F
+    from sketch2img_amd.unet import pack_conv, pack_conv_dgrad
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(6, 5, 3, 3, generator=g)
+    x = torch.randn(1, 5, 7, 7, generator=g)
+    wp = pack_conv(w, "cpu").float().reshape(6, 3, 3, 5)
+    xp = F.pad(x, (1, 1, 1, 1))
+    y = torch.zeros(1, 6, 7, 7)
+    for ky in range(3):
+        for kx in range(3):
+            y += torch.einsum("oc,bchw->bohw", wp[:, ky, kx], xp[:, :, ky:ky + 7, kx:kx + 7])
+    assert torch.allclose(y, F.conv2d(x.half().float(), w.half().float(), padding=1), atol=2e-2)
+    gy = torch.randn(1, 6, 7, 7, generator=g).half().float()
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w.half().float(), padding=1).backward(gy)
+    wd = pack_conv_dgrad(w, "cpu").float().reshape(5, 3, 3, 6)
+    gp = F.pad(gy, (1, 1, 1, 1))
+    gx = torch.zeros(1, 5, 7, 7)
+    for ky in range(3):
+        for kx in range(3):
+            gx += torch.einsum("co,bohw->bchw", wd[:, ky, kx], gp[:, :, ky:ky + 7, kx:kx + 7])
+    assert torch.allclose(gx, xr.grad, atol=2e-2)
+
+
+def test_injection_routing_and_names_match_oracle():
+    from oracle import attn_inject
+    from sketch2img_amd import inject
+    from sketch2img_amd.config import SD15
+    from oracle import unet as ounet
+    assert inject.transformer_block_paths(SD15) == ounet.transformer_block_paths(ounet.SD15)
+    assert inject.block_dims(SD15) == attn_inject.block_dims(ounet.SD15)
+    rs = [tuple(torch.full((1,), 10 * i + j) for j in range(3 if i < 3 else 2)) for i in range(4)]
+    assert [int(t) for t in inject.route_res_samples(rs)] == [int(t) for t in attn_inject.route_res_samples(rs)]
+    assert inject.module_name("mid_block.attentions.0.transformer_blocks.0") == \
+        "sketch_attn_mid_block_attentions_0_transformer_blocks_0"
+
+
+def test_module_mirror_state_dict_layouts():
+    """The drop-in nn.Modules expose the reference's checkpoint key layouts (LGP: golden manifest)."""
+    import json
+    from modules.latent_predictor import LatentEdgePredictor
+    from tests.util import GOLDEN
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
+    m = LatentEdgePredictor(9320, 4, 9)
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(meta["manifest"]) and m.training
+    for k, v in sd.items():
+        assert list(v.shape) == meta["manifest"][k][0] and str(v.dtype) == meta["manifest"][k][1]
+    assert sum(p.numel() for p in m.parameters()) == meta["n_params"]
+    assert torch.count_nonzero(m.layers[0].bias) == 0                      # zeros_ init (:35)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, torch
+    sys.path.insert(0, %r)
+    import torch.distributed as dist
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import TINY
+    from sketch2img_amd.dist import broadcast_state_dict, gather_latents, shard_range
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ref = synthetic.unet_state_dict(TINY)
+    sd = broadcast_state_dict(ref if rank == 0 else None, synthetic.unet_param_shapes(TINY), "cpu", src=0)
+    assert list(sd) == list(ref) and all(torch.equal(sd[k].float(), ref[k]) for k in ref), "unet broadcast"
+    lref = synthetic.lgp_state_dict(488)
+    lsd = broadcast_state_dict(lref if rank == 0 else None, None, "cpu", src=0)
+    assert list(lsd) == list(lref)
+    assert all(torch.equal(lsd[k].float(), lref[k].float()) for k in lref), "lgp broadcast"
+    assert lsd["layers.2.num_batches_tracked"].dtype == torch.int64
+    total = 5
+    first, count = shard_range(total, rank, world)
+    x = synthetic.initial_latents(first, count, 8) + 1.0
+    if count < 3:
+        x = torch.cat([x, torch.zeros(3 - count, 4, 8, 8)])            # equal-size gather
+    got = gather_latents(x, world, dst=0)
+    if rank == 0:
+        allx = torch.cat([g[:shard_range(total, r, world)[1]] for r, g in enumerate(got)])
+        assert torch.equal(allx, synthetic.initial_latents(0, total, 8) + 1.0), "gather"
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank", rank, "ok")
+""")
+
+
+def test_two_process_gloo_broadcast_and_gather(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o[-2000:]
+
+
+def test_shard_range_covers_everything():
+    from sketch2img_amd.dist import shard_range
+    for total in (1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == total
+            nxt = 0
+            for f, c in spans:
+                assert f == nxt
+                nxt += c
