@@ -28,7 +28,7 @@ import torch
 from . import ops
 from .config import UNetConfig, up_block_plan
 
-CIN_PAD = 32      # latent channels padded to one BK slice of the implicit-GEMM conv
+CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
 CTX_PAD = 8       # text tokens padded to a multiple of 8 (77 -> 80)
 
