@@ -35,7 +35,6 @@ namespace {
 float* g_ws = nullptr;          // caller-owned split-K workspace (skg_set_workspace)
 size_t g_ws_bytes = 0;
 
-constexpr int BM = 128;
 constexpr int BK = 64;
 constexpr unsigned OOB = 0x80000000u;     // voffset that fails the descriptor's range check -> zeros
 
@@ -46,15 +45,24 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, half_t* lds_w
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
-template <int BN, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
-                                                       unsigned a_bytes, unsigned b_bytes, unsigned a_shift,
-                                                       int kt_per_split, float* __restrict__ ws) {
-  constexpr int WN = BN / 2;
+// Tile configurations: <BM, BN, WGM, WGN> = block tile and wave grid.
+//   128 x {160,128,64}, 2 x 2 waves (wave tile 64 x BN/2), 2 workgroups per CU   - the general case
+//   256 x 320,          2 x 4 waves (wave tile 128 x 80),  1 workgroup per CU    - 64x64-resolution layers:
+//     half the L2->LDS bytes per output, the activation panel of an N = 320 layer is read exactly once
+template <int BM, int BN, int WGM, int WGN, int MODE>
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
+                                                                  unsigned a_bytes, unsigned b_bytes,
+                                                                  unsigned a_shift, int kt_per_split,
+                                                                  float* __restrict__ ws) {
+  constexpr int NW = WGM * WGN;       // waves
+  constexpr int NTHR = NW * 64;
+  constexpr int WM = BM / WGM;        // wave tile rows (64 or 128)
+  constexpr int WN = BN / WGN;        // wave tile columns
   constexpr int NT = WN / 16;         // 5, 4 or 2
-  constexpr int MT = 4;
-  constexpr int ACH = BM / 8 / 4;     // A 8-row chunks per wave (4)
-  constexpr int BCH = BN / 8 / 4;     // B 8-row chunks per wave (5, 4, 2)
+  constexpr int MT = WM / 16;         // 4 or 8
+  constexpr int ACH = BM / 8 / NW;    // A 8-row chunks per wave (4)
+  constexpr int BCH = BN / 8 / NW;    // B 8-row chunks per wave (5, 4, 2)
+  static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
   constexpr int STAGE = (BM + BN) * BK;               // halves per stage: A tile then B tile
   constexpr bool AFFINE = (MODE == MODE_DIRECT || MODE == MODE_S1 || MODE == MODE_S2);
   __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
   const int g = lane >> 4, l16 = lane & 15;
 
   // ---- XCD-aware tile assignment (bijective) ------------------------------------------------------
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
   unsigned a_img[ACH];                // UP2/S2T: byte offset of the image + piece
 #pragma unroll
   for (int j = 0; j < ACH; ++j) {
-    const int r = (j * 4 + wave) * 8 + lr;
+    const int r = (j * NW + wave) * 8 + lr;
     const unsigned pk = (unsigned)(lq ^ ((r >> 1) & 7)) * 16u;      // byte offset of the logical piece
     const int m = m0 + r;
     const bool ok = m < p.M;
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
   unsigned b_voff[BCH];
 #pragma unroll
   for (int j = 0; j < BCH; ++j) {
-    const int r = (j * 4 + wave) * 8 + lr;
+    const int r = (j * NW + wave) * 8 + lr;
     const unsigned pk = (unsigned)(lq ^ ((r >> 1) & 7)) * 16u;
     const int n = n0 + r;
     b_voff[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb * 2u + pk : OOB;
@@ -171,11 +179,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
       }
       unsigned so = soff;
       if (!AFFINE) so = (unsigned)(k0 - tap * p.Cin) * 2u;     // gather modes carry the pixel in voffset
-      dma16(rA, &smem[buf * STAGE + (j * 4 + wave) * 8 * BK], v, so);
+      dma16(rA, &smem[buf * STAGE + (j * NW + wave) * 8 * BK], v, so);
     }
     const unsigned sb = (unsigned)k0 * 2u;
 #pragma unroll
-    for (int j = 0; j < BCH; ++j) dma16(rB, &smem[buf * STAGE + BM * BK + (j * 4 + wave) * 8 * BK], b_voff[j], sb);
+    for (int j = 0; j < BCH; ++j) dma16(rB, &smem[buf * STAGE + BM * BK + (j * NW + wave) * 8 * BK], b_voff[j], sb);
   };
 
   float4_t acc[MT][NT];
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
   int a_ad[MT][2], b_ad[NT][2];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int row = wm * 64 + i * 16 + l16;
+    const int row = wm * WM + i * 16 + l16;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) a_ad[i][ks] = row * BK + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 3);
   }
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
     float* slab = ws + (size_t)split * p.M * p.N;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + l16;
+      const int m = m0 + wm * WM + i * 16 + l16;
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -252,48 +260,58 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmParams p, int t
   if (staged) {
     // Final fp16 values go through LDS (the stages are dead now) so that the global stores are 16 bytes
     // per lane over whole output rows, instead of 8-byte fragments of 16 different rows per instruction.
+    // The tile is staged in slabs of WM rows x BN (one wave-row of the wave grid at a time).
     constexpr int OP = BN + 8;                 // staging pitch (halves)
-    __syncthreads();                           // every wave has finished reading the last stage
+    constexpr bool ONE = BM * OP <= 2 * STAGE; // whole tile fits: one slab, else one wave-row at a time
+    constexpr int SLABS = ONE ? 1 : WGM;
+    constexpr int SROWS = ONE ? BM : WM;
+    static_assert(SROWS * OP <= 2 * STAGE, "staging slab must fit in the pipeline stages");
+    constexpr int PPR = BN / 8;                // 16-byte pieces per tile row
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int ml = wm * 64 + i * 16 + l16;
-      const int m = m0 + ml;
+    for (int slab = 0; slab < SLABS; ++slab) {
+      __syncthreads();                         // stage reads (slab 0) / previous slab's stores are done
+      if (ONE || wm == slab) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int nl = wn * WN + j * 16 + g * 4;
-        const int n = n0 + nl;
-        float4_t v = acc[i][j];
-        if (m < p.M && n < p.N) {
-          if (p.bias) {
-            const half4_t b = ld_half4(p.bias + n);
-            v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
-          }
-          v *= p.alpha;
-          if (p.res) {
-            const half4_t r = ld_half4(p.res + (size_t)m * p.ldr + n);
-            v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-          }
-          if (relu) {
-            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        for (int i = 0; i < MT; ++i) {
+          const int ml = (ONE ? wm * WM : 0) + i * 16 + l16;
+          const int m = m0 + slab * SROWS + ml;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            const int nl = wn * WN + j * 16 + g * 4;
+            const int n = n0 + nl;
+            float4_t v = acc[i][j];
+            if (m < p.M && n < p.N) {
+              if (p.bias) {
+                const half4_t b = ld_half4(p.bias + n);
+                v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+              }
+              v *= p.alpha;
+              if (p.res) {
+                const half4_t r = ld_half4(p.res + (size_t)m * p.ldr + n);
+                v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+              }
+              if (relu) {
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+              }
+            }
+            half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            st_half4(&smem[ml * OP + nl], o);
           }
         }
-        half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        st_half4(&smem[ml * OP + nl], o);
       }
-    }
-    __syncthreads();
-    constexpr int PPR = BN / 8;                // 16-byte pieces per tile row
-    for (int pi = tid; pi < BM * PPR; pi += 256) {
-      const int r = pi / PPR, c = (pi - r * PPR) * 8;
-      const int m = m0 + r, n = n0 + c;
-      if (m < p.M && n < p.N)
-        st_half8(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n, ld_half8(&smem[r * OP + c]));
+      __syncthreads();
+      for (int pi = tid; pi < SROWS * PPR; pi += NTHR) {
+        const int r = pi / PPR, c = (pi - r * PPR) * 8;
+        const int m = m0 + slab * SROWS + r, n = n0 + c;
+        if (m < p.M && n < p.N)
+          st_half8(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n, ld_half8(&smem[r * OP + c]));
+      }
     }
     return;
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + l16;
+    const int m = m0 + wm * WM + i * 16 + l16;
     if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -387,43 +405,50 @@ inline bool eligible(const GemmParams& p, int mode) {
   return operand_bytes(p, mode, a, b, s);
 }
 
-// largest tile width that divides N and still gives >= ~0.8 workgroups per CU; else 64
-inline int pick_bn(int M, int N) {
-  const long tm = skg_cdiv(M, BM);
-  if (N % 160 == 0 && tm * (N / 160) >= 200) return 160;
-  if (N % 128 == 0 && tm * (N / 128) >= 200) return 128;
-  return 64;
+struct TileCfg { int bm, bn; };
+
+// 256 x 320 (8 waves) when it still puts a workgroup on (almost) every CU; else the widest 128-row tile that
+// divides N and gives >= ~0.8 workgroups per CU; else 128 x 64 (with split-K if a workspace is set)
+inline TileCfg pick_tile(int M, int N, int K) {
+  // the 8-wave tile pays off (+3..18 % measured) once the K loop is long; short-K layers are bound by their
+  // output write and prefer two resident workgroups per CU
+  if (K >= 1024 && N % 320 == 0 && (long)skg_cdiv(M, 256) * (N / 320) >= 240) return {256, 320};
+  const long tm = skg_cdiv(M, 128);
+  if (N % 160 == 0 && tm * (N / 160) >= 200) return {128, 160};
+  if (N % 128 == 0 && tm * (N / 128) >= 200) return {128, 128};
+  return {128, 64};
 }
 
-template <int BN, int MODE>
-void launch_bn(const GemmParams& p, hipStream_t st) {
+template <int BM, int BN, int WGM, int WGN, int MODE>
+void launch_cfg(const GemmParams& p, hipStream_t st) {
   const int tiles_n = skg_cdiv(p.N, BN);
   const int ntiles = skg_cdiv(p.M, BM) * tiles_n;
   unsigned long long a, b, s;
   operand_bytes(p, MODE, a, b, s);
   const int KT = p.K / BK;
   const int splits = BN == 64 ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
+  constexpr int NTHR = WGM * WGN * 64;
   if (splits > 1) {
     const int per = skg_cdiv(KT, splits);
     const int ns = skg_cdiv(KT, per);            // every split non-empty
-    hipLaunchKernelGGL((gemm2_kernel<BN, MODE>), dim3(ntiles * ns), dim3(256), 0, st, p, tiles_n, ntiles * ns,
-                       (unsigned)a, (unsigned)b, (unsigned)s, per, g_ws);
+    hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(ntiles * ns), dim3(NTHR), 0, st, p, tiles_n,
+                       ntiles * ns, (unsigned)a, (unsigned)b, (unsigned)s, per, g_ws);
     size_t blocks = ((size_t)p.M * (p.N / 4) + 255) / 256;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p,
                        (const float*)g_ws, ns);
     return;
   }
-  hipLaunchKernelGGL((gemm2_kernel<BN, MODE>), dim3(ntiles), dim3(256), 0, st, p, tiles_n, ntiles, (unsigned)a,
-                     (unsigned)b, (unsigned)s, KT, (float*)nullptr);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles,
+                     (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
 }
 
 template <int MODE>
 void launch_mode(const GemmParams& p, hipStream_t st) {
-  switch (pick_bn(p.M, p.N)) {
-    case 160: launch_bn<160, MODE>(p, st); break;
-    case 128: launch_bn<128, MODE>(p, st); break;
-    default: launch_bn<64, MODE>(p, st); break;
-  }
+  const TileCfg t = pick_tile(p.M, p.N, p.K);
+  if (t.bm == 256) launch_cfg<256, 320, 2, 4, MODE>(p, st);
+  else if (t.bn == 160) launch_cfg<128, 160, 2, 2, MODE>(p, st);
+  else if (t.bn == 128) launch_cfg<128, 128, 2, 2, MODE>(p, st);
+  else launch_cfg<128, 64, 2, 2, MODE>(p, st);
 }
 
 }  // namespace
@@ -432,7 +457,7 @@ void skg_gemm2_set_workspace(float* ws, size_t bytes) { g_ws = ws; g_ws_bytes = 
 
 int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode) {
   if (K % BK != 0 || M < 1 || (mode != MODE_DIRECT && Cin % BK != 0)) return 0;
-  return pick_bn(M, N);
+  return pick_tile(M, N, K).bn;
 }
 
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {

@@ -104,16 +104,25 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(
 
 // ---- stage 2: fold the chunk partials.  KIND 0 -> (mean, rstd); KIND 1 -> (m1, m2) -------------
 template <int KIND>
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nch, int groups, float inv_n,
-                                   float eps, float* __restrict__ out, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (b, group)
-  if (i >= total) return;
-  const int b = i / groups, grp = i - b * groups;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nch, int groups,
+                                                          float inv_n, float eps, float* __restrict__ out, int total) {
+  // one 16-lane group per (row, group): lanes stride over the chunk partials, fixed-order xor reduction
+  const int i = (blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
   float s1 = 0.f, s2 = 0.f;
-  for (int c = 0; c < nch; ++c) {
-    const float* q = partial + (((size_t)b * nch + c) * groups + grp) * 2;
-    s1 += q[0]; s2 += q[1];
+  if (i < total) {
+    const int b = i / groups, grp = i - b * groups;
+    for (int c = sub; c < nch; c += 16) {
+      const float* q = partial + (((size_t)b * nch + c) * groups + grp) * 2;
+      s1 += q[0]; s2 += q[1];
+    }
   }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if (i >= total || sub != 0) return;
   if (KIND == 0) {
     const float mean = s1 * inv_n;
     const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
@@ -302,7 +311,7 @@ extern "C" int skg_groupnorm_stats(const void* X, int ldx, int rows, int HW, int
                      (const half_t*)nullptr, 0, HW, C, groups, (const float*)nullptr, (const half_t*)nullptr,
                      (const half_t*)nullptr, 0, partial);
   const int total = rows * groups;
-  hipLaunchKernelGGL((gn_finalize_kernel<0>), dim3(skg_cdiv(total, 256)), dim3(256), 0, st, partial, nch,
+  hipLaunchKernelGGL((gn_finalize_kernel<0>), dim3(skg_cdiv(total * 16, 256)), dim3(256), 0, st, partial, nch,
                      groups, 1.f / ((float)HW * (C / groups)), eps, stats, total);
   SKG_CHECK_LAUNCH("skg_groupnorm_stats");
   return SKG_OK;
@@ -338,7 +347,7 @@ extern "C" int skg_groupnorm_bwd(const void* X, int ldx, const void* dY, int ldd
                      (const half_t*)dY, lddy, HW, C, groups, stats, (const half_t*)gamma, (const half_t*)beta,
                      silu, partial);
   const int total = rows * groups;
-  hipLaunchKernelGGL((gn_finalize_kernel<1>), dim3(skg_cdiv(total, 256)), dim3(256), 0, st, partial, nch,
+  hipLaunchKernelGGL((gn_finalize_kernel<1>), dim3(skg_cdiv(total * 16, 256)), dim3(256), 0, st, partial, nch,
                      groups, 1.f / ((float)HW * (C / groups)), 0.f, sums, total);
   const size_t items = (size_t)rows * HW * (C / 8);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_grid(items)), dim3(256), 0, st, (const half_t*)X, ldx,
