@@ -276,3 +276,56 @@ def test_unet_sd15_forward_vs_oracle_full_size():
         assert report(f"unet sd15 tap{i}", from_nhwc(tp, 2, s, s), r)[0] < 1e-2
     _, m = report("unet sd15 eps (abs)", ops.nhwc_to_nchw(eps, 2, 4, 64, 64).cpu(), re)
     print(f"[parity] max |eps - eps_oracle| = {m:.3e} (north-star aspiration 1e-3 at fp16)")
+
+
+def test_sd15_full_size_guided_step_and_backward_vs_oracle():
+    """BASELINE's full size (SD1.5, 64x64 latents, 9320-channel LGP), one sample: the UNet backward-to-input
+    for random tap gradients, then one complete guided step (i = 0, t = 981), against the CPU oracle."""
+    import os
+    from oracle import ddim as oddim, guidance as og, unet as ounet
+    from sketch2img_amd import ops, synthetic
+    from sketch2img_amd.config import SD15, tap_channels
+    from sketch2img_amd.lgp import HipLGP
+    from sketch2img_amd.sampler import DDIMTables, HipSampler
+    from sketch2img_amd.unet import CIN_PAD, HipUNet, Stash
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    cfg = ounet.SD15
+    W = synthetic.unet_state_dict(SD15)
+    sd = synthetic.lgp_state_dict(synthetic.lgp_input_dim(SD15))
+    h = 64
+    x0 = synthetic.initial_latents(0, 1, h)
+    target = synthetic.sketch_targets(0, 1, h)
+    ehs = synthetic.text_embeddings(1)
+    net = HipUNet(SD15, W, DEV)
+    net.prepare_context(ehs)
+    tab = DDIMTables.make(50)
+    t = int(tab.timesteps[0])
+    net.prepare_timesteps([t])
+    # ---- backward-to-input with random tap gradients
+    xx = torch.cat([x0, x0]).half().float()
+    stash = Stash()
+    eps, taps = net.forward(ops.nchw_to_nhwc(xx.to(DEV), CIN_PAD), t, 2, h, stash)
+    g = torch.Generator().manual_seed(77)
+    tg = [torch.randn(1, tp.shape[1], s, s, generator=g).half().float() for tp, s in taps]
+    dx = net.backward(stash, [nhwc16(v) for v in tg])
+    xr = xx.clone().requires_grad_(True)
+    re, rt = ounet.unet_forward(cfg, W, xr, t, ehs)
+    gr = torch.autograd.grad(sum((r[1:] * v).sum() for r, v in zip(rt, tg)), xr, retain_graph=True)[0][1:]
+    assert report("sd15 d/dx (random tap grads)", ops.nhwc_to_nchw(dx, 1, 4, h, h).cpu(), gr)[0] < 2e-2
+    del stash, dx
+    # ---- one full guided step
+    sampler = HipSampler(net, HipLGP(sd, tap_channels(SD15), DEV))
+    xp, e_hip, aux = sampler.step(x0.to(DEV), x0.to(DEV), target.to(DEV), tab, 0, 7.5, 1.6, want_eps=True)
+    otab = oddim.make_tables(50)
+    eu, ec = re.detach().chunk(2)
+    e_ref = eu + 7.5 * (ec - eu)
+    nxt = oddim.ddim_step(otab, e_ref, t, x0)
+    new, oaux = og.apply_anti_gradient(rt, sd, otab.alphas_cumprod, xr, nxt, x0, t, target, 1.6, return_aux=True)
+    assert report("sd15 guided step eps", e_hip.cpu(), e_ref)[0] < 1e-2
+    upd_ref, upd = new - nxt, xp.cpu() - nxt
+    nr = float(upd.norm() / upd_ref.norm())
+    cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm()))
+    print(f"[parity] sd15 guided step: |update| hip/oracle={nr:.4f} cos={cos:.5f} loss hip={float(aux[0, 3]):.4e} "
+          f"oracle={float(oaux['loss']):.4e}")
+    assert abs(nr - 1) < 2e-2 and cos > 0.995
+    assert abs(float(aux[0, 3]) - float(oaux["loss"])) < 2e-2 * float(oaux["loss"])
