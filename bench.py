@@ -54,8 +54,14 @@ class LaunchTimer:
         from sketch2img_amd._lib import lib
         ops = self.ops
 
+        MODES = {"DIRECT": 0, "S1": 1, "S2": 2, "UP2": 3, "S2T": 4}
+
         def kname(variant, mode):
-            return f"{'gemm2_kernel' if variant >= 2000 else 'gemm_kernel'}<{variant % 1000},{mode}>"
+            """The name rocprofv3 prints for the instantiation that ran (template arguments spelled out)."""
+            bn = variant % 1000
+            if variant >= 2000:
+                return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}>"
+            return f"gemm_kernel<{bn}, {MODES[mode]}>"
 
         def gemm(A, B, *a, **k):
             M, K = A.shape
@@ -64,7 +70,8 @@ class LaunchTimer:
             e0.record()
             out = self._gemm(A, B, *a, **k)
             e1.record()
-            self.rec.append((kname(lib.skg_gemm_variant(M, N, K, 0, 0), "DIRECT"), 2.0 * M * N * K, e0, e1))
+            nbytes = 2.0 * (M * K + N * K + M * N * (2 if k.get("out_f32") else 1) + (M * N if k.get("residual") is not None else 0))
+            self.rec.append((kname(lib.skg_gemm_variant(M, N, K, 0, 0), "DIRECT"), 2.0 * M * N * K, e0, e1, nbytes))
             return out
 
         def conv(X, Wp, rows, IH, IW, mode=0, *a, **k):
@@ -76,7 +83,8 @@ class LaunchTimer:
             out = self._conv(X, Wp, rows, IH, IW, mode, *a, **k)
             e1.record()
             name = ("S1", "S2", "UP2", "S2T")[mode]
-            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, 9 * Cin, Cin, 1 + mode), name), 2.0 * M * Cout * 9 * Cin, e0, e1))
+            nbytes = 2.0 * (X.shape[0] * Cin + Cout * 9 * Cin + M * Cout + (M * Cout if k.get("residual") is not None else 0))
+            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, 9 * Cin, Cin, 1 + mode), name), 2.0 * M * Cout * 9 * Cin, e0, e1, nbytes))
             return out
 
         ops.gemm, ops.conv3x3 = gemm, conv
@@ -88,10 +96,26 @@ class LaunchTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, e0, e1 in self.rec:
-            a = agg.setdefault(name, [0, 0.0, 0.0])
-            a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3
+        for name, fl, e0, e1, nb in self.rec:
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += nb
         return agg
+
+
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes (profiles/
+    r01_hbm_counters.json: FETCH_SIZE and WRITE_SIZE collected in separate passes over the same workload).
+    Units are KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads (MI355X_MICROARCH.md
+    section HBM; re-checked here on GEGLU / GroupNorm-apply whose read:write byte ratio is known) -> doubled."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_counters.json")
+    if not os.path.exists(path):
+        return None
+    data = json.load(open(path))
+    for k, v in data.items():
+        if kernel_name in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            f, w = v["FETCH_SIZE"], v["WRITE_SIZE"]
+            return (2.0 * f["sum"] / f["launches"] + w["sum"] / w["launches"]) * 1024.0
+    return None
 
 
 def cpu_baseline(sd_unet, sd_lgp, ehs2, latent0, target0):
@@ -195,10 +219,12 @@ def main():
         with LaunchTimer(ops) as lt:
             sampler.sample(lat0, target, T, tables=tab)
         agg = lt.summary()
-        name, (n, fl, sec) = max(agg.items(), key=lambda kv: kv[1][2])
+        name, (n, fl, sec, nb) = max(agg.items(), key=lambda kv: kv[1][2])
         tot_sec = sum(v[2] for v in agg.values())
         roof = dict(bound="mfma", kernel=name, achieved=fl / sec / 1e12, peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
-                    frac=fl / sec / 1e12 / PEAK_FP16_TFLOPS, traffic=None, launches=n,
+                    frac=fl / sec / 1e12 / PEAK_FP16_TFLOPS, traffic=pmc_traffic(name), algorithmic_bytes=nb / n,
+                    traffic_source="profiles/r01_hbm_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 10-step run; "
+                                   "bytes per launch = (2*FETCH + WRITE)*1024)", launches=n,
                     avg_launch_us=sec / n * 1e6, avg_launch_gflop=fl / n / 1e9,
                     all_gemm_conv_tflops=sum(v[1] for v in agg.values()) / tot_sec / 1e12,
                     gemm_conv_share_of_step=tot_sec / (dt / args.steps),
