@@ -27,7 +27,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-F_IMG_TFLOP = 107.65          # algorithmic TFLOP per image, SURVEY.md section 8(d)
+F_IMG_TFLOP = 107.65          # algorithmic TFLOP per image at 50 steps / 26 guided, SURVEY.md section 8(d)
+
+
+def f_img_tflop(T):
+    """SURVEY 8(d) per-image work for T DDIM steps: UNet fwd 2 rows/step, + per guided step (i <= 0.5*T) the
+    cond-row UNet backward and the LGP forward (2 rows) + backward (1 row).  T = 50 -> 107.65."""
+    guided = sum(1 for i in range(T) if not (i > 0.5 * T))
+    return (T * 2 * 803.27 + guided * (929.33 + 3 * 40.50)) / 1e3
 PEAK_FP16_TFLOPS = 2500.0     # dense fp16 MFMA peak, MI355X_MICROARCH.md
 
 
@@ -155,13 +162,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    # test-only switches: run the N > 1 code path with several ranks on ONE GPU (gloo carries CUDA tensors)
+    backend = os.environ.get("SKG_BENCH_BACKEND", "nccl")
+    if "SKG_BENCH_DEVICE" in os.environ:
+        local = int(os.environ["SKG_BENCH_DEVICE"])
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)        # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)    # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
 
     from sketch2img_amd import ops, synthetic
     from sketch2img_amd.config import SD15, tap_channels
@@ -244,7 +258,7 @@ def main():
                                    "CFG 7.5, LGP sketch guidance on steps 0..25 (beta 1.6)",
                        "samples_per_gpu": S, "global_batch": world * S, "ddim_steps": T,
                        "parallelism": f"replicas x{world} (samples sharded, weights broadcast, latents gathered)"},
-            "achieved_tflops_per_gpu": value / world * F_IMG_TFLOP,
+            "achieved_tflops_per_gpu": value / world * f_img_tflop(T),
             "outputs_finite": finite, "setup_s": t_setup,
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -130,7 +130,7 @@ __device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __rest
 // Softmax arithmetic is kept to ~6 VALU per score: raw v_exp_f32 (arguments are <= 0, no range fix-up),
 // scale folded into one FMA, masking only on a ragged last tile.
 template <int KS, int ND>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   constexpr int KP = KS * 32 + 8;
   __shared__ __attribute__((aligned(16))) half_t Ks[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Vs[ND * 16 * TP];
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 
 // dQ: per 64-query block, loop over key tiles.  dS^T = P^T o (dP^T - delta);  dQ^T += K^T dS^T.
 template <int KS, int ND>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
   constexpr int KP = KS * 32 + 8;
   __shared__ __attribute__((aligned(16))) half_t Ks[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Vr[64 * KP];
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
 //   S = Q K^T (rows q), P = exp(S*scale - lse[q]), dP = dO V^T, dS = P o (dP - delta[q])
 //   dV^T += dO^T P,   dK^T += Q^T dS      (A operands = transposed tiles, B = registers)
 template <int KS, int ND>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(const AttnParams p) {
   constexpr int KP = KS * 32 + 8;
   __shared__ __attribute__((aligned(16))) half_t Qs[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Ds[64 * KP];
