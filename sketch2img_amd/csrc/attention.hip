@@ -132,8 +132,12 @@ __device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __rest
 template <int KS, int ND>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   constexpr int KP = KS * 32 + 8;
-  __shared__ __attribute__((aligned(16))) half_t Ks[64 * KP];
-  __shared__ __attribute__((aligned(16))) half_t Vs[ND * 16 * TP];
+  constexpr int KSZ = 64 * KP, VSZ = ND * 16 * TP;
+  __shared__ __attribute__((aligned(16))) half_t lds[2 * (KSZ + VSZ)];      // two (K, V^T) stages
+  half_t* const Ks0 = lds;
+  half_t* const Vs0 = lds + KSZ;
+  half_t* const Ks1 = lds + KSZ + VSZ;
+  half_t* const Vs1 = lds + 2 * KSZ + VSZ;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -156,15 +160,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
   const half_t* Vb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
   const int nt = (p.Nkv + 63) / 64;
-  KVRegs<KS, ND> regs;
-  kv_load<KS, ND>(regs, Kb, p.ldk, Vb, p.ldvt, 0, p.kv_stride, dh);
-  kv_store<KS, ND>(regs, Ks, Vs);
-  __syncthreads();
-  for (int t0 = 0; t0 < nt; ++t0) {
-    const int kv0 = t0 * 64;
-    const bool more = t0 + 1 < nt;
-    if (more) kv_load<KS, ND>(regs, Kb, p.ldk, Vb, p.ldvt, kv0 + 64, p.kv_stride, dh);
 
+  // one 64-key tile: S^T = K Q^T, online softmax, O^T += V^T P^T
+  auto tile = [&](const half_t* __restrict__ Ks, const half_t* __restrict__ Vs, int kv0) {
     float4_t s[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -209,10 +207,47 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
       for (int k2 = 0; k2 < 2; ++k2)
         o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag(Vs, u, k2, l16, g), pb[k2], o[u], 0, 0, 0);
     }
-    if (more) {
-      __syncthreads();               // every wave is done reading tile t0
-      kv_store<KS, ND>(regs, Ks, Vs);
+  };
+
+  // Two LDS stages + two register sets: tile t computes from stage t&1 while tile t+1 sits in registers on
+  // its way to the other stage and tile t+2 is in flight from L2/HBM - a prefetch distance of two tiles of
+  // compute with ONE barrier per tile.  Invariant at the top of the (unrolled-by-2) loop, t even:
+  // stage 0 = tile t, r0 = tile t+1, r1 = tile t+2.
+  constexpr bool DEEP = KS < 5;      // d = 160: a second register set would not fit 2 waves / SIMD
+  KVRegs<KS, ND> r0;
+  kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, 0, p.kv_stride, dh);
+  kv_store<KS, ND>(r0, Ks0, Vs0);
+  if (nt > 1) kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, 64, p.kv_stride, dh);
+  if constexpr (DEEP) {
+    KVRegs<KS, ND> r1;
+    if (nt > 2) kv_load<KS, ND>(r1, Kb, p.ldk, Vb, p.ldvt, 128, p.kv_stride, dh);
+    __syncthreads();
+    for (int t0 = 0; t0 < nt; t0 += 2) {
+      tile(Ks0, Vs0, t0 * 64);
+      if (t0 + 1 < nt) kv_store<KS, ND>(r0, Ks1, Vs1);
+      if (t0 + 3 < nt) kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 3) * 64, p.kv_stride, dh);
       __syncthreads();
+      if (t0 + 1 < nt) {
+        tile(Ks1, Vs1, (t0 + 1) * 64);
+        if (t0 + 2 < nt) kv_store<KS, ND>(r1, Ks0, Vs0);
+        if (t0 + 4 < nt) kv_load<KS, ND>(r1, Kb, p.ldk, Vb, p.ldvt, (t0 + 4) * 64, p.kv_stride, dh);
+        __syncthreads();
+      }
+    }
+  } else {
+    // one register set: r0 = tile t+1 while tile t computes (prefetch distance one tile)
+    __syncthreads();
+    for (int t0 = 0; t0 < nt; t0 += 2) {
+      tile(Ks0, Vs0, t0 * 64);
+      if (t0 + 1 < nt) kv_store<KS, ND>(r0, Ks1, Vs1);
+      __syncthreads();
+      if (t0 + 1 < nt) {
+        if (t0 + 2 < nt) kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 2) * 64, p.kv_stride, dh);
+        tile(Ks1, Vs1, (t0 + 1) * 64);
+        if (t0 + 2 < nt) kv_store<KS, ND>(r0, Ks0, Vs0);
+        if (t0 + 3 < nt) kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 3) * 64, p.kv_stride, dh);
+        __syncthreads();
+      }
     }
   }
   l += __shfl_xor(l, 16, 64);
