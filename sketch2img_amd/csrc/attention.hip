@@ -80,6 +80,53 @@ __device__ __forceinline__ void pack_p(const float4_t (&s)[4], half8_t (&pb)[2])
     for (int i = 0; i < 8; ++i) pb[k2][i] = (half_t)s[2 * k2 + (i >> 2)][i & 3];
 }
 
+// register staging of [64][dh] row tiles and [dh][64] transposed tiles (global -> VGPR now, VGPR -> LDS later)
+template <int KS>
+struct RowRegs { half8_t v[KS]; };               // 64 * KS*4 pieces / 256 threads
+template <int ND>
+struct ColRegs { half8_t v[(ND + 1) / 2]; };     // ND*16*8 pieces / 256 threads
+
+template <int KS>
+__device__ __forceinline__ void rows_load(RowRegs<KS>& r, const half_t* __restrict__ src, int ld, int r0, int rlim,
+                                          int dh) {
+  constexpr int PPR = KS * 4;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    const int row = pi / PPR, pc = (pi - row * PPR) * 8;
+    r.v[q] = (r0 + row < rlim && pc < dh) ? ld_half8(src + (size_t)(r0 + row) * ld + pc) : zero_half8();
+  }
+}
+template <int KS>
+__device__ __forceinline__ void rows_store(const RowRegs<KS>& r, half_t* __restrict__ dst) {
+  constexpr int KP = KS * 32 + 8;
+  constexpr int PPR = KS * 4;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    const int row = pi / PPR, pc = (pi - row * PPR) * 8;
+    st_half8(dst + row * KP + pc, r.v[q]);
+  }
+}
+template <int ND>
+__device__ __forceinline__ void cols_load(ColRegs<ND>& r, const half_t* __restrict__ src, int ld, int c0, int clim,
+                                          int dh) {
+#pragma unroll
+  for (int q = 0; q < (ND + 1) / 2; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    const int d = pi >> 3, pc = (pi & 7) * 8;
+    r.v[q] = (pi < ND * 128 && d < dh && c0 + pc < clim) ? ld_half8(src + (size_t)d * ld + c0 + pc) : zero_half8();
+  }
+}
+template <int ND>
+__device__ __forceinline__ void cols_store(const ColRegs<ND>& r, half_t* __restrict__ dst) {
+#pragma unroll
+  for (int q = 0; q < (ND + 1) / 2; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    if (pi < ND * 128) st_half8(dst + (pi >> 3) * TP + (pi & 7) * 8, r.v[q]);
+  }
+}
+
 // -------------------------------------------------------------------------------------------------
 // register staging of one K tile ([64][dh] rows) and one transposed V tile ([dh][64]) per workgroup
 template <int KS, int ND>
@@ -129,8 +176,10 @@ __device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __rest
 // registers into LDS: the HBM/L2 latency of tile t+1 hides under the MFMA + VALU work of tile t.
 // Softmax arithmetic is kept to ~6 VALU per score: raw v_exp_f32 (arguments are <= 0, no range fix-up),
 // scale folded into one FMA, masking only on a ragged last tile.
-template <int KS, int ND>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+template <int KS, int ND, int QT>
+__global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const AttnParams p) {
+  // QT query tiles of 16 per wave: a workgroup covers 64 * QT queries, so every K / V^T fragment read from LDS
+  // (and every byte of K/V streamed from L2) is used by QT MFMAs instead of one.
   constexpr int KP = KS * 32 + 8;
   constexpr int KSZ = 64 * KP, VSZ = ND * 16 * TP;
   __shared__ __attribute__((aligned(16))) half_t lds[2 * (KSZ + VSZ)];      // two (K, V^T) stages
@@ -141,78 +190,94 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, g = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * 64 + wave * 16 + l16;
-  const bool qok = q < p.Nq;
   const int dh = p.dh;
-
-  half8_t qf[KS];
+  int q[QT];
+  bool qok[QT];
+  half8_t qf[QT][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int c = 32 * ks + 8 * g;
-    qf[ks] = (qok && c < dh) ? ld_half8(p.Q + (size_t)(b * p.Nq + q) * p.ldq + h * dh + c) : zero_half8();
+  for (int i = 0; i < QT; ++i) {
+    q[i] = blockIdx.x * (64 * QT) + (wave * QT + i) * 16 + l16;
+    qok[i] = q[i] < p.Nq;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = 32 * ks + 8 * g;
+      qf[i][ks] = (qok[i] && c < dh) ? ld_half8(p.Q + (size_t)(b * p.Nq + q[i]) * p.ldq + h * dh + c) : zero_half8();
+    }
   }
-  float4_t o[ND];
+  float4_t o[QT][ND];
+  float m[QT], l[QT];               // m: running max of the RAW scores times sc (log2 domain)
 #pragma unroll
-  for (int u = 0; u < ND; ++u) o[u] = float4_t{0.f, 0.f, 0.f, 0.f};
-  float m = NEG_BIG, l = 0.f;       // m: running max of the RAW scores times sc (log2 domain)
+  for (int i = 0; i < QT; ++i) {
+    m[i] = NEG_BIG; l[i] = 0.f;
+#pragma unroll
+    for (int u = 0; u < ND; ++u) o[i][u] = float4_t{0.f, 0.f, 0.f, 0.f};
+  }
   const float sc = p.scale * LOG2E;
 
   const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
   const half_t* Vb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
   const int nt = (p.Nkv + 63) / 64;
 
-  // one 64-key tile: S^T = K Q^T, online softmax, O^T += V^T P^T
+  // one 64-key tile: S^T = K Q^T, online softmax, O^T += V^T P^T   (for the wave's QT query tiles)
   auto tile = [&](const half_t* __restrict__ Ks, const half_t* __restrict__ Vs, int kv0) {
-    float4_t s[4];
+    float4_t s[QT][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      s[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < QT; ++i) s[i][t] = float4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const half8_t kf = ld_half8(Ks + (16 * t + l16) * KP + 32 * ks + 8 * g);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[t], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < QT; ++i) s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[i][ks], s[i][t], 0, 0, 0);
       }
     }
-    if (kv0 + 64 > p.Nkv) {          // ragged last tile only (wave-uniform)
+    half8_t pb[QT][2];
+    float alpha[QT];
+#pragma unroll
+    for (int i = 0; i < QT; ++i) {
+      if (kv0 + 64 > p.Nkv) {          // ragged last tile only (wave-uniform)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + 16 * t + 4 * g + r >= p.Nkv) s[i][t][r] = NEG_BIG;
+      }
+      float mx = fmaxf(fmaxf(s[i][0][0], s[i][0][1]), fmaxf(s[i][0][2], s[i][0][3]));
+#pragma unroll
+      for (int t = 1; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[i][t][0], s[i][t][1])), fmaxf(s[i][t][2], s[i][t][3]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m[i], mx * sc);
+      alpha[i] = __builtin_amdgcn_exp2f(m[i] - mn);
+      m[i] = mn;
+      float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (kv0 + 16 * t + 4 * g + r >= p.Nkv) s[t][r] = NEG_BIG;
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(s[i][t][r], sc, -mn));
+          s[i][t][r] = e;
+          ps += e;
+        }
+      l[i] = l[i] * alpha[i] + ps;
+      pack_p(s[i], pb[i]);
+#pragma unroll
+      for (int u = 0; u < ND; ++u) o[i][u] *= alpha[i];
     }
-    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
-    for (int t = 1; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[t][0], s[t][1])), fmaxf(s[t][2], s[t][3]));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx * sc);
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);
-    m = mn;
-    float ps = 0.f;
+    for (int u = 0; u < ND; ++u)
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const half8_t vf = tfrag(Vs, u, k2, l16, g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -mn));
-        s[t][r] = e;
-        ps += e;
+        for (int i = 0; i < QT; ++i) o[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[i][k2], o[i][u], 0, 0, 0);
       }
-    l = l * alpha + ps;
-    half8_t pb[2];
-    pack_p(s, pb);
-#pragma unroll
-    for (int u = 0; u < ND; ++u) {
-      o[u] *= alpha;
-#pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2)
-        o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag(Vs, u, k2, l16, g), pb[k2], o[u], 0, 0, 0);
-    }
   };
 
-  // Two LDS stages + two register sets: tile t computes from stage t&1 while tile t+1 sits in registers on
-  // its way to the other stage and tile t+2 is in flight from L2/HBM - a prefetch distance of two tiles of
-  // compute with ONE barrier per tile.  Invariant at the top of the (unrolled-by-2) loop, t even:
-  // stage 0 = tile t, r0 = tile t+1, r1 = tile t+2.
+  // Two LDS stages (+ two register sets when they fit): tile t computes from stage t&1 while tile t+1 sits in
+  // registers on its way to the other stage and tile t+2 is in flight from L2/HBM, ONE barrier per tile.
+  // Invariant at the top of the (unrolled-by-2) loop, t even: stage 0 = tile t, r0 = tile t+1, r1 = tile t+2.
   constexpr bool DEEP = KS < 5;      // d = 160: a second register set would not fit 2 waves / SIMD
   KVRegs<KS, ND> r0;
   kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, 0, p.kv_stride, dh);
@@ -250,21 +315,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
       }
     }
   }
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  const float inv = 1.f / l;
-  if (qok) {
-    half_t* orow = p.O + (size_t)(b * p.Nq + q) * p.ldo + h * dh;
 #pragma unroll
-    for (int u = 0; u < ND; ++u) {
-      const int d = 16 * u + 4 * g;
-      if (d < dh) {
-        half4_t v = {(half_t)(o[u][0] * inv), (half_t)(o[u][1] * inv), (half_t)(o[u][2] * inv),
-                     (half_t)(o[u][3] * inv)};
-        st_half4(orow + d, v);
+  for (int i = 0; i < QT; ++i) {
+    float li = l[i];
+    li += __shfl_xor(li, 16, 64);
+    li += __shfl_xor(li, 32, 64);
+    const float inv = 1.f / li;
+    if (qok[i]) {
+      half_t* orow = p.O + (size_t)(b * p.Nq + q[i]) * p.ldo + h * dh;
+#pragma unroll
+      for (int u = 0; u < ND; ++u) {
+        const int d = 16 * u + 4 * g;
+        if (d < dh) {
+          half4_t v = {(half_t)(o[i][u][0] * inv), (half_t)(o[i][u][1] * inv), (half_t)(o[i][u][2] * inv),
+                       (half_t)(o[i][u][3] * inv)};
+          st_half4(orow + d, v);
+        }
       }
+      if (p.lse && g == 0) p.lse[((size_t)b * p.heads + h) * p.Nq + q[i]] = (m[i] + log2f(li)) * LN2;
     }
-    if (p.lse && g == 0) p.lse[((size_t)b * p.heads + h) * p.Nq + q] = (m + log2f(l)) * LN2;
   }
 }
 
@@ -302,13 +371,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   const half_t* Vb = p.V + (size_t)b * p.kv_stride * p.ldv + h * dh;
   const half_t* Ktb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
   const int nt = (p.Nkv + 63) / 64;
+  // register prefetch: the three tiles of key block t+1 are loaded while block t computes
+  RowRegs<KS> rk, rv;
+  ColRegs<ND> rkt;
+  rows_load<KS>(rk, Kb, p.ldk, 0, p.kv_stride, dh);
+  rows_load<KS>(rv, Vb, p.ldv, 0, p.kv_stride, dh);
+  cols_load<ND>(rkt, Ktb, p.ldvt, 0, p.kv_stride, dh);
   for (int t0 = 0; t0 < nt; ++t0) {
     const int kv0 = t0 * 64;
+    __syncthreads();                     // everyone is done reading the previous block
+    rows_store<KS>(rk, Ks);
+    rows_store<KS>(rv, Vr);
+    cols_store<ND>(rkt, Kt);
     __syncthreads();
-    stage_rows<KS>(Ks, Kb, p.ldk, kv0, p.kv_stride, dh);
-    stage_rows<KS>(Vr, Vb, p.ldv, kv0, p.kv_stride, dh);
-    stage_cols<ND>(Kt, Ktb, p.ldvt, kv0, p.kv_stride, dh);
-    __syncthreads();
+    if (t0 + 1 < nt) {
+      rows_load<KS>(rk, Kb, p.ldk, kv0 + 64, p.kv_stride, dh);
+      rows_load<KS>(rv, Vb, p.ldv, kv0 + 64, p.kv_stride, dh);
+      cols_load<ND>(rkt, Ktb, p.ldvt, kv0 + 64, p.kv_stride, dh);
+    }
     float4_t s[4], dp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -391,19 +471,32 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
   const half_t* Dtb = p.dOt + (size_t)h * dh * p.lddot + (size_t)b * p.Nq;
   const size_t sbase = ((size_t)b * p.heads + h) * p.Nq;
   const int nt = (p.Nq + 63) / 64;
+  // register prefetch of query block t+1 (Q, dO row tiles, their transposes, lse, delta) under block t's math
+  RowRegs<KS> rq, rd;
+  ColRegs<ND> rqt, rdt;
+  float r_lse = 0.f, r_del = 0.f;
+  auto prefetch = [&](int q0) {
+    rows_load<KS>(rq, Qb, p.ldq, q0, p.Nq, dh);
+    rows_load<KS>(rd, Db, p.lddo, q0, p.Nq, dh);
+    cols_load<ND>(rqt, Qtb, p.ldqt, q0, p.Nq, dh);
+    cols_load<ND>(rdt, Dtb, p.lddot, q0, p.Nq, dh);
+    if (threadIdx.x < 64) {
+      const int qq = q0 + threadIdx.x;
+      r_lse = qq < p.Nq ? p.lse[sbase + qq] * LOG2E : -NEG_BIG;
+      r_del = qq < p.Nq ? p.delta[sbase + qq] : 0.f;
+    }
+  };
+  prefetch(0);
   for (int t0 = 0; t0 < nt; ++t0) {
     const int q0 = t0 * 64;
     __syncthreads();
-    stage_rows<KS>(Qs, Qb, p.ldq, q0, p.Nq, dh);
-    stage_rows<KS>(Ds, Db, p.lddo, q0, p.Nq, dh);
-    stage_cols<ND>(Qt, Qtb, p.ldqt, q0, p.Nq, dh);
-    stage_cols<ND>(Dt, Dtb, p.lddot, q0, p.Nq, dh);
-    if (threadIdx.x < 64) {
-      const int qq = q0 + threadIdx.x;
-      lse_s[threadIdx.x] = qq < p.Nq ? p.lse[sbase + qq] * LOG2E : -NEG_BIG;
-      del_s[threadIdx.x] = qq < p.Nq ? p.delta[sbase + qq] : 0.f;
-    }
+    rows_store<KS>(rq, Qs);
+    rows_store<KS>(rd, Ds);
+    cols_store<ND>(rqt, Qt);
+    cols_store<ND>(rdt, Dt);
+    if (threadIdx.x < 64) { lse_s[threadIdx.x] = r_lse; del_s[threadIdx.x] = r_del; }
     __syncthreads();
+    if (t0 + 1 < nt) prefetch(q0 + 64);
     float4_t s[4], dp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -483,6 +576,18 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
   }
 }
 
+// forward: two query tiles per wave (128 queries per workgroup) except at d = 160 (register budget)
+#define SKG_ATTN_FWD_DISPATCH(grid1, grid2)                                                              \
+  switch (p.dh) {                                                                                        \
+    case 16: hipLaunchKernelGGL((attn_fwd_kernel<1, 1, 2>), grid2, dim3(256), 0, st, p); break;          \
+    case 32: hipLaunchKernelGGL((attn_fwd_kernel<1, 2, 2>), grid2, dim3(256), 0, st, p); break;          \
+    case 40: hipLaunchKernelGGL((attn_fwd_kernel<2, 3, 2>), grid2, dim3(256), 0, st, p); break;          \
+    case 64: hipLaunchKernelGGL((attn_fwd_kernel<2, 4, 2>), grid2, dim3(256), 0, st, p); break;          \
+    case 80: hipLaunchKernelGGL((attn_fwd_kernel<3, 5, 2>), grid2, dim3(256), 0, st, p); break;          \
+    case 160: hipLaunchKernelGGL((attn_fwd_kernel<5, 10, 1>), grid1, dim3(256), 0, st, p); break;        \
+    default: return SKG_E_UNSUPPORTED;                                                                   \
+  }
+
 #define SKG_ATTN_DISPATCH(KERNEL, grid)                                                          \
   switch (p.dh) {                                                                                \
     case 16: hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(256), 0, st, p); break;               \
@@ -511,8 +616,8 @@ extern "C" int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, cons
   p.O = (half_t*)O; p.ldo = ldo; p.lse = lse;
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(skg_cdiv(Nq, 64), heads, batch);
-  SKG_ATTN_DISPATCH(attn_fwd_kernel, grid);
+  dim3 grid1(skg_cdiv(Nq, 64), heads, batch), grid2(skg_cdiv(Nq, 128), heads, batch);
+  SKG_ATTN_FWD_DISPATCH(grid1, grid2);
   SKG_CHECK_LAUNCH("skg_attn_fwd");
   return SKG_OK;
 }
