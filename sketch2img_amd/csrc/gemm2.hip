@@ -29,6 +29,7 @@
 // Workgroup ids are remapped so that each XCD (private 4 MiB L2, workgroup b -> XCD b % 8) owns a
 // contiguous range of tiles, n fastest: the tiles that share an activation row panel hit the same L2.
 #include "gemm_params.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -73,10 +74,21 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
   const int wm = wave / WGN, wn = wave - wm * WGN;
   const int g = lane >> 4, l16 = lane & 15;
 
+  // descriptors: A is based `a_shift` bytes BEFORE p.A (conv: one row + one pixel) so tap offsets are >= 0
+  const __amdgpu_buffer_rsrc_t rA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - a_shift), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, b_bytes, 0x00020000);
+
+  // Persistent workgroups: the grid holds at most one resident wave of workgroups; each walks tiles
+  // vb = blockIdx.x, blockIdx.x + gridDim.x, ...  A workgroup's s_endpgm waits for all of its stores to be
+  // acknowledged; inside the loop the stores of tile i simply drain under the main loop of tile i+1.
+  // (gridDim.x is a multiple of 8 whenever it is smaller than nwg, so vb keeps the workgroup's XCD.)
+  for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
+  if (vb != (int)blockIdx.x) __syncthreads();      // previous tile's epilogue reads of the LDS staging area
   // ---- XCD-aware tile assignment (bijective) ------------------------------------------------------
   int lid;
   {
-    const int bid = blockIdx.x;
+    const int bid = vb;
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -88,11 +100,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
   const int tile_m = lid / tiles_n;
   const int tile_n = lid - tile_m * tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  // descriptors: A is based `a_shift` bytes BEFORE p.A (conv: one row + one pixel) so tap offsets are >= 0
-  const __amdgpu_buffer_rsrc_t rA =
-      __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - a_shift), 0, a_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, b_bytes, 0x00020000);
 
   // ---- per-lane DMA source description ---------------------------------------------------------------
   const int lr = lane >> 3;           // row within an 8-row chunk
@@ -225,23 +232,25 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
 
   const int kt_begin = split * kt_per_split;
   const int KT = min(p.K / BK, kt_begin + kt_per_split);
+  const bool abl_nocompute = p.flags & 0x100u, abl_nodma = p.flags & 0x200u;   // ablation (tools/gemm_bench.py)
   issue(kt_begin, 0);
   for (int kt = kt_begin; kt < KT; kt += 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (kt + 1 < KT) issue(kt + 1, 1);
-    compute(0);
+    if (kt + 1 < KT && !abl_nodma) issue(kt + 1, 1);
+    if (!abl_nocompute) compute(0);
     if (kt + 1 < KT) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (kt + 2 < KT) issue(kt + 2, 0);
-      compute(1);
+      if (kt + 2 < KT && !abl_nodma) issue(kt + 2, 0);
+      if (!abl_nocompute) compute(1);
     }
   }
 
   // ---- epilogue: lane holds C[m = .. + l16][n = .. + 4g .. 4g+3] -----------------------------------
   const bool relu = p.flags & SKG_EPI_RELU;
   const bool f32out = p.flags & SKG_EPI_OUT_F32;
+  if (p.flags & 0x400u) continue;        // ablation: no epilogue
   if (ws) {   // split-K partial: raw fp32 accumulators, epilogue happens in splitk_reduce_kernel
     float* slab = ws + (size_t)split * p.M * p.N;
 #pragma unroll
@@ -254,60 +263,74 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
         if (n < p.N) *reinterpret_cast<float4_t*>(slab + (size_t)m * p.N + n) = acc[i][j];
       }
     }
-    return;
+    continue;
   }
-  const bool staged = !f32out && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0);
+  const bool staged = !f32out && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                      (!p.res || ((p.ldr % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
   if (staged) {
-    // Final fp16 values go through LDS (the stages are dead now) so that the global stores are 16 bytes
-    // per lane over whole output rows, instead of 8-byte fragments of 16 different rows per instruction.
-    // The tile is staged in slabs of WM rows x BN (one wave-row of the wave grid at a time).
-    constexpr int OP = BN + 8;                 // staging pitch (halves)
-    constexpr bool ONE = BM * OP <= 2 * STAGE; // whole tile fits: one slab, else one wave-row at a time
-    constexpr int SLABS = ONE ? 1 : WGM;
-    constexpr int SROWS = ONE ? BM : WM;
-    static_assert(SROWS * OP <= 2 * STAGE, "staging slab must fit in the pipeline stages");
-    constexpr int PPR = BN / 8;                // 16-byte pieces per tile row
+    // The raw fp32 accumulators go through LDS (the pipeline stages are dead now), 64 tile rows at a time:
+    // phase 1 is branch-free register -> LDS traffic; phase 2 walks whole output rows with 16-byte residual
+    // loads / 16-byte stores (full 320-byte lines instead of 8-byte fragments of 16 different rows), applies
+    // bias, alpha, residual and ReLU in fp32 and rounds to fp16 once.
+    constexpr int OPF = BN + 4;                // staging pitch (floats)
+    constexpr int SROWS = 64;
+    constexpr int SLABS = BM / SROWS;
+    static_assert(SROWS * OPF * 4 <= 2 * STAGE * 2, "staging slab must fit in the pipeline stages");
+    constexpr int PPR = BN / 8;                // 8-column pieces per tile row
+    float* const stg = reinterpret_cast<float*>(smem);
+    float* const bias_s = stg + SROWS * OPF;     // the tile's bias slice, fp32, read from LDS in phase 2
+    static_assert((SROWS * OPF + BN) * 4 <= 2 * STAGE * 2, "bias slice must fit behind the staging slab");
+    constexpr int ITER = SROWS * PPR / NTHR;     // pieces per thread per slab (5, 4 or 2)
+    static_assert(SROWS * PPR % NTHR == 0, "piece loop must have a compile-time trip count");
 #pragma unroll
-    for (int slab = 0; slab < SLABS; ++slab) {
-      __syncthreads();                         // stage reads (slab 0) / previous slab's stores are done
-      if (ONE || wm == slab) {
+    for (int sl = 0; sl < SLABS; ++sl) {
+      __syncthreads();                         // stage reads (slab 0) / previous slab's reads are done
+      if (sl == 0 && tid < BN) bias_s[tid] = (p.bias && n0 + tid < p.N) ? (float)p.bias[n0 + tid] : 0.f;
+      if (wm == (sl * SROWS) / WM) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const int ml = (ONE ? wm * WM : 0) + i * 16 + l16;
-          const int m = m0 + slab * SROWS + ml;
+        for (int ii = 0; ii < SROWS / 16; ++ii) {
+          const int i = ((sl * SROWS) % WM) / 16 + ii;
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            const int nl = wn * WN + j * 16 + g * 4;
-            const int n = n0 + nl;
-            float4_t v = acc[i][j];
-            if (m < p.M && n < p.N) {
-              if (p.bias) {
-                const half4_t b = ld_half4(p.bias + n);
-                v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
-              }
-              v *= p.alpha;
-              if (p.res) {
-                const half4_t r = ld_half4(p.res + (size_t)m * p.ldr + n);
-                v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-              }
-              if (relu) {
-                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-              }
-            }
-            half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-            st_half4(&smem[ml * OP + nl], o);
-          }
+          for (int j = 0; j < NT; ++j)
+            *reinterpret_cast<float4_t*>(&stg[(ii * 16 + l16) * OPF + wn * WN + j * 16 + g * 4]) = acc[i][j];
         }
       }
       __syncthreads();
-      for (int pi = tid; pi < SROWS * PPR; pi += NTHR) {
+      // fully unrolled: all residual loads of a thread are issued before the first one is consumed
+      half8_t rv[ITER];
+      bool ok[ITER];
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) {
+        const int pi = tid + k * NTHR;
         const int r = pi / PPR, c = (pi - r * PPR) * 8;
-        const int m = m0 + slab * SROWS + r, n = n0 + c;
-        if (m < p.M && n < p.N)
-          st_half8(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n, ld_half8(&smem[r * OP + c]));
+        const int m = m0 + sl * SROWS + r, n = n0 + c;
+        ok[k] = m < p.M && n < p.N;
+        rv[k] = (ok[k] && p.res) ? ld_half8(p.res + (size_t)m * p.ldr + n) : zero_half8();
+      }
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) {
+        const int pi = tid + k * NTHR;
+        const int r = pi / PPR, c = (pi - r * PPR) * 8;
+        const int m = m0 + sl * SROWS + r, n = n0 + c;
+        if (ok[k]) {
+          const float4_t v0 = *reinterpret_cast<const float4_t*>(&stg[r * OPF + c]);
+          const float4_t v1 = *reinterpret_cast<const float4_t*>(&stg[r * OPF + c + 4]);
+          const float4_t b0 = *reinterpret_cast<const float4_t*>(&bias_s[c]);
+          const float4_t b1 = *reinterpret_cast<const float4_t*>(&bias_s[c + 4]);
+          float v[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3],
+                        v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
+          half8_t o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e] * p.alpha + (float)rv[k][e];
+            if (relu) x = fmaxf(x, 0.f);
+            o[e] = (half_t)x;
+          }
+          st_half8(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n, o);
+        }
       }
     }
-    return;
+    continue;
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -338,6 +361,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
       }
     }
   }
+  }   // persistent tile loop
 }
 
 // out = epi(sum_s slab[s]) for a split-K launch; 4 outputs per thread
@@ -410,6 +434,12 @@ struct TileCfg { int bm, bn; };
 // 256 x 320 (8 waves) when it still puts a workgroup on (almost) every CU; else the widest 128-row tile that
 // divides N and gives >= ~0.8 workgroups per CU; else 128 x 64 (with split-K if a workspace is set)
 inline TileCfg pick_tile(int M, int N, int K) {
+  static const char* force = getenv("SKG_FORCE_BN");          // tuning / ablation only
+  if (force) {
+    const int bn = atoi(force);
+    if (bn == 320 && N % 320 == 0) return {256, 320};
+    if ((bn == 160 || bn == 128 || bn == 64) && (N % bn == 0 || bn == 64)) return {128, bn};
+  }
   // the 8-wave tile pays off (+3..18 % measured) once the K loop is long; short-K layers are bound by their
   // output write and prefer two resident workgroups per CU
   if (K >= 1024 && N % 320 == 0 && (long)skg_cdiv(M, 256) * (N / 320) >= 240) return {256, 320};
@@ -417,6 +447,17 @@ inline TileCfg pick_tile(int M, int N, int K) {
   if (N % 160 == 0 && tm * (N / 160) >= 200) return {128, 160};
   if (N % 128 == 0 && tm * (N / 128) >= 200) return {128, 128};
   return {128, 64};
+}
+
+// Grid size.  The kernel body is a tile loop (vb += gridDim.x), so any grid <= nwg is valid; measured on MI355X
+// a one-resident-wave persistent grid (512 / 256 workgroups) is 5-30 % SLOWER than one workgroup per tile
+// (dispatch of the next workgroup overlaps the tail of the previous one better than the in-kernel loop does
+// with a 2-stage pipeline), so the launch uses nwg.  SKG_PERSISTENT=1 switches for experiments.
+inline int persistent_grid(int nwg, int nthr) {
+  static const bool on = getenv("SKG_PERSISTENT") != nullptr;
+  if (!on) return nwg;
+  const int resident = (nthr > 256 ? 1 : 2) * 256;
+  return nwg < resident ? nwg : resident;
 }
 
 template <int BM, int BN, int WGM, int WGN, int MODE>
@@ -431,15 +472,15 @@ void launch_cfg(const GemmParams& p, hipStream_t st) {
   if (splits > 1) {
     const int per = skg_cdiv(KT, splits);
     const int ns = skg_cdiv(KT, per);            // every split non-empty
-    hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(ntiles * ns), dim3(NTHR), 0, st, p, tiles_n,
-                       ntiles * ns, (unsigned)a, (unsigned)b, (unsigned)s, per, g_ws);
+    hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles * ns, NTHR)), dim3(NTHR),
+                       0, st, p, tiles_n, ntiles * ns, (unsigned)a, (unsigned)b, (unsigned)s, per, g_ws);
     size_t blocks = ((size_t)p.M * (p.N / 4) + 255) / 256;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p,
                        (const float*)g_ws, ns);
     return;
   }
-  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles,
-                     (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles, NTHR)), dim3(NTHR), 0, st,
+                     p, tiles_n, ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
 }
 
 template <int MODE>
