@@ -38,6 +38,9 @@ const char* skg_last_error(void);
 /* ---- epilogue flags shared by skg_gemm_f16 / skg_conv3x3_f16 ---------------------------------- */
 #define SKG_EPI_RELU 1u      /* max(.,0) applied last */
 #define SKG_EPI_OUT_F32 2u   /* C is float* instead of fp16 */
+#define SKG_EPI_GEGLU 4u     /* skg_gemm_f16 only: B / bias rows are the interleaved FF1 pack (groups of four output
+                              * columns [a a g g]); C is [M][N/2] = a * gelu(g).  No residual, fp16 out, K % 64 == 0
+                              * (else SKG_E_UNSUPPORTED).  Fuses diffusers GEGLU into ff.net.0.proj. */
 
 /* C[m][n] = epi( alpha * (sum_k A[m][k] * B[n][k] + bias[n]) + residual[m][n] )
  * A fp16 [M][K] (lda), B fp16 [N][K] (ldb), C fp16|fp32 [M][N] (ldc), bias fp16 [N] or NULL,
@@ -110,12 +113,14 @@ int skg_layernorm_bwd(const void* X, int ldx, const void* dY, int lddy, void* dX
                       const void* residual, int ldr, int M, int C, const void* gamma,
                       const float* stats, void* stream);
 
-/* ---- GEGLU: Y[m][j] = H[m][j] * gelu(H[m][F + j]),  H fp16 [M][2F] ------------------------------
- * bwd writes dH [M][2F] from dY [M][F] and the saved H.  F % 8 == 0.
+/* ---- GEGLU: Y[m][j] = a_j * gelu(g_j),  H fp16 [M][2F] -----------------------------------------------
+ * interleaved == 0: H = [a (F columns) | g (F columns)] (diffusers' chunk(2));  interleaved == 1: groups of four
+ * columns [a_2t a_2t+1 g_2t g_2t+1] (the pack SKG_EPI_GEGLU uses).  bwd writes dH [M][2F] in the same layout from
+ * dY [M][F] and the saved H.  F % 8 == 0.
  * Replaces: diffusers GEGLU (ff.net.0) inside BasicTransformerBlock. */
-int skg_geglu_fwd(const void* H, int ldh, void* Y, int ldy, int M, int F, void* stream);
+int skg_geglu_fwd(const void* H, int ldh, void* Y, int ldy, int M, int F, int interleaved, void* stream);
 int skg_geglu_bwd(const void* H, int ldh, const void* dY, int lddy, void* dH, int lddh, int M,
-                  int F, void* stream);
+                  int F, int interleaved, void* stream);
 
 /* ---- fused multi-head attention (flash style), fp16 --------------------------------------------
  * Q [batch*Nq][..] (ldq), K [batch*kv_stride][..] (ldk), head h occupies columns

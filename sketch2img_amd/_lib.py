@@ -25,8 +25,8 @@ SIGNATURES = {
     "skg_groupnorm_bwd": ("i", "pipipipiiiiipppipp"),
     "skg_layernorm_fwd": ("i", "pipiiippfpp"),
     "skg_layernorm_bwd": ("i", "pipipipiiippp"),
-    "skg_geglu_fwd": ("i", "pipiiip"),
-    "skg_geglu_bwd": ("i", "pipipiiip"),
+    "skg_geglu_fwd": ("i", "pipiiiip"),
+    "skg_geglu_bwd": ("i", "pipipiiiip"),
     "skg_attn_fwd": ("i", "pipipipipiiiiiifp"),
     "skg_attn_bwd_delta": ("i", "pipipiiiip"),
     "skg_attn_bwd_dq": ("i", "pipipipipipppiiiiiiifp"),

@@ -73,6 +73,19 @@ __device__ __forceinline__ float silu_grad_f(float x) {
   return s * (1.f + x * (1.f - s));
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU with erf from Abramowitz & Stegun 7.1.26 (|abs error| < 1.5e-7, far below the fp16 output
+// rounding): one v_rcp + one v_exp + a 5-term Horner chain, ~half the instructions of erff().  Used where the
+// GELU sits on a compute-bound path (fused GEMM epilogue).
+__device__ __forceinline__ float gelu_fast_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = 1.f - p * t * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);   // erf(|x|/sqrt2)
+  return 0.5f * x + 0.5f * fabsf(x) * e;            // 0.5*x*(1 + sign(x)*erf)
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
   const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
   const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);

@@ -12,6 +12,9 @@ inline int ew_grid(size_t total_items) {
   return (int)b;
 }
 
+// IL = 0: H = [a (F cols) | g (F cols)];  IL = 1: interleaved groups of four columns [a a g g] (the FF1 pack
+// the fused GEMM epilogue uses), so both layouts produce the same Y.
+template <int IL>
 __global__ __launch_bounds__(256) void geglu_fwd_kernel(const half_t* __restrict__ H, int ldh,
                                                         half_t* __restrict__ Y, int ldy, int M, int F) {
   const int F8 = F >> 3;
@@ -19,8 +22,15 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const half_t* __restrict
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t m = i / F8;
     const int c = (int)(i - m * F8) * 8;
-    const half8_t a = ld_half8(H + m * ldh + c);
-    const half8_t g = ld_half8(H + m * ldh + F + c);
+    half8_t a, g;
+    if (IL) {
+      const half8_t h0 = ld_half8(H + m * ldh + 2 * c), h1 = ld_half8(H + m * ldh + 2 * c + 8);
+      a = half8_t{h0[0], h0[1], h0[4], h0[5], h1[0], h1[1], h1[4], h1[5]};
+      g = half8_t{h0[2], h0[3], h0[6], h0[7], h1[2], h1[3], h1[6], h1[7]};
+    } else {
+      a = ld_half8(H + m * ldh + c);
+      g = ld_half8(H + m * ldh + F + c);
+    }
     half8_t o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] * gelu_f((float)g[j]));
@@ -28,6 +38,7 @@ __global__ __launch_bounds__(256) void geglu_fwd_kernel(const half_t* __restrict
   }
 }
 
+template <int IL>
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const half_t* __restrict__ H, int ldh,
                                                         const half_t* __restrict__ dY, int lddy,
                                                         half_t* __restrict__ dH, int lddh, int M, int F) {
@@ -36,8 +47,15 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const half_t* __restrict
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t m = i / F8;
     const int c = (int)(i - m * F8) * 8;
-    const half8_t a = ld_half8(H + m * ldh + c);
-    const half8_t g = ld_half8(H + m * ldh + F + c);
+    half8_t a, g;
+    if (IL) {
+      const half8_t h0 = ld_half8(H + m * ldh + 2 * c), h1 = ld_half8(H + m * ldh + 2 * c + 8);
+      a = half8_t{h0[0], h0[1], h0[4], h0[5], h1[0], h1[1], h1[4], h1[5]};
+      g = half8_t{h0[2], h0[3], h0[6], h0[7], h1[2], h1[3], h1[6], h1[7]};
+    } else {
+      a = ld_half8(H + m * ldh + c);
+      g = ld_half8(H + m * ldh + F + c);
+    }
     const half8_t d = ld_half8(dY + m * lddy + c);
     half8_t da, dg;
 #pragma unroll
@@ -46,8 +64,13 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const half_t* __restrict
       da[j] = (half_t)(df * gelu_f(gf));
       dg[j] = (half_t)(df * (float)a[j] * gelu_grad_f(gf));
     }
-    st_half8(dH + m * lddh + c, da);
-    st_half8(dH + m * lddh + F + c, dg);
+    if (IL) {
+      st_half8(dH + m * lddh + 2 * c, half8_t{da[0], da[1], dg[0], dg[1], da[2], da[3], dg[2], dg[3]});
+      st_half8(dH + m * lddh + 2 * c + 8, half8_t{da[4], da[5], dg[4], dg[5], da[6], da[7], dg[6], dg[7]});
+    } else {
+      st_half8(dH + m * lddh + c, da);
+      st_half8(dH + m * lddh + F + c, dg);
+    }
   }
 }
 
@@ -233,21 +256,30 @@ __global__ __launch_bounds__(256) void guidance_update_kernel(const half_t* __re
 
 }  // namespace
 
-extern "C" int skg_geglu_fwd(const void* H, int ldh, void* Y, int ldy, int M, int F, void* stream) {
+extern "C" int skg_geglu_fwd(const void* H, int ldh, void* Y, int ldy, int M, int F, int interleaved,
+                             void* stream) {
   SKG_REQUIRE(H && Y && M > 0 && F > 0 && F % 8 == 0 && ldh % 8 == 0 && ldy % 8 == 0 && ldh >= 2 * F);
   SKG_REQUIRE(skg_aligned(H, 16) && skg_aligned(Y, 16));
-  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(ew_grid((size_t)M * F / 8)), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)H, ldh, (half_t*)Y, ldy, M, F);
+  if (interleaved)
+    hipLaunchKernelGGL((geglu_fwd_kernel<1>), dim3(ew_grid((size_t)M * F / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)H, ldh, (half_t*)Y, ldy, M, F);
+  else
+    hipLaunchKernelGGL((geglu_fwd_kernel<0>), dim3(ew_grid((size_t)M * F / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)H, ldh, (half_t*)Y, ldy, M, F);
   SKG_CHECK_LAUNCH("skg_geglu_fwd");
   return SKG_OK;
 }
 
 extern "C" int skg_geglu_bwd(const void* H, int ldh, const void* dY, int lddy, void* dH, int lddh, int M,
-                             int F, void* stream) {
+                             int F, int interleaved, void* stream) {
   SKG_REQUIRE(H && dY && dH && M > 0 && F % 8 == 0 && ldh % 8 == 0 && lddy % 8 == 0 && lddh % 8 == 0);
   SKG_REQUIRE(skg_aligned(H, 16) && skg_aligned(dY, 16) && skg_aligned(dH, 16));
-  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_grid((size_t)M * F / 8)), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)H, ldh, (const half_t*)dY, lddy, (half_t*)dH, lddh, M, F);
+  if (interleaved)
+    hipLaunchKernelGGL((geglu_bwd_kernel<1>), dim3(ew_grid((size_t)M * F / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)H, ldh, (const half_t*)dY, lddy, (half_t*)dH, lddh, M, F);
+  else
+    hipLaunchKernelGGL((geglu_bwd_kernel<0>), dim3(ew_grid((size_t)M * F / 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)H, ldh, (const half_t*)dY, lddy, (half_t*)dH, lddh, M, F);
   SKG_CHECK_LAUNCH("skg_geglu_bwd");
   return SKG_OK;
 }

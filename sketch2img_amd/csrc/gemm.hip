@@ -184,6 +184,7 @@ int launch(const GemmParams& p, hipStream_t st) {
     SKG_CHECK_LAUNCH("skg_gemm (v2)");
     return SKG_OK;
   }
+  if (p.flags & SKG_EPI_GEGLU) return SKG_E_UNSUPPORTED;     // fused GEGLU exists in the LDS-DMA kernel only
   const int tm = skg_cdiv(p.M, BM);
   if (use_wide(p.M, p.N)) {
     dim3 grid(p.N / 128, tm);
@@ -217,7 +218,7 @@ extern "C" int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void
   SKG_REQUIRE(skg_aligned(A, 16) && skg_aligned(B, 16) && skg_aligned(C, 8));
   SKG_REQUIRE(!bias || skg_aligned(bias, 8));
   SKG_REQUIRE(!residual || (skg_aligned(residual, 8) && ldr % 4 == 0));
-  SKG_REQUIRE(lda >= K && ldb >= K && ldc >= N);
+  SKG_REQUIRE(lda >= K && ldb >= K && ldc >= ((flags & SKG_EPI_GEGLU) ? N / 2 : N));
   GemmParams p{};
   p.A = (const half_t*)A; p.lda = lda; p.B = (const half_t*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
   p.bias = (const half_t*)bias; p.res = (const half_t*)residual; p.ldr = ldr;

@@ -319,6 +319,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
           const float4_t b1 = *reinterpret_cast<const float4_t*>(&bias_s[c + 4]);
           float v[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3],
                         v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
+          if (p.flags & SKG_EPI_GEGLU) {
+            // interleaved FF1 pack: columns [a0 a1 g0 g1 | a2 a3 g2 g3] -> 4 outputs a * gelu(g) at column n/2
+            half4_t y = {(half_t)(v[0] * gelu_fast_f(v[2])), (half_t)(v[1] * gelu_fast_f(v[3])),
+                         (half_t)(v[4] * gelu_fast_f(v[6])), (half_t)(v[5] * gelu_fast_f(v[7]))};
+            st_half4(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + (n >> 1), y);
+            continue;
+          }
           half8_t o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -467,7 +474,8 @@ void launch_cfg(const GemmParams& p, hipStream_t st) {
   unsigned long long a, b, s;
   operand_bytes(p, MODE, a, b, s);
   const int KT = p.K / BK;
-  const int splits = BN == 64 ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
+  // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
+  const int splits = (BN == 64 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
   constexpr int NTHR = WGM * WGN * 64;
   if (splits > 1) {
     const int per = skg_cdiv(KT, splits);
@@ -503,6 +511,9 @@ int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode) {
 
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
   if (!eligible(p, mode)) return false;
+  if ((p.flags & SKG_EPI_GEGLU) && ((p.flags & SKG_EPI_OUT_F32) || p.res || p.ldc % 8 != 0 ||
+                                     (reinterpret_cast<uintptr_t>(p.C) & 15) != 0))
+    return false;
   switch (mode) {
     case MODE_DIRECT: launch_mode<MODE_DIRECT>(p, st); break;
     case MODE_S1: launch_mode<MODE_S1>(p, st); break;

@@ -13,7 +13,7 @@ import torch
 
 from ._lib import SkgTap, check, lib
 
-EPI_RELU, EPI_OUT_F32 = 1, 2
+EPI_RELU, EPI_OUT_F32, EPI_GEGLU = 1, 2, 4
 CONV_S1, CONV_S2, CONV_UP2, CONV_S2T = 0, 1, 2, 3
 
 
@@ -46,15 +46,17 @@ def _f16(*ts):
 
 def gemm(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-         alpha: float = 1.0, relu: bool = False, out_f32: bool = False) -> torch.Tensor:
-    """out[m][n] = epi(alpha*(A[m,:] . B[n,:] + bias[n]) + residual[m][n]);  A [M,K], B [N,K]."""
+         alpha: float = 1.0, relu: bool = False, out_f32: bool = False, geglu: bool = False) -> torch.Tensor:
+    """out[m][n] = epi(alpha*(A[m,:] . B[n,:] + bias[n]) + residual[m][n]);  A [M,K], B [N,K].
+    geglu=True: B / bias are the interleaved FF1 pack and out is [M, N/2] = a * gelu(g)."""
     _f16(A, B, bias, residual)
     M, K = A.shape
     N = B.shape[0]
     assert B.shape[1] == K
     if out is None:
-        out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else torch.float16)
-    flags = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0)
+        out = torch.empty(M, N // 2 if geglu else N, device=A.device,
+                          dtype=torch.float32 if out_f32 else torch.float16)
+    flags = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_GEGLU if geglu else 0)
     check(lib.skg_gemm_f16(_p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out), M, N, K, _p(bias),
                            _p(residual), _ld(residual) if residual is not None else 0, alpha, flags,
                            _stream()), "skg_gemm_f16")
@@ -153,24 +155,32 @@ def layernorm_bwd(X, dY, gamma, stats, residual=None, out=None):
     return out
 
 
-def geglu(H, out=None):
+def geglu(H, out=None, interleaved: bool = False):
     _f16(H)
     M, F2 = H.shape
     F = F2 // 2
     if out is None:
         out = torch.empty(M, F, device=H.device, dtype=torch.float16)
-    check(lib.skg_geglu_fwd(_p(H), _ld(H), _p(out), _ld(out), M, F, _stream()), "skg_geglu_fwd")
+    check(lib.skg_geglu_fwd(_p(H), _ld(H), _p(out), _ld(out), M, F, int(interleaved), _stream()), "skg_geglu_fwd")
     return out
 
 
-def geglu_bwd(H, dY, out=None):
+def geglu_bwd(H, dY, out=None, interleaved: bool = False):
     _f16(H, dY)
     M, F2 = H.shape
     if out is None:
         out = torch.empty(M, F2, device=H.device, dtype=torch.float16)
-    check(lib.skg_geglu_bwd(_p(H), _ld(H), _p(dY), _ld(dY), _p(out), _ld(out), M, F2 // 2, _stream()),
-          "skg_geglu_bwd")
+    check(lib.skg_geglu_bwd(_p(H), _ld(H), _p(dY), _ld(dY), _p(out), _ld(out), M, F2 // 2, int(interleaved),
+                            _stream()), "skg_geglu_bwd")
     return out
+
+
+def geglu_interleave_index(F: int) -> torch.Tensor:
+    """Row permutation that turns diffusers' FF1 weight [a rows (F) ; g rows (F)] into the interleaved pack:
+    packed row 4t+e is a_{2t+e} for e < 2 and g_{2t+e-2} for e >= 2."""
+    r = torch.arange(2 * F)
+    t, e = r // 4, r % 4
+    return torch.where(e < 2, 2 * t + e, F + 2 * t + (e - 2))
 
 
 def transpose(X, out=None):

@@ -119,6 +119,14 @@ class HipUNet:
                     W[k + ":T"] = _h(v.t(), dev)
             else:
                 W[k] = _h(_pad_vec(v, COUT_PAD) if k == "conv_out.bias" else v, dev)
+        # FF1 (GEGLU projection): rows interleaved [a a g g] so the GEMM epilogue can gate in registers
+        for k in list(sd.keys()):
+            if k.endswith(".ff.net.0.proj.weight"):
+                idx = ops.geglu_interleave_index(sd[k].shape[0] // 2)
+                W[k] = _h(sd[k][idx], dev)
+                W[k[:-len("weight")] + "bias"] = _h(sd[k[:-len("weight")] + "bias"][idx], dev)
+                if bw:
+                    W[k + ":T"] = _h(sd[k][idx].t(), dev)
         for k in list(sd.keys()):
             if k.endswith(".attn1.to_q.weight"):
                 p = k[: -len(".to_q.weight")]
@@ -223,8 +231,12 @@ class HipUNet:
                                 want_lse=True)
         p2 = ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], bias=W[t + ".attn2.to_out.0.bias"], residual=p1)
         a3, st3 = ops.layernorm(p2, W[t + ".norm3.weight"], W[t + ".norm3.bias"], want_stats=True)
-        f = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"])
-        gg = ops.geglu(f)
+        if not keep and C % 64 == 0:        # no backward will follow: gate inside the GEMM epilogue (half the bytes)
+            f = None
+            gg = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"], geglu=True)
+        else:
+            f = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"])
+            gg = ops.geglu(f, interleaved=True)
         p3 = ops.gemm(gg, W[t + ".ff.net.2.weight"], bias=W[t + ".ff.net.2.bias"], residual=p2)
         out = ops.gemm(p3, W[p + ".proj_out.weight"], bias=W[p + ".proj_out.bias"], residual=x)
         if keep:
@@ -326,7 +338,7 @@ class HipUNet:
         c = lambda a: a[M0:]
         dp3 = ops.gemm(dout, W[p + ".proj_out.weight:T"])
         dgg = ops.gemm(dp3, W[t + ".ff.net.2.weight:T"])
-        df = ops.geglu_bwd(c(st["f"]), dgg)
+        df = ops.geglu_bwd(c(st["f"]), dgg, interleaved=True)
         da3 = ops.gemm(df, W[t + ".ff.net.0.proj.weight:T"])
         dp2 = ops.layernorm_bwd(c(st["p2"]), da3, W[t + ".norm3.weight"], c(st["st3"]), residual=dp3)
         # cross-attention: only dQ (K/V come from the constant text embeddings)

@@ -192,6 +192,42 @@ def test_geglu_fwd_bwd(ops):
     assert report("geglu bwd", dh.float().cpu(), hr.grad)[0] < FP16_RND
 
 
+def test_geglu_interleaved_and_fused_gemm(ops):
+    """The interleaved FF1 pack: separate kernels and the GEMM-epilogue fusion give diffusers' GEGLU."""
+    M, C = 700, 128
+    Fd = 4 * C
+    x, w, b = rnd(M, C, seed=1), rnd(2 * Fd, C, seed=2, scale=C ** -0.5), rnd(2 * Fd, seed=3)
+    d = dev()
+    idx = ops.geglu_interleave_index(Fd)
+    wp, bp = w[idx].contiguous().to(d), b[idx].contiguous().to(d)
+    hr = (x.float() @ w.float().t() + b.float()).requires_grad_(True)
+    a, g = hr.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    y_fused = ops.gemm(x.to(d), wp, bias=bp, geglu=True)
+    assert y_fused.shape == (M, Fd)
+    assert report("gemm+geglu fused", y_fused.float().cpu(), ref)[0] < FP16_RND
+    f = ops.gemm(x.to(d), wp, bias=bp)                       # interleaved pre-activation
+    assert report("ff1 interleaved", f.float().cpu()[:, torch.argsort(idx)], hr)[0] < FP16_RND
+    y = ops.geglu(f, interleaved=True)
+    # two roundings here (f stored in fp16) vs one in the fused path
+    assert report("geglu interleaved fwd", y.float().cpu(), ref)[0] < 2 * FP16_RND
+    dy = rnd(M, Fd, seed=4)
+    f16 = f.float().cpu()[:, torch.argsort(idx)].requires_grad_(True)
+    a2, g2 = f16.chunk(2, dim=-1)
+    (a2 * F.gelu(g2)).backward(dy.float())
+    dh = ops.geglu_bwd(f, dy.to(d), interleaved=True)
+    assert report("geglu interleaved bwd", dh.float().cpu()[:, torch.argsort(idx)], f16.grad)[0] < FP16_RND
+    # small M, long K: the shape class that would take the split-K path without the GEGLU flag
+    xs, ws, bs = rnd(128, 1280, seed=5), rnd(2048, 1280, seed=6, scale=1280 ** -0.5), rnd(2048, seed=7)
+    i2 = ops.geglu_interleave_index(1024)
+    ys = ops.gemm(xs.to(d), ws[i2].contiguous().to(d), bias=bs[i2].contiguous().to(d), geglu=True)
+    hs = xs.float() @ ws.float().t() + bs.float()
+    assert report("gemm+geglu fused small-M", ys.float().cpu(), hs[:, :1024] * F.gelu(hs[:, 1024:]))[0] < FP16_RND
+    from sketch2img_amd._lib import SkgError
+    with pytest.raises(SkgError):                            # K % 64 != 0 -> generic kernel -> no fused GEGLU
+        ops.gemm(rnd(64, 32).to(d), rnd(16, 32).to(d), geglu=True)
+
+
 def test_data_movement(ops):
     d = dev()
     x = rnd(200, 72, seed=1)
