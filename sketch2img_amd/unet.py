@@ -246,7 +246,7 @@ class HipUNet:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x32: torch.Tensor, t: int, rows: int, H: int, stash: Optional[Stash] = None,
-                want_taps: bool = True, want_eps: bool = True):
+                want_taps: bool = True, want_eps: bool = True, down_only: bool = False):
         """x32: fp16 [rows*H*H, 32] (latent channels zero-padded).  Returns (eps [rows*H*H, 8] or None,
         taps: list of 9 (tensor [rows*s*s, C], s))."""
         cfg, W = self.cfg, self.W
@@ -272,6 +272,16 @@ class HipUNet:
                 skips.append(h)
             if i < 3:
                 taps_down.append((h, cur))
+        if down_only:
+            # modules/sketch_encoder.py:39-98: the forward stops after the down path and returns the per-block
+            # tuples of residual samples ((tensor [rows*s*s, C], s), ...) - what SatMixin.set_res_samples consumes
+            out, k = [], 1
+            for i in range(nb):
+                n = cfg.layers_per_block + (1 if i < nb - 1 else 0)
+                sizes = [H >> i] * cfg.layers_per_block + ([H >> (i + 1)] if i < nb - 1 else [])
+                out.append(tuple((skips[k + j], sizes[j]) for j in range(n)))
+                k += n
+            return out
         h = self._res_fwd("mid_block.resnets.0", h, rows, cur, tb, stash)
         tap_r0 = (h, cur)
         h = self._tr_fwd("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash)

@@ -192,3 +192,41 @@ def test_sd21_style_architecture_vs_oracle():
     with torch.no_grad():
         ref, _ = ounet.unet_forward(ocfg, W, x, 501, ehs)
     assert report("sd21-style eps", ops.nhwc_to_nchw(eps, 2, 4, 32, 32).cpu(), ref)[0] < 1e-2
+
+
+def test_sketch_encoder_feeds_sketch_guided_attn():
+    """modules.sketch_encoder.SketchEncoder (UNet down path on HIP) -> SatMixin.set_res_samples: the full
+    config-4 data flow, res samples checked against the oracle's down_only forward."""
+    from modules.pipeline import AntiGradientPipeline
+    from modules.sketch_encoder import SketchEncoder
+    from modules.sketch_guided_attn import SatMixin
+    from oracle import attn_inject, unet as ounet
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import TINY
+    p = AntiGradientPipeline.from_pretrained(None, unet_config=TINY).to("cuda")
+    W = p.unet.state_dict()
+    enc = SketchEncoder(TINY, W, "cuda:0")                  # same architecture / weights as the UNet here
+    g = torch.Generator().manual_seed(12)
+    h = 32
+    sk = torch.randn(2, 4, h, h, generator=g).half().float()
+    x = torch.randn(2, 4, h, h, generator=g).half().float()
+    ehs = torch.randn(2, 77, TINY.cross_attention_dim, generator=g).half().float()
+    res = enc(sk.to(DEV), 301, ehs).sample
+    with torch.no_grad():
+        ref = ounet.unet_forward(ounet.TINY, W, sk, 301, ehs, down_only=True)
+    assert [len(b) for b in res] == [3, 3, 3, 2]
+    for bi, (bh, br) in enumerate(zip(res, ref)):
+        for j, (a, r) in enumerate(zip(bh, br)):
+            assert a.shape == r.shape
+            assert report(f"sketch encoder block{bi} sample{j}", a.float().cpu(), r)[0] < 1e-2
+    sat = quiet(SatMixin, p.unet)
+    sd = attn_inject.init_state_dict(ounet.TINY, "sketch")
+    sat.load_state_dict(sd)
+    sat.to(torch.device("cuda"), dtype=p.unet.dtype)
+    sat.set_res_samples(res)
+    sat.set_scale(0.8)
+    eps = p.unet(x.to(DEV), 301, ehs).sample.cpu()
+    with torch.no_grad():
+        refe, _ = ounet.unet_forward(ounet.TINY, W, x, 301, ehs,
+                                     inject=attn_inject.make_sketch_inject(ounet.TINY, sd, ref, 0.8))
+    assert report("config-4 flow eps", eps, refe)[0] < 1e-2
