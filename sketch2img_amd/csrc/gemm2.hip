@@ -50,6 +50,80 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, half_t* lds_w
 //   128 x {160,128,64}, 2 x 2 waves (wave tile 64 x BN/2), 2 workgroups per CU   - the general case
 //   256 x 320,          2 x 4 waves (wave tile 128 x 80),  1 workgroup per CU    - 64x64-resolution layers:
 //     half the L2->LDS bytes per output, the activation panel of an N = 320 layer is read exactly once
+// ---- issue-order plan for one stage of the main loop (see `compute`) ---------------------------------------------
+template <int MASK, int N>
+__device__ __forceinline__ void sgb() {
+  if constexpr (N > 0) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+}
+constexpr int SGB_MFMA = 0x008, SGB_VMEM = 0x010, SGB_DSREAD = 0x100;
+// one group of NT MFMAs; after each of the first R an LDS fragment read is issued, after each of the next V one
+// LDS-DMA instruction of the NEXT stage
+template <int NT, int R, int V>
+__device__ __forceinline__ void sched_group() {
+  if constexpr (NT > 0) {
+    sgb<SGB_MFMA, 1>();
+    if constexpr (R > 0) {
+      sgb<SGB_DSREAD, 1>();
+      sched_group<NT - 1, R - 1, V>();
+    } else if constexpr (V > 0) {
+      sgb<SGB_VMEM, 1>();
+      sched_group<NT - 1, 0, V - 1>();
+    } else {
+      sgb<SGB_MFMA, NT - 1>();
+    }
+  }
+}
+// fragment reads: NT+1 up front, then RPG per group until all 2*(MT+NT) are issued
+template <int MT, int NT>
+constexpr int plan_initial() { return NT + 1; }
+template <int MT, int NT>
+constexpr int plan_reads(int g) {
+  const int rpg = NT < 3 ? NT : 3;
+  const int left = 2 * (MT + NT) - (NT + 1) - g * rpg;
+  return left < 0 ? 0 : (left < rpg ? left : rpg);
+}
+// LDS-DMA instructions woven into group g: the MFMA slots its fragment reads leave free, until all nd are placed
+template <int MT, int NT>
+constexpr int plan_vmem(int g, int nd) {
+  int left = nd;
+  for (int h = 0; h <= g; ++h) {
+    const int v = (NT - plan_reads<MT, NT>(h)) < left ? (NT - plan_reads<MT, NT>(h)) : left;
+    if (h == g) return v;
+    left -= v;
+  }
+  return 0;
+}
+template <int MT, int NT, int G, int VLEFT>
+__device__ __forceinline__ void sched_groups() {
+  if constexpr (G < 2 * MT) {
+    constexpr int R = plan_reads<MT, NT>(G);
+    constexpr int V = (NT - R) < VLEFT ? (NT - R) : VLEFT;
+    sched_group<NT, R, V>();
+    sched_groups<MT, NT, G + 1, VLEFT - V>();
+  } else {
+    static_assert(VLEFT == 0, "not every DMA instruction found a slot");
+  }
+}
+template <int MT, int NT, int ND>
+__device__ __forceinline__ void sched_plan() {
+  static_assert(plan_reads<MT, NT>(MT - 1) <= NT, "more woven reads than MFMAs in a group");
+  sgb<SGB_DSREAD, plan_initial<MT, NT>()>();
+  sched_groups<MT, NT, 0, ND>();
+}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + barrier and hipcc lowers the fence to
+// s_waitcnt vmcnt(0): in the epilogue that parks every wave until its global STORES are acknowledged (measured with
+// the phase stamps below: ~3.7 us per 64-row slab, the largest single item of a short-K tile).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// ---- optional phase stamps (make PHASES=1; tools/gemm_phases.py): per workgroup s_memtime at tile start, before the
+// K loop, after it, after the first epilogue slab and at tile end, plus HW_ID / XCC_ID of wave 0 -------------------
+#ifdef SKG_PHASES
+__device__ unsigned long long g_phase[1 << 15][8];
+#define SKG_PH(i) do { if (tid == 0 && vb < (1 << 15)) g_phase[vb][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SKG_PH(i) do { } while (0)
+#endif
+
 template <int BM, int BN, int WGM, int WGN, int MODE>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
                                                                   unsigned a_bytes, unsigned b_bytes,
@@ -84,7 +158,15 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
   // acknowledged; inside the loop the stores of tile i simply drain under the main loop of tile i+1.
   // (gridDim.x is a multiple of 8 whenever it is smaller than nwg, so vb keeps the workgroup's XCD.)
   for (int vb = blockIdx.x; vb < nwg; vb += gridDim.x) {
-  if (vb != (int)blockIdx.x) __syncthreads();      // previous tile's epilogue reads of the LDS staging area
+  if (vb != (int)blockIdx.x) lds_barrier();        // previous tile's epilogue reads of the LDS staging area
+  SKG_PH(0);
+#ifdef SKG_PHASES
+  if (tid == 0 && vb < (1 << 15)) {
+    g_phase[vb][6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+    g_phase[vb][7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+    g_phase[vb][5] = __builtin_amdgcn_s_getreg((31 << 11) | 6);      // LDS_ALLOC
+  }
+#endif
   // ---- XCD-aware tile assignment (bijective) ------------------------------------------------------
   int lid;
   {
@@ -151,8 +233,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
     b_voff[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb * 2u + pk : OOB;
   }
 
-  // issue the LDS-DMA of K tile kt into stage `buf` (buf is a compile-time constant at every call site)
-  auto issue = [&](int kt, int buf) {
+  // LDS-DMA of K tile kt into stage `buf`, split into the per-step address part (`dma_prepare`: SALU + a few VALU
+  // selects) and the individual instructions (`dma_one`, d = 0 .. ACH+BCH-1) so that the main loop can place each
+  // instruction between MFMAs.  !live: every lane out of range -> zero fill, no memory traffic.
+  struct DmaStep { unsigned va[ACH]; unsigned vb[BCH]; unsigned soa, sob; };
+  auto dma_prepare = [&](int kt, bool live) {
+    DmaStep d;
     const int k0 = kt * BK;
     unsigned soff = (unsigned)k0 * 2u;
     int tap = 0, ky = 0, kx = 0;
@@ -184,13 +270,17 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
         }
         v = ok ? a_img[j] + (unsigned)((iy * p.IW + ix) * p.lda) * 2u : OOB;
       }
-      unsigned so = soff;
-      if (!AFFINE) so = (unsigned)(k0 - tap * p.Cin) * 2u;     // gather modes carry the pixel in voffset
-      dma16(rA, &smem[buf * STAGE + (j * NW + wave) * 8 * BK], v, so);
+      d.va[j] = live ? v : OOB;
     }
-    const unsigned sb = (unsigned)k0 * 2u;
 #pragma unroll
-    for (int j = 0; j < BCH; ++j) dma16(rB, &smem[buf * STAGE + BM * BK + (j * NW + wave) * 8 * BK], b_voff[j], sb);
+    for (int j = 0; j < BCH; ++j) d.vb[j] = live ? b_voff[j] : OOB;
+    d.soa = AFFINE ? soff : (unsigned)(k0 - tap * p.Cin) * 2u;     // gather modes carry the pixel in voffset
+    d.sob = (unsigned)k0 * 2u;
+    return d;
+  };
+  auto dma_one = [&](const DmaStep& d, int buf, int i) {     // buf, i: compile-time constants at every call site
+    if (i < ACH) dma16(rA, &smem[buf * STAGE + (i * NW + wave) * 8 * BK], d.va[i], d.soa);
+    else dma16(rB, &smem[buf * STAGE + BM * BK + ((i - ACH) * NW + wave) * 8 * BK], d.vb[i - ACH], d.sob);
   };
 
   float4_t acc[MT][NT];
@@ -214,43 +304,95 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
     for (int ks = 0; ks < 2; ++ks) b_ad[j][ks] = BM * BK + row * BK + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 3);
   }
 
-  auto compute = [&](int buf) {
+  // One pipeline step = the LDS-DMA of the next K tile + 2 k-steps x MT row groups of NT MFMAs on the current one, as
+  // ONE basic block whose issue order is pinned with sched_group_barrier.  Two things hipcc does not do by itself:
+  //  * a buffer_load...lds occupies its wave for ~100 cycles (the texture path takes 64 B/clk per CU), so issuing the
+  //    9 DMA instructions of a stage back to back ahead of the MFMAs costs ~a third of the step; woven one by one
+  //    between MFMAs they run under the matrix pipe;
+  //  * hipcc keeps ONE x-fragment register set and emits ds_read -> s_waitcnt lgkmcnt(0) -> NT MFMAs per group,
+  //    exposing the LDS latency 2*MT times per stage.  All fragment reads are issued at least one group (NT*16
+  //    cycles) ahead of their first use.
+  // LDS reads and LDS-DMA writes keep their program order, so the source below emits them in exactly the order
+  // the plan wants (reads of group g, then the DMA instructions of group g); the MFMAs are free to move and the
+  // plan drops them in between.  The DMA is unconditional (out of range on the last step: zero fill into the idle
+  // stage) to keep the block whole.
+  constexpr int ND = ACH + BCH;
+  auto step = [&](int knext, int ibuf, int cbuf, int KT_) {
+    const DmaStep d = dma_prepare(knext, knext < KT_);
+    const half_t* sb = &smem[cbuf * STAGE];
+    if constexpr (MT >= 8) {      // 160 accumulator registers: no room to pre-load every fragment
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8_t xf[MT], wf[NT];
+      for (int ks = 0; ks < 2; ++ks) {
+        half8_t xf[MT], wf[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) xf[i] = ld_half8(&smem[buf * STAGE + a_ad[i][ks]]);
+        for (int i = 0; i < MT; ++i) xf[i] = ld_half8(sb + a_ad[i][ks]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = ld_half8(&smem[buf * STAGE + b_ad[j][ks]]);
+        for (int j = 0; j < NT; ++j) wf[j] = ld_half8(sb + b_ad[j][ks]);
+        if (ks == 1) {
+#pragma unroll
+          for (int i = 0; i < ND; ++i) dma_one(d, ibuf, i);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+      }
+      return;
+    }
+    half8_t xf[2][MT], wf[2][NT];
+    auto rd = [&](int idx) {     // fragment reads in order of first use: w[0][*], x[0][*], w[1][*], x[1][*]
+      if (idx < NT) wf[0][idx] = ld_half8(sb + b_ad[idx][0]);
+      else if (idx < NT + MT) xf[0][idx - NT] = ld_half8(sb + a_ad[idx - NT][0]);
+      else if (idx < 2 * NT + MT) wf[1][idx - NT - MT] = ld_half8(sb + b_ad[idx - NT - MT][1]);
+      else xf[1][idx - 2 * NT - MT] = ld_half8(sb + a_ad[idx - 2 * NT - MT][1]);
+    };
+    int ri = 0, di = 0;          // compile-time after unrolling
+#pragma unroll
+    for (int r = 0; r < plan_initial<MT, NT>(); ++r) rd(ri++);
+#pragma unroll
+    for (int gq = 0; gq < 2 * MT; ++gq) {
+#pragma unroll
+      for (int r = 0; r < plan_reads<MT, NT>(gq); ++r) rd(ri++);
+#pragma unroll
+      for (int v = 0; v < plan_vmem<MT, NT>(gq, ND); ++v) dma_one(d, ibuf, di++);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-    }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
+    sched_plan<MT, NT, ND>();
   };
 
   const int kt_begin = split * kt_per_split;
   const int KT = min(p.K / BK, kt_begin + kt_per_split);
-  const bool abl_nocompute = p.flags & 0x100u, abl_nodma = p.flags & 0x200u;   // ablation (tools/gemm_bench.py)
-  issue(kt_begin, 0);
+  // the tile's bias slice is fetched now and parked in a register until the epilogue puts it into LDS
+  const float bias_r = (tid < BN && p.bias && n0 + tid < p.N) ? (float)p.bias[n0 + tid] : 0.f;
+  SKG_PH(1);
+  {
+    const DmaStep d0 = dma_prepare(kt_begin, true);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) dma_one(d0, 0, i);
+  }
   for (int kt = kt_begin; kt < KT; kt += 2) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < KT && !abl_nodma) issue(kt + 1, 1);
-    if (!abl_nocompute) compute(0);
+    lds_barrier();
+    step(kt + 1, 1, 0, KT);
     if (kt + 1 < KT) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (kt + 2 < KT && !abl_nodma) issue(kt + 2, 0);
-      if (!abl_nocompute) compute(1);
+      lds_barrier();
+      step(kt + 2, 0, 1, KT);
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last step's zero-fill DMA must not land in the staging area
 
+  SKG_PH(2);
   // ---- epilogue: lane holds C[m = .. + l16][n = .. + 4g .. 4g+3] -----------------------------------
   const bool relu = p.flags & SKG_EPI_RELU;
   const bool f32out = p.flags & SKG_EPI_OUT_F32;
-  if (p.flags & 0x400u) continue;        // ablation: no epilogue
   if (ws) {   // split-K partial: raw fp32 accumulators, epilogue happens in splitk_reduce_kernel
     float* slab = ws + (size_t)split * p.M * p.N;
 #pragma unroll
@@ -282,10 +424,26 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
     static_assert((SROWS * OPF + BN) * 4 <= 2 * STAGE * 2, "bias slice must fit behind the staging slab");
     constexpr int ITER = SROWS * PPR / NTHR;     // pieces per thread per slab (5, 4 or 2)
     static_assert(SROWS * PPR % NTHR == 0, "piece loop must have a compile-time trip count");
+    // all residual loads of the tile are issued before the first store: vmcnt retires in order, so a load issued
+    // behind a store could not be waited for without waiting for the store's acknowledgement too
+    constexpr bool RES_UP_FRONT = SLABS * ITER <= 10;
+    half8_t rv[SLABS][ITER];
+    if (RES_UP_FRONT) {
+#pragma unroll
+      for (int sl = 0; sl < SLABS; ++sl)
+#pragma unroll
+        for (int k = 0; k < ITER; ++k) {
+          const int pi = tid + k * NTHR;
+          const int r = pi / PPR, c = (pi - r * PPR) * 8;
+          const int m = m0 + sl * SROWS + r, n = n0 + c;
+          rv[sl][k] = (p.res && m < p.M && n < p.N) ? ld_half8(p.res + (size_t)m * p.ldr + n) : zero_half8();
+        }
+    }
 #pragma unroll
     for (int sl = 0; sl < SLABS; ++sl) {
-      __syncthreads();                         // stage reads (slab 0) / previous slab's reads are done
-      if (sl == 0 && tid < BN) bias_s[tid] = (p.bias && n0 + tid < p.N) ? (float)p.bias[n0 + tid] : 0.f;
+      lds_barrier();                           // stage reads (slab 0) / previous slab's reads are done
+      if (sl == 1) SKG_PH(3);
+      if (sl == 0 && tid < BN) bias_s[tid] = bias_r;
       if (wm == (sl * SROWS) / WM) {
 #pragma unroll
         for (int ii = 0; ii < SROWS / 16; ++ii) {
@@ -295,24 +453,22 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
             *reinterpret_cast<float4_t*>(&stg[(ii * 16 + l16) * OPF + wn * WN + j * 16 + g * 4]) = acc[i][j];
         }
       }
-      __syncthreads();
-      // fully unrolled: all residual loads of a thread are issued before the first one is consumed
-      half8_t rv[ITER];
-      bool ok[ITER];
+      lds_barrier();
+      if (!RES_UP_FRONT) {
 #pragma unroll
-      for (int k = 0; k < ITER; ++k) {
-        const int pi = tid + k * NTHR;
-        const int r = pi / PPR, c = (pi - r * PPR) * 8;
-        const int m = m0 + sl * SROWS + r, n = n0 + c;
-        ok[k] = m < p.M && n < p.N;
-        rv[k] = (ok[k] && p.res) ? ld_half8(p.res + (size_t)m * p.ldr + n) : zero_half8();
+        for (int k = 0; k < ITER; ++k) {
+          const int pi = tid + k * NTHR;
+          const int r = pi / PPR, c = (pi - r * PPR) * 8;
+          const int m = m0 + sl * SROWS + r, n = n0 + c;
+          rv[sl][k] = (p.res && m < p.M && n < p.N) ? ld_half8(p.res + (size_t)m * p.ldr + n) : zero_half8();
+        }
       }
 #pragma unroll
       for (int k = 0; k < ITER; ++k) {
         const int pi = tid + k * NTHR;
         const int r = pi / PPR, c = (pi - r * PPR) * 8;
         const int m = m0 + sl * SROWS + r, n = n0 + c;
-        if (ok[k]) {
+        if (m < p.M && n < p.N) {
           const float4_t v0 = *reinterpret_cast<const float4_t*>(&stg[r * OPF + c]);
           const float4_t v1 = *reinterpret_cast<const float4_t*>(&stg[r * OPF + c + 4]);
           const float4_t b0 = *reinterpret_cast<const float4_t*>(&bias_s[c]);
@@ -329,7 +485,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
           half8_t o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float x = v[e] * p.alpha + (float)rv[k][e];
+            float x = v[e] * p.alpha + (float)rv[sl][k][e];
             if (relu) x = fmaxf(x, 0.f);
             o[e] = (half_t)x;
           }
@@ -337,6 +493,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
         }
       }
     }
+    SKG_PH(4);
     continue;
   }
 #pragma unroll
@@ -506,7 +663,8 @@ void skg_gemm2_set_workspace(float* ws, size_t bytes) { g_ws = ws; g_ws_bytes = 
 
 int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode) {
   if (K % BK != 0 || M < 1 || (mode != MODE_DIRECT && Cin % BK != 0)) return 0;
-  return pick_tile(M, N, K).bn;
+  const int bn = pick_tile(M, N, K).bn;
+  return bn;
 }
 
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
@@ -524,3 +682,9 @@ bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
   }
   return true;
 }
+
+#ifdef SKG_PHASES
+extern "C" int skg_debug_phases(void* host_out, int nblocks) {      // not part of the ABI: profiling builds only
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase), (size_t)nblocks * 8 * sizeof(unsigned long long));
+}
+#endif

@@ -65,6 +65,17 @@ def test_gemm_rejects_bad_args(ops):
         ops.gemm(A, B)
 
 
+@pytest.mark.parametrize("force,env", [("320", {}), ("160", {}), ("128", {}), ("64", {})])
+def test_forced_tiles(force, env):
+    """Every tile configuration on small ragged shapes."""
+    import os, subprocess, sys
+    e = dict(os.environ, SKG_FORCE_BN=force, **env)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_tile_check.py")], env=e,
+                       capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ALL OK" in r.stdout
+
+
 # ---------------------------------------------------------------------------------------------- conv
 def nhwc(x):   # [B,C,H,W] -> [B*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
