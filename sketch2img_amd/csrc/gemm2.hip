@@ -604,9 +604,10 @@ inline TileCfg pick_tile(int M, int N, int K) {
     if (bn == 320 && N % 320 == 0) return {256, 320};
     if ((bn == 160 || bn == 128 || bn == 64) && (N % bn == 0 || bn == 64)) return {128, bn};
   }
-  // the 8-wave tile pays off (+3..18 % measured) once the K loop is long; short-K layers are bound by their
-  // output write and prefer two resident workgroups per CU
-  if (K >= 1024 && N % 320 == 0 && (long)skg_cdiv(M, 256) * (N / 320) >= 240) return {256, 320};
+  // with the pinned issue order the 4-wave 128 x 160 tile matches or beats the 8-wave tile on every N = 320 layer
+  // (conv 320->320 @ 64x64: 122 vs 139 us); the wide tile still wins (+7 %) when there are many column tiles of a
+  // long K loop to share each activation panel (FF1 of the 16x16 level: N = 10240, K = 1280)
+  if (K >= 1024 && N >= 2560 && N % 320 == 0 && (long)skg_cdiv(M, 256) * (N / 320) >= 240) return {256, 320};
   const long tm = skg_cdiv(M, 128);
   if (N % 160 == 0 && tm * (N / 160) >= 200) return {128, 160};
   if (N % 128 == 0 && tm * (N / 128) >= 200) return {128, 128};
