@@ -231,6 +231,14 @@ int skg_lgp_mse_seed(const void* out, int ldo, const float* target, void* dOut, 
 int skg_cfg_ddim_step(const void* eps_u, const void* eps_c, int ld, const float* x, float* x_prev,
                       float* eps_out, int samples, int HW, float g, float c0, float c1, float c2,
                       float c3, void* stream);
+/* CFG combine + one DPM-Solver++ (2M, midpoint) update - the scheduler app.py:13-25 configures - on float NCHW latents:
+ *   eps = eps_u + g*(eps_c - eps_u);  x0 = (x - sigma_s*eps)/alpha_s;  x_prev = a*x + b*x0 + c*x0_before
+ * x0_io [samples][4][HW] float: the previous step's x0 on entry (not read when c == 0: first-order step), this
+ * step's x0 on exit.  The five scalars are host-side fp32 table arithmetic (sketch2img_amd/sampler.py DPMTables).
+ * Replaces modules/pipeline.py:99-104 when the pipeline was built with DPMSolverMultistepScheduler. */
+int skg_cfg_dpmpp2m_step(const void* eps_u, const void* eps_c, int ld, const float* x, float* x0_io,
+                         float* x_prev, float* eps_out, int samples, int HW, float g, float alpha_s,
+                         float sigma_s, float a, float b, float c, void* stream);
 /* guidance update, modules/pipeline.py:159-161, per sample s:
  *   g = -grad[s] (fp16 NHWC [HW][ld], first 4 ch);  alpha = sqrt(2)*||x_in - x_prev|| / ||g|| * beta
  *   x_prev += alpha * g.   aux float [samples][4] receives (alpha, ||g||, ||x_in-x_prev||*sqrt2, 0). */

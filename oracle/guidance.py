@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ddim as _ddim
+from . import dpmsolver as _dpm
 from . import lgp as _lgp
 from . import unet as _unet
 
@@ -77,10 +78,14 @@ def sample_one(cfg: _unet.UNetConfig, W: Dict[str, torch.Tensor], lgp_sd, ehs: t
                latents0: torch.Tensor, target: Optional[torch.Tensor], num_inference_steps: int,
                guidance_scale: float = 7.5, beta: float = 1.6, *, emulate_fp16: bool = True,
                inject=None, trace: Optional[list] = None,
-               step_hook: Optional[Callable] = None) -> torch.Tensor:
+               step_hook: Optional[Callable] = None, scheduler: str = "ddim") -> torch.Tensor:
     """One B=1 trajectory, modules/pipeline.py:83-115.  ``ehs`` is (2,77,D) = [uncond; cond];
     ``latents0`` (1,4,h,h).  Returns the final latents (1,4,h,h)."""
-    tab = _ddim.make_tables(num_inference_steps)
+    # scheduler: "ddim" (the BASELINE metric) or "dpm++2m" (what app.py:13-25 configures)
+    dpm = scheduler == "dpm++2m"
+    assert dpm or scheduler == "ddim"
+    tab = _dpm.make_tables(num_inference_steps) if dpm else _ddim.make_tables(num_inference_steps)
+    dpm_state = _dpm.DPMState()
     latents = latents0.clone()
     noise = latents0.detach().clone()
     T = len(tab.timesteps)
@@ -91,7 +96,7 @@ def sample_one(cfg: _unet.UNetConfig, W: Dict[str, torch.Tensor], lgp_sd, ehs: t
             eps, taps = _unet.unet_forward(cfg, W, x_in, t, ehs, inject=inject)
         eu, ec = eps.detach().chunk(2)
         e = eu + guidance_scale * (ec - eu)
-        nxt = _ddim.ddim_step(tab, e, t, latents)
+        nxt = _dpm.dpm_step(tab, dpm_state, e, i, latents) if dpm else _ddim.ddim_step(tab, e, t, latents)
         aux = None
         if guided:
             nxt, aux = apply_anti_gradient(taps, lgp_sd, tab.alphas_cumprod, x_in, nxt, noise, t,

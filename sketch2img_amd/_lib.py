@@ -47,6 +47,7 @@ SIGNATURES = {
     "skg_bn_relu_bwd": ("i", "pipipiiiiippipp"),
     "skg_lgp_mse_seed": ("i", "pippipiifp"),
     "skg_cfg_ddim_step": ("i", "ppipppiifffffp"),
+    "skg_cfg_dpmpp2m_step": ("i", "ppippppiiffffffp"),
     "skg_guidance_update": ("i", "pipppiifp"),
 }
 

@@ -222,6 +222,32 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const half_t* __restrict_
   }
 }
 
+// CFG combine + one DPM-Solver++ (2M) update: x0 = (x - sigma_s*eps)/alpha_s; x_prev = a*x + b*x0 + c*x0_before.
+// x0_io holds the previous step's x0 on entry (ignored when c == 0) and this step's x0 on exit.
+__global__ __launch_bounds__(256) void cfg_dpm_kernel(const half_t* __restrict__ eu, const half_t* __restrict__ ec,
+                                                      int ld, const float* __restrict__ x, float* __restrict__ x0_io,
+                                                      float* __restrict__ xp, float* __restrict__ eps_out,
+                                                      int samples, int HW, float g, float alpha_s, float sigma_s,
+                                                      float a, float b, float c) {
+  const size_t total = (size_t)samples * 4 * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const size_t t = i / HW;
+    const int ch = (int)(t & 3);
+    const size_t s = t >> 2;
+    const size_t off = (s * HW + p) * ld + ch;
+    const float u = (float)eu[off], v = (float)ec[off];
+    const float e = u + g * (v - u);
+    const float xv = x[i];
+    const float x0 = (xv - sigma_s * e) / alpha_s;
+    float r = a * xv + b * x0;
+    if (c != 0.f) r += c * x0_io[i];
+    x0_io[i] = x0;
+    xp[i] = r;
+    if (eps_out) eps_out[i] = e;
+  }
+}
+
 // one block per sample: alpha = sqrt(2)*||x_in - x_prev|| / ||g|| * beta; x_prev += alpha*g, g = -grad
 __global__ __launch_bounds__(256) void guidance_update_kernel(const half_t* __restrict__ grad, int ld,
                                                               const float* __restrict__ x_in,
@@ -360,6 +386,17 @@ extern "C" int skg_cfg_ddim_step(const void* eps_u, const void* eps_c, int ld, c
                      (hipStream_t)stream, (const half_t*)eps_u, (const half_t*)eps_c, ld, x, x_prev, eps_out,
                      samples, HW, g, c0, c1, c2, c3);
   SKG_CHECK_LAUNCH("skg_cfg_ddim_step");
+  return SKG_OK;
+}
+
+extern "C" int skg_cfg_dpmpp2m_step(const void* eps_u, const void* eps_c, int ld, const float* x, float* x0_io,
+                                    float* x_prev, float* eps_out, int samples, int HW, float g, float alpha_s,
+                                    float sigma_s, float a, float b, float c, void* stream) {
+  SKG_REQUIRE(eps_u && eps_c && x && x0_io && x_prev && samples > 0 && HW > 0 && ld >= 4 && alpha_s > 0.f);
+  hipLaunchKernelGGL(cfg_dpm_kernel, dim3(ew_grid((size_t)samples * 4 * HW)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)eps_u, (const half_t*)eps_c, ld, x, x0_io, x_prev, eps_out, samples, HW, g,
+                     alpha_s, sigma_s, a, b, c);
+  SKG_CHECK_LAUNCH("skg_cfg_dpmpp2m_step");
   return SKG_OK;
 }
 

@@ -11,7 +11,7 @@ Out of the hot path, handled by PyTorch modules the caller provides (next rows i
   * ``text_encoder`` a callable ``(list[str]) -> (B, 77, D) tensor``; without one, prompts map to seeded
                      pseudo-embeddings (deterministic in the prompt text) so that the pipeline stays runnable
                      on a box with no CLIP weights.
-Only the DDIM scheduler (the BASELINE metric) is implemented; DPM-Solver++ (what app.py configures) is a next row.
+Schedulers: DDIM (the BASELINE metric) and DPM-Solver++ 2M (what app.py configures); see `sketch2img_amd.schedulers`.
 """
 from __future__ import annotations
 
@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from ..config import SD15, SD21, UNetConfig, tap_channels
-from ..sampler import DDIMTables, HipSampler
+from ..sampler import DDIMTables, DPMTables, HipSampler
 from .latent_predictor import LatentEdgePredictor, hook_unet
 
 
@@ -230,7 +230,7 @@ class AntiGradientPipeline:
         if height != width:
             raise RuntimeError("sketch guidance resizes with size=latents.shape[2] only: square images (SURVEY Q8)")
         if eta != 0.0:
-            raise NotImplementedError("only eta = 0 (deterministic DDIM) is implemented")
+            raise NotImplementedError("only eta = 0 (deterministic sampling) is implemented")
         batch_size = 1 if isinstance(prompt, str) else len(prompt)
         device = self._execution_device
         if guidance_scale <= 1.0:
@@ -273,14 +273,22 @@ class AntiGradientPipeline:
             return (image, None)
         return image                                # sic: the reference returns the bare list (:130, Q10)
 
-    def _tables(self, num_inference_steps: int) -> DDIMTables:
+    def _tables(self, num_inference_steps: int):
         sch = self.scheduler
         if sch is None:
             return DDIMTables.make(num_inference_steps)
         cfg = getattr(sch, "config", sch)
         get = lambda k, d: (cfg.get(k, d) if isinstance(cfg, dict) else getattr(cfg, k, d))
-        if "DDIM" not in type(sch).__name__ and not isinstance(sch, (dict, SimpleNamespace)):
-            raise NotImplementedError(f"{type(sch).__name__}: only DDIM is implemented (DPM-Solver++ is a next row)")
+        name = type(sch).__name__
+        if "DPMSolverMultistep" in name or get("algorithm_type", None) is not None:
+            if get("algorithm_type", "dpmsolver++") != "dpmsolver++" or get("solver_type", "midpoint") != "midpoint":
+                raise NotImplementedError("DPM-Solver: only algorithm_type='dpmsolver++', solver_type='midpoint'")
+            if get("thresholding", False) or not get("predict_epsilon", True):
+                raise NotImplementedError("DPM-Solver++: epsilon prediction without thresholding only")
+            return DPMTables.make(num_inference_steps, get("num_train_timesteps", 1000), get("beta_start", 0.00085),
+                                  get("beta_end", 0.012), get("lower_order_final", True), get("solver_order", 2))
+        if "DDIM" not in name and not isinstance(sch, (dict, SimpleNamespace)):
+            raise NotImplementedError(f"{name}: DDIMScheduler and DPMSolverMultistepScheduler are implemented")
         return DDIMTables.make(num_inference_steps, get("num_train_timesteps", 1000), get("beta_start", 0.00085),
                                get("beta_end", 0.012), get("steps_offset", 1), get("set_alpha_to_one", False))
 

@@ -381,6 +381,18 @@ def cfg_ddim_step(eps_u, eps_c, x, samples, HW, g, coeffs: Tuple[float, float, f
     return (x_prev, eps_out) if want_eps else x_prev
 
 
+def cfg_dpmpp2m_step(eps_u, eps_c, x, x0_io, samples, HW, g, coeffs: Tuple[float, float, float, float, float],
+                     want_eps=False):
+    """coeffs = (alpha_s, sigma_s, a, b, c); x0_io is updated in place (previous x0 in, this step's x0 out)."""
+    _f16(eps_u, eps_c)
+    x_prev = torch.empty_like(x)
+    eps_out = torch.empty_like(x) if want_eps else None
+    al, sg, a, b, c = coeffs
+    check(lib.skg_cfg_dpmpp2m_step(_p(eps_u), _p(eps_c), _ld(eps_u), _p(x), _p(x0_io), _p(x_prev), _p(eps_out),
+                                   samples, HW, g, al, sg, a, b, c, _stream()), "skg_cfg_dpmpp2m_step")
+    return (x_prev, eps_out) if want_eps else x_prev
+
+
 def guidance_update(grad, x_in, x_prev, samples, HW, beta):
     """In place: x_prev += alpha * (-grad).  Returns aux [samples,4] = (alpha, ||g||, sqrt2*||dx||, 0)."""
     _f16(grad)

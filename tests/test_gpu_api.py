@@ -84,6 +84,46 @@ def test_pipeline_call_matches_sampler_and_oracle(pipe):
     assert report("pipeline unguided vs oracle", out0.cpu(), ref0)[0] < 1e-2
 
 
+def test_pipeline_with_dpmsolver_scheduler_vs_oracle(pipe):
+    """The scheduler app.py ships (DPM-Solver++ 2M): unguided 4-step call vs the oracle (tight), a guided call runs
+    the LGP update on steps 0..T/2 on top of it, and the scheduler choice is per pipeline object."""
+    from oracle import guidance as og, unet as ounet
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.schedulers import DPMSolverMultistepScheduler
+    h = 32
+    lat = torch.randn(1, 4, h, h, generator=torch.Generator().manual_seed(5))
+    target = synthetic.sketch_targets(0, 1, h)
+    old = pipe.scheduler
+    pipe.scheduler = DPMSolverMultistepScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                                 num_train_timesteps=1000, algorithm_type="dpmsolver++",
+                                                 solver_type="midpoint", lower_order_final=True)
+    try:
+        ehs = pipe._encode_prompt("a cat", "cpu", 1, True, "blurry").half().float()
+        out0 = pipe("a cat", negative_prompt="blurry", height=8 * h, width=8 * h, num_inference_steps=4, latents=lat,
+                    output_type="latent")
+        ref0 = og.sample_one(ounet.TINY, pipe.unet.state_dict(), None, ehs, lat, None, 4, scheduler="dpm++2m")
+        assert report("pipeline dpm++2m unguided vs oracle", out0.cpu(), ref0)[0] < 1e-2
+        ddim0 = og.sample_one(ounet.TINY, pipe.unet.state_dict(), None, ehs, lat, None, 4)
+        assert (ref0 - ddim0).norm() / ddim0.norm() > 5e-2          # a different trajectory than DDIM
+        out = pipe("a cat", negative_prompt="blurry", height=8 * h, width=8 * h, num_inference_steps=4, latents=lat,
+                   sketch_image=target, output_type="latent")
+        assert torch.isfinite(out).all()
+        assert [a is not None for a in pipe.last_aux] == [True, True, True, False]
+        lgp_sd = {k: (v.float().cpu() if v.dtype.is_floating_point else v.cpu())
+                  for k, v in pipe.lgp_model.state_dict().items()}
+        tr = []
+        og.sample_one(ounet.TINY, pipe.unet.state_dict(), lgp_sd, ehs, lat, target, 4, scheduler="dpm++2m", trace=tr)
+        # step 0 is teacher-exact (same start): the guided update's norm is pinned by alpha = sqrt2*|dx|/|g|*beta
+        a0, r0 = pipe.last_aux[0][0], tr[0]["aux"]
+        upd_hip, upd_ref = float(a0[0]) * float(a0[1]), float(r0["alpha"]) * float(r0["gnorm"])
+        print(f"[parity] dpm++2m guided step 0: |update| hip {upd_hip:.4f} oracle {upd_ref:.4f}; "
+              f"loss hip {float(a0[3]):.4e} oracle {float(r0['loss']):.4e}")
+        assert abs(upd_hip / upd_ref - 1) < 2e-2
+        assert abs(float(a0[3]) - float(r0["loss"])) < 1e-2 * float(r0["loss"])
+    finally:
+        pipe.scheduler = old
+
+
 def test_pipeline_return_conventions_and_errors(pipe):
     from PIL import Image
     h = 32

@@ -460,3 +460,31 @@ def test_cfg_ddim_and_guidance_update(ops):
         alpha = num / float(gref[s].norm()) * 1.6
         assert abs(float(aux[s, 0]) - alpha) / alpha < 1e-5
         assert report(f"guidance update s{s}", xprev[s].cpu(), xp[s].cpu() + alpha * gref[s])[1] < 1e-4
+
+
+def test_cfg_dpmpp2m_step_vs_oracle(ops):
+    """First-order then second-order DPM-Solver++ updates against oracle/dpmsolver.py (fp32 latents)."""
+    from oracle import dpmsolver as odpm
+    from sketch2img_amd.sampler import DPMTables
+    S, h, ld = 2, 16, 8
+    hw = h * h
+    d = dev()
+    tab, otab = DPMTables.make(25), odpm.make_tables(25)
+    st = odpm.DPMState()
+    x = torch.randn(S, 4, h, h, generator=torch.Generator().manual_seed(1))
+    x0_io = torch.zeros(S, 4, h, h, device=d)
+    xg, seen = x.to(d), 0
+    for i in range(3):
+        eps = rnd(2 * S * hw, ld, seed=10 + i)
+        eu, ec = eps[:S * hw, :4].float(), eps[S * hw:, :4].float()
+        er = (eu + 7.5 * (ec - eu)).reshape(S, hw, 4).permute(0, 2, 1).reshape(S, 4, h, h)
+        order = tab.order(i, seen)
+        xp, e = ops.cfg_dpmpp2m_step(eps.to(d)[:S * hw], eps.to(d)[S * hw:], xg, x0_io, S, hw, 7.5,
+                                     tab.coeffs(i, order), want_eps=True)
+        seen = min(seen + 1, 2)
+        ref = odpm.dpm_step(otab, st, er, i, x)
+        assert st.history[-1] == order
+        assert report(f"dpm++ step {i} (order {order}) eps", e.cpu(), er)[1] < 1e-5
+        assert report(f"dpm++ step {i} (order {order}) x_prev", xp.cpu(), ref)[1] < 2e-5
+        assert report(f"dpm++ step {i} x0 history", x0_io.cpu(), st.x0_before)[0] < 1e-6      # |x0| ~ 450 at t = 999
+        x, xg = ref, ref.to(d)

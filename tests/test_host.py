@@ -211,3 +211,39 @@ def test_shard_range_covers_everything():
             for f, c in spans:
                 assert f == nxt
                 nxt += c
+
+
+def test_dpm_tables_bit_exact_vs_oracle_and_scheduler_selection():
+    from types import SimpleNamespace
+    from oracle import dpmsolver as odpm
+    from sketch2img_amd.sampler import DDIMTables, DPMTables
+    from sketch2img_amd.schedulers import DDIMScheduler, DPMSolverMultistepScheduler
+    from sketch2img_amd.modules.pipeline import AntiGradientPipeline
+    for N in (10, 25, 50):
+        a, b = DPMTables.make(N), odpm.make_tables(N)
+        assert np.array_equal(a.timesteps, b.timesteps) and a.timesteps.dtype == np.int64
+        assert torch.equal(a.lambda_t, b.lambda_t)
+        seen = 0
+        for i in range(N):
+            od = a.order(i, seen)
+            assert od == odpm.step_order(b, i, seen)
+            assert a.coeffs(i, od) == odpm.step_coeffs(b, i, od)
+            seen = min(seen + 1, 2)
+    # the scheduler object decides which tables the pipeline builds (constructor as app.py:13-25)
+    dpm = DPMSolverMultistepScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                      num_train_timesteps=1000, trained_betas=None, predict_epsilon=True,
+                                      thresholding=False, algorithm_type="dpmsolver++", solver_type="midpoint",
+                                      lower_order_final=True)
+    p = AntiGradientPipeline.__new__(AntiGradientPipeline)
+    p.scheduler = dpm
+    assert isinstance(p._tables(25), DPMTables)
+    p.scheduler = DDIMScheduler()
+    assert isinstance(p._tables(50), DDIMTables) and p._tables(50).timesteps[0] == 981
+    p.scheduler = None
+    assert isinstance(p._tables(50), DDIMTables)
+    p.scheduler = DPMSolverMultistepScheduler(solver_type="heun")
+    with pytest.raises(NotImplementedError):
+        p._tables(25)
+    p.scheduler = type("EulerDiscreteScheduler", (), {"config": SimpleNamespace()})()
+    with pytest.raises(NotImplementedError):
+        p._tables(25)

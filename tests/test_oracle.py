@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle import attn_inject, ddim, guidance, lgp, unet
+from oracle import attn_inject, ddim, dpmsolver, guidance, lgp, unet
 from tests.util import GOLDEN, load_npz, sd_from_npz
 
 torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
@@ -216,3 +216,62 @@ def test_injected_attention_changes_output_and_zero_scale_is_identity():
     res = unet.unet_forward(cfg, W, x, 301, ehs, down_only=True)
     e2, _ = unet.unet_forward(cfg, W, x, 301, ehs, inject=attn_inject.make_sketch_inject(cfg, sds, res, 1.0))
     assert (e2 - base).abs().max() > 1e-4
+
+
+# ------------------------------------------------------------------------------- DPM-Solver++ 2M (app.py:13-25)
+def test_dpmsolver_tables_known_answers():
+    t25, t50, t10 = dpmsolver.make_tables(25), dpmsolver.make_tables(50), dpmsolver.make_tables(10)
+    # linspace(0, 999, N + 1).round()[::-1][:-1]
+    assert t25.timesteps.tolist()[:3] == [999, 959, 919] and t25.timesteps.tolist()[-2:] == [80, 40]
+    assert t50.timesteps.tolist()[:3] == [999, 979, 959] and t50.timesteps.tolist()[-2:] == [40, 20]
+    assert t10.timesteps.tolist() == [999, 899, 799, 699, 599, 500, 400, 300, 200, 100]
+    assert t25.timesteps.dtype == np.int64
+    assert abs(float(t25.alphas_cumprod[0]) - 0.99915) < 1e-6
+    assert abs(float(t25.lambda_t[0]) - 0.5 * np.log(0.99915 / 0.00085)) < 1e-4
+    # update orders: first step first-order, then second-order; the final step drops to first order only for
+    # schedules shorter than 15 steps (lower_order_final)
+    for tab, last in ((t10, 1), (t25, 2)):
+        st, x = dpmsolver.DPMState(), torch.zeros(1, 4, 2, 2)
+        for i in range(len(tab.timesteps)):
+            x = dpmsolver.dpm_step(tab, st, torch.zeros_like(x), i, x)
+        assert st.history[0] == 1 and set(st.history[1:-1]) == {2} and st.history[-1] == last
+
+
+def test_dpmsolver_exact_for_constant_prediction_and_second_order():
+    """(1) If the data prediction is the same x0* at every step (eps consistent with it), every DPM-Solver++ update
+    is exact: x_prev = alpha_p x0* + sigma_p eps.  (2) On the analytic eps model of Gaussian data N(0, s^2) the
+    probability-flow ODE has the closed form x_t = x_T * sqrt(alpha_t^2 s^2 + sigma_t^2) / sqrt(alpha_T^2 s^2 +
+    sigma_T^2); halving the step size must cut the first-order solver's error by ~2 and the 2M solver's by ~4."""
+    g = torch.Generator().manual_seed(0)
+    x0s, e = torch.randn(1, 4, 8, 8, generator=g, dtype=torch.float64), torch.randn(1, 4, 8, 8, generator=g, dtype=torch.float64)
+    tab = dpmsolver.make_tables(20)
+    st = dpmsolver.DPMState()
+    T0 = int(tab.timesteps[0])
+    x = float(tab.alpha_t[T0]) * x0s + float(tab.sigma_t[T0]) * e
+    for i in range(20):
+        x = dpmsolver.dpm_step(tab, st, e, i, x)
+        tp = 0 if i == 19 else int(tab.timesteps[i + 1])
+        ref = float(tab.alpha_t[tp]) * x0s + float(tab.sigma_t[tp]) * e
+        assert (x - ref).abs().max() < 2e-5            # coefficients are fp32 table values
+    s2 = 0.25
+
+    def final_error(N, order):
+        tab = dpmsolver.make_tables(N, lower_order_final=False)
+        tab.solver_order = order
+        al, sg = tab.alpha_t.double(), tab.sigma_t.double()
+        var = lambda t: al[t] ** 2 * s2 + sg[t] ** 2
+        st = dpmsolver.DPMState()
+        xT = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(1), dtype=torch.float64)
+        x = xT.clone()
+        for i, t in enumerate(tab.timesteps.tolist()):
+            eps = sg[t] * x / var(t)                     # E[eps | x_t] for x0 ~ N(0, s2)
+            x = dpmsolver.dpm_step(tab, st, eps, i, x)
+        exact = xT * torch.sqrt(var(0) / var(int(tab.timesteps[0])))
+        return float((x - exact).abs().max())
+
+    # measured: order 1 ratios 1.95, 1.95; order 2 ratios 3.0, 3.5 (-> 4: the steep last steps dominate the error)
+    e1 = [final_error(N, 1) for N in (100, 200, 400)]
+    e2 = [final_error(N, 2) for N in (100, 200, 400)]
+    assert 1.8 < e1[0] / e1[1] < 2.2 and 1.8 < e1[1] / e1[2] < 2.2, e1
+    assert e2[0] / e2[1] > 2.8 and e2[1] / e2[2] > 3.3, e2
+    assert e2[2] < 0.3 * e1[2]
