@@ -231,6 +231,15 @@ int skg_lgp_mse_seed(const void* out, int ldo, const float* target, void* dOut, 
 int skg_cfg_ddim_step(const void* eps_u, const void* eps_c, int ld, const float* x, float* x_prev,
                       float* eps_out, int samples, int HW, float g, float c0, float c1, float c2,
                       float c3, void* stream);
+/* ---- VAE decoder helpers (modules/pipeline.py:118 decode_latents; third-party AutoencoderKL.decode) -------------
+ * Row softmax y[m][:] = softmax(x[m][:]) of fp16 scores, fp32 arithmetic: the decoder's single-head mid attention
+ * (AttentionBlock: softmax(q k^T / sqrt(C)) v over HW tokens) is GEMM -> this -> GEMM.  N % 8 == 0. */
+int skg_softmax_rows_f16(const void* x, int ldx, void* y, int ldy, int M, int N, void* stream);
+/* decode_latents tail: out[px][c] = clamp(x[px][c]*scale + shift, 0, 1), fp16 NHWC (row pitch ld) -> float NHWC
+ * (the (B, H, W, 3) array the pipeline converts to PIL; scale 0.5, shift 0.5). */
+int skg_image_postprocess(const void* x, int ld, float* out, size_t pixels, int C, float scale, float shift,
+                          void* stream);
+
 /* CFG combine + one DPM-Solver++ (2M, midpoint) update - the scheduler app.py:13-25 configures - on float NCHW latents:
  *   eps = eps_u + g*(eps_c - eps_u);  x0 = (x - sigma_s*eps)/alpha_s;  x_prev = a*x + b*x0 + c*x0_before
  * x0_io [samples][4][HW] float: the previous step's x0 on entry (not read when c == 0: first-order step), this

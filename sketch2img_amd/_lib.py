@@ -47,6 +47,8 @@ SIGNATURES = {
     "skg_bn_relu_bwd": ("i", "pipipiiiiippipp"),
     "skg_lgp_mse_seed": ("i", "pippipiifp"),
     "skg_cfg_ddim_step": ("i", "ppipppiifffffp"),
+    "skg_softmax_rows_f16": ("i", "pipiiip"),
+    "skg_image_postprocess": ("i", "pipziffp"),
     "skg_cfg_dpmpp2m_step": ("i", "ppippppiiffffffp"),
     "skg_guidance_update": ("i", "pipppiifp"),
 }

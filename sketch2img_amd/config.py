@@ -56,3 +56,30 @@ def tap_channels(cfg: UNetConfig) -> List[int]:
 
 def tap_sizes(h: int) -> List[int]:
     return [h // 2, h // 4, h // 8, h // 8, h // 8, h // 8, h // 4, h // 2, h]
+
+
+# ---------------------------------------------------------------------------------------- VAE decoder
+@dataclass(frozen=True)
+class VAEConfig:
+    """AutoencoderKL decoder of Stable Diffusion (app.py:28-30 loads runwayml/stable-diffusion-v1-5 subfolder vae)."""
+    latent_channels: int = 4
+    out_channels: int = 3
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_groups: int = 32
+    scaling_factor: float = 0.18215
+
+
+SD_VAE = VAEConfig()
+TINY_VAE = VAEConfig(block_out_channels=(32, 64, 64, 64), layers_per_block=1, norm_groups=8)
+
+
+def vae_up_plan(cfg: VAEConfig):
+    """[(up block index, [(cin, cout) per resnet], has_upsampler)] in execution order (channels reversed,
+    layers_per_block + 1 resnets per block, nearest-2x + conv after every block but the last)."""
+    rev = list(reversed(cfg.block_out_channels))
+    plan, prev = [], rev[0]
+    for i, co in enumerate(rev):
+        plan.append((i, [(prev if j == 0 else co, co) for j in range(cfg.layers_per_block + 1)], i != len(rev) - 1))
+        prev = co
+    return plan

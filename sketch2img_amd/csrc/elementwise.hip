@@ -222,6 +222,52 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const half_t* __restrict_
   }
 }
 
+// Row softmax of fp16 scores (one workgroup per row, fp32 arithmetic, fp16 probabilities): the single-head
+// attention of the VAE decoder (N = HW = 4096 keys, head width 512) runs as GEMM -> softmax -> GEMM.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* __restrict__ x, int ldx,
+                                                           half_t* __restrict__ y, int ldy, int N) {
+  __shared__ float red[8];
+  const size_t row = blockIdx.x;
+  const half_t* xr = x + row * ldx;
+  half_t* yr = y + row * ldy;
+  float m = -3.0e38f;
+  for (int i = threadIdx.x * 8; i < N; i += 256 * 8) {
+    const half8_t v = ld_half8(xr + i);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m = fmaxf(m, (float)v[e]);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int i = threadIdx.x * 8; i < N; i += 256 * 8) {
+    const half8_t v = ld_half8(xr + i);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += __expf((float)v[e] - m);
+  }
+  sum = block_sum<256>(sum, red + 4);
+  const float inv = 1.f / sum;
+  for (int i = threadIdx.x * 8; i < N; i += 256 * 8) {
+    const half8_t v = ld_half8(xr + i);
+    half8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)(__expf((float)v[e] - m) * inv);
+    st_half8(yr + i, o);
+  }
+}
+
+// decode_latents tail: fp16 NHWC [pixels][ld] (first C channels) -> float NHWC [pixels][C] = clamp(x*scale + shift, 0, 1)
+__global__ __launch_bounds__(256) void image_post_kernel(const half_t* __restrict__ x, int ld, float* __restrict__ out,
+                                                         size_t pixels, int C, float scale, float shift) {
+  const size_t total = pixels * C;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t px = i / C;
+    const int c = (int)(i - px * C);
+    out[i] = fminf(fmaxf((float)x[px * ld + c] * scale + shift, 0.f), 1.f);
+  }
+}
+
 // CFG combine + one DPM-Solver++ (2M) update: x0 = (x - sigma_s*eps)/alpha_s; x_prev = a*x + b*x0 + c*x0_before.
 // x0_io holds the previous step's x0 on entry (ignored when c == 0) and this step's x0 on exit.
 __global__ __launch_bounds__(256) void cfg_dpm_kernel(const half_t* __restrict__ eu, const half_t* __restrict__ ec,
@@ -386,6 +432,24 @@ extern "C" int skg_cfg_ddim_step(const void* eps_u, const void* eps_c, int ld, c
                      (hipStream_t)stream, (const half_t*)eps_u, (const half_t*)eps_c, ld, x, x_prev, eps_out,
                      samples, HW, g, c0, c1, c2, c3);
   SKG_CHECK_LAUNCH("skg_cfg_ddim_step");
+  return SKG_OK;
+}
+
+extern "C" int skg_softmax_rows_f16(const void* x, int ldx, void* y, int ldy, int M, int N, void* stream) {
+  SKG_REQUIRE(x && y && M > 0 && N > 0 && N % 8 == 0 && ldx >= N && ldy >= N && ldx % 8 == 0 && ldy % 8 == 0);
+  SKG_REQUIRE(skg_aligned(x, 16) && skg_aligned(y, 16));
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx,
+                     (half_t*)y, ldy, N);
+  SKG_CHECK_LAUNCH("skg_softmax_rows_f16");
+  return SKG_OK;
+}
+
+extern "C" int skg_image_postprocess(const void* x, int ld, float* out, size_t pixels, int C, float scale,
+                                     float shift, void* stream) {
+  SKG_REQUIRE(x && out && pixels > 0 && C > 0 && ld >= C);
+  hipLaunchKernelGGL(image_post_kernel, dim3(ew_grid((size_t)pixels * C)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x, ld, out, (size_t)pixels, C, scale, shift);
+  SKG_CHECK_LAUNCH("skg_image_postprocess");
   return SKG_OK;
 }
 

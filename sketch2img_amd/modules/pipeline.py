@@ -193,11 +193,14 @@ class AntiGradientPipeline:
     def decode_latents(self, latents):
         """diffusers decode_latents: /0.18215, VAE decode, /2 + 0.5, clamp, NHWC fp32 numpy."""
         if self.vae is None:
-            # latent preview: no VAE weights on this box (VAE decoder is a "next" row, SURVEY 8f)
+            # latent preview when the pipeline was built without a VAE (pass vae=sketch2img_amd.vae.AutoencoderKL(...))
             m = torch.tensor([[0.298, 0.207, 0.208], [0.187, 0.286, 0.173], [-0.158, 0.189, 0.264],
                               [-0.184, -0.271, -0.473]], device=latents.device)
             img = torch.einsum("bchw,cr->brhw", latents.float(), m)
             img = torch.nn.functional.interpolate(img, scale_factor=8.0, mode="nearest")
+        elif hasattr(self.vae, "decode_latents"):
+            # sketch2img_amd.vae.AutoencoderKL: the whole of decode_latents on libskg.so kernels, NHWC fp32 out
+            return self.vae.decode_latents(latents).cpu().numpy()
         else:
             img = self.vae.decode((latents / 0.18215).to(getattr(self.vae, "dtype", latents.dtype)))
             img = getattr(img, "sample", img)

@@ -370,6 +370,25 @@ def lgp_mse_seed(out16, target, samples, h, ldd, loss_scale):
 
 
 # ---- sampler ------------------------------------------------------------------------------------------
+def softmax_rows(X, out=None):
+    """Row softmax of fp16 scores (fp32 arithmetic); in place when out is X."""
+    _f16(X)
+    M, N = X.shape
+    if out is None:
+        out = torch.empty(M, N, device=X.device, dtype=torch.float16)
+    check(lib.skg_softmax_rows_f16(_p(X), _ld(X), _p(out), _ld(out), M, N, _stream()), "skg_softmax_rows_f16")
+    return out
+
+
+def image_postprocess(X, pixels: int, C: int, scale: float = 0.5, shift: float = 0.5):
+    """fp16 NHWC rows (first C channels of pitch ld) -> float [pixels, C] = clamp(x*scale + shift, 0, 1)."""
+    _f16(X)
+    out = torch.empty(pixels, C, device=X.device, dtype=torch.float32)
+    check(lib.skg_image_postprocess(_p(X), _ld(X), _p(out), pixels, C, scale, shift, _stream()),
+          "skg_image_postprocess")
+    return out
+
+
 def cfg_ddim_step(eps_u, eps_c, x, samples, HW, g, coeffs: Tuple[float, float, float, float],
                   want_eps=False):
     _f16(eps_u, eps_c)

@@ -13,7 +13,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from .config import UNetConfig, tap_channels, up_block_plan
+from .config import UNetConfig, VAEConfig, tap_channels, up_block_plan, vae_up_plan
 
 WEIGHT_SEED = 20260929
 
@@ -157,3 +157,57 @@ def sketch_targets(first: int, count: int, h: int) -> torch.Tensor:
 
 def lgp_input_dim(cfg: UNetConfig) -> int:
     return sum(tap_channels(cfg)) + 4 + 36
+
+
+# ---------------------------------------------------------------------------------------------- VAE decoder
+VAE_WEIGHT_SEED = 20260930
+
+
+def _vae_res(p, ci, co, s):
+    s[p + ".norm1.weight"] = (ci,); s[p + ".norm1.bias"] = (ci,)
+    s[p + ".conv1.weight"] = (co, ci, 3, 3); s[p + ".conv1.bias"] = (co,)
+    s[p + ".norm2.weight"] = (co,); s[p + ".norm2.bias"] = (co,)
+    s[p + ".conv2.weight"] = (co, co, 3, 3); s[p + ".conv2.bias"] = (co,)
+    if ci != co:
+        s[p + ".conv_shortcut.weight"] = (co, ci, 1, 1); s[p + ".conv_shortcut.bias"] = (co,)
+
+
+def vae_decoder_param_shapes(cfg: VAEConfig) -> "OrderedDict[str, tuple]":
+    """diffusers AutoencoderKL state_dict keys (decoder.*, post_quant_conv.*) -> shapes."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    ct, L = cfg.block_out_channels[-1], cfg.latent_channels
+    s["post_quant_conv.weight"] = (L, L, 1, 1); s["post_quant_conv.bias"] = (L,)
+    s["decoder.conv_in.weight"] = (ct, L, 3, 3); s["decoder.conv_in.bias"] = (ct,)
+    _vae_res("decoder.mid_block.resnets.0", ct, ct, s)
+    a = "decoder.mid_block.attentions.0"
+    s[a + ".group_norm.weight"] = (ct,); s[a + ".group_norm.bias"] = (ct,)
+    for n in ("query", "key", "value", "proj_attn"):
+        s[f"{a}.{n}.weight"] = (ct, ct); s[f"{a}.{n}.bias"] = (ct,)
+    _vae_res("decoder.mid_block.resnets.1", ct, ct, s)
+    for i, res, up in vae_up_plan(cfg):
+        for j, (ci, co) in enumerate(res):
+            _vae_res(f"decoder.up_blocks.{i}.resnets.{j}", ci, co, s)
+        if up:
+            co = res[-1][1]
+            s[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"] = (co, co, 3, 3)
+            s[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"] = (co,)
+    c0 = cfg.block_out_channels[0]
+    s["decoder.conv_norm_out.weight"] = (c0,); s["decoder.conv_norm_out.bias"] = (c0,)
+    s["decoder.conv_out.weight"] = (cfg.out_channels, c0, 3, 3); s["decoder.conv_out.bias"] = (cfg.out_channels,)
+    return s
+
+
+def vae_decoder_state_dict(cfg: VAEConfig, seed: int = VAE_WEIGHT_SEED) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic decoder weights (same recipe and draw order as oracle/vae.py init_weights, which the
+    parity tests use as the checker's copy): conv / linear U(+-1/sqrt(fan_in)), gamma 1 + 0.1 N, biases 0.05 N."""
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, torch.Tensor] = {}
+    for k, shp in vae_decoder_param_shapes(cfg).items():
+        if "norm" in k and k.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            w = 0.05 * torch.randn(shp, generator=g)
+        else:
+            w = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(math.prod(shp[1:]))
+        W[k] = w.half().float()
+    return W

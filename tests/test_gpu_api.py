@@ -270,3 +270,64 @@ def test_sketch_encoder_feeds_sketch_guided_attn():
         refe, _ = ounet.unet_forward(ounet.TINY, W, x, 301, ehs,
                                      inject=attn_inject.make_sketch_inject(ounet.TINY, sd, ref, 0.8))
     assert report("config-4 flow eps", eps, refe)[0] < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ VAE decoder
+@pytest.mark.gpu
+def test_vae_decoder_tiny_vs_oracle():
+    """decode() and decode_latents() of a narrow 4-level decoder, 3 images in chunks of 2, vs oracle/vae.py."""
+    from oracle import vae as ovae
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import TINY_VAE
+    from sketch2img_amd.vae import HipVAEDecoder
+    W = ovae.init_weights(ovae.TINY_VAE)
+    dec = HipVAEDecoder(TINY_VAE, synthetic.vae_decoder_state_dict(TINY_VAE), DEV, max_images_per_pass=2)
+    z = torch.randn(3, 4, 8, 8, generator=torch.Generator().manual_seed(2)) * 3.0
+    y = dec.decode(z)
+    ref = ovae.decode(ovae.TINY_VAE, W, z)
+    assert y.shape == ref.shape == (3, 3, 64, 64)
+    assert report("vae tiny decode", y.cpu(), ref)[0] < 3e-3
+    lat = 0.18215 * z
+    img = dec.decode_latents(lat)
+    iref = ovae.decode_latents(ovae.TINY_VAE, W, lat)
+    assert img.shape == iref.shape == (3, 64, 64, 3) and img.dtype == torch.float32
+    assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+    assert report("vae tiny decode_latents", img.cpu(), iref)[1] < 1.0 / 255
+
+
+@pytest.mark.gpu
+def test_vae_decoder_sd_full_width_vs_oracle():
+    """The SD VAE decoder (49 490 179 + 20 parameters, single-head 512-wide mid attention) on a 32x32 latent ->
+    256x256 image vs the CPU oracle; then the pipeline with vae= returns PIL images of the right size."""
+    from oracle import vae as ovae
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import SD_VAE
+    from sketch2img_amd.vae import AutoencoderKL
+    W = ovae.init_weights(ovae.SD_VAE)
+    vae = AutoencoderKL(SD_VAE).to("cuda")
+    assert all(torch.equal(vae.state_dict()[k], W[k]) for k in W)
+    z = torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(4)) * 4.0
+    y = vae.decode(z).sample
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    ref = ovae.decode(ovae.SD_VAE, W, z)
+    assert y.shape == (1, 3, 256, 256)
+    assert report("vae sd decode 256x256", y.cpu(), ref)[0] < 4e-3
+    img = vae.decode_latents(0.18215 * z)
+    assert report("vae sd decode_latents", img.cpu(), ovae.decode_latents(ovae.SD_VAE, W, 0.18215 * z))[1] < 2.0 / 255
+
+
+@pytest.mark.gpu
+def test_pipeline_decodes_with_hip_vae(pipe):
+    from sketch2img_amd.config import TINY_VAE
+    from sketch2img_amd.vae import AutoencoderKL
+    old = pipe.vae
+    pipe.vae = AutoencoderKL(TINY_VAE).to("cuda")
+    try:
+        h = 32
+        lat = torch.randn(2, 4, h, h, generator=torch.Generator().manual_seed(6))
+        imgs = pipe(["a cat", "a dog"], height=8 * h, width=8 * h, num_inference_steps=2, latents=lat)
+        assert isinstance(imgs, list) and len(imgs) == 2 and imgs[0].size == (8 * h, 8 * h) and imgs[0].mode == "RGB"
+        arr = pipe(["a cat", "a dog"], height=8 * h, width=8 * h, num_inference_steps=2, latents=lat, output_type="np.array")
+        assert arr.shape == (2, 8 * h, 8 * h, 3) and arr.dtype == "float32" and 0.0 <= arr.min() and arr.max() <= 1.0
+    finally:
+        pipe.vae = old

