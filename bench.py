@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, separately reported) VAE decode")
     return ap.parse_args()
 
 
@@ -247,6 +248,23 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(sd_unet, sd_lgp, ehs[[0, S]], lat0[:1].cpu(), target[:1].cpu())
 
+    vae_info = None
+    if rank == 0 and not args.no_vae:
+        # latents -> pixels (modules/pipeline.py:118) is outside the per-step path and outside `value` (SURVEY 8d:
+        # F_img excludes the 2.51 TFLOP VAE decode); timed separately on this rank's S final latents
+        from sketch2img_amd.config import SD_VAE
+        from sketch2img_amd.vae import AutoencoderKL
+        vae = AutoencoderKL(SD_VAE).to(dev)
+        img = vae.decode_latents(out)
+        torch.cuda.synchronize()
+        tv = time.perf_counter()
+        img = vae.decode_latents(out)
+        torch.cuda.synchronize()
+        tv = time.perf_counter() - tv
+        vae_info = {"ms_per_image": tv / S * 1e3, "tflops": 2.5145 * S / tv, "images": S, "out_shape": list(img.shape),
+                    "finite": bool(torch.isfinite(img).all()), "note": "SD VAE decoder on the HIP kernels, synthetic "
+                    "seeded weights; not included in value / ms_per_step"}
+
     if rank == 0:
         res = {
             "metric": "sketch-guided images/sec whole-node, SD1.5 512px 50-step DDIM",
@@ -260,7 +278,7 @@ def main():
                        "parallelism": f"replicas x{world} (samples sharded, weights broadcast, latents gathered)"},
             "achieved_tflops_per_gpu": value / world * f_img_tflop(T),
             "outputs_finite": finite, "setup_s": t_setup,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "vae_decode": vae_info,
         }
         print(json.dumps(res))
     if world > 1:
