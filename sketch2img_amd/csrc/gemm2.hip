@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 }
 
 
-// number of K splits for a launch of `nwg` 64-wide tiles over KT K-tiles (1 = no split)
+// number of K splits for a launch of `nwg` 128-row tiles over KT K-tiles (1 = no split)
 inline int pick_splits(long nwg, int KT, size_t slab_bytes) {
   if (!g_ws || nwg >= 256 || KT < 16) return 1;
   int s = (int)((512 + nwg - 1) / nwg);
@@ -610,6 +610,9 @@ inline TileCfg pick_tile(int M, int N, int K) {
   if (K >= 1024 && N >= 2560 && N % 320 == 0 && (long)skg_cdiv(M, 256) * (N / 320) >= 240) return {256, 320};
   const long tm = skg_cdiv(M, 128);
   if (N % 160 == 0 && tm * (N / 160) >= 200) return {128, 160};
+  // few row tiles but a long K loop (the 8x8-resolution convolutions): the wide tile + split-K moves 40 % fewer
+  // operand bytes per flop than 128 x 64 + split-K (conv 2560->1280 @ 8x8: 68 vs 86 us)
+  if (N % 160 == 0 && K >= 2048 && tm * (N / 160) >= 24) return {128, 160};
   if (N % 128 == 0 && tm * (N / 128) >= 200) return {128, 128};
   return {128, 64};
 }
@@ -633,7 +636,7 @@ void launch_cfg(const GemmParams& p, hipStream_t st) {
   operand_bytes(p, MODE, a, b, s);
   const int KT = p.K / BK;
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
-  const int splits = (BN == 64 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
+  const int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
   constexpr int NTHR = WGM * WGN * 64;
   if (splits > 1) {
     const int per = skg_cdiv(KT, splits);
