@@ -70,6 +70,7 @@ int skg_gemm_variant(int M, int N, int K, int Cin, int mode);
  *   mode SKG_CONV_S2      stride 2                         out = in / 2
  *   mode SKG_CONV_UP2     nearest 2x upsample then stride 1  out = 2 * in
  *   mode SKG_CONV_S2T     transpose of S2 (its dgrad)      out = 2 * in
+ *   mode SKG_CONV_S2A     stride 2, padding (0,1,0,1): bottom/right only (the VAE encoder's Downsample2D)  out = in / 2
  * X fp16 [rows*IH*IW][Cin] (ldx), Wp fp16 [Cout][3][3][Cin] (tap-major, Cin contiguous),
  * Y [rows*OH*OW][Cout] (ldy).  IH, IW are the INPUT sizes.  Requires Cin % 32 == 0, Cout % 8 == 0.
  * bias / residual / alpha / flags as skg_gemm_f16.  For a dgrad pass Wp is the flipped,
@@ -80,6 +81,7 @@ int skg_gemm_variant(int M, int N, int K, int Cin, int mode);
 #define SKG_CONV_S2 1
 #define SKG_CONV_UP2 2
 #define SKG_CONV_S2T 3
+#define SKG_CONV_S2A 4
 int skg_conv3x3_f16(const void* X, int ldx, const void* Wp, void* Y, int ldy,
                     int rows, int IH, int IW, int Cin, int Cout, int mode,
                     const void* bias, const void* residual, int ldr, float alpha,
@@ -239,6 +241,13 @@ int skg_softmax_rows_f16(const void* x, int ldx, void* y, int ldy, int M, int N,
  * (the (B, H, W, 3) array the pipeline converts to PIL; scale 0.5, shift 0.5). */
 int skg_image_postprocess(const void* x, int ld, float* out, size_t pixels, int C, float scale, float shift,
                           void* stream);
+
+/* VAE encoder tail (app.py:109: vae.encode(img).latent_dist.sample() * 0.18215): from the fp16 NHWC moments
+ * [samples*HW][ld] = (mean[0..L), logvar[L..2L)) to float NCHW [samples][L][HW]:
+ *   out = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale;   noise NULL -> the mode (mean * scale).
+ * noise is a caller-drawn standard normal tensor in the output layout (the reference draws it from torch's RNG). */
+int skg_gaussian_sample(const void* moments, int ld, const float* noise, float* out, int samples, int L, int HW,
+                        float scale, void* stream);
 
 /* CFG combine + one DPM-Solver++ (2M, midpoint) update - the scheduler app.py:13-25 configures - on float NCHW latents:
  *   eps = eps_u + g*(eps_c - eps_u);  x0 = (x - sigma_s*eps)/alpha_s;  x_prev = a*x + b*x0 + c*x0_before

@@ -1,4 +1,4 @@
-"""Oracle: Stable Diffusion VAE decoder (AutoencoderKL.decode), plain PyTorch, NCHW.  TEST INFRASTRUCTURE.
+"""Oracle: Stable Diffusion VAE (AutoencoderKL.decode / .encode), plain PyTorch, NCHW.  TEST INFRASTRUCTURE.
 
 Restates what the reference reaches at ``modules/pipeline.py:118`` (``self.decode_latents(latents)``: third-party
 StableDiffusionPipeline.decode_latents = ``latents / 0.18215`` -> ``vae.decode(...).sample`` -> ``/2 + 0.5`` ->
@@ -18,7 +18,16 @@ Attn(C):  GN -> q,k,v Linear(C,C)+b over the HW tokens, ONE head of width C: sof
           proj_attn Linear(C,C)+b -> + residual.  Scores / probabilities are kept in the activation dtype with an
           fp32 softmax, as AttentionBlock does.
 
-Weights are a flat dict with the diffusers AutoencoderKL state_dict key names (``decoder.*``, ``post_quant_conv.*``).
+Encoder (``app.py:109``: ``vae.encode(img).latent_dist.sample() * 0.18215`` makes the sketch target; third-party
+diffusers Encoder / DownEncoderBlock2D / Downsample2D / DiagonalGaussianDistribution, PARITY UNPINNED; validated by
+the exact parameter count 34 163 592 + 72 for quant_conv):
+          conv_in 3x3 3->C0;  down blocks over block_out: layers_per_block x Res, then (except the last)
+          F.pad(0,1,0,1) + conv3x3 stride 2 padding 0;  mid: Res, Attn, Res;  GroupNorm -> SiLU ->
+          conv_out 3x3 C3->2*latent;  quant_conv 1x1;  moments = (mean, logvar): logvar clamped to [-30, 20],
+          sample = mean + exp(0.5 logvar) * noise, mode = mean.
+
+Weights are a flat dict with the diffusers AutoencoderKL state_dict key names (``decoder.*``, ``post_quant_conv.*``,
+``encoder.*``, ``quant_conv.*``).
 """
 from __future__ import annotations
 
@@ -188,3 +197,76 @@ def decoder_flops(cfg: VAEConfig, h: int) -> float:
         fl += 2.0 * math.prod(shp) * side * side
     fl += 2.0 * 2.0 * (h * h) ** 2 * c_top          # q k^T and p v
     return fl
+
+
+# ------------------------------------------------------------------------------------------------------ encoder
+def encoder_param_shapes(cfg: VAEConfig = SD_VAE) -> "OrderedDict[str, tuple]":
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+    boc, L = cfg.block_out_channels, cfg.latent_channels
+    out["encoder.conv_in.weight"] = (boc[0], cfg.out_channels, 3, 3)
+    out["encoder.conv_in.bias"] = (boc[0],)
+    prev = boc[0]
+    for i, co in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            _res_shapes(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else co, co, out)
+        if i != len(boc) - 1:
+            out[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (co, co, 3, 3)
+            out[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (co,)
+        prev = co
+    ct = boc[-1]
+    _res_shapes("encoder.mid_block.resnets.0", ct, ct, out)
+    a = "encoder.mid_block.attentions.0"
+    out[a + ".group_norm.weight"] = (ct,)
+    out[a + ".group_norm.bias"] = (ct,)
+    for n in ("query", "key", "value", "proj_attn"):
+        out[f"{a}.{n}.weight"] = (ct, ct)
+        out[f"{a}.{n}.bias"] = (ct,)
+    _res_shapes("encoder.mid_block.resnets.1", ct, ct, out)
+    out["encoder.conv_norm_out.weight"] = (ct,)
+    out["encoder.conv_norm_out.bias"] = (ct,)
+    out["encoder.conv_out.weight"] = (2 * L, ct, 3, 3)
+    out["encoder.conv_out.bias"] = (2 * L,)
+    out["quant_conv.weight"] = (2 * L, 2 * L, 1, 1)
+    out["quant_conv.bias"] = (2 * L,)
+    return out
+
+
+def init_encoder_weights(cfg: VAEConfig = SD_VAE, seed: int = 20261001) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, torch.Tensor] = {}
+    for k, shp in encoder_param_shapes(cfg).items():
+        if "norm" in k and k.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            w = 0.05 * torch.randn(shp, generator=g)
+        else:
+            w = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(math.prod(shp[1:]))
+        W[k] = w.half().float()
+    return W
+
+
+def encode_moments(cfg: VAEConfig, W: Dict[str, torch.Tensor], img: torch.Tensor):
+    """AutoencoderKL.encode(img).latent_dist -> (mean, logvar clamped), each (B, 4, H/8, W/8)."""
+    g = cfg.norm_groups
+    x = F.conv2d(img, W["encoder.conv_in.weight"], W["encoder.conv_in.bias"], padding=1)
+    nb = len(cfg.block_out_channels)
+    for i in range(nb):
+        for j in range(cfg.layers_per_block):
+            x = _resnet(W, f"encoder.down_blocks.{i}.resnets.{j}", x, g)
+        if i != nb - 1:
+            x = F.conv2d(F.pad(x, (0, 1, 0, 1)), W[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"],
+                         W[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"], stride=2)
+    x = _resnet(W, "encoder.mid_block.resnets.0", x, g)
+    x = _attn(W, "encoder.mid_block.attentions.0", x, g)
+    x = _resnet(W, "encoder.mid_block.resnets.1", x, g)
+    x = F.silu(_gn(W, "encoder.conv_norm_out", x, g))
+    x = F.conv2d(x, W["encoder.conv_out.weight"], W["encoder.conv_out.bias"], padding=1)
+    m = F.conv2d(x, W["quant_conv.weight"], W["quant_conv.bias"])
+    mean, logvar = m.chunk(2, dim=1)
+    return mean, logvar.clamp(-30.0, 20.0)
+
+
+def encode_sample(cfg: VAEConfig, W, img: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """latent_dist.sample() with the standard-normal draw passed in (the reference draws it from torch's RNG)."""
+    mean, logvar = encode_moments(cfg, W, img)
+    return mean + torch.exp(0.5 * logvar) * noise

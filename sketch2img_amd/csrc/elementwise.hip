@@ -268,6 +268,27 @@ __global__ __launch_bounds__(256) void image_post_kernel(const half_t* __restric
   }
 }
 
+// DiagonalGaussianDistribution.sample() * scale from the encoder's moments: fp16 NHWC [px][ld] = (mean[0..L), logvar[L..2L))
+// -> float NCHW [S][L][HW]; logvar clamped to [-30, 20]; noise = caller-drawn N(0,1), NCHW (NULL: the mode = mean)
+__global__ __launch_bounds__(256) void gaussian_sample_kernel(const half_t* __restrict__ m, int ld,
+                                                              const float* __restrict__ noise, float* __restrict__ out,
+                                                              int S, int L, int HW, float scale) {
+  const size_t total = (size_t)S * L * HW;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int p = (int)(i % HW);
+    const size_t t = i / HW;
+    const int c = (int)(t % L);
+    const size_t s = t / L;
+    const half_t* px = m + (s * HW + p) * ld;
+    float v = (float)px[c];
+    if (noise) {
+      const float lv = fminf(fmaxf((float)px[L + c], -30.f), 20.f);
+      v += __expf(0.5f * lv) * noise[i];
+    }
+    out[i] = v * scale;
+  }
+}
+
 // CFG combine + one DPM-Solver++ (2M) update: x0 = (x - sigma_s*eps)/alpha_s; x_prev = a*x + b*x0 + c*x0_before.
 // x0_io holds the previous step's x0 on entry (ignored when c == 0) and this step's x0 on exit.
 __global__ __launch_bounds__(256) void cfg_dpm_kernel(const half_t* __restrict__ eu, const half_t* __restrict__ ec,
@@ -450,6 +471,15 @@ extern "C" int skg_image_postprocess(const void* x, int ld, float* out, size_t p
   hipLaunchKernelGGL(image_post_kernel, dim3(ew_grid((size_t)pixels * C)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x, ld, out, (size_t)pixels, C, scale, shift);
   SKG_CHECK_LAUNCH("skg_image_postprocess");
+  return SKG_OK;
+}
+
+extern "C" int skg_gaussian_sample(const void* moments, int ld, const float* noise, float* out, int samples, int L,
+                                   int HW, float scale, void* stream) {
+  SKG_REQUIRE(moments && out && samples > 0 && L > 0 && HW > 0 && ld >= 2 * L);
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3(ew_grid((size_t)samples * L * HW)), dim3(256), 0,
+                     (hipStream_t)stream, (const half_t*)moments, ld, noise, out, samples, L, HW, scale);
+  SKG_CHECK_LAUNCH("skg_gaussian_sample");
   return SKG_OK;
 }
 

@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
         if (MODE == MODE_S1) {
           iy = ty; ix = tx;
           ok = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        } else if (MODE == MODE_S2) {
-          iy = ty + a_oy[q]; ix = tx + a_ox[q];     // 2*o + k - 1
+        } else if (MODE == MODE_S2 || MODE == MODE_S2A) {
+          iy = ty + a_oy[q] + (MODE == MODE_S2A); ix = tx + a_ox[q] + (MODE == MODE_S2A);     // 2*o + k - 1 (+1)
           ok = ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
         } else if (MODE == MODE_UP2) {
           ok = ok && ty >= 0 && ty < p.OH && tx >= 0 && tx < p.OW;
@@ -249,6 +249,10 @@ extern "C" int skg_conv3x3_f16(const void* X, int ldx, const void* Wp, void* Y, 
       SKG_REQUIRE(IH % 2 == 0 && IW % 2 == 0);
       p.OH = IH / 2; p.OW = IW / 2; p.M = rows * p.OH * p.OW;
       return launch<MODE_S2>(p, st);
+    case SKG_CONV_S2A:
+      SKG_REQUIRE(IH % 2 == 0 && IW % 2 == 0);
+      p.OH = IH / 2; p.OW = IW / 2; p.M = rows * p.OH * p.OW;
+      return launch<MODE_S2A>(p, st);
     case SKG_CONV_UP2:
       p.OH = IH * 2; p.OW = IW * 2; p.M = rows * p.OH * p.OW;
       return launch<MODE_UP2>(p, st);

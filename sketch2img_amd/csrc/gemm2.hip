@@ -139,7 +139,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
   constexpr int BCH = BN / 8 / NW;    // B 8-row chunks per wave (5, 4, 2)
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
   constexpr int STAGE = (BM + BN) * BK;               // halves per stage: A tile then B tile
-  constexpr bool AFFINE = (MODE == MODE_DIRECT || MODE == MODE_S1 || MODE == MODE_S2);
+  constexpr bool AFFINE = (MODE == MODE_DIRECT || MODE == MODE_S1 || MODE == MODE_S2 || MODE == MODE_S2A);
   __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
 
   const int tid = threadIdx.x;
@@ -206,8 +206,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
       const int rr = mm - b * ohw;
       const int oy = rr / p.OW, ox = rr - oy * p.OW;
       const unsigned img = (unsigned)b * (unsigned)(p.IH * p.IW);
-      if (MODE == MODE_S1 || MODE == MODE_S2) {
-        const int cy = MODE == MODE_S2 ? 2 * oy : oy, cx = MODE == MODE_S2 ? 2 * ox : ox;
+      if (MODE == MODE_S1 || MODE == MODE_S2 || MODE == MODE_S2A) {
+        // centre pixel of output (oy, ox): stride 1 / stride 2 with padding 1 / stride 2 with padding (0,1,0,1)
+        const int cy = MODE == MODE_S1 ? oy : 2 * oy + (MODE == MODE_S2A), cx = MODE == MODE_S1 ? ox : 2 * ox + (MODE == MODE_S2A);
         // with the shifted base, tap (ky,kx) of this row is at voff + ((ky*IW + kx)*lda + c0)*2
         a_voff[j] = ok ? ((img + (unsigned)(cy * p.IW + cx)) * (unsigned)p.lda) * 2u + pk : OOB;
         unsigned mk = 0;
@@ -682,6 +683,7 @@ bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
     case MODE_S2: launch_mode<MODE_S2>(p, st); break;
     case MODE_UP2: launch_mode<MODE_UP2>(p, st); break;
     case MODE_S2T: launch_mode<MODE_S2T>(p, st); break;
+    case MODE_S2A: launch_mode<MODE_S2A>(p, st); break;
     default: return false;
   }
   return true;

@@ -2,7 +2,7 @@
 #pragma once
 #include "common.h"
 
-enum { MODE_DIRECT = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_UP2 = 3, MODE_S2T = 4 };
+enum { MODE_DIRECT = 0, MODE_S1 = 1, MODE_S2 = 2, MODE_UP2 = 3, MODE_S2T = 4, MODE_S2A = 5 };
 
 struct GemmParams {
   const half_t* A; int lda;

@@ -14,7 +14,7 @@ import torch
 from ._lib import SkgTap, check, lib
 
 EPI_RELU, EPI_OUT_F32, EPI_GEGLU = 1, 2, 4
-CONV_S1, CONV_S2, CONV_UP2, CONV_S2T = 0, 1, 2, 3
+CONV_S1, CONV_S2, CONV_UP2, CONV_S2T, CONV_S2A = 0, 1, 2, 3, 4
 
 
 _workspace = {}
@@ -73,7 +73,7 @@ def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode
     assert Wp.shape[1] == 9 * Cin and Wp.is_contiguous() and X.shape[0] == rows * IH * IW
     if mode == CONV_S1:
         OH, OW = IH, IW
-    elif mode == CONV_S2:
+    elif mode in (CONV_S2, CONV_S2A):
         OH, OW = IH // 2, IW // 2
     else:
         OH, OW = IH * 2, IW * 2
@@ -386,6 +386,15 @@ def image_postprocess(X, pixels: int, C: int, scale: float = 0.5, shift: float =
     out = torch.empty(pixels, C, device=X.device, dtype=torch.float32)
     check(lib.skg_image_postprocess(_p(X), _ld(X), _p(out), pixels, C, scale, shift, _stream()),
           "skg_image_postprocess")
+    return out
+
+
+def gaussian_sample(moments, samples: int, L: int, HW: int, noise=None, scale: float = 1.0):
+    """(mean + exp(0.5*clamp(logvar))*noise)*scale from fp16 NHWC moments [samples*HW, >=2L] -> float [samples, L, HW]."""
+    _f16(moments)
+    out = torch.empty(samples, L, HW, device=moments.device, dtype=torch.float32)
+    check(lib.skg_gaussian_sample(_p(moments), _ld(moments), _p(noise), _p(out), samples, L, HW, scale, _stream()),
+          "skg_gaussian_sample")
     return out
 
 

@@ -211,3 +211,46 @@ def vae_decoder_state_dict(cfg: VAEConfig, seed: int = VAE_WEIGHT_SEED) -> Dict[
             w = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(math.prod(shp[1:]))
         W[k] = w.half().float()
     return W
+
+
+VAE_ENC_WEIGHT_SEED = 20261001
+
+
+def vae_encoder_param_shapes(cfg: VAEConfig) -> "OrderedDict[str, tuple]":
+    """diffusers AutoencoderKL state_dict keys (encoder.*, quant_conv.*) -> shapes."""
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    boc, L = cfg.block_out_channels, cfg.latent_channels
+    s["encoder.conv_in.weight"] = (boc[0], cfg.out_channels, 3, 3); s["encoder.conv_in.bias"] = (boc[0],)
+    prev = boc[0]
+    for i, co in enumerate(boc):
+        for j in range(cfg.layers_per_block):
+            _vae_res(f"encoder.down_blocks.{i}.resnets.{j}", prev if j == 0 else co, co, s)
+        if i != len(boc) - 1:
+            s[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (co, co, 3, 3)
+            s[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (co,)
+        prev = co
+    ct = boc[-1]
+    _vae_res("encoder.mid_block.resnets.0", ct, ct, s)
+    a = "encoder.mid_block.attentions.0"
+    s[a + ".group_norm.weight"] = (ct,); s[a + ".group_norm.bias"] = (ct,)
+    for n in ("query", "key", "value", "proj_attn"):
+        s[f"{a}.{n}.weight"] = (ct, ct); s[f"{a}.{n}.bias"] = (ct,)
+    _vae_res("encoder.mid_block.resnets.1", ct, ct, s)
+    s["encoder.conv_norm_out.weight"] = (ct,); s["encoder.conv_norm_out.bias"] = (ct,)
+    s["encoder.conv_out.weight"] = (2 * L, ct, 3, 3); s["encoder.conv_out.bias"] = (2 * L,)
+    s["quant_conv.weight"] = (2 * L, 2 * L, 1, 1); s["quant_conv.bias"] = (2 * L,)
+    return s
+
+
+def vae_encoder_state_dict(cfg: VAEConfig, seed: int = VAE_ENC_WEIGHT_SEED) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, torch.Tensor] = {}
+    for k, shp in vae_encoder_param_shapes(cfg).items():
+        if "norm" in k and k.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            w = 0.05 * torch.randn(shp, generator=g)
+        else:
+            w = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(math.prod(shp[1:]))
+        W[k] = w.half().float()
+    return W

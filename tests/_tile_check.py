@@ -60,6 +60,9 @@ check("conv s1", from_nhwc(y.float().cpu(), Bn, H, H),
       F.conv2d(x.float(), w.float(), b.float(), padding=1) + from_nhwc(res.float(), Bn, H, H))
 y = ops.conv3x3(nhwc(x).to(D), pack_conv(w, D), Bn, H, H, ops.CONV_S2)
 check("conv s2", from_nhwc(y.float().cpu(), Bn, H // 2, H // 2), F.conv2d(x.float(), w.float(), stride=2, padding=1))
+y = ops.conv3x3(nhwc(x).to(D), pack_conv(w, D), Bn, H, H, ops.CONV_S2A, bias=b.to(D))
+check("conv s2 asym pad", from_nhwc(y.float().cpu(), Bn, H // 2, H // 2),
+      F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), b.float(), stride=2))
 y = ops.conv3x3(nhwc(x).to(D), pack_conv(w, D), Bn, H, H, ops.CONV_UP2)
 check("conv up2", from_nhwc(y.float().cpu(), Bn, 2 * H, 2 * H),
       F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), padding=1))

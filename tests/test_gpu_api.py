@@ -331,3 +331,30 @@ def test_pipeline_decodes_with_hip_vae(pipe):
         assert arr.shape == (2, 8 * h, 8 * h, 3) and arr.dtype == "float32" and 0.0 <= arr.min() and arr.max() <= 1.0
     finally:
         pipe.vae = old
+
+
+@pytest.mark.gpu
+def test_vae_encoder_tiny_and_full_width_vs_oracle():
+    """AutoencoderKL.encode(img).latent_dist: moments, mode and sample (shared noise) vs oracle/vae.py - a narrow
+    config on 3 images in chunks of 2, then the SD encoder (34 163 592 + 72 parameters) on one 256x256 image."""
+    from oracle import vae as ovae
+    from sketch2img_amd.config import SD_VAE, TINY_VAE
+    from sketch2img_amd.vae import AutoencoderKL
+    for cfg, ocfg, S, H, tol in ((TINY_VAE, ovae.TINY_VAE, 3, 64, 3e-3), (SD_VAE, ovae.SD_VAE, 1, 256, 4e-3)):
+        W = ovae.init_encoder_weights(ocfg)
+        vae = AutoencoderKL(cfg).to("cuda")
+        vae._hip_enc.chunk = 2
+        assert all(torch.equal(vae.state_dict()[k], W[k]) for k in W)
+        g = torch.Generator().manual_seed(8)
+        img = (torch.rand(S, 3, H, H, generator=g) * 2 - 1)
+        mean, logvar = ovae.encode_moments(ocfg, W, img)
+        dist = vae.encode(img.to(DEV)).latent_dist
+        assert report(f"vae encode mean C0={cfg.block_out_channels[0]}", dist.mean.cpu(), mean)[0] < tol
+        assert report("vae encode logvar", dist.logvar.cpu(), logvar)[1] < 2e-2
+        assert report("vae encode mode", dist.mode().cpu(), mean)[0] < tol
+        noise = torch.randn(S, 4, H // 8, H // 8, generator=g)
+        z = vae._hip_enc.encode(img, noise, 0.18215)
+        assert report("vae encode sample*0.18215", z.cpu(), 0.18215 * ovae.encode_sample(ocfg, W, img, noise))[0] < tol
+        s1 = dist.sample(generator=torch.Generator(DEV).manual_seed(3))
+        s2 = dist.sample(generator=torch.Generator(DEV).manual_seed(3))
+        assert s1.shape == (S, 4, H // 8, H // 8) and torch.equal(s1, s2) and not torch.equal(s1, dist.mode())

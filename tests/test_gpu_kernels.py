@@ -105,6 +105,10 @@ def test_conv3x3_stride2_up2_and_dgrads(ops):
     y = ops.conv3x3(nhwc(x).to(d), pack_conv(w, d), B, H, H, ops.CONV_S2)
     ref = F.conv2d(x.float(), w.float(), stride=2, padding=1)
     assert report("conv s2", from_nhwc(y.float().cpu(), B, H // 2, H // 2), ref)[0] < FP16_RND
+    # stride 2 with padding (0,1,0,1): the VAE encoder's Downsample2D
+    y = ops.conv3x3(nhwc(x).to(d), pack_conv(w, d), B, H, H, ops.CONV_S2A)
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w.float(), stride=2)
+    assert report("conv s2 asym", from_nhwc(y.float().cpu(), B, H // 2, H // 2), ref)[0] < FP16_RND
     # nearest-2x upsample fused into the gather
     y = ops.conv3x3(nhwc(x).to(d), pack_conv(w, d), B, H, H, ops.CONV_UP2)
     ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), padding=1)

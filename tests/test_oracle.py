@@ -301,3 +301,26 @@ def test_vae_decoder_inventory_known_answers():
     # a horizontally flipped latent is NOT the flip of the decode (sanity that the graph is not degenerate)
     img = vae.decode_latents(vae.TINY_VAE, W, 0.18215 * z)
     assert img.shape == (2, 64, 64, 3) and 0.0 <= float(img.min()) and float(img.max()) <= 1.0
+
+
+def test_vae_encoder_inventory_known_answers():
+    import math
+    from oracle import vae
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import SD_VAE, TINY_VAE
+    n = sum(math.prod(s) for s in vae.encoder_param_shapes(vae.SD_VAE).values())
+    assert n - 72 == 34_163_592                        # encoder.* ; quant_conv adds 72
+    nd = sum(math.prod(s) for s in vae.decoder_param_shapes(vae.SD_VAE).values())
+    assert n + nd == 83_653_863                        # the whole AutoencoderKL
+    for c, o in ((TINY_VAE, vae.TINY_VAE), (SD_VAE, vae.SD_VAE)):
+        assert list(synthetic.vae_encoder_param_shapes(c).items()) == list(vae.encoder_param_shapes(o).items())
+    a, b = synthetic.vae_encoder_state_dict(TINY_VAE), vae.init_encoder_weights(vae.TINY_VAE)
+    assert all(torch.equal(a[k], b[k]) for k in b)
+    W = vae.init_encoder_weights(vae.TINY_VAE)
+    img = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    mean, logvar = vae.encode_moments(vae.TINY_VAE, W, img)
+    assert mean.shape == logvar.shape == (2, 4, 8, 8) and float(logvar.max()) <= 20.0
+    z = vae.encode_sample(vae.TINY_VAE, W, img, torch.zeros_like(mean))
+    assert torch.equal(z, mean)                        # zero noise -> the mode
+    # Downsample2D pads bottom/right only: shifting the image by one pixel changes the latent (not stride-2 aligned)
+    assert not torch.allclose(vae.encode_moments(vae.TINY_VAE, W, torch.roll(img, 1, 3))[0], mean, atol=1e-3)
