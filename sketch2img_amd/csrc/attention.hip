@@ -33,7 +33,31 @@ struct AttnParams {
   const float* delta;             // [batch][heads][Nq]
   int batch, heads, Nq, Nkv, kv_stride, dh;
   float scale;
+  int nx;                         // workgroups per (batch row, head): launches are 1-D, nx * heads * batch
 };
+
+// Workgroup -> (tile, head, batch row).  Workgroup b runs on XCD b % 8 and every XCD has its own L2, so all nx
+// workgroups of one (row, head) - which stream the same K / V (or Q / dO) panels - are placed on ONE XCD: pair
+// = 8 * (slot / nx) + xcd.  With the plain x-fastest 3-D grid the 32 query tiles of a head were spread over all 8
+// XCDs and each L2 fetched the panel again (rocprofv3 FETCH_SIZE: 428 MB per forward launch at 64x64, 2.5 x the
+// algorithmic bytes).  Falls back to the plain order when heads * batch is not a multiple of 8.
+struct BlkMap { int bx, h, b; };
+__device__ __forceinline__ BlkMap attn_block_map(const AttnParams& p) {
+  const int lid = blockIdx.x, nx = p.nx;
+  const int pairs = p.heads * p.batch;
+  int pair, bx;
+  if ((pairs & 7) == 0) {
+    const int xcd = lid & 7, slot = lid >> 3;
+    const int grp = slot / nx;
+    pair = grp * 8 + xcd;
+    bx = slot - grp * nx;
+  } else {
+    pair = lid / nx;
+    bx = lid - pair * nx;
+  }
+  const int b = pair / p.heads;
+  return {bx, pair - b * p.heads, b};
+}
 
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float LOG2E = 1.4426950408889634f;
@@ -189,14 +213,15 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
   half_t* const Vs1 = lds + 2 * KSZ + VSZ;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const BlkMap bm = attn_block_map(p);
+  const int b = bm.b, h = bm.h;
   const int dh = p.dh;
   int q[QT];
   bool qok[QT];
   half8_t qf[QT][KS];
 #pragma unroll
   for (int i = 0; i < QT; ++i) {
-    q[i] = blockIdx.x * (64 * QT) + (wave * QT + i) * 16 + l16;
+    q[i] = bm.bx * (64 * QT) + (wave * QT + i) * 16 + l16;
     qok[i] = q[i] < p.Nq;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -346,8 +371,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   __shared__ __attribute__((aligned(16))) half_t Kt[ND * 16 * TP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * 64 + wave * 16 + l16;
+  const BlkMap bm = attn_block_map(p);
+  const int b = bm.b, h = bm.h;
+  const int q = bm.bx * 64 + wave * 16 + l16;
   const bool qok = q < p.Nq;
   const int dh = p.dh;
 
@@ -445,8 +471,9 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
   __shared__ float lse_s[64], del_s[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, g = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int kv = blockIdx.x * 64 + wave * 16 + l16;
+  const BlkMap bm = attn_block_map(p);
+  const int b = bm.b, h = bm.h;
+  const int kv = bm.bx * 64 + wave * 16 + l16;
   const bool kok = kv < p.Nkv;
   const int dh = p.dh;
 
@@ -616,8 +643,9 @@ extern "C" int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, cons
   p.O = (half_t*)O; p.ldo = ldo; p.lse = lse;
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid1(skg_cdiv(Nq, 64), heads, batch), grid2(skg_cdiv(Nq, 128), heads, batch);
-  SKG_ATTN_FWD_DISPATCH(grid1, grid2);
+  p.nx = skg_cdiv(Nq, dh == 160 ? 64 : 128);       // query tiles per workgroup: see SKG_ATTN_FWD_DISPATCH
+  dim3 grid((unsigned)p.nx * heads * batch);
+  SKG_ATTN_FWD_DISPATCH(grid, grid);
   SKG_CHECK_LAUNCH("skg_attn_fwd");
   return SKG_OK;
 }
@@ -647,7 +675,8 @@ extern "C" int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, c
   p.lse = const_cast<float*>(lse); p.delta = delta; p.O = (half_t*)dQ; p.ldo = lddq;
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(skg_cdiv(Nq, 64), heads, batch);
+  p.nx = skg_cdiv(Nq, 64);
+  dim3 grid((unsigned)p.nx * heads * batch);
   SKG_ATTN_DISPATCH(attn_bwd_dq_kernel, grid);
   SKG_CHECK_LAUNCH("skg_attn_bwd_dq");
   return SKG_OK;
@@ -670,7 +699,8 @@ extern "C" int skg_attn_bwd_dkv(const void* Q, int ldq, const void* Qt, int ldqt
   p.O2 = (half_t*)dV; p.ldo2 = lddv;
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = Nkv; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(skg_cdiv(Nkv, 64), heads, batch);
+  p.nx = skg_cdiv(Nkv, 64);
+  dim3 grid((unsigned)p.nx * heads * batch);
   SKG_ATTN_DISPATCH(attn_bwd_dkv_kernel, grid);
   SKG_CHECK_LAUNCH("skg_attn_bwd_dkv");
   return SKG_OK;
