@@ -160,7 +160,9 @@ struct KVRegs {
   half8_t k[NK], v[NV];
 };
 
-template <int KS, int ND>
+// ONES: V^T row `dh` (the first padding row of the last 16-row tile) is filled with 1.0, so that row of
+// O^T = V^T P^T accumulates the softmax denominator sum_k p[k] on the matrix pipe instead of the VALU.
+template <int KS, int ND, bool ONES = false>
 __device__ __forceinline__ void kv_load(KVRegs<KS, ND>& r, const half_t* __restrict__ Kb, int ldk,
                                         const half_t* __restrict__ Vb, int ldvt, int kv0, int kvlim, int dh) {
   constexpr int PPR = KS * 4;
@@ -175,6 +177,10 @@ __device__ __forceinline__ void kv_load(KVRegs<KS, ND>& r, const half_t* __restr
     const int pi = threadIdx.x + q * 256;
     const int d = pi >> 3, pc = (pi & 7) * 8;
     r.v[q] = (pi < ND * 128 && d < dh && kv0 + pc < kvlim) ? ld_half8(Vb + (size_t)d * ldvt + kv0 + pc) : zero_half8();
+    if (ONES && d == dh) {
+      const half_t one = (half_t)1.f;
+      r.v[q] = half8_t{one, one, one, one, one, one, one, one};
+    }
   }
 }
 
@@ -238,6 +244,9 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
     for (int u = 0; u < ND; ++u) o[i][u] = float4_t{0.f, 0.f, 0.f, 0.f};
   }
   const float sc = p.scale * LOG2E;
+  // <2, 3> is dispatched for d = 40 only: 8 spare rows in the 48-row V^T tile -> the denominator comes out of the
+  // PV MFMA (row 40 of O^T) and the 16 adds per tile and query tile leave the VALU, which bounds this head size
+  constexpr bool ONES = (KS == 2 && ND == 3);
 
   const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
   const half_t* Vb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
@@ -258,7 +267,6 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
       }
     }
     half8_t pb[QT][2];
-    float alpha[QT];
 #pragma unroll
     for (int i = 0; i < QT; ++i) {
       if (kv0 + 64 > p.Nkv) {          // ragged last tile only (wave-uniform)
@@ -274,8 +282,14 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mn = fmaxf(m[i], mx * sc);
-      alpha[i] = __builtin_amdgcn_exp2f(m[i] - mn);
-      m[i] = mn;
+      // rescale only when some query of this wave saw a new maximum (rare after the first tiles): wave-uniform
+      if (__builtin_amdgcn_ballot_w64(mn != m[i]) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m[i] - mn);
+        m[i] = mn;
+        if (!ONES) l[i] *= alpha;
+#pragma unroll
+        for (int u = 0; u < ND; ++u) o[i][u] *= alpha;
+      }
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -283,12 +297,10 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
         for (int r = 0; r < 4; ++r) {
           const float e = __builtin_amdgcn_exp2f(fmaf(s[i][t][r], sc, -mn));
           s[i][t][r] = e;
-          ps += e;
+          if (!ONES) ps += e;
         }
-      l[i] = l[i] * alpha[i] + ps;
+      if (!ONES) l[i] += ps;
       pack_p(s[i], pb[i]);
-#pragma unroll
-      for (int u = 0; u < ND; ++u) o[i][u] *= alpha[i];
     }
 #pragma unroll
     for (int u = 0; u < ND; ++u)
@@ -305,22 +317,22 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
   // Invariant at the top of the (unrolled-by-2) loop, t even: stage 0 = tile t, r0 = tile t+1, r1 = tile t+2.
   constexpr bool DEEP = KS < 5;      // d = 160: a second register set would not fit 2 waves / SIMD
   KVRegs<KS, ND> r0;
-  kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, 0, p.kv_stride, dh);
+  kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, 0, p.kv_stride, dh);
   kv_store<KS, ND>(r0, Ks0, Vs0);
-  if (nt > 1) kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, 64, p.kv_stride, dh);
+  if (nt > 1) kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, 64, p.kv_stride, dh);
   if constexpr (DEEP) {
     KVRegs<KS, ND> r1;
-    if (nt > 2) kv_load<KS, ND>(r1, Kb, p.ldk, Vb, p.ldvt, 128, p.kv_stride, dh);
+    if (nt > 2) kv_load<KS, ND, ONES>(r1, Kb, p.ldk, Vb, p.ldvt, 128, p.kv_stride, dh);
     __syncthreads();
     for (int t0 = 0; t0 < nt; t0 += 2) {
       tile(Ks0, Vs0, t0 * 64);
       if (t0 + 1 < nt) kv_store<KS, ND>(r0, Ks1, Vs1);
-      if (t0 + 3 < nt) kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 3) * 64, p.kv_stride, dh);
+      if (t0 + 3 < nt) kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 3) * 64, p.kv_stride, dh);
       __syncthreads();
       if (t0 + 1 < nt) {
         tile(Ks1, Vs1, (t0 + 1) * 64);
         if (t0 + 2 < nt) kv_store<KS, ND>(r1, Ks0, Vs0);
-        if (t0 + 4 < nt) kv_load<KS, ND>(r1, Kb, p.ldk, Vb, p.ldvt, (t0 + 4) * 64, p.kv_stride, dh);
+        if (t0 + 4 < nt) kv_load<KS, ND, ONES>(r1, Kb, p.ldk, Vb, p.ldvt, (t0 + 4) * 64, p.kv_stride, dh);
         __syncthreads();
       }
     }
@@ -332,19 +344,24 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
       if (t0 + 1 < nt) kv_store<KS, ND>(r0, Ks1, Vs1);
       __syncthreads();
       if (t0 + 1 < nt) {
-        if (t0 + 2 < nt) kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 2) * 64, p.kv_stride, dh);
+        if (t0 + 2 < nt) kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 2) * 64, p.kv_stride, dh);
         tile(Ks1, Vs1, (t0 + 1) * 64);
         if (t0 + 2 < nt) kv_store<KS, ND>(r0, Ks0, Vs0);
-        if (t0 + 3 < nt) kv_load<KS, ND>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 3) * 64, p.kv_stride, dh);
+        if (t0 + 3 < nt) kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 3) * 64, p.kv_stride, dh);
         __syncthreads();
       }
     }
   }
 #pragma unroll
   for (int i = 0; i < QT; ++i) {
-    float li = l[i];
-    li += __shfl_xor(li, 16, 64);
-    li += __shfl_xor(li, 32, 64);
+    float li;
+    if (ONES) {      // denominator = row dh = 40 of O^T: tile 2, row 8 -> lanes g == 2, element 0
+      li = __shfl(o[i][ND - 1][0], 32 + l16, 64);
+    } else {
+      li = l[i];
+      li += __shfl_xor(li, 16, 64);
+      li += __shfl_xor(li, 32, 64);
+    }
     const float inv = 1.f / li;
     if (qok[i]) {
       half_t* orow = p.O + (size_t)(b * p.Nq + q[i]) * p.ldo + h * dh;
