@@ -166,6 +166,9 @@ int skg_batch_copy_f16(const void* In, int ldi, int in_batch_rows, void* Out, in
 /* Y = silu(X), fp16 [M][C], C % 8 == 0.  Used once per timestep for the time-embedding MLP
  * (diffusers TimestepEmbedding / ResnetBlock2D.time_emb_proj input), off the per-step path. */
 int skg_silu_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, void* stream);
+/* Y = X * sigmoid(1.702 X): transformers' "quick_gelu", the MLP activation of the CLIP vision tower that
+ * modules/clip_guided_inf.py:49-54,103 runs to produce the sketch tokens. */
+int skg_quick_gelu_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, void* stream);
 /* adjoint of nearest 2x upsample: Y[b][y][x][c] = sum of the 2x2 block of X.  X [rows*2H*2W][C]. */
 int skg_sumpool2x2_f16(const void* X, int ldx, void* Y, int ldy, int rows, int H, int W, int C,
                        void* stream);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "skg_axpby_f16": ("i", "pipipiiiffp"),
     "skg_batch_copy_f16": ("i", "piipiiiiip"),
     "skg_silu_f16": ("i", "pipiiip"),
+    "skg_quick_gelu_f16": ("i", "pipiiip"),
     "skg_sumpool2x2_f16": ("i", "pipiiiiip"),
     "skg_nchw_f32_to_nhwc_f16": ("i", "ppiiiip"),
     "skg_nhwc_f16_to_nchw_f32": ("i", "pipiiip"),

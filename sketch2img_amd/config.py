@@ -83,3 +83,25 @@ def vae_up_plan(cfg: VAEConfig):
         plan.append((i, [(prev if j == 0 else co, co) for j in range(cfg.layers_per_block + 1)], i != len(rev) - 1))
         prev = co
     return plan
+
+
+# ---------------------------------------------------------------------------------------- CLIP vision tower
+@dataclass(frozen=True)
+class CLIPVisionConfig:
+    """transformers CLIPVisionModel (modules/clip_guided_inf.py:49-54 loads openai/clip-vit-large-patch14)."""
+    hidden_size: int = 1024
+    intermediate_size: int = 4096
+    num_hidden_layers: int = 24
+    num_attention_heads: int = 16
+    image_size: int = 224
+    patch_size: int = 14
+    layer_norm_eps: float = 1e-5
+
+    @property
+    def num_tokens(self) -> int:
+        return (self.image_size // self.patch_size) ** 2 + 1
+
+
+VIT_L_14 = CLIPVisionConfig()
+TINY_CLIP = CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                             image_size=56, patch_size=14)

@@ -219,6 +219,15 @@ def silu(X, out=None):
     return out
 
 
+def quick_gelu(X, out=None):
+    _f16(X)
+    M, C = X.shape
+    if out is None:
+        out = torch.empty(M, C, device=X.device, dtype=torch.float16)
+    check(lib.skg_quick_gelu_f16(_p(X), _ld(X), _p(out), _ld(out), M, C, _stream()), "skg_quick_gelu_f16")
+    return out
+
+
 def sumpool2x2(X, rows, H, W, out=None):
     """X [rows*2H*2W, C] -> [rows*H*W, C]."""
     _f16(X)

@@ -13,7 +13,7 @@ from typing import Dict, Tuple
 
 import torch
 
-from .config import UNetConfig, VAEConfig, tap_channels, up_block_plan, vae_up_plan
+from .config import CLIPVisionConfig, UNetConfig, VAEConfig, tap_channels, up_block_plan, vae_up_plan
 
 WEIGHT_SEED = 20260929
 
@@ -250,6 +250,47 @@ def vae_encoder_state_dict(cfg: VAEConfig, seed: int = VAE_ENC_WEIGHT_SEED) -> D
             w = 1.0 + 0.1 * torch.randn(shp, generator=g)
         elif k.endswith(".bias"):
             w = 0.05 * torch.randn(shp, generator=g)
+        else:
+            w = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(math.prod(shp[1:]))
+        W[k] = w.half().float()
+    return W
+
+
+# ---------------------------------------------------------------------------------------------- CLIP vision tower
+CLIP_WEIGHT_SEED = 20261002
+
+
+def clip_vision_param_shapes(cfg: CLIPVisionConfig) -> "OrderedDict[str, tuple]":
+    """transformers CLIPVisionModel state_dict keys (without the 4.x ``vision_model.`` prefix) -> shapes."""
+    D, I = cfg.hidden_size, cfg.intermediate_size
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["embeddings.class_embedding"] = (D,)
+    s["embeddings.patch_embedding.weight"] = (D, 3, cfg.patch_size, cfg.patch_size)
+    s["embeddings.position_embedding.weight"] = (cfg.num_tokens, D)
+    s["pre_layrnorm.weight"] = (D,); s["pre_layrnorm.bias"] = (D,)
+    for l in range(cfg.num_hidden_layers):
+        p = f"encoder.layers.{l}"
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            s[f"{p}.self_attn.{n}.weight"] = (D, D); s[f"{p}.self_attn.{n}.bias"] = (D,)
+        s[f"{p}.layer_norm1.weight"] = (D,); s[f"{p}.layer_norm1.bias"] = (D,)
+        s[f"{p}.mlp.fc1.weight"] = (I, D); s[f"{p}.mlp.fc1.bias"] = (I,)
+        s[f"{p}.mlp.fc2.weight"] = (D, I); s[f"{p}.mlp.fc2.bias"] = (D,)
+        s[f"{p}.layer_norm2.weight"] = (D,); s[f"{p}.layer_norm2.bias"] = (D,)
+    s["post_layernorm.weight"] = (D,); s["post_layernorm.bias"] = (D,)
+    return s
+
+
+def clip_vision_state_dict(cfg: CLIPVisionConfig, seed: int = CLIP_WEIGHT_SEED) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights, same recipe and draw order as oracle/clip_vision.py init_weights."""
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, torch.Tensor] = {}
+    for k, shp in clip_vision_param_shapes(cfg).items():
+        if ("norm" in k) and k.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias") or k.endswith("class_embedding"):
+            w = 0.05 * torch.randn(shp, generator=g)
+        elif "position_embedding" in k:
+            w = 0.02 * torch.randn(shp, generator=g)
         else:
             w = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(math.prod(shp[1:]))
         W[k] = w.half().float()

@@ -358,3 +358,42 @@ def test_vae_encoder_tiny_and_full_width_vs_oracle():
         s1 = dist.sample(generator=torch.Generator(DEV).manual_seed(3))
         s2 = dist.sample(generator=torch.Generator(DEV).manual_seed(3))
         assert s1.shape == (S, 4, H // 8, H // 8) and torch.equal(s1, s2) and not torch.equal(s1, dist.mode())
+
+
+# ------------------------------------------------------------------------------------------------ CLIP vision tower
+@pytest.mark.gpu
+def test_clip_vision_tiny_matches_transformers_golden():
+    """HIP tower vs the output of transformers' own CLIPVisionModel (committed golden vector) and vs the oracle."""
+    import os
+    from oracle import clip_vision as oc
+    from sketch2img_amd.clip_vision import CLIPVisionModel
+    from sketch2img_amd.config import TINY_CLIP
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_vision_tiny.npz"))
+    W = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w.")}
+    m = CLIPVisionModel(TINY_CLIP)
+    m.load_state_dict({"vision_model." + k: v for k, v in W.items()})          # 4.x-style keys load
+    m.to(torch.device("cuda"), dtype=torch.float16)
+    x = torch.from_numpy(d["pixel_values"])
+    h = m(x.to("cuda"), output_hidden_states=True).last_hidden_state
+    assert h.shape == (2, 17, 64) and h.dtype == torch.float16
+    assert report("clip vision tiny vs transformers golden", h.float().cpu(), torch.from_numpy(d["last_hidden_state"]))[0] < 3e-3
+    assert report("clip vision tiny vs oracle", h.float().cpu(), oc.last_hidden_state(oc.TINY_CLIP, W, x))[0] < 3e-3
+
+
+@pytest.mark.gpu
+def test_clip_vision_vit_l14_vs_oracle_and_feeds_satmixin():
+    """The full ViT-L/14 tower (303 179 776 parameters, 257 tokens) vs the CPU oracle, then its tokens drive the
+    CLIP-guided injection exactly as modules/clip_guided_inf.py:103-106 does."""
+    from oracle import clip_vision as oc
+    from sketch2img_amd.clip_vision import CLIPVisionModel
+    from sketch2img_amd.config import VIT_L_14
+    m = CLIPVisionModel(VIT_L_14).to("cuda")
+    W = oc.init_weights(oc.VIT_L_14)
+    assert all(torch.equal(m.state_dict()[k], W[k]) for k in W)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(2))
+    h = m(x.to("cuda"), output_hidden_states=True).last_hidden_state
+    ref = oc.last_hidden_state(oc.VIT_L_14, W, x)
+    assert h.shape == (2, 257, 1024)
+    assert report("clip vision ViT-L/14 vs oracle", h.float().cpu(), ref)[0] < 5e-3
+    state = torch.stack([torch.zeros_like(h[:1]), h[:1]]).squeeze(1)          # clip_guided_inf.py:105
+    assert state.shape == (2, 257, 1024) and float(state[0].abs().max()) == 0.0

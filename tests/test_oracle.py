@@ -324,3 +324,41 @@ def test_vae_encoder_inventory_known_answers():
     assert torch.equal(z, mean)                        # zero noise -> the mode
     # Downsample2D pads bottom/right only: shifting the image by one pixel changes the latent (not stride-2 aligned)
     assert not torch.allclose(vae.encode_moments(vae.TINY_VAE, W, torch.roll(img, 1, 3))[0], mean, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ CLIP vision tower
+def test_clip_vision_oracle_pinned_by_transformers_golden():
+    """tests/golden/clip_vision_tiny.npz was produced by transformers' own CLIPVisionModel (tools/gen_golden_clip.py),
+    the class the reference calls at modules/clip_guided_inf.py:49-54,103."""
+    import math
+    import os
+    from oracle import clip_vision as oc
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_vision_tiny.npz"))
+    W = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w.")}
+    assert list(W) == list(oc.param_shapes(oc.TINY_CLIP)) and all(torch.equal(W[k], v) for k, v in oc.init_weights(oc.TINY_CLIP).items())
+    out = oc.last_hidden_state(oc.TINY_CLIP, W, torch.from_numpy(d["pixel_values"]))
+    ref = torch.from_numpy(d["last_hidden_state"])
+    assert out.shape == ref.shape == (2, 17, 64)
+    assert (out - ref).abs().max() < 5e-6
+    assert sum(math.prod(s) for s in oc.param_shapes(oc.VIT_L_14).values()) == 303_179_776      # ViT-L/14 tower
+    # the 4.x key prefix is accepted
+    assert list(oc.strip_prefix({"vision_model." + k: v for k, v in W.items()})) == list(W)
+
+
+def test_clip_vision_oracle_vs_live_transformers():
+    """When transformers is importable (it is in this image): a second configuration, fresh seed, directly."""
+    tr = pytest.importorskip("transformers")
+    from oracle import clip_vision as oc
+    cfg = oc.CLIPVisionConfig(hidden_size=96, intermediate_size=160, num_hidden_layers=3, num_attention_heads=3,
+                              image_size=42, patch_size=14)
+    hf = tr.CLIPVisionConfig(hidden_size=96, intermediate_size=160, num_hidden_layers=3, num_attention_heads=3,
+                             image_size=42, patch_size=14, hidden_act="quick_gelu")
+    model = tr.CLIPVisionModel(hf).eval()
+    W = oc.init_weights(cfg, seed=77)
+    pre = "vision_model." if any(k.startswith("vision_model.") for k in model.state_dict()) else ""
+    res = model.load_state_dict({pre + k: v for k, v in W.items()}, strict=False)
+    assert not res.unexpected_keys and all("position_ids" in k for k in res.missing_keys)
+    x = torch.randn(3, 3, 42, 42, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = model(x, output_hidden_states=True).last_hidden_state
+    assert (oc.last_hidden_state(cfg, W, x) - ref).abs().max() < 5e-6
