@@ -246,7 +246,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const half_t* __restrict_
   }
 }
 
-// one block per sample: loss, and the seed gradient for the cond row (zeros for the uncond row)
+// one block per sample: loss, and the seed gradient for the cond row.  dOut has been zero-filled by the launcher
+// (uncond rows and the padding columns stay zero); this kernel only writes the 4 real channels of the cond rows,
+// one pixel (8 bytes) per thread and iteration.
 __global__ __launch_bounds__(256) void mse_seed_kernel(const half_t* __restrict__ out, int ldo,
                                                        const float* __restrict__ target, half_t* __restrict__ dOut,
                                                        int ldd, float* __restrict__ loss, int S, int h,
@@ -256,17 +258,17 @@ __global__ __launch_bounds__(256) void mse_seed_kernel(const half_t* __restrict_
   const int hw = h * h;
   const float k = loss_scale * 2.f / (4.f * hw);
   float acc = 0.f;
-  for (int i = threadIdx.x; i < hw * ldd; i += 256) {
-    const int p = i / ldd, c = i - p * ldd;
-    const size_t urow = (size_t)s * hw + p, crow = ((size_t)S + s) * hw + p;
-    dOut[urow * ldd + c] = (half_t)0.f;
-    float gval = 0.f;
-    if (c < 4) {
-      const float d = (float)out[crow * ldo + c] - target[((size_t)s * 4 + c) * hw + p];
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    const size_t crow = ((size_t)S + s) * hw + p;
+    const half4_t o = ld_half4(out + crow * ldo);
+    half4_t gq;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = (float)o[c] - target[((size_t)s * 4 + c) * hw + p];
       acc += d * d;
-      gval = k * d;
+      gq[c] = (half_t)(k * d);
     }
-    dOut[crow * ldd + c] = (half_t)gval;
+    st_half4(dOut + crow * ldd, gq);
   }
   acc = block_sum<256>(acc, red);
   if (threadIdx.x == 0 && loss) loss[s] = acc / (4.f * hw);
@@ -372,7 +374,10 @@ extern "C" int skg_bn_relu_bwd(const void* X, int ldx, const void* dY, int lddy,
 
 extern "C" int skg_lgp_mse_seed(const void* out, int ldo, const float* target, void* dOut, int ldd, float* loss,
                                 int samples, int h, float loss_scale, void* stream) {
-  SKG_REQUIRE(out && target && dOut && samples > 0 && h > 0 && ldo >= 4 && ldd >= 4);
+  SKG_REQUIRE(out && target && dOut && samples > 0 && h > 0 && ldo >= 4 && ldd >= 4 && ldo % 4 == 0 && ldd % 4 == 0);
+  SKG_REQUIRE(skg_aligned(out, 8) && skg_aligned(dOut, 8));
+  if (hipMemsetAsync(dOut, 0, (size_t)2 * samples * h * h * ldd * sizeof(half_t), (hipStream_t)stream) != hipSuccess)
+    return SKG_E_LAUNCH;
   hipLaunchKernelGGL(mse_seed_kernel, dim3(samples), dim3(256), 0, (hipStream_t)stream, (const half_t*)out, ldo,
                      target, (half_t*)dOut, ldd, loss, samples, h, loss_scale);
   SKG_CHECK_LAUNCH("skg_lgp_mse_seed");
