@@ -228,6 +228,31 @@ int skg_bn_relu_bwd(const void* X, int ldx, const void* dY, int lddy, void* dX, 
 int skg_lgp_mse_seed(const void* out, int ldo, const float* target, void* dOut, int ldd,
                      float* loss, int samples, int h, float loss_scale, void* stream);
 
+/* ---- LGP training (trainer.py:208-252: forward taps -> LGP -> MSE -> backward with weight gradients -> optimizer) --
+ * The reference trains with accelerate fp16 autocast + bitsandbytes AdamW8bit; here: fp16 compute with a static loss
+ * scale, fp32 master weights, plain AdamW.  Weight gradients are GEMMs on transposed operands (skg_transpose_f16 +
+ * skg_gemm_f16 with SKG_EPI_OUT_F32); these are the remaining pieces. */
+/* out[c] = scale * sum_m X[m][c]  (bias gradients).  scratch: skg_colsum_scratch_floats(C) floats. */
+size_t skg_colsum_scratch_floats(int C);
+int skg_colsum_f16(const void* X, int ldx, int M, int C, float scale, float* out, float* scratch, void* stream);
+/* BatchNorm1d parameter gradients over `rows` rows of ONE batch: dgamma[c] = scale * sum dY*xhat, dbeta[c] = scale *
+ * sum dY, xhat from stats (mean, rstd)[C] of skg_bn_stats(samples = 1).  scratch: skg_bn_scratch_floats(1, C). */
+int skg_bn_param_grads(const void* X, int ldx, const void* dY, int lddy, int rows, int C, const float* stats,
+                       float scale, float* dgamma, float* dbeta, float* scratch, void* stream);
+/* The 40 extra input channels of LGP layer 0 (noise level x4, sin(2 pi nl 2^-l) x36; modules/latent_predictor.py:39-41),
+ * fp16, E [rows*h*h][ld] with columns >= 40 zeroed: the operand of the layer-0 weight gradient for those columns. */
+int skg_lgp_extra_features(const float* noise, float sigma, int samples, int rows, int h, void* E, int ld,
+                           void* stream);
+/* Training loss (trainer.py:240): mean((out - target)^2) over samples*4*h*h; dOut = loss_scale * d loss / d out
+ * (fp16 [samples*h*h][ldd], columns >= 4 zero); loss_parts[s] = this sample's share of the mean (sum them). */
+int skg_lgp_mse_train(const void* out, int ldo, const float* target, void* dOut, int ldd, float* loss_parts,
+                      int samples, int h, float loss_scale, void* stream);
+/* One AdamW step on a flat fp32 parameter vector (decoupled weight decay, bias correction for `step` >= 1); grad is
+ * multiplied by inv_grad_scale first; param_f16 (optional) receives the fp16 working copy. */
+int skg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_f16, size_t n,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, float inv_grad_scale,
+                   void* stream);
+
 /* ---- sampler elementwise -------------------------------------------------------------------------
  * CFG combine + DDIM step (eta = 0) on float NCHW latents:
  *   eps = eps_u + g*(eps_c - eps_u);  x0 = (x - c1*eps)/c0;  x_prev = c2*x0 + c3*eps

@@ -46,6 +46,12 @@ SIGNATURES = {
     "skg_bn_stats_from_running": ("i", "ppiifpp"),
     "skg_bn_apply": ("i", "pipiiiiipppp"),
     "skg_bn_relu_bwd": ("i", "pipipiiiiippipp"),
+    "skg_colsum_scratch_floats": ("z", "i"),
+    "skg_colsum_f16": ("i", "piiifppp"),
+    "skg_bn_param_grads": ("i", "pipiiipfpppp"),
+    "skg_lgp_extra_features": ("i", "pfiiipip"),
+    "skg_lgp_mse_train": ("i", "pippipiifp"),
+    "skg_adamw_step": ("i", "pppppzfffffifp"),
     "skg_lgp_mse_seed": ("i", "pippipiifp"),
     "skg_cfg_ddim_step": ("i", "ppipppiifffffp"),
     "skg_softmax_rows_f16": ("i", "pipiiip"),

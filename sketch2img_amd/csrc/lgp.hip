@@ -274,6 +274,119 @@ __global__ __launch_bounds__(256) void mse_seed_kernel(const half_t* __restrict_
   if (threadIdx.x == 0 && loss) loss[s] = acc / (4.f * hw);
 }
 
+// ---- training-only kernels (LGP weight gradients + AdamW: SURVEY 8f row 4, trainer.py:208-252) --------------------
+// column sums of a [M][C] fp16 matrix (bias gradients): block (x = 8-channel piece, y = row chunk) -> partial[chunk][C]
+constexpr int CS_CHUNKS = 32;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const half_t* __restrict__ X, int ldx, int M, int C,
+                                                             float* __restrict__ partial) {
+  __shared__ float red[256][8];
+  const int c0 = blockIdx.x * 8, chunk = blockIdx.y;
+  const int per = (M + CS_CHUNKS - 1) / CS_CHUNKS;
+  const int r0 = chunk * per, r1 = min(M, r0 + per);
+  float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+    const half8_t v = ld_half8(X + (size_t)r * ldx + c0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += (float)v[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = a[j];
+  __syncthreads();
+  if (threadIdx.x < 8) {          // fixed-order fold: deterministic
+    float t = 0.f;
+    for (int i = 0; i < 256; ++i) t += red[i][threadIdx.x];
+    partial[(size_t)chunk * C + c0 + threadIdx.x] = t;
+  }
+}
+__global__ void colsum_final_kernel(const float* __restrict__ partial, int C, float scale, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int k = 0; k < CS_CHUNKS; ++k) t += partial[(size_t)k * C + c];
+  out[c] = t * scale;
+}
+
+// (d gamma, d beta) = (sum dy*xhat, sum dy) * scale from the folded chunk partials of bn_partial_kernel<1>
+__global__ void bn_param_grads_kernel(const float* __restrict__ partial, int C, float scale,
+                                      float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < BN_CHUNKS; ++k) {
+    const float* q = partial + ((size_t)k * C + c) * 2;
+    s1 += q[0]; s2 += q[1];
+  }
+  dbeta[c] = s1 * scale;
+  dgamma[c] = s2 * scale;
+}
+
+// the 40 extra input channels of layer 0 (noise level + 36 sinusoids), fp16-rounded like the reference's cast:
+// E [rows*hw][ld] with columns >= 40 zero.  Same arithmetic as lgp_gather_kernel.
+__global__ __launch_bounds__(256) void lgp_extra_kernel(const float* __restrict__ noise, float sigma, int S, int rows,
+                                                        int h, half_t* __restrict__ E, int ld) {
+  const int hw = h * h;
+  const size_t total = (size_t)rows * hw * ld;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t pix = i / ld;
+    const int tl = (int)(i - pix * ld);
+    float v = 0.f;
+    if (tl < NEXTRA) {
+      const int row = (int)(pix / hw), pp = (int)(pix - (size_t)row * hw);
+      const int smp = row % S;
+      const int c = tl < 4 ? tl : (tl - 4) & 3;
+      const float nl = sigma * noise[((size_t)smp * 4 + c) * hw + pp];
+      v = nl;
+      if (tl >= 4) v = sinf((6.283185307179586f * nl) * exp2f(-(float)((tl - 4) >> 2)));
+    }
+    E[i] = (half_t)v;
+  }
+}
+
+// training loss: one scalar MSE over all samples; dOut = loss_scale * 2 (out - target) / (S*4*hw) on every row
+__global__ __launch_bounds__(256) void mse_train_kernel(const half_t* __restrict__ out, int ldo,
+                                                        const float* __restrict__ target, half_t* __restrict__ dOut,
+                                                        int ldd, float* __restrict__ loss_part, int S, int h,
+                                                        float loss_scale) {
+  __shared__ float red[8];
+  const int s = blockIdx.x;
+  const int hw = h * h;
+  const float n = 4.f * hw * S;
+  const float k = loss_scale * 2.f / n;
+  float acc = 0.f;
+  for (int p = threadIdx.x; p < hw; p += 256) {
+    const size_t row = (size_t)s * hw + p;
+    const half4_t o = ld_half4(out + row * ldo);
+    half4_t gq;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d = (float)o[c] - target[((size_t)s * 4 + c) * hw + p];
+      acc += d * d;
+      gq[c] = (half_t)(k * d);
+    }
+    st_half4(dOut + row * ldd, gq);
+  }
+  acc = block_sum<256>(acc, red);
+  if (threadIdx.x == 0) loss_part[s] = acc / n;       // the caller sums the S partials (fixed order)
+}
+
+// AdamW (decoupled weight decay), fp32 master weights + fp16 working copy; g is the loss-scaled gradient
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    half_t* __restrict__ p16, size_t n, float lr, float b1, float b2,
+                                                    float eps, float wd, float bc1, float bc2, float inv_scale) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float gi = g[i] * inv_scale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float w = p[i] * (1.f - lr * wd);
+    w -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+    p[i] = w;
+    if (p16) p16[i] = (half_t)w;
+  }
+}
+
 inline int ew_grid(size_t total_items) {
   size_t b = (total_items + 255) / 256;
   if (b > 4096) b = 4096;
@@ -381,5 +494,63 @@ extern "C" int skg_lgp_mse_seed(const void* out, int ldo, const float* target, v
   hipLaunchKernelGGL(mse_seed_kernel, dim3(samples), dim3(256), 0, (hipStream_t)stream, (const half_t*)out, ldo,
                      target, (half_t*)dOut, ldd, loss, samples, h, loss_scale);
   SKG_CHECK_LAUNCH("skg_lgp_mse_seed");
+  return SKG_OK;
+}
+
+// ---- training entry points ----------------------------------------------------------------------------------------
+extern "C" size_t skg_colsum_scratch_floats(int C) { return (size_t)CS_CHUNKS * C; }
+
+extern "C" int skg_colsum_f16(const void* X, int ldx, int M, int C, float scale, float* out, float* scratch,
+                              void* stream) {
+  SKG_REQUIRE(X && out && scratch && M > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldx >= C && skg_aligned(X, 16));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(C / 8, CS_CHUNKS), dim3(256), 0, st, (const half_t*)X, ldx, M, C,
+                     scratch);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(skg_cdiv(C, 128)), dim3(128), 0, st, scratch, C, scale, out);
+  SKG_CHECK_LAUNCH("skg_colsum_f16");
+  return SKG_OK;
+}
+
+extern "C" int skg_bn_param_grads(const void* X, int ldx, const void* dY, int lddy, int rows, int C,
+                                  const float* stats, float scale, float* dgamma, float* dbeta, float* scratch,
+                                  void* stream) {
+  SKG_REQUIRE(X && dY && stats && dgamma && dbeta && scratch && rows > 0 && C % 2 == 0 && ldx % 2 == 0 && lddy % 2 == 0);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(BN_CHUNKS, 1), dim3(256), 0, st, (const half_t*)X, ldx,
+                     (const half_t*)dY, lddy, 1, 1, rows, C, stats, scratch);
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(skg_cdiv(C, 128)), dim3(128), 0, st, scratch, C, scale, dgamma, dbeta);
+  SKG_CHECK_LAUNCH("skg_bn_param_grads");
+  return SKG_OK;
+}
+
+extern "C" int skg_lgp_extra_features(const float* noise, float sigma, int samples, int rows, int h, void* E, int ld,
+                                      void* stream) {
+  SKG_REQUIRE(noise && E && samples > 0 && rows > 0 && rows % samples == 0 && h > 0 && ld >= NEXTRA);
+  hipLaunchKernelGGL(lgp_extra_kernel, dim3(ew_grid((size_t)rows * h * h * ld)), dim3(256), 0, (hipStream_t)stream,
+                     noise, sigma, samples, rows, h, (half_t*)E, ld);
+  SKG_CHECK_LAUNCH("skg_lgp_extra_features");
+  return SKG_OK;
+}
+
+extern "C" int skg_lgp_mse_train(const void* out, int ldo, const float* target, void* dOut, int ldd,
+                                 float* loss_parts, int samples, int h, float loss_scale, void* stream) {
+  SKG_REQUIRE(out && target && dOut && loss_parts && samples > 0 && h > 0 && ldo >= 4 && ldd >= 4 && ldo % 4 == 0 &&
+              ldd % 4 == 0 && skg_aligned(out, 8) && skg_aligned(dOut, 8));
+  if (hipMemsetAsync(dOut, 0, (size_t)samples * h * h * ldd * sizeof(half_t), (hipStream_t)stream) != hipSuccess)
+    return SKG_E_LAUNCH;
+  hipLaunchKernelGGL(mse_train_kernel, dim3(samples), dim3(256), 0, (hipStream_t)stream, (const half_t*)out, ldo,
+                     target, (half_t*)dOut, ldd, loss_parts, samples, h, loss_scale);
+  SKG_CHECK_LAUNCH("skg_lgp_mse_train");
+  return SKG_OK;
+}
+
+extern "C" int skg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, void* param_f16,
+                              size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                              float inv_grad_scale, void* stream) {
+  SKG_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1 && lr >= 0.f);
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, (half_t*)param_f16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, inv_grad_scale);
+  SKG_CHECK_LAUNCH("skg_adamw_step");
   return SKG_OK;
 }

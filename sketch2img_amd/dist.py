@@ -82,3 +82,16 @@ def shard_range(total: int, rank: int, world: int):
     q, r = divmod(total, world)
     first = rank * q + min(rank, r)
     return first, q + (1 if rank < r else 0)
+
+
+def allreduce_mean_(flat: torch.Tensor, bucket_bytes: int = 15 << 20) -> torch.Tensor:
+    """In-place mean of a flat gradient vector over all ranks, in buckets of <= bucket_bytes (the reference's DDP:
+    trainer.py:91 bucket_cap_mb=15).  The one per-step collective of the LGP training path (RCCL all-reduce over
+    xGMI on GPUs; gloo in the CPU tests).  No-op when torch.distributed is not initialised or on one rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return flat
+    per = max(1, bucket_bytes // flat.element_size())
+    for o in range(0, flat.numel(), per):
+        dist.all_reduce(flat[o:o + per], op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    return flat

@@ -300,8 +300,9 @@ def attn_bwd_dkv(Q, Qt, K, V, dO, dOt, lse, delta, batch, heads, Nq, Nkv, dh, sc
 
 # ---- LGP --------------------------------------------------------------------------------------------
 def lgp_layer0_gather(P: Sequence[torch.Tensor], sizes: Sequence[int], Wextra, bias0, noise, sigma: float,
-                      samples: int, h: int, H0: int, out=None):
-    rows = 2 * samples
+                      samples: int, h: int, H0: int, out=None, rows: Optional[int] = None):
+    """rows defaults to 2*samples ([uncond ; cond] blocks of the sampler); the trainer passes rows = samples."""
+    rows = 2 * samples if rows is None else rows
     arr = (SkgTap * len(P))()
     for i, (t, s) in enumerate(zip(P, sizes)):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (rows * s * s, H0)
@@ -376,6 +377,53 @@ def lgp_mse_seed(out16, target, samples, h, ldd, loss_scale):
     check(lib.skg_lgp_mse_seed(_p(out16), _ld(out16), _p(target), _p(dOut), ldd, _p(loss), samples, h,
                                loss_scale, _stream()), "skg_lgp_mse_seed")
     return dOut, loss
+
+
+# ---- LGP training ------------------------------------------------------------------------------------
+def colsum(X, scale: float = 1.0):
+    _f16(X)
+    M, C = X.shape
+    out = torch.empty(C, device=X.device, dtype=torch.float32)
+    key = ("colsum", X.device, C)
+    if key not in _scratch:
+        _scratch[key] = torch.empty(lib.skg_colsum_scratch_floats(C), device=X.device, dtype=torch.float32)
+    check(lib.skg_colsum_f16(_p(X), _ld(X), M, C, scale, _p(out), _p(_scratch[key]), _stream()), "skg_colsum_f16")
+    return out
+
+
+def bn_param_grads(X, dY, stats, scale: float = 1.0):
+    """(dgamma, dbeta) of one BatchNorm1d batch = all rows of X; stats [1, C, 2] from bn_stats(samples=1)."""
+    _f16(X, dY)
+    M, C = X.shape
+    dg = torch.empty(C, device=X.device, dtype=torch.float32)
+    db = torch.empty(C, device=X.device, dtype=torch.float32)
+    check(lib.skg_bn_param_grads(_p(X), _ld(X), _p(dY), _ld(dY), M, C, _p(stats), scale, _p(dg), _p(db),
+                                 _p(_bn_scratch(1, C, X.device)), _stream()), "skg_bn_param_grads")
+    return dg, db
+
+
+def lgp_extra_features(noise, sigma: float, samples: int, rows: int, h: int, ld: int = 64):
+    out = torch.empty(rows * h * h, ld, device=noise.device, dtype=torch.float16)
+    check(lib.skg_lgp_extra_features(_p(noise), sigma, samples, rows, h, _p(out), ld, _stream()),
+          "skg_lgp_extra_features")
+    return out
+
+
+def lgp_mse_train(out16, target, samples, h, ldd, loss_scale):
+    _f16(out16)
+    dOut = torch.empty(samples * h * h, ldd, device=out16.device, dtype=torch.float16)
+    parts = torch.empty(samples, device=out16.device, dtype=torch.float32)
+    check(lib.skg_lgp_mse_train(_p(out16), _ld(out16), _p(target), _p(dOut), ldd, _p(parts), samples, h, loss_scale,
+                                _stream()), "skg_lgp_mse_train")
+    return dOut, parts
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, param_f16, lr, beta1, beta2, eps, weight_decay, step: int,
+               inv_grad_scale: float = 1.0):
+    n = param.numel()
+    assert param.dtype == grad.dtype == exp_avg.dtype == exp_avg_sq.dtype == torch.float32 and grad.numel() == n
+    check(lib.skg_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), _p(param_f16), n, lr, beta1, beta2,
+                             eps, weight_decay, step, inv_grad_scale, _stream()), "skg_adamw_step")
 
 
 # ---- sampler ------------------------------------------------------------------------------------------

@@ -329,3 +329,98 @@ def test_sd15_full_size_guided_step_and_backward_vs_oracle():
           f"oracle={float(oaux['loss']):.4e}")
     assert abs(nr - 1) < 2e-2 and cos > 0.995
     assert abs(float(aux[0, 3]) - float(oaux["loss"])) < 2e-2 * float(oaux["loss"])
+
+
+# ------------------------------------------------------------------------------------------------ LGP training step
+def test_lgp_training_step_vs_oracle_autograd():
+    """One training step (trainer.py:208-252 as intended): loss and the gradient of every LGP parameter vs PyTorch
+    autograd through the oracle LGP (fp16-emulating forward, ONE BatchNorm batch of B*h*h rows), then one AdamW
+    update vs torch.optim.AdamW on the same gradients, and the running-stat side effects."""
+    from oracle import lgp as olgp, unet as ounet
+    from sketch2img_amd.lgp import LOSS_SCALE
+    from sketch2img_amd.lgp_train import HipLGPTrainer, TRAINABLE
+    cfg = ounet.TINY
+    chans, h, B = ounet.tap_channels(cfg), 16, 4
+    sizes = tap_sizes(h)
+    sd = olgp.init_state_dict(sum(chans) + 40, seed=13)
+    gen = torch.Generator().manual_seed(6)
+    feats = [torch.randn(B, c, s, s, generator=gen).half().float() for c, s in zip(chans, sizes)]
+    noise_level = 0.7 * torch.randn(B, 4, h, h, generator=gen)
+    target = 0.2 * torch.randn(B, 4, h, h, generator=gen)
+    tr = HipLGPTrainer(sd, chans, DEV, lr=2e-4, warmup_steps=0)
+    taps = [(nhwc16(f), s) for f, s in zip(feats, sizes)]
+    loss, g = tr.loss_and_grads(taps, noise_level, target)
+    # ---- oracle: autograd w.r.t. the parameters
+    params = {k: sd[k].clone().float().requires_grad_(True) for k in TRAINABLE}
+    full = dict(sd)
+    full.update(params)
+    upd = {k: v.clone() for k, v in sd.items() if "running" in k or "num_batches" in k}
+    x = torch.cat([F.interpolate(f, size=h, mode="bilinear") for f in feats], 1)
+    o = olgp.lgp_forward(full, x, noise_level, training=True, update_running=upd)
+    res = o.reshape(B, h, h, 4).permute(0, 3, 2, 1)                     # "(b w h) c -> b c h w"
+    ref_loss = F.mse_loss(res, target)
+    ref_g = torch.autograd.grad(ref_loss, [params[k] for k in TRAINABLE])
+    assert abs(float(loss) - float(ref_loss)) < 2e-3 * max(1.0, float(ref_loss))
+    worst = 0.0
+    for k, rg in zip(TRAINABLE, ref_g):
+        got = tr.grad_view(g, k).cpu() / LOSS_SCALE
+        r = float((got - rg).norm() / (rg.norm() + 1e-12))
+        worst = max(worst, r)
+        print(f"[parity] lgp dL/d {k:22s} rel={r:.3e} |ref|={float(rg.norm()):.3e}")
+        # same bound as the feature gradients: fp16 ReLU-gate flips + fp16 storage of the backward activations
+        assert r < 0.08, k
+    # running statistics (momentum 0.1, unbiased variance) follow the oracle's
+    assert (tr.running_mean[0].cpu() - upd["layers.2.running_mean"]).abs().max() < 2e-3
+    assert (tr.running_var[3].cpu() - upd["layers.11.running_var"]).abs().max() < 2e-3
+    # ---- AdamW on the HIP gradients vs torch.optim.AdamW on the same numbers
+    p0 = {k: sd[k].clone().float().requires_grad_(True) for k in TRAINABLE}
+    opt = torch.optim.AdamW([p0[k] for k in TRAINABLE], lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    for k in TRAINABLE:
+        p0[k].grad = tr.grad_view(g, k).cpu().clone() / LOSS_SCALE
+    opt.step()
+    tr.step(g)
+    new = tr.state_dict()
+    for k in TRAINABLE:
+        assert (new[k].cpu() - p0[k].detach()).abs().max() < 1e-6 + 1e-5 * float(p0[k].detach().abs().max()), k
+        o16, _ = tr.layout[k][0], None
+        assert torch.equal(tr.w16(k).float().cpu(), new[k].cpu().half().float())      # fp16 working copy refreshed
+    assert sorted(new) == sorted(sd) and int(new["layers.2.num_batches_tracked"]) == 1
+    # a second step with the updated weights runs and lowers the loss on the same batch
+    losses = [float(loss)]
+    for _ in range(25):
+        l2, g2 = tr.loss_and_grads(taps, noise_level, target)
+        tr.step(g2)
+        losses.append(float(l2))
+    print("[parity] lgp training losses:", " ".join(f"{v:.4f}" for v in losses[::5]))
+    assert losses[-1] < losses[0]
+
+
+def test_lgp_train_step_end_to_end_tiny(tiny):
+    """train_step = add_noise + frozen UNet taps (per-sample timesteps) + LGP loss/grads + AdamW, on the TINY UNet;
+    the loss of the first step is checked against the oracle UNet + oracle LGP on the same batch."""
+    from oracle import ddim as oddim, lgp as olgp, unet as ounet
+    from sketch2img_amd.lgp_train import HipLGPTrainer, add_noise, train_step
+    cfg, h, B = tiny["cfg"], 32, 2
+    chans = ounet.tap_channels(cfg)
+    sd = olgp.init_state_dict(sum(chans) + 40, seed=17)
+    gen = torch.Generator().manual_seed(9)
+    lat = torch.randn(B, 4, h, h, generator=gen)
+    sketch = 0.2 * torch.randn(B, 4, h, h, generator=gen)
+    noise = torch.randn(B, 4, h, h, generator=gen)
+    ts = [801, 133]
+    ehs = tiny["ehs"][:B]
+    acp = oddim.make_tables(50).alphas_cumprod
+    tr = HipLGPTrainer(sd, chans, DEV, warmup_steps=0)
+    loss = train_step(tr, tiny["net"], lat, sketch, ehs, ts, noise, acp)
+    tiny["net"].prepare_context(tiny["ehs"])                    # restore the fixture's context for later tests
+    noisy, nl = add_noise(lat, noise, ts, acp)
+    feats = []
+    for b in range(B):
+        _, taps = ounet.unet_forward(cfg, tiny["W"], noisy[b:b + 1], ts[b], ehs[b:b + 1])
+        feats.append(taps)
+    x = torch.cat([torch.cat([F.interpolate(f, size=h, mode="bilinear") for f in feats[b]], 1) for b in range(B)])
+    o = olgp.lgp_forward(sd, x, nl, training=True)
+    ref = F.mse_loss(o.reshape(B, h, h, 4).permute(0, 3, 2, 1), sketch)
+    print(f"[parity] lgp train_step loss hip {float(loss):.5f} oracle {float(ref):.5f}")
+    assert abs(float(loss) - float(ref)) < 1e-2 * float(ref)
+    assert tr.step_count == 1 and int(tr.state_dict()["layers.5.num_batches_tracked"]) == 1

@@ -184,6 +184,11 @@ WORKER = textwrap.dedent("""
         assert torch.equal(allx, synthetic.initial_latents(0, total, 8) + 1.0), "gather"
     else:
         assert got is None
+    # the LGP-training collective: bucketed mean all-reduce of a flat gradient vector
+    from sketch2img_amd.dist import allreduce_mean_
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    allreduce_mean_(g, bucket_bytes=1024)                              # 4 buckets of 256 floats
+    assert torch.equal(g, torch.arange(1000, dtype=torch.float32) * 1.5), "allreduce mean"
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")
