@@ -392,6 +392,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
 
   SKG_PH(2);
   // ---- epilogue: lane holds C[m = .. + l16][n = .. + 4g .. 4g+3] -----------------------------------
+  // Outputs much larger than the 32 MB of L2 are stored non-temporally: a write-allocated 336 MB FF1 output
+  // otherwise evicts the activation panel and the weights every other workgroup is still streaming (N = 2560, K = 320:
+  // 185 vs 239 us); small outputs stay cacheable for the consumer kernel.
+  const bool stream_out = p.flags & 0x800u;
   const bool relu = p.flags & SKG_EPI_RELU;
   const bool f32out = p.flags & SKG_EPI_OUT_F32;
   if (ws) {   // split-K partial: raw fp32 accumulators, epilogue happens in splitk_reduce_kernel
@@ -480,7 +484,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
             // interleaved FF1 pack: columns [a0 a1 g0 g1 | a2 a3 g2 g3] -> 4 outputs a * gelu(g) at column n/2
             half4_t y = {(half_t)(v[0] * gelu_fast_f(v[2])), (half_t)(v[1] * gelu_fast_f(v[3])),
                          (half_t)(v[4] * gelu_fast_f(v[6])), (half_t)(v[5] * gelu_fast_f(v[7]))};
-            st_half4(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + (n >> 1), y);
+            half4_t* dst4 = reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + (n >> 1));
+            if (stream_out) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst4), "v"(y) : "memory");
+            else *dst4 = y;
             continue;
           }
           half8_t o;
@@ -490,7 +496,10 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
             if (relu) x = fmaxf(x, 0.f);
             o[e] = (half_t)x;
           }
-          st_half8(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n, o);
+          half8_t* dst8 = reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n);
+          // (inline asm: hipcc merges an if/else pair of builtin stores into ONE plain store and drops the hint)
+          if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst8), "v"(o) : "memory");
+          else *dst8 = o;
         }
       }
     }
@@ -629,8 +638,13 @@ inline int persistent_grid(int nwg, int nthr) {
   return nwg < resident ? nwg : resident;
 }
 
+constexpr size_t STREAM_OUT_BYTES = (size_t)96 << 20;      // 3 x the aggregate L2
+
 template <int BM, int BN, int WGM, int WGN, int MODE>
-void launch_cfg(const GemmParams& p, hipStream_t st) {
+void launch_cfg(const GemmParams& p_in, hipStream_t st) {
+  GemmParams p = p_in;
+  const size_t out_bytes = (size_t)p.M * ((p.flags & SKG_EPI_GEGLU) ? p.N / 2 : p.N) * ((p.flags & SKG_EPI_OUT_F32) ? 4 : 2);
+  if (out_bytes >= STREAM_OUT_BYTES) p.flags |= 0x800u;
   const int tiles_n = skg_cdiv(p.N, BN);
   const int ntiles = skg_cdiv(p.M, BM) * tiles_n;
   unsigned long long a, b, s;
