@@ -392,7 +392,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
 
   SKG_PH(2);
   // ---- epilogue: lane holds C[m = .. + l16][n = .. + 4g .. 4g+3] -----------------------------------
-  // Outputs much larger than the 32 MB of L2 are stored non-temporally: a write-allocated 336 MB FF1 output
+  // Outputs that cannot stay in the 32 MB of L2 anyway are stored non-temporally: a write-allocated 336 MB FF1 output
   // otherwise evicts the activation panel and the weights every other workgroup is still streaming (N = 2560, K = 320:
   // 185 vs 239 us); small outputs stay cacheable for the consumer kernel.
   const bool stream_out = p.flags & 0x800u;
@@ -638,13 +638,14 @@ inline int persistent_grid(int nwg, int nthr) {
   return nwg < resident ? nwg : resident;
 }
 
-constexpr size_t STREAM_OUT_BYTES = (size_t)96 << 20;      // 3 x the aggregate L2
+constexpr size_t STREAM_OUT_BYTES = (size_t)32 << 20;      // the aggregate L2 (8 x 4 MB)
 
 template <int BM, int BN, int WGM, int WGN, int MODE>
 void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   GemmParams p = p_in;
   const size_t out_bytes = (size_t)p.M * ((p.flags & SKG_EPI_GEGLU) ? p.N / 2 : p.N) * ((p.flags & SKG_EPI_OUT_F32) ? 4 : 2);
-  if (out_bytes >= STREAM_OUT_BYTES) p.flags |= 0x800u;
+  static const char* smb = getenv("SKG_STREAM_MB");          // tuning only
+  if (out_bytes >= (smb ? (size_t)atoi(smb) << 20 : STREAM_OUT_BYTES)) p.flags |= 0x800u;
   const int tiles_n = skg_cdiv(p.N, BN);
   const int ntiles = skg_cdiv(p.M, BM) * tiles_n;
   unsigned long long a, b, s;
