@@ -237,15 +237,29 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
   // LDS-DMA of K tile kt into stage `buf`, split into the per-step address part (`dma_prepare`: SALU + a few VALU
   // selects) and the individual instructions (`dma_one`, d = 0 .. ACH+BCH-1) so that the main loop can place each
   // instruction between MFMAs.  !live: every lane out of range -> zero fill, no memory traffic.
+  const bool tap_minor = (p.flags & 0x1000u) != 0;
   struct DmaStep { unsigned va[ACH]; unsigned vb[BCH]; unsigned soa, sob; };
   auto dma_prepare = [&](int kt, bool live) {
     DmaStep d;
     const int k0 = kt * BK;
     unsigned soff = (unsigned)k0 * 2u;
-    int tap = 0, ky = 0, kx = 0;
+    int tap = 0, ky = 0, kx = 0, c0 = 0;
+    unsigned kb = (unsigned)k0;            // position of this K tile in a weight row
     if (MODE != MODE_DIRECT) {
-      tap = k0 / p.Cin;
-      const int c0 = k0 - tap * p.Cin;
+      // K order of the implicit GEMM: channel block outermost, the 9 taps innermost (the weight pack stays
+      // [Cout][tap][Cin]; only the walk changes).  A tile then re-reads the SAME 64-channel slice of its ~3 input rows
+      // for nine consecutive K steps - 32 KB per workgroup instead of the whole 3-row halo of all channels - so the
+      // slices of all workgroups of an XCD fit its 4 MB L2 (tap-major order: 2.5 x the algorithmic bytes fetched
+      // from beyond L2, rocprofv3 FETCH_SIZE).
+      if (tap_minor) {
+        const int cb = kt / 9;
+        tap = kt - cb * 9;
+        c0 = cb * BK;
+      } else {
+        tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+      }
+      kb = (unsigned)(tap * p.Cin + c0);
       ky = tap / 3;
       kx = tap - ky * 3;
       soff = (unsigned)((ky * p.IW + kx) * p.lda + c0) * 2u;
@@ -275,8 +289,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
     }
 #pragma unroll
     for (int j = 0; j < BCH; ++j) d.vb[j] = live ? b_voff[j] : OOB;
-    d.soa = AFFINE ? soff : (unsigned)(k0 - tap * p.Cin) * 2u;     // gather modes carry the pixel in voffset
-    d.sob = (unsigned)k0 * 2u;
+    d.soa = AFFINE ? soff : (unsigned)c0 * 2u;     // gather modes carry the pixel in voffset
+    d.sob = kb * 2u;
     return d;
   };
   auto dma_one = [&](const DmaStep& d, int buf, int i) {     // buf, i: compile-time constants at every call site
@@ -644,6 +658,8 @@ template <int BM, int BN, int WGM, int WGN, int MODE>
 void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   GemmParams p = p_in;
   const size_t out_bytes = (size_t)p.M * ((p.flags & SKG_EPI_GEGLU) ? p.N / 2 : p.N) * ((p.flags & SKG_EPI_OUT_F32) ? 4 : 2);
+  static const bool tap_major = getenv("SKG_TAP_MAJOR") != nullptr;        // A/B switch for the K order (tools/gemm_bench.py)
+  if (MODE != MODE_DIRECT && !tap_major) p.flags |= 0x1000u;
   static const char* smb = getenv("SKG_STREAM_MB");          // tuning only
   if (out_bytes >= (smb ? (size_t)atoi(smb) << 20 : STREAM_OUT_BYTES)) p.flags |= 0x800u;
   const int tiles_n = skg_cdiv(p.N, BN);
