@@ -9,10 +9,18 @@ namespace {
 constexpr int GN_MAX_CHUNKS = 128;
 constexpr int GN_MAX_C = 4096;
 
-// pixels per workgroup ~32: enough workgroups (2048 at 64x64 x 16 rows) to cover the chip several times
+// pixels per workgroup ~48: enough workgroups (1376 at 64x64 x 16 rows) to cover the chip several times
 __host__ __device__ inline int gn_chunks(int HW) {
-  int c = (HW + 31) / 32;
+  int c = (HW + 47) / 48;                  // ~48 pixels per workgroup = 8 per thread at C = 320 (6 pixel lanes)
   return c > GN_MAX_CHUNKS ? GN_MAX_CHUNKS : (c < 1 ? 1 : c);
+}
+
+// apply kernels: each thread should see >= 8 pixels (two unrolled iterations of four) of its channel piece
+__host__ __device__ inline int gn_apply_chunks(int HW, int C) {
+  const int C8 = C >> 3;
+  const int P = C8 <= 256 ? 256 / C8 : 1;
+  int c = HW / (8 * P);
+  return c > 512 ? 512 : (c < 1 ? 1 : c);
 }
 
 // ---- stage 1: per (row, pixel-chunk) partial sums of two per-element quantities, per group ----
@@ -56,10 +64,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(
         gv = ld_half8(gamma + c0);
         bv = ld_half8(beta + c0);
       }
-      for (int p = p0 + pl; p < p1; p += P) {
-        const half8_t xv = ld_half8(X + ((size_t)b * HW + p) * ldx + c0);
-        half8_t dv = zero_half8();
-        if (KIND == 1) dv = ld_half8(dY + ((size_t)b * HW + p) * lddy + c0);
+      auto accum = [&](const half8_t& xv, const half8_t& dv) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float x = (float)xv[j];
@@ -76,7 +81,23 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(
           }
           if (j < nlo) { s1lo += q1; s2lo += q2; } else { s1hi += q1; s2hi += q2; }
         }
+      };
+      // four pixels per iteration: the loads of all four are issued before the first is consumed (see gn_apply_kernel)
+      const half_t* xp = X + ((size_t)b * HW) * ldx + c0;
+      const half_t* dp = KIND == 1 ? dY + ((size_t)b * HW) * lddy + c0 : nullptr;
+      int p = p0 + pl;
+      for (; p + 3 * P < p1; p += 4 * P) {
+        half8_t xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xv[u] = ld_half8(xp + (size_t)(p + u * P) * ldx);
+          dv[u] = KIND == 1 ? ld_half8(dp + (size_t)(p + u * P) * lddy) : zero_half8();
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) accum(xv[u], dv[u]);
       }
+      for (; p < p1; p += P)
+        accum(ld_half8(xp + (size_t)p * ldx), KIND == 1 ? ld_half8(dp + (size_t)p * lddy) : zero_half8());
     }
     red[tid + k * 256][0] = s1lo; red[tid + k * 256][1] = s2lo;
     red[tid + k * 256][2] = s1hi; red[tid + k * 256][3] = s2hi;
@@ -134,113 +155,200 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
-// ---- apply (forward): y = act((x - mean) * rstd * gamma + beta) ------------------------------------
+// ---- apply (forward): y = act(x * a + sh), a = rstd * gamma, sh = beta - mean * a -------------------------
+// Same decomposition as stage 1: workgroup = (pixel chunk, row), thread = fixed 8-channel piece x strided pixels, so
+// the per-channel scale / shift are loop invariant registers; FOUR pixels per iteration so four independent 16-byte
+// loads are in flight per thread.  (One load in flight per thread caps a streaming kernel at ~4 TB/s on this chip -
+// 32 waves x 64 lanes x 16 B per CU against ~2 us of latency; the first version, which also re-derived the group of
+// every element, ran at 2.6 TB/s.)
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ X, int ldx,
-                                                       half_t* __restrict__ Y, int ldy, int rows, int HW,
-                                                       int C, int groups, const float* __restrict__ stats,
+                                                       half_t* __restrict__ Y, int ldy, int HW, int C, int groups,
+                                                       const float* __restrict__ stats,
                                                        const half_t* __restrict__ gamma,
                                                        const half_t* __restrict__ beta, int silu) {
-  const int C8 = C >> 3;
+  const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
   const int cpg = C / groups;
-  const size_t total = (size_t)rows * HW * C8;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t m = i / C8;
-    const int c0 = (int)(i - m * C8) * 8;
-    const int b = (int)(m / HW);
-    const half8_t xv = ld_half8(X + m * ldx + c0);
-    const half8_t gv = ld_half8(gamma + c0);
-    const half8_t bv = ld_half8(beta + c0);
-    const float* st = stats + (size_t)b * groups * 2;
-    half8_t o;
+  const int per = (HW + nch - 1) / nch;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const int C8 = C >> 3;
+  const int P = C8 <= 256 ? 256 / C8 : 1;       // pixel lanes
+  const int T = C8 <= 256 ? P * C8 : 256;       // active threads
+  const int tid = threadIdx.x;
+  const int pl = C8 <= 256 ? tid / C8 : 0;
+  const int np = C8 <= 256 ? 1 : (C8 + 255) / 256;
+  for (int k = 0; k < np; ++k) {
+    const int piece = C8 <= 256 ? tid - pl * C8 : tid + k * 256;
+    if (tid >= T || piece >= C8) continue;
+    const int c0 = piece * 8;
+    const int glo = c0 / cpg;
+    const int nlo = min(8, (glo + 1) * cpg - c0);        // channels [c0, c0+nlo) belong to glo, the rest to glo+1
+    const float* st = stats + ((size_t)b * groups + glo) * 2;
+    const float mlo = st[0], rlo = st[1];
+    const float mhi = nlo < 8 ? st[2] : 0.f, rhi = nlo < 8 ? st[3] : 0.f;
+    const half8_t gv = ld_half8(gamma + c0), bv = ld_half8(beta + c0);
+    float a[8], sh[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int grp = (c0 + j) / cpg;
-      float v = ((float)xv[j] - st[grp * 2]) * st[grp * 2 + 1] * (float)gv[j] + (float)bv[j];
-      if (silu) v = silu_f(v);
-      o[j] = (half_t)v;
+      const bool lo = j < nlo;
+      a[j] = (lo ? rlo : rhi) * (float)gv[j];
+      sh[j] = (float)bv[j] - (lo ? mlo : mhi) * a[j];
     }
-    st_half8(Y + m * ldy + c0, o);
+    const half_t* xp = X + ((size_t)b * HW) * ldx + c0;
+    half_t* yp = Y + ((size_t)b * HW) * ldy + c0;
+    int p = p0 + pl;
+    for (; p + 3 * P < p1; p += 4 * P) {
+      half8_t xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) xv[u] = ld_half8(xp + (size_t)(p + u * P) * ldx);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float v = fmaf((float)xv[u][j], a[j], sh[j]);
+          if (silu) v = silu_f(v);
+          o[j] = (half_t)v;
+        }
+        st_half8(yp + (size_t)(p + u * P) * ldy, o);
+      }
+    }
+    for (; p < p1; p += P) {
+      const half8_t xv = ld_half8(xp + (size_t)p * ldx);
+      half8_t o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = fmaf((float)xv[j], a[j], sh[j]);
+        if (silu) v = silu_f(v);
+        o[j] = (half_t)v;
+      }
+      st_half8(yp + (size_t)p * ldy, o);
+    }
   }
 }
 
 // ---- apply (backward): dx = rstd * (dyh*gamma - m1 - xhat*m2) + residual --------------------------
+// same decomposition and unrolling as gn_apply_kernel (two pixels per iteration: three streams per pixel)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const half_t* __restrict__ X, int ldx, const half_t* __restrict__ dY, int lddy, half_t* __restrict__ dX,
-    int lddx, const half_t* __restrict__ R, int ldr, int rows, int HW, int C, int groups,
+    int lddx, const half_t* __restrict__ R, int ldr, int HW, int C, int groups,
     const float* __restrict__ stats, const float* __restrict__ sums, const half_t* __restrict__ gamma,
     const half_t* __restrict__ beta, int silu) {
-  const int C8 = C >> 3;
+  const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
   const int cpg = C / groups;
-  const size_t total = (size_t)rows * HW * C8;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t m = i / C8;
-    const int c0 = (int)(i - m * C8) * 8;
-    const int b = (int)(m / HW);
-    const half8_t xv = ld_half8(X + m * ldx + c0);
-    const half8_t dv = ld_half8(dY + m * lddy + c0);
-    const half8_t gv = ld_half8(gamma + c0);
-    const half8_t bv = ld_half8(beta + c0);
-    half8_t rv = zero_half8();
-    if (R) rv = ld_half8(R + m * ldr + c0);
-    const float* st = stats + (size_t)b * groups * 2;
-    const float* sm = sums + (size_t)b * groups * 2;
-    half8_t o;
+  const int per = (HW + nch - 1) / nch;
+  const int p0 = chunk * per, p1 = min(HW, p0 + per);
+  const int C8 = C >> 3;
+  const int P = C8 <= 256 ? 256 / C8 : 1;
+  const int T = C8 <= 256 ? P * C8 : 256;
+  const int tid = threadIdx.x;
+  const int pl = C8 <= 256 ? tid / C8 : 0;
+  const int np = C8 <= 256 ? 1 : (C8 + 255) / 256;
+  for (int k = 0; k < np; ++k) {
+    const int piece = C8 <= 256 ? tid - pl * C8 : tid + k * 256;
+    if (tid >= T || piece >= C8) continue;
+    const int c0 = piece * 8;
+    const int glo = c0 / cpg;
+    const int nlo = min(8, (glo + 1) * cpg - c0);
+    const float* st = stats + ((size_t)b * groups + glo) * 2;
+    const float* sm = sums + ((size_t)b * groups + glo) * 2;
+    const bool two = nlo < 8;
+    const float mlo = st[0], rlo = st[1], m1lo = sm[0], m2lo = sm[1];
+    const float mhi = two ? st[2] : 0.f, rhi = two ? st[3] : 0.f, m1hi = two ? sm[2] : 0.f, m2hi = two ? sm[3] : 0.f;
+    const half8_t gv = ld_half8(gamma + c0), bv = ld_half8(beta + c0);
+    const size_t row0 = (size_t)b * HW;
+    auto one = [&](const half8_t& xv, const half8_t& dv, const half8_t& rv, size_t m) {
+      half8_t o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int grp = (c0 + j) / cpg;
-      const float rstd = st[grp * 2 + 1];
-      const float xh = ((float)xv[j] - st[grp * 2]) * rstd;
-      float d = (float)dv[j];
-      if (silu) d *= silu_grad_f(xh * (float)gv[j] + (float)bv[j]);
-      d *= (float)gv[j];
-      o[j] = (half_t)(rstd * (d - sm[grp * 2] - xh * sm[grp * 2 + 1]) + (float)rv[j]);
+      for (int j = 0; j < 8; ++j) {
+        const bool lo = j < nlo;
+        const float rstd = lo ? rlo : rhi;
+        const float xh = ((float)xv[j] - (lo ? mlo : mhi)) * rstd;
+        float d = (float)dv[j];
+        if (silu) d *= silu_grad_f(xh * (float)gv[j] + (float)bv[j]);
+        d *= (float)gv[j];
+        o[j] = (half_t)(rstd * (d - (lo ? m1lo : m1hi) - xh * (lo ? m2lo : m2hi)) + (float)rv[j]);
+      }
+      st_half8(dX + m * lddx + c0, o);
+    };
+    int p = p0 + pl;
+    for (; p + P < p1; p += 2 * P) {
+      const size_t ma = row0 + p, mb = row0 + p + P;
+      const half8_t xa = ld_half8(X + ma * ldx + c0), xb = ld_half8(X + mb * ldx + c0);
+      const half8_t da = ld_half8(dY + ma * lddy + c0), db = ld_half8(dY + mb * lddy + c0);
+      const half8_t ra = R ? ld_half8(R + ma * ldr + c0) : zero_half8();
+      const half8_t rb = R ? ld_half8(R + mb * ldr + c0) : zero_half8();
+      one(xa, da, ra, ma);
+      one(xb, db, rb, mb);
     }
-    st_half8(dX + m * lddx + c0, o);
+    for (; p < p1; p += P) {
+      const size_t m = row0 + p;
+      one(ld_half8(X + m * ldx + c0), ld_half8(dY + m * lddy + c0), R ? ld_half8(R + m * ldr + c0) : zero_half8(), m);
+    }
   }
 }
 
 // ---- LayerNorm: one wave per row, values held in registers ----------------------------------------
 constexpr int LN_MAXP = 4;   // 16-byte pieces per lane -> C <= 2048
 
+// NQ 16-byte pieces per lane cover a row (C <= NQ*512), RW rows per wave are processed together so that NQ*RW = 4
+// independent loads are in flight per lane (one load per lane caps a streaming kernel at ~4 TB/s, see gn_apply_kernel)
+template <int NQ, int RW>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const half_t* __restrict__ X, int ldx, half_t* __restrict__ Y,
                                                      int ldy, int M, int C, const half_t* __restrict__ gamma,
                                                      const half_t* __restrict__ beta, float eps,
                                                      float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RW;
+  if (row0 >= M) return;
   const int C8 = C >> 3;
-  float v[LN_MAXP][8];
-  float s = 0.f;
+  float v[RW][NQ][8];
+  float s[RW];
 #pragma unroll
-  for (int q = 0; q < LN_MAXP; ++q) {
-    const int pc = lane + q * 64;
-    if (pc < C8) {
-      const half8_t x = ld_half8(X + (size_t)row * ldx + pc * 8);
+  for (int r = 0; r < RW; ++r) {
+    s[r] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { v[q][j] = (float)x[j]; s += v[q][j]; }
+    for (int q = 0; q < NQ; ++q) {
+      const int pc = lane + q * 64;
+      half8_t x = zero_half8();
+      if (pc < C8 && row0 + r < M) x = ld_half8(X + (size_t)(row0 + r) * ldx + pc * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[r][q][j] = (float)x[j]; s[r] += v[r][q][j]; }
     }
   }
-  const float mean = wave_sum(s) / C;
-  float s2 = 0.f;
+  float mean[RW], rstd[RW];
 #pragma unroll
-  for (int q = 0; q < LN_MAXP; ++q)
-    if (lane + q * 64 < C8)
+  for (int r = 0; r < RW; ++r) mean[r] = wave_sum(s[r]) / C;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[q][j] - mean; s2 += d * d; }
-  const float rstd = rsqrtf(wave_sum(s2) / C + eps);
+  for (int r = 0; r < RW; ++r) {
+    float s2 = 0.f;
 #pragma unroll
-  for (int q = 0; q < LN_MAXP; ++q) {
+    for (int q = 0; q < NQ; ++q)
+      if (lane + q * 64 < C8)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[r][q][j] - mean[r]; s2 += d * d; }
+    rstd[r] = rsqrtf(wave_sum(s2) / C + eps);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
     const int pc = lane + q * 64;
     if (pc < C8) {
       const half8_t gv = ld_half8(gamma + pc * 8), bv = ld_half8(beta + pc * 8);
-      half8_t o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (half_t)((v[q][j] - mean) * rstd * (float)gv[j] + (float)bv[j]);
-      st_half8(Y + (size_t)row * ldy + pc * 8, o);
+      for (int r = 0; r < RW; ++r) {
+        if (row0 + r >= M) break;
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          o[j] = (half_t)((v[r][q][j] - mean[r]) * rstd[r] * (float)gv[j] + (float)bv[j]);
+        st_half8(Y + (size_t)(row0 + r) * ldy + pc * 8, o);
+      }
     }
   }
-  if (stats && lane == 0) { stats[(size_t)row * 2] = mean; stats[(size_t)row * 2 + 1] = rstd; }
+  if (stats && lane == 0) {
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+      if (row0 + r < M) { stats[(size_t)(row0 + r) * 2] = mean[r]; stats[(size_t)(row0 + r) * 2 + 1] = rstd[r]; }
+  }
 }
 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const half_t* __restrict__ X, int ldx,
@@ -322,10 +430,10 @@ extern "C" int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int
                                    int silu, void* stream) {
   SKG_REQUIRE(X && Y && stats && gamma && beta && rows > 0 && HW > 0);
   SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
+  SKG_REQUIRE((C / groups) >= 4 && C <= GN_MAX_C);      // an 8-channel piece spans at most two groups
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
-  const size_t total = (size_t)rows * HW * (C / 8);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)X, ldx, (half_t*)Y, ldy, rows, HW, C, groups, stats, (const half_t*)gamma,
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, groups, stats, (const half_t*)gamma,
                      (const half_t*)beta, silu);
   SKG_CHECK_LAUNCH("skg_groupnorm_apply");
   return SKG_OK;
@@ -349,10 +457,9 @@ extern "C" int skg_groupnorm_bwd(const void* X, int ldx, const void* dY, int ldd
   const int total = rows * groups;
   hipLaunchKernelGGL((gn_finalize_kernel<1>), dim3(skg_cdiv(total * 16, 256)), dim3(256), 0, st, partial, nch,
                      groups, 1.f / ((float)HW * (C / groups)), 0.f, sums, total);
-  const size_t items = (size_t)rows * HW * (C / 8);
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(ew_grid(items)), dim3(256), 0, st, (const half_t*)X, ldx,
-                     (const half_t*)dY, lddy, (half_t*)dX, lddx, (const half_t*)residual, ldr, rows, HW, C,
-                     groups, stats, sums, (const half_t*)gamma, (const half_t*)beta, silu);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, st, (const half_t*)X,
+                     ldx, (const half_t*)dY, lddy, (half_t*)dX, lddx, (const half_t*)residual, ldr, HW, C, groups,
+                     stats, sums, (const half_t*)gamma, (const half_t*)beta, silu);
   SKG_CHECK_LAUNCH("skg_groupnorm_bwd");
   return SKG_OK;
 }
@@ -362,8 +469,14 @@ extern "C" int skg_layernorm_fwd(const void* X, int ldx, void* Y, int ldy, int M
   SKG_REQUIRE(X && Y && gamma && beta && M > 0 && C % 8 == 0 && C <= LN_MAXP * 64 * 8);
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && skg_aligned(X, 16) && skg_aligned(Y, 16) &&
               skg_aligned(gamma, 16) && skg_aligned(beta, 16));
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(skg_cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, (const half_t*)X,
-                     ldx, (half_t*)Y, ldy, M, C, (const half_t*)gamma, (const half_t*)beta, eps, stats);
+  hipStream_t st = (hipStream_t)stream;
+  const half_t *x = (const half_t*)X, *g = (const half_t*)gamma, *b = (const half_t*)beta;
+  if (C <= 512)
+    hipLaunchKernelGGL((ln_fwd_kernel<1, 4>), dim3(skg_cdiv(M, 16)), dim3(256), 0, st, x, ldx, (half_t*)Y, ldy, M, C, g, b, eps, stats);
+  else if (C <= 1024)
+    hipLaunchKernelGGL((ln_fwd_kernel<2, 2>), dim3(skg_cdiv(M, 8)), dim3(256), 0, st, x, ldx, (half_t*)Y, ldy, M, C, g, b, eps, stats);
+  else
+    hipLaunchKernelGGL((ln_fwd_kernel<LN_MAXP, 1>), dim3(skg_cdiv(M, 4)), dim3(256), 0, st, x, ldx, (half_t*)Y, ldy, M, C, g, b, eps, stats);
   SKG_CHECK_LAUNCH("skg_layernorm_fwd");
   return SKG_OK;
 }
