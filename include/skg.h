@@ -97,6 +97,10 @@ int skg_conv3x3_f16(const void* X, int ldx, const void* Wp, void* Y, int ldy,
 size_t skg_groupnorm_scratch_floats(int rows, int groups);
 int skg_groupnorm_stats(const void* X, int ldx, int rows, int HW, int C, int groups, float eps,
                         float* stats, float* partial, void* stream);
+/* stats + apply in two launches (the apply kernel folds the chunk partials itself and publishes `stats` for a later
+ * skg_groupnorm_bwd): what the UNet / VAE forward use. */
+int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups, float eps,
+                      const void* gamma, const void* beta, int silu, float* stats, float* partial, void* stream);
 int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C,
                         int groups, const float* stats, const void* gamma, const void* beta,
                         int silu, void* stream);

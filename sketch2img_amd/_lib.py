@@ -21,6 +21,7 @@ SIGNATURES = {
     "skg_conv3x3_f16": ("i", "pippiiiiiiippifup"),
     "skg_groupnorm_scratch_floats": ("z", "ii"),
     "skg_groupnorm_stats": ("i", "piiiiifppp"),
+    "skg_groupnorm_fwd": ("i", "pipiiiiifppippp"),
     "skg_groupnorm_apply": ("i", "pipiiiiipppip"),
     "skg_groupnorm_bwd": ("i", "pipipipiiiiipppipp"),
     "skg_layernorm_fwd": ("i", "pipiiippfpp"),

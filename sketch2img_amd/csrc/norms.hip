@@ -161,12 +161,41 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // loads are in flight per thread.  (One load in flight per thread caps a streaming kernel at ~4 TB/s on this chip -
 // 32 waves x 64 lanes x 16 B per CU against ~2 us of latency; the first version, which also re-derived the group of
 // every element, ran at 2.6 TB/s.)
+// FOLD: the statistics are folded here from the stage-1 chunk partials (every workgroup of a row repeats the same
+// fixed-order fold into LDS; chunk 0 also publishes (mean, rstd) for the backward pass) - this removes the separate
+// finalize launch (4.7 us of an otherwise ~15-40 us GroupNorm).
+template <bool FOLD>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ X, int ldx,
                                                        half_t* __restrict__ Y, int ldy, int HW, int C, int groups,
                                                        const float* __restrict__ stats,
                                                        const half_t* __restrict__ gamma,
-                                                       const half_t* __restrict__ beta, int silu) {
+                                                       const half_t* __restrict__ beta, int silu,
+                                                       const float* __restrict__ partial, int pch, float inv_n,
+                                                       float eps, float* __restrict__ stats_out) {
   const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
+  __shared__ float st_s[64][2];
+  if (FOLD) {
+    // 8 lanes per group, lanes stride over the pch chunk partials, xor-shuffle fold (fixed order)
+    for (int g0 = 0; g0 < groups; g0 += 32) {
+      const int grp = g0 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
+      float s1 = 0.f, s2 = 0.f;
+      if (grp < groups)
+        for (int c = sub; c < pch; c += 8) {
+          const float* q = partial + (((size_t)b * pch + c) * groups + grp) * 2;
+          s1 += q[0]; s2 += q[1];
+        }
+#pragma unroll
+      for (int o = 4; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      if (grp < groups && sub == 0) {
+        const float mean = s1 * inv_n;
+        const float var = fmaxf(s2 * inv_n - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        st_s[grp][0] = mean; st_s[grp][1] = rstd;
+        if (chunk == 0) { stats_out[((size_t)b * groups + grp) * 2] = mean; stats_out[((size_t)b * groups + grp) * 2 + 1] = rstd; }
+      }
+    }
+    __syncthreads();
+  }
   const int cpg = C / groups;
   const int per = (HW + nch - 1) / nch;
   const int p0 = chunk * per, p1 = min(HW, p0 + per);
@@ -182,7 +211,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     const int c0 = piece * 8;
     const int glo = c0 / cpg;
     const int nlo = min(8, (glo + 1) * cpg - c0);        // channels [c0, c0+nlo) belong to glo, the rest to glo+1
-    const float* st = stats + ((size_t)b * groups + glo) * 2;
+    const float* st = FOLD ? &st_s[glo][0] : stats + ((size_t)b * groups + glo) * 2;
     const float mlo = st[0], rlo = st[1];
     const float mhi = nlo < 8 ? st[2] : 0.f, rhi = nlo < 8 ? st[3] : 0.f;
     const half8_t gv = ld_half8(gamma + c0), bv = ld_half8(beta + c0);
@@ -432,10 +461,30 @@ extern "C" int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int
   SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
   SKG_REQUIRE((C / groups) >= 4 && C <= GN_MAX_C);      // an 8-channel piece spans at most two groups
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, groups, stats, (const half_t*)gamma,
-                     (const half_t*)beta, silu);
+                     (const half_t*)beta, silu, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr);
   SKG_CHECK_LAUNCH("skg_groupnorm_apply");
+  return SKG_OK;
+}
+
+extern "C" int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
+                                 float eps, const void* gamma, const void* beta, int silu, float* stats,
+                                 float* partial, void* stream) {
+  SKG_REQUIRE(X && Y && stats && partial && gamma && beta && rows > 0 && HW > 0 && groups > 0 && groups <= 64);
+  SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && (C / groups) % 2 == 0 && (C / groups) >= 4 && C <= GN_MAX_C);
+  SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = gn_chunks(HW);
+  hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(nch, rows), dim3(256), 0, st, (const half_t*)X, ldx,
+                     (const half_t*)nullptr, 0, HW, C, groups, (const float*)nullptr, (const half_t*)nullptr,
+                     (const half_t*)nullptr, 0, partial);
+  hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, st,
+                     (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, groups, (const float*)nullptr,
+                     (const half_t*)gamma, (const half_t*)beta, silu, (const float*)partial, nch,
+                     1.f / ((float)HW * (C / groups)), eps, stats);
+  SKG_CHECK_LAUNCH("skg_groupnorm_fwd");
   return SKG_OK;
 }
 

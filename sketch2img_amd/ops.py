@@ -117,8 +117,21 @@ def groupnorm_apply(X, rows, HW, groups, stats, gamma, beta, silu: bool, out=Non
 
 
 def groupnorm(X, rows, HW, groups, eps, gamma, beta, silu: bool, out=None):
-    st = groupnorm_stats(X, rows, HW, groups, eps)
-    return groupnorm_apply(X, rows, HW, groups, st, gamma, beta, silu, out), st
+    """Forward GroupNorm.  Up to 32x32 maps: two launches (chunk partial sums; apply, which folds the partials itself
+    and publishes the statistics) - at 64x64 the 86 chunk partials per group make the in-kernel fold dearer than the
+    4.7 us finalize launch it replaces, so the three-launch path stays (measured: tools/ew_bench.py)."""
+    if HW >= 4096:
+        st = groupnorm_stats(X, rows, HW, groups, eps)
+        return groupnorm_apply(X, rows, HW, groups, st, gamma, beta, silu, out), st
+    _f16(X, gamma, beta)
+    C = X.shape[1]
+    if out is None:
+        out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
+    st = torch.empty(rows, groups, 2, device=X.device, dtype=torch.float32)
+    check(lib.skg_groupnorm_fwd(_p(X), _ld(X), _p(out), _ld(out), rows, HW, C, groups, eps, _p(gamma), _p(beta),
+                                int(silu), _p(st), _p(_gn_scratch(rows, groups, X.device)), _stream()),
+          "skg_groupnorm_fwd")
+    return out, st
 
 
 def groupnorm_bwd(X, dY, rows, HW, groups, stats, gamma, beta, silu: bool, residual=None, out=None):

@@ -48,3 +48,13 @@ f = torch.empty(M, 4 * C, device=D).half()
 line("geglu_fwd M 65536 F 1280", timeit(lambda: ops.geglu(h, out=f, interleaved=True)), M * C * 24)
 v = torch.randn(M, C, device=D).half()
 line("transpose M 65536 C 320", timeit(lambda: ops.transpose(v)), 2 * M * C * 2)
+for rows, hw, C in ((16, 4096, 320), (16, 1024, 640), (16, 256, 1280), (16, 64, 1280)):
+    x = torch.randn(rows * hw, C, device=D).half()
+    g, b = torch.ones(C, device=D).half(), torch.zeros(C, device=D).half()
+    y = torch.empty_like(x)
+
+    def split():
+        st = ops.groupnorm_stats(x, rows, hw, 32, 1e-5)
+        ops.groupnorm_apply(x, rows, hw, 32, st, g, b, True, y)
+    line(f"gn fwd 3 launches rows {rows} hw {hw} C {C}", timeit(split), 3 * x.numel() * 2)
+    line(f"gn fwd fused      rows {rows} hw {hw} C {C}", timeit(lambda: ops.groupnorm(x, rows, hw, 32, 1e-5, g, b, True, y)), 3 * x.numel() * 2)
