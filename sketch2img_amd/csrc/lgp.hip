@@ -135,66 +135,113 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const half_t* __restric
                                                          const half_t* __restrict__ dY, int lddy, int S, int segs,
                                                          int seg_rows, int C, const float* __restrict__ stats,
                                                          float* __restrict__ partial) {
+  // thread = (8-channel piece, row lane): 16-byte loads, two rows in flight per iteration, fixed-order LDS fold
+  __shared__ float red[256][17];
   const int g = blockIdx.y, chunk = blockIdx.x;
   const int n = segs * seg_rows;
   const int per = (n + BN_CHUNKS - 1) / BN_CHUNKS;
   const int i0 = chunk * per, i1 = min(n, i0 + per);
-  for (int cp = threadIdx.x; cp < (C >> 1); cp += 256) {
-    const int c = cp * 2;
-    float s1a = 0.f, s1b = 0.f, s2a = 0.f, s2b = 0.f;
-    float ma = 0.f, mb = 0.f, ra = 0.f, rb = 0.f;
-    if (KIND == 1) {
-      ma = stats[((size_t)g * C + c) * 2]; ra = stats[((size_t)g * C + c) * 2 + 1];
-      mb = stats[((size_t)g * C + c + 1) * 2]; rb = stats[((size_t)g * C + c + 1) * 2 + 1];
-    }
-    for (int i = i0; i < i1; ++i) {
-      const int j = i / seg_rows, ii = i - j * seg_rows;
-      const size_t row = ((size_t)j * S + g) * seg_rows + ii;
-      const half2_t xv = *reinterpret_cast<const half2_t*>(X + row * ldx + c);
-      if (KIND == 0) {
-        const float a = (float)xv[0], b = (float)xv[1];
-        s1a += a; s1b += b; s2a += a * a; s2b += b * b;
-      } else {
-        const half2_t dv = *reinterpret_cast<const half2_t*>(dY + row * lddy + c);
-        const float da = (float)dv[0], db = (float)dv[1];
-        s1a += da; s1b += db;
-        s2a += da * ((float)xv[0] - ma) * ra;
-        s2b += db * ((float)xv[1] - mb) * rb;
+  const int C8 = C >> 3;
+  for (int pb = 0; pb < C8; pb += 256) {               // C <= 2048: one pass
+    const int npc = min(256, C8 - pb);                   // pieces in this pass
+    const int RL = 256 / npc;                            // row lanes
+    const int piece = threadIdx.x % npc, rl = threadIdx.x / npc;
+    const int c0 = (pb + piece) * 8;
+    float s1[8], s2[8], mu[8], rs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1[j] = 0.f; s2[j] = 0.f; mu[j] = 0.f; rs[j] = 0.f; }
+    if (rl < RL) {
+      if (KIND == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          mu[j] = stats[((size_t)g * C + c0 + j) * 2];
+          rs[j] = stats[((size_t)g * C + c0 + j) * 2 + 1];
+        }
+      }
+      auto rowof = [&](int i) {
+        const int jseg = i / seg_rows, ii = i - jseg * seg_rows;
+        return ((size_t)jseg * S + g) * seg_rows + ii;
+      };
+      auto accum = [&](const half8_t& xv, const half8_t& dv) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (KIND == 0) {
+            const float a = (float)xv[j];
+            s1[j] += a; s2[j] += a * a;
+          } else {
+            const float d = (float)dv[j];
+            s1[j] += d; s2[j] += d * ((float)xv[j] - mu[j]) * rs[j];
+          }
+        }
+      };
+      int i = i0 + rl;
+      for (; i + RL < i1; i += 2 * RL) {
+        const size_t ra = rowof(i), rb = rowof(i + RL);
+        const half8_t xa = ld_half8(X + ra * ldx + c0), xb = ld_half8(X + rb * ldx + c0);
+        const half8_t da = KIND == 1 ? ld_half8(dY + ra * lddy + c0) : zero_half8();
+        const half8_t db = KIND == 1 ? ld_half8(dY + rb * lddy + c0) : zero_half8();
+        accum(xa, da);
+        accum(xb, db);
+      }
+      for (; i < i1; i += RL) {
+        const size_t r = rowof(i);
+        accum(ld_half8(X + r * ldx + c0), KIND == 1 ? ld_half8(dY + r * lddy + c0) : zero_half8());
       }
     }
-    float* o = partial + (((size_t)g * BN_CHUNKS + chunk) * C + c) * 2;
-    o[0] = s1a; o[1] = s2a; o[2] = s1b; o[3] = s2b;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][8 + j] = s2[j]; }
+    __syncthreads();
+    if (threadIdx.x < npc) {
+      float* o = partial + (((size_t)g * BN_CHUNKS + chunk) * C + c0) * 2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int l = 0; l < RL; ++l) { t1 += red[l * npc + threadIdx.x][j]; t2 += red[l * npc + threadIdx.x][8 + j]; }
+        o[2 * j] = t1; o[2 * j + 1] = t2;
+      }
+    }
   }
 }
 
-// fold chunks; KIND 0 -> (mean, rstd) + running-stat side effects, groups visited in order
+// fold chunks, one (channel, sample) per thread; KIND 0 -> (mean, rstd), KIND 1 -> (m1, m2).  var_out (KIND 0, optional)
+// receives the biased variance for the running-statistics update.
 template <int KIND>
 __global__ void bn_finalize_kernel(const float* __restrict__ partial, int S, int C, int n, float eps,
-                                   float* __restrict__ out, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var) {
+                                   float* __restrict__ out, float* __restrict__ var_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = 0; k < BN_CHUNKS; ++k) {
+    const float* q = partial + (((size_t)g * BN_CHUNKS + k) * C + c) * 2;
+    s1 += q[0]; s2 += q[1];
+  }
+  if (KIND == 0) {
+    const float mean = s1 / n;
+    const float var = fmaxf(s2 / n - mean * mean, 0.f);
+    out[((size_t)g * C + c) * 2] = mean;
+    out[((size_t)g * C + c) * 2 + 1] = rsqrtf(var + eps);
+    if (var_out) var_out[(size_t)g * C + c] = var;
+  } else {
+    out[((size_t)g * C + c) * 2] = s1 / n;
+    out[((size_t)g * C + c) * 2 + 1] = s2 / n;
+  }
+}
+
+// running statistics: the S samples of a call are S successive BatchNorm batches (momentum 0.1, unbiased variance),
+// applied in sample order exactly like S separate module calls
+__global__ void bn_running_kernel(const float* __restrict__ stats, const float* __restrict__ var, int S, int C, int n,
+                                  float* __restrict__ running_mean, float* __restrict__ running_var) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  float rm = 0.f, rv = 0.f;
-  if (KIND == 0 && running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+  float rm = running_mean[c], rv = running_var[c];
   for (int g = 0; g < S; ++g) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < BN_CHUNKS; ++k) {
-      const float* q = partial + (((size_t)g * BN_CHUNKS + k) * C + c) * 2;
-      s1 += q[0]; s2 += q[1];
-    }
-    if (KIND == 0) {
-      const float mean = s1 / n;
-      const float var = fmaxf(s2 / n - mean * mean, 0.f);
-      out[((size_t)g * C + c) * 2] = mean;
-      out[((size_t)g * C + c) * 2 + 1] = rsqrtf(var + eps);
-      rm = 0.9f * rm + 0.1f * mean;
-      rv = 0.9f * rv + 0.1f * var * ((float)n / (float)(n - 1));
-    } else {
-      out[((size_t)g * C + c) * 2] = s1 / n;
-      out[((size_t)g * C + c) * 2 + 1] = s2 / n;
-    }
+    rm = 0.9f * rm + 0.1f * stats[((size_t)g * C + c) * 2];
+    rv = 0.9f * rv + 0.1f * var[(size_t)g * C + c] * ((float)n / (float)(n - 1));
   }
-  if (KIND == 0 && running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+  running_mean[c] = rm;
+  running_var[c] = rv;
 }
 
 __global__ void bn_from_running_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int S, int C,
@@ -431,13 +478,18 @@ extern "C" size_t skg_bn_scratch_floats(int samples, int C) {
 
 extern "C" int skg_bn_stats(const void* X, int ldx, int samples, int segs, int seg_rows, int C, float eps,
                             float* stats, float* scratch, float* running_mean, float* running_var, void* stream) {
-  SKG_REQUIRE(X && stats && scratch && samples > 0 && segs > 0 && seg_rows > 0 && C % 2 == 0 && ldx % 2 == 0);
+  SKG_REQUIRE(X && stats && scratch && samples > 0 && segs > 0 && seg_rows > 0 && C % 8 == 0 && ldx % 8 == 0 &&
+              skg_aligned(X, 16));
   SKG_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(BN_CHUNKS, samples), dim3(256), 0, st, (const half_t*)X, ldx,
                      (const half_t*)nullptr, 0, samples, segs, seg_rows, C, (const float*)nullptr, scratch);
-  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(skg_cdiv(C, 128)), dim3(128), 0, st, scratch, samples, C,
-                     segs * seg_rows, eps, stats, running_mean, running_var);
+  float* var = scratch + (size_t)samples * BN_CHUNKS * C * 2;      // [samples][C] (the "sums" area of the backward)
+  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(skg_cdiv(C, 128), samples), dim3(128), 0, st, scratch, samples, C,
+                     segs * seg_rows, eps, stats, running_mean ? var : (float*)nullptr);
+  if (running_mean)
+    hipLaunchKernelGGL(bn_running_kernel, dim3(skg_cdiv(C, 128)), dim3(128), 0, st, stats, var, samples, C,
+                       segs * seg_rows, running_mean, running_var);
   SKG_CHECK_LAUNCH("skg_bn_stats");
   return SKG_OK;
 }
@@ -474,8 +526,8 @@ extern "C" int skg_bn_relu_bwd(const void* X, int ldx, const void* dY, int lddy,
   if (train_mode) {
     hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(BN_CHUNKS, samples), dim3(256), 0, st, (const half_t*)X, ldx,
                        (const half_t*)dY, lddy, samples, segs, seg_rows, C, stats, scratch);
-    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(skg_cdiv(C, 128)), dim3(128), 0, st, scratch, samples, C,
-                       segs * seg_rows, 0.f, sums, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(skg_cdiv(C, 128), samples), dim3(128), 0, st, scratch, samples, C,
+                       segs * seg_rows, 0.f, sums, (float*)nullptr);
   }
   const size_t nrows = (size_t)samples * segs * seg_rows;
   hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(ew_grid(nrows * C / 8)), dim3(256), 0, st, (const half_t*)X, ldx,
@@ -514,7 +566,8 @@ extern "C" int skg_colsum_f16(const void* X, int ldx, int M, int C, float scale,
 extern "C" int skg_bn_param_grads(const void* X, int ldx, const void* dY, int lddy, int rows, int C,
                                   const float* stats, float scale, float* dgamma, float* dbeta, float* scratch,
                                   void* stream) {
-  SKG_REQUIRE(X && dY && stats && dgamma && dbeta && scratch && rows > 0 && C % 2 == 0 && ldx % 2 == 0 && lddy % 2 == 0);
+  SKG_REQUIRE(X && dY && stats && dgamma && dbeta && scratch && rows > 0 && C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 &&
+              skg_aligned(X, 16) && skg_aligned(dY, 16));
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(BN_CHUNKS, 1), dim3(256), 0, st, (const half_t*)X, ldx,
                      (const half_t*)dY, lddy, 1, 1, rows, C, stats, scratch);
