@@ -478,8 +478,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 // dK/dV: per 64-key block (lane column = key), loop over query tiles.
 //   S = Q K^T (rows q), P = exp(S*scale - lse[q]), dP = dO V^T, dS = P o (dP - delta[q])
 //   dV^T += dO^T P,   dK^T += Q^T dS      (A operands = transposed tiles, B = registers)
-template <int KS, int ND>
+template <int KS, int ND, int KT>
 __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(const AttnParams p) {
+  // KT key tiles of 16 per wave: a workgroup owns 64 * KT keys, so every Q / dO / Q^T / dO^T fragment read from LDS
+  // (and every byte of those panels streamed from L2) feeds KT MFMAs instead of one (same idea as QT in the forward).
   constexpr int KP = KS * 32 + 8;
   __shared__ __attribute__((aligned(16))) half_t Qs[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Ds[64 * KP];
@@ -490,25 +492,31 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
   const int l16 = lane & 15, g = lane >> 4;
   const BlkMap bm = attn_block_map(p);
   const int b = bm.b, h = bm.h;
-  const int kv = bm.bx * 64 + wave * 16 + l16;
-  const bool kok = kv < p.Nkv;
   const int dh = p.dh;
-
-  half8_t kf[KS], vf[KS];
+  int kv[KT];
+  bool kok[KT];
+  half8_t kf[KT][KS], vf[KT][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int c = 32 * ks + 8 * g;
-    const bool ok = kok && c < dh;
-    kf[ks] = ok ? ld_half8(p.K + (size_t)(b * p.kv_stride + kv) * p.ldk + h * dh + c) : zero_half8();
-    vf[ks] = ok ? ld_half8(p.V + (size_t)(b * p.kv_stride + kv) * p.ldv + h * dh + c) : zero_half8();
+  for (int i = 0; i < KT; ++i) {
+    kv[i] = bm.bx * (64 * KT) + (wave * KT + i) * 16 + l16;
+    kok[i] = kv[i] < p.Nkv;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = 32 * ks + 8 * g;
+      const bool ok = kok[i] && c < dh;
+      kf[i][ks] = ok ? ld_half8(p.K + (size_t)(b * p.kv_stride + kv[i]) * p.ldk + h * dh + c) : zero_half8();
+      vf[i][ks] = ok ? ld_half8(p.V + (size_t)(b * p.kv_stride + kv[i]) * p.ldv + h * dh + c) : zero_half8();
+    }
   }
   const float sc = p.scale * LOG2E;
-  float4_t dk[ND], dv[ND];
+  float4_t dk[KT][ND], dv[KT][ND];
 #pragma unroll
-  for (int u = 0; u < ND; ++u) {
-    dk[u] = float4_t{0.f, 0.f, 0.f, 0.f};
-    dv[u] = float4_t{0.f, 0.f, 0.f, 0.f};
-  }
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      dk[i][u] = float4_t{0.f, 0.f, 0.f, 0.f};
+      dv[i][u] = float4_t{0.f, 0.f, 0.f, 0.f};
+    }
   const half_t* Qb = p.Q + (size_t)b * p.Nq * p.ldq + h * dh;
   const half_t* Db = p.dO + (size_t)b * p.Nq * p.lddo + h * dh;
   const half_t* Qtb = p.Qt + (size_t)h * dh * p.ldqt + (size_t)b * p.Nq;
@@ -541,49 +549,65 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
     if (threadIdx.x < 64) { lse_s[threadIdx.x] = r_lse; del_s[threadIdx.x] = r_del; }
     __syncthreads();
     if (t0 + 1 < nt) prefetch(q0 + 64);
-    float4_t s[4], dp[4];
+    float4_t s[KT][4], dp[KT][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      s[t] = float4_t{0.f, 0.f, 0.f, 0.f};
-      dp[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < KT; ++i) {
+        s[i][t] = float4_t{0.f, 0.f, 0.f, 0.f};
+        dp[i][t] = float4_t{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int off = (16 * t + l16) * KP + 32 * ks + 8 * g;
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(Qs + off), kf[ks], s[t], 0, 0, 0);
-        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(Ds + off), vf[ks], dp[t], 0, 0, 0);
+        const half8_t qfr = ld_half8(Qs + off), dfr = ld_half8(Ds + off);
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+          s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qfr, kf[i][ks], s[i][t], 0, 0, 0);
+          dp[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dfr, vf[i][ks], dp[i][t], 0, 0, 0);
+        }
       }
     }
-    float4_t ds[4];
+    half8_t pb[KT][2], sb[KT][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < KT; ++i) {
+      float4_t ds[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ql = 16 * t + 4 * g + r;
-        const float pr = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -lse_s[ql]));
-        s[t][r] = pr;
-        ds[t][r] = pr * (dp[t][r] - del_s[ql]);
-      }
-    half8_t pb[2], sb[2];
-    pack_p(s, pb);
-    pack_p(ds, sb);
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = 16 * t + 4 * g + r;
+          const float pr = __builtin_amdgcn_exp2f(fmaf(s[i][t][r], sc, -lse_s[ql]));
+          s[i][t][r] = pr;
+          ds[t][r] = pr * (dp[i][t][r] - del_s[ql]);
+        }
+      pack_p(s[i], pb[i]);
+      pack_p(ds, sb[i]);
+    }
 #pragma unroll
     for (int u = 0; u < ND; ++u)
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        dv[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag(Dt, u, k2, l16, g), pb[k2], dv[u], 0, 0, 0);
-        dk[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag(Qt, u, k2, l16, g), sb[k2], dk[u], 0, 0, 0);
+        const half8_t dtf = tfrag(Dt, u, k2, l16, g), qtf = tfrag(Qt, u, k2, l16, g);
+#pragma unroll
+        for (int i = 0; i < KT; ++i) {
+          dv[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dtf, pb[i][k2], dv[i][u], 0, 0, 0);
+          dk[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qtf, sb[i][k2], dk[i][u], 0, 0, 0);
+        }
       }
   }
-  if (kok) {
-    half_t* krow = p.O + (size_t)(b * p.kv_stride + kv) * p.ldo + h * dh;
-    half_t* vrow = p.O2 + (size_t)(b * p.kv_stride + kv) * p.ldo2 + h * dh;
+#pragma unroll
+  for (int i = 0; i < KT; ++i) {
+    if (!kok[i]) continue;
+    half_t* krow = p.O + (size_t)(b * p.kv_stride + kv[i]) * p.ldo + h * dh;
+    half_t* vrow = p.O2 + (size_t)(b * p.kv_stride + kv[i]) * p.ldo2 + h * dh;
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
       const int d = 16 * u + 4 * g;
       if (d < dh) {
-        half4_t a = {(half_t)(dk[u][0] * p.scale), (half_t)(dk[u][1] * p.scale), (half_t)(dk[u][2] * p.scale),
-                     (half_t)(dk[u][3] * p.scale)};
-        half4_t c = {(half_t)dv[u][0], (half_t)dv[u][1], (half_t)dv[u][2], (half_t)dv[u][3]};
+        half4_t a = {(half_t)(dk[i][u][0] * p.scale), (half_t)(dk[i][u][1] * p.scale),
+                     (half_t)(dk[i][u][2] * p.scale), (half_t)(dk[i][u][3] * p.scale)};
+        half4_t c = {(half_t)dv[i][u][0], (half_t)dv[i][u][1], (half_t)dv[i][u][2], (half_t)dv[i][u][3]};
         st_half4(krow + d, a);
         st_half4(vrow + d, c);
       }
@@ -716,9 +740,17 @@ extern "C" int skg_attn_bwd_dkv(const void* Q, int ldq, const void* Qt, int ldqt
   p.O2 = (half_t*)dV; p.ldo2 = lddv;
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = Nkv; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
-  p.nx = skg_cdiv(Nkv, 64);
+  p.nx = skg_cdiv(Nkv, dh <= 40 ? 128 : 64);        // key tiles per wave: 2 up to d = 40, 1 beyond (register budget)
   dim3 grid((unsigned)p.nx * heads * batch);
-  SKG_ATTN_DISPATCH(attn_bwd_dkv_kernel, grid);
+  switch (dh) {
+    case 16: hipLaunchKernelGGL((attn_bwd_dkv_kernel<1, 1, 2>), grid, dim3(256), 0, st, p); break;
+    case 32: hipLaunchKernelGGL((attn_bwd_dkv_kernel<1, 2, 2>), grid, dim3(256), 0, st, p); break;
+    case 40: hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 3, 2>), grid, dim3(256), 0, st, p); break;
+    case 64: hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 4, 1>), grid, dim3(256), 0, st, p); break;
+    case 80: hipLaunchKernelGGL((attn_bwd_dkv_kernel<3, 5, 1>), grid, dim3(256), 0, st, p); break;
+    case 160: hipLaunchKernelGGL((attn_bwd_dkv_kernel<5, 10, 1>), grid, dim3(256), 0, st, p); break;
+    default: return SKG_E_UNSUPPORTED;
+  }
   SKG_CHECK_LAUNCH("skg_attn_bwd_dkv");
   return SKG_OK;
 }
