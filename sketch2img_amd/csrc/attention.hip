@@ -380,8 +380,9 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
 }
 
 // dQ: per 64-query block, loop over key tiles.  dS^T = P^T o (dP^T - delta);  dQ^T += K^T dS^T.
-template <int KS, int ND>
+template <int KS, int ND, int QT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
+  // QT query tiles of 16 per wave (64 * QT queries per workgroup): each K / V / K^T fragment read feeds QT MFMAs
   constexpr int KP = KS * 32 + 8;
   __shared__ __attribute__((aligned(16))) half_t Ks[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Vr[64 * KP];
@@ -390,25 +391,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   const int l16 = lane & 15, g = lane >> 4;
   const BlkMap bm = attn_block_map(p);
   const int b = bm.b, h = bm.h;
-  const int q = bm.bx * 64 + wave * 16 + l16;
-  const bool qok = q < p.Nq;
   const int dh = p.dh;
-
-  half8_t qf[KS], dof[KS];
+  int q[QT];
+  bool qok[QT];
+  half8_t qf[QT][KS], dof[QT][KS];
+  float lse2[QT], dl[QT];
+  float4_t dq[QT][ND];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    const int c = 32 * ks + 8 * g;
-    const bool ok = qok && c < dh;
-    qf[ks] = ok ? ld_half8(p.Q + (size_t)(b * p.Nq + q) * p.ldq + h * dh + c) : zero_half8();
-    dof[ks] = ok ? ld_half8(p.dO + (size_t)(b * p.Nq + q) * p.lddo + h * dh + c) : zero_half8();
+  for (int i = 0; i < QT; ++i) {
+    q[i] = bm.bx * (64 * QT) + (wave * QT + i) * 16 + l16;
+    qok[i] = q[i] < p.Nq;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int c = 32 * ks + 8 * g;
+      const bool ok = qok[i] && c < dh;
+      qf[i][ks] = ok ? ld_half8(p.Q + (size_t)(b * p.Nq + q[i]) * p.ldq + h * dh + c) : zero_half8();
+      dof[i][ks] = ok ? ld_half8(p.dO + (size_t)(b * p.Nq + q[i]) * p.lddo + h * dh + c) : zero_half8();
+    }
+    const size_t sidx = ((size_t)b * p.heads + h) * p.Nq + (qok[i] ? q[i] : 0);
+    lse2[i] = qok[i] ? p.lse[sidx] * LOG2E : -NEG_BIG;
+    dl[i] = qok[i] ? p.delta[sidx] : 0.f;
+#pragma unroll
+    for (int u = 0; u < ND; ++u) dq[i][u] = float4_t{0.f, 0.f, 0.f, 0.f};
   }
-  const size_t sidx = ((size_t)b * p.heads + h) * p.Nq + (qok ? q : 0);
-  const float lse2 = qok ? p.lse[sidx] * LOG2E : -NEG_BIG;
-  const float dl = qok ? p.delta[sidx] : 0.f;
   const float sc = p.scale * LOG2E;
-  float4_t dq[ND];
-#pragma unroll
-  for (int u = 0; u < ND; ++u) dq[u] = float4_t{0.f, 0.f, 0.f, 0.f};
 
   const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
   const half_t* Vb = p.V + (size_t)b * p.kv_stride * p.ldv + h * dh;
@@ -432,43 +438,58 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
       rows_load<KS>(rv, Vb, p.ldv, kv0 + 64, p.kv_stride, dh);
       cols_load<ND>(rkt, Ktb, p.ldvt, kv0 + 64, p.kv_stride, dh);
     }
-    float4_t s[4], dp[4];
+    float4_t s[QT][4], dp[QT][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      s[t] = float4_t{0.f, 0.f, 0.f, 0.f};
-      dp[t] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < QT; ++i) {
+        s[i][t] = float4_t{0.f, 0.f, 0.f, 0.f};
+        dp[i][t] = float4_t{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int off = (16 * t + l16) * KP + 32 * ks + 8 * g;
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(Ks + off), qf[ks], s[t], 0, 0, 0);
-        dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(Vr + off), dof[ks], dp[t], 0, 0, 0);
+        const half8_t kfr = ld_half8(Ks + off), vfr = ld_half8(Vr + off);
+#pragma unroll
+        for (int i = 0; i < QT; ++i) {
+          s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr, qf[i][ks], s[i][t], 0, 0, 0);
+          dp[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr, dof[i][ks], dp[i][t], 0, 0, 0);
+        }
       }
     }
     const bool ragged = kv0 + 64 > p.Nkv;      // wave-uniform
+    half8_t sb[QT][2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < QT; ++i) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float pr = __builtin_amdgcn_exp2f(fmaf(s[t][r], sc, -lse2));
-        if (ragged && kv0 + 16 * t + 4 * g + r >= p.Nkv) pr = 0.f;
-        s[t][r] = pr * (dp[t][r] - dl);
-      }
-    half8_t sb[2];
-    pack_p(s, sb);
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pr = __builtin_amdgcn_exp2f(fmaf(s[i][t][r], sc, -lse2[i]));
+          if (ragged && kv0 + 16 * t + 4 * g + r >= p.Nkv) pr = 0.f;
+          s[i][t][r] = pr * (dp[i][t][r] - dl[i]);
+        }
+      pack_p(s[i], sb[i]);
+    }
 #pragma unroll
     for (int u = 0; u < ND; ++u)
 #pragma unroll
-      for (int k2 = 0; k2 < 2; ++k2)
-        dq[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag(Kt, u, k2, l16, g), sb[k2], dq[u], 0, 0, 0);
+      for (int k2 = 0; k2 < 2; ++k2) {
+        const half8_t ktf = tfrag(Kt, u, k2, l16, g);
+#pragma unroll
+        for (int i = 0; i < QT; ++i) dq[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktf, sb[i][k2], dq[i][u], 0, 0, 0);
+      }
   }
-  if (qok) {
-    half_t* orow = p.O + (size_t)(b * p.Nq + q) * p.ldo + h * dh;
+#pragma unroll
+  for (int i = 0; i < QT; ++i) {
+    if (!qok[i]) continue;
+    half_t* orow = p.O + (size_t)(b * p.Nq + q[i]) * p.ldo + h * dh;
 #pragma unroll
     for (int u = 0; u < ND; ++u) {
       const int d = 16 * u + 4 * g;
       if (d < dh) {
-        half4_t v = {(half_t)(dq[u][0] * p.scale), (half_t)(dq[u][1] * p.scale), (half_t)(dq[u][2] * p.scale),
-                     (half_t)(dq[u][3] * p.scale)};
+        half4_t v = {(half_t)(dq[i][u][0] * p.scale), (half_t)(dq[i][u][1] * p.scale), (half_t)(dq[i][u][2] * p.scale),
+                     (half_t)(dq[i][u][3] * p.scale)};
         st_half4(orow + d, v);
       }
     }
@@ -656,17 +677,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
     default: return SKG_E_UNSUPPORTED;                                                                   \
   }
 
-#define SKG_ATTN_DISPATCH(KERNEL, grid)                                                          \
-  switch (p.dh) {                                                                                \
-    case 16: hipLaunchKernelGGL((KERNEL<1, 1>), grid, dim3(256), 0, st, p); break;               \
-    case 32: hipLaunchKernelGGL((KERNEL<1, 2>), grid, dim3(256), 0, st, p); break;               \
-    case 40: hipLaunchKernelGGL((KERNEL<2, 3>), grid, dim3(256), 0, st, p); break;               \
-    case 64: hipLaunchKernelGGL((KERNEL<2, 4>), grid, dim3(256), 0, st, p); break;               \
-    case 80: hipLaunchKernelGGL((KERNEL<3, 5>), grid, dim3(256), 0, st, p); break;               \
-    case 160: hipLaunchKernelGGL((KERNEL<5, 10>), grid, dim3(256), 0, st, p); break;             \
-    default: return SKG_E_UNSUPPORTED;                                                           \
-  }
-
 inline bool common_ok(int batch, int heads, int Nq, int Nkv, int kv_stride, int dh) {
   return batch > 0 && heads > 0 && Nq > 0 && Nkv > 0 && kv_stride >= Nkv && kv_stride % 8 == 0 && dh % 8 == 0;
 }
@@ -716,9 +726,17 @@ extern "C" int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, c
   p.lse = const_cast<float*>(lse); p.delta = delta; p.O = (half_t*)dQ; p.ldo = lddq;
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
-  p.nx = skg_cdiv(Nq, 64);
+  p.nx = skg_cdiv(Nq, dh <= 40 ? 128 : 64);         // query tiles per wave: 2 up to d = 40, 1 beyond
   dim3 grid((unsigned)p.nx * heads * batch);
-  SKG_ATTN_DISPATCH(attn_bwd_dq_kernel, grid);
+  switch (dh) {
+    case 16: hipLaunchKernelGGL((attn_bwd_dq_kernel<1, 1, 2>), grid, dim3(256), 0, st, p); break;
+    case 32: hipLaunchKernelGGL((attn_bwd_dq_kernel<1, 2, 2>), grid, dim3(256), 0, st, p); break;
+    case 40: hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 3, 2>), grid, dim3(256), 0, st, p); break;
+    case 64: hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 4, 1>), grid, dim3(256), 0, st, p); break;
+    case 80: hipLaunchKernelGGL((attn_bwd_dq_kernel<3, 5, 1>), grid, dim3(256), 0, st, p); break;
+    case 160: hipLaunchKernelGGL((attn_bwd_dq_kernel<5, 10, 1>), grid, dim3(256), 0, st, p); break;
+    default: return SKG_E_UNSUPPORTED;
+  }
   SKG_CHECK_LAUNCH("skg_attn_bwd_dq");
   return SKG_OK;
 }
