@@ -492,3 +492,64 @@ def test_cfg_dpmpp2m_step_vs_oracle(ops):
         assert report(f"dpm++ step {i} (order {order}) x_prev", xp.cpu(), ref)[1] < 2e-5
         assert report(f"dpm++ step {i} x0 history", x0_io.cpu(), st.x0_before)[0] < 1e-6      # |x0| ~ 450 at t = 999
         x, xg = ref, ref.to(d)
+
+
+# ------------------------------------------------------------------------------------------------ round-1 additions
+def test_softmax_rows_and_quick_gelu(ops):
+    x = rnd(300, 4096, seed=1, scale=3.0)
+    y = ops.softmax_rows(x.to(dev()))
+    ref = torch.softmax(x.float(), dim=-1)
+    assert report("softmax rows", y.float().cpu(), ref)[0] < FP16_RND and abs(float(y.float().sum(1).mean()) - 1) < 1e-3
+    big = torch.zeros(16, 64, dtype=torch.float16)
+    big[:, 3] = 60000.0                                           # near the fp16 maximum: no overflow in the kernel
+    z = ops.softmax_rows(big.to(dev())).cpu()
+    assert torch.isfinite(z).all() and float(z[:, 3].min()) == 1.0
+    h = rnd(777, 256, seed=2, scale=2.0)
+    g = ops.quick_gelu(h.to(dev()))
+    assert report("quick_gelu", g.float().cpu(), h.float() * torch.sigmoid(1.702 * h.float()))[0] < FP16_RND
+
+
+def test_image_postprocess_and_gaussian_sample(ops):
+    S, h = 3, 8
+    y = rnd(S * h * h, 8, seed=3, scale=1.5)
+    img = ops.image_postprocess(y.to(dev()), S * h * h, 3)
+    ref = (y[:, :3].float() / 2 + 0.5).clamp(0, 1)
+    assert img.shape == (S * h * h, 3) and report("image postprocess", img.cpu(), ref)[1] < 1e-6
+    m = rnd(S * h * h, 8, seed=4)
+    m[:, 4:] = m[:, 4:] * 30                                       # exercise the logvar clamp [-30, 20]
+    noise = torch.randn(S, 4, h, h, generator=torch.Generator().manual_seed(5))
+    z = ops.gaussian_sample(m.to(dev()), S, 4, h * h, noise.to(dev()), 0.18215).reshape(S, 4, h, h)
+    mm = m.float().reshape(S, h * h, 8).permute(0, 2, 1).reshape(S, 8, h, h)
+    ref = (mm[:, :4] + torch.exp(0.5 * mm[:, 4:].clamp(-30, 20)) * noise) * 0.18215
+    assert report("gaussian sample", z.cpu(), ref)[0] < 1e-5
+    mode = ops.gaussian_sample(m.to(dev()), S, 4, h * h, None, 1.0).reshape(S, 4, h, h)
+    assert report("gaussian mode", mode.cpu(), mm[:, :4])[1] < 1e-6
+
+
+def test_training_helpers_colsum_bn_param_grads_adamw(ops):
+    M, C = 5000, 256
+    x, dy = rnd(M, C, seed=6), rnd(M, C, seed=7, scale=0.1)
+    cs = ops.colsum(x.to(dev()), 0.5)
+    assert report("colsum", cs.cpu(), 0.5 * x.float().sum(0))[0] < 1e-5
+    st = ops.bn_stats(x.to(dev()), 1, 1, M)
+    dg, db = ops.bn_param_grads(x.to(dev()), dy.to(dev()), st)
+    xf = x.float()
+    xhat = (xf - xf.mean(0)) / torch.sqrt(xf.var(0, unbiased=False) + 1e-5)
+    assert report("bn dgamma", dg.cpu(), (dy.float() * xhat).sum(0))[0] < 1e-4
+    assert report("bn dbeta", db.cpu(), dy.float().sum(0))[0] < 1e-5
+    n = 10007
+    gen = torch.Generator().manual_seed(8)
+    p0, g0 = torch.randn(n, generator=gen), torch.randn(n, generator=gen) * 4096
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    p, m, v = p0.clone().to(dev()), torch.zeros(n, device=dev()), torch.zeros(n, device=dev())
+    p16 = torch.empty(n, device=dev(), dtype=torch.float16)
+    for step in (1, 2, 3):
+        pt.grad = g0.clone() / 4096 * step
+        opt.step()
+        ops.adamw_step(p, (g0 * step).to(dev()), m, v, p16, 1e-3, 0.9, 0.999, 1e-8, 0.05, step, 1.0 / 4096)
+    assert report("adamw 3 steps", p.cpu(), pt.detach())[1] < 2e-6
+    assert torch.equal(p16.float().cpu(), p.cpu().half().float())
+    E = ops.lgp_extra_features(torch.ones(2, 4, 4, 4, device=dev()) * 0.25, 2.0, 2, 2, 4, 64).float().cpu()
+    assert E.shape == (32, 64) and float(E[:, 40:].abs().max()) == 0.0
+    assert abs(float(E[0, 0]) - 0.5) < 1e-3 and abs(float(E[0, 4]) - math.sin(2 * math.pi * 0.5)) < 2e-3
