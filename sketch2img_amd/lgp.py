@@ -11,7 +11,7 @@ resized and summed by one gather kernel that also adds the 40 noise-level / sinu
 bias, rounds to fp16 and applies the ReLU: 7.3x fewer MACs and no 9320-channel tensor in HBM.
 The reference rounds the resized features to fp16 before the GEMM; here the (already fp16)
 native features enter the GEMM exactly and the resize runs on fp32 partial sums, so this path is
-at least as accurate; tests/test_gpu_lgp.py bounds the difference against the oracle.
+at least as accurate; tests/test_gpu_pipeline.py bounds the difference against the oracle and the reference's golden vectors.
 
 BatchNorm1d runs in train mode when ``training`` is True (the reference never calls .eval():
 SURVEY Q3) with one sample's 2*h*h rows as the batch, and updates running stats as a side effect.

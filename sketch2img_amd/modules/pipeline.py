@@ -6,8 +6,9 @@ and ``__call__`` with the reference's keyword list (modules/pipeline.py:20-37) a
 the bare list of PIL images when ``return_dict`` is true, ``(images, None)`` otherwise).  The sampling loop, the
 UNet, the LGP and the guidance gradient run in libskg.so; there is no diffusers dependency.
 
-Out of the hot path, handled by PyTorch modules the caller provides (next rows in SURVEY.md section 8f):
-  * ``vae``          any object with ``decode(latents) -> tensor | .sample`` (and ``encode`` for app.py:109);
+Around the hot path:
+  * ``vae``          ``sketch2img_amd.vae.AutoencoderKL`` decodes / encodes on the HIP kernels; any other object with
+                     ``decode(latents) -> tensor | .sample`` (and ``encode`` for app.py:109) is used as a PyTorch module;
   * ``text_encoder`` a callable ``(list[str]) -> (B, 77, D) tensor``; without one, prompts map to seeded
                      pseudo-embeddings (deterministic in the prompt text) so that the pipeline stays runnable
                      on a box with no CLIP weights.
