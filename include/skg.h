@@ -196,6 +196,9 @@ typedef struct {
   int s;            /* native side */
   int pad_;
 } SkgLgpTap;
+/* Wextra may be NULL (h % 8 == 0 and H0 % 128 == 0 required): the caller then supplies the product of the 40 extra
+ * channels (skg_lgp_extra_features x W0[:, E:], an fp32 GEMM) as one more tap with s == h - the matrix pipe does the
+ * 40-wide dot products instead of 160 cached vector loads per thread. */
 int skg_lgp_layer0_gather(const SkgLgpTap* taps, int ntaps, const void* Wextra, int ldw,
                           const void* bias0, const float* noise, float sigma, int samples,
                           void* Z, int rows, int h, int H0, void* stream);

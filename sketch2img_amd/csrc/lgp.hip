@@ -94,9 +94,117 @@ __global__ __launch_bounds__(256) void lgp_gather_kernel(const TapArgs taps, con
   }
 }
 
-// adjoint of the bilinear resize for one tap: one block per native pixel
+// Tiled variant (h % 8 == 0, H0 % 128 == 0): one workgroup = an 8x8 output tile x 128 channels of one row.  For every
+// tap the source window of the tile (<= 8x8 native pixels; 3x3 for an 8x-upsampled tap) is staged ONCE in LDS and
+// every thread interpolates from there: the per-pixel kernel above re-read four 2 KB corner rows per tap and output
+// pixel from L2 (73 KB per output pixel, ~8 TB/s of L2 traffic for 589 us at 64x64); here the taps cost ~5 KB per
+// output pixel.  thread = (output pixel = tid / 4, 32-channel group = tid % 4).
+constexpr int GT = 8, GC = 128, GPITCH = GC + 4;
+__global__ __launch_bounds__(256) void lgp_gather_tiled_kernel(const TapArgs taps, const half_t* __restrict__ Wx, int ldw,
+                                                               const half_t* __restrict__ bias0,
+                                                               const float* __restrict__ noise, float sigma, int S,
+                                                               half_t* __restrict__ Z, int rows, int h, int H0) {
+  __shared__ __attribute__((aligned(16))) float patch[GT * GT * GPITCH];
+  __shared__ float e_s[GT * GT][NEXTRA];
+  const int hw = h * h;
+  const int tiles = h / GT;
+  const int ty = blockIdx.x / tiles, tx = blockIdx.x - ty * tiles;
+  const int row = blockIdx.y, cbase = blockIdx.z * GC;
+  const int tid = threadIdx.x;
+  const int pix = tid >> 2, cg = tid & 3;
+  const int py = pix >> 3, px = pix & 7;
+  const int oy = ty * GT + py, ox = tx * GT + px;
+  const int smp = row % S;
+  for (int i = tid; Wx != nullptr && i < GT * GT * NEXTRA; i += 256) {
+    const int p = i / NEXTRA, tl = i - p * NEXTRA;
+    const int pp = (ty * GT + (p >> 3)) * h + tx * GT + (p & 7);
+    const int c = tl < 4 ? tl : (tl - 4) & 3;
+    const float nl = sigma * noise[((size_t)smp * 4 + c) * hw + pp];
+    float v = nl;
+    if (tl >= 4) v = sinf((6.283185307179586f * nl) * exp2f(-(float)((tl - 4) >> 2)));
+    e_s[p][tl] = (float)(half_t)v;          // the reference casts the concatenated input to fp16
+  }
+  float4_t acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = float4_t{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < taps.n; ++i) {
+    const int s = taps.s[i];
+    int sy0, sx0, nrow, ncol;
+    if (s == h) {
+      sy0 = ty * GT; sx0 = tx * GT; nrow = ncol = GT;
+    } else {
+      int a0, a1, b0, b1;
+      float w;
+      bil_coord(ty * GT, s, h, a0, a1, w);
+      bil_coord(ty * GT + GT - 1, s, h, b0, b1, w);
+      sy0 = a0; nrow = b1 - a0 + 1;
+      bil_coord(tx * GT, s, h, a0, a1, w);
+      bil_coord(tx * GT + GT - 1, s, h, b0, b1, w);
+      sx0 = a0; ncol = b1 - a0 + 1;
+    }
+    __syncthreads();                                   // the previous tap's window has been consumed
+    const float* P = taps.P[i] + (size_t)row * s * s * H0 + cbase;
+    for (int idx = tid; idx < nrow * ncol * (GC / 4); idx += 256) {
+      const int sp = idx / (GC / 4), q = idx - sp * (GC / 4);
+      const int sy = sp / ncol, sx = sp - sy * ncol;
+      *reinterpret_cast<float4_t*>(&patch[sp * GPITCH + q * 4]) =
+          *reinterpret_cast<const float4_t*>(P + (size_t)((sy0 + sy) * s + sx0 + sx) * H0 + q * 4);
+    }
+    __syncthreads();
+    const float* pc = patch + cg * 32;
+    if (s == h) {
+      const float* a = pc + (py * GT + px) * GPITCH;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += *reinterpret_cast<const float4_t*>(a + q * 4);
+    } else {
+      int y0, y1, x0, x1;
+      float wy, wx;
+      bil_coord(oy, s, h, y0, y1, wy);
+      bil_coord(ox, s, h, x0, x1, wx);
+      const float* p00 = pc + ((y0 - sy0) * ncol + (x0 - sx0)) * GPITCH;
+      const float* p01 = pc + ((y0 - sy0) * ncol + (x1 - sx0)) * GPITCH;
+      const float* p10 = pc + ((y1 - sy0) * ncol + (x0 - sx0)) * GPITCH;
+      const float* p11 = pc + ((y1 - sy0) * ncol + (x1 - sx0)) * GPITCH;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const float4_t v00 = *reinterpret_cast<const float4_t*>(p00 + q * 4);
+        const float4_t v01 = *reinterpret_cast<const float4_t*>(p01 + q * 4);
+        const float4_t v10 = *reinterpret_cast<const float4_t*>(p10 + q * 4);
+        const float4_t v11 = *reinterpret_cast<const float4_t*>(p11 + q * 4);
+        acc[q] += (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+      }
+    }
+  }
+  const size_t orow = (size_t)row * hw + (size_t)oy * h + ox;
+  half_t* zo = Z + orow * H0 + cbase + cg * 32;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    half4_t o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cbase + cg * 32 + q * 4 + j;
+      float d = 0.f;
+      if (Wx != nullptr) {       // (callers normally pass the 40 extra channels as one more s == h tap instead)
+        const half_t* w = Wx + (size_t)c * ldw;
+#pragma unroll
+        for (int k = 0; k < NEXTRA; k += 8) {
+          const half8_t wv = ld_half8(w + k);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) d += (float)wv[u] * e_s[pix][k + u];
+        }
+      }
+      const float v = acc[q][j] + d + (float)bias0[c];
+      o[j] = (half_t)fmaxf((float)(half_t)v, 0.f);
+    }
+    st_half4(zo + q * 4, o);
+  }
+}
+
+// adjoint of the bilinear resize for one tap: one block per native pixel; thread = (8-channel piece, window lane):
+// 16-byte loads, the (2f)^2 window pixels are dealt round-robin to the 256 / (H0/8) window lanes and folded in LDS
 __global__ __launch_bounds__(256) void lgp_scatter_kernel(const half_t* __restrict__ dZ, int lddz,
                                                           half_t* __restrict__ dP, int rows, int h, int s, int H0) {
+  __shared__ float red[256][9];
   const int ss = s * s;
   const int row = blockIdx.x / ss;
   const int np = blockIdx.x - row * ss;
@@ -104,27 +212,44 @@ __global__ __launch_bounds__(256) void lgp_scatter_kernel(const half_t* __restri
   const int f = h / s;
   const int ylo = max(0, f * py - f), yhi = min(h - 1, f * py + 2 * f - 1);
   const int xlo = max(0, f * px - f), xhi = min(h - 1, f * px + 2 * f - 1);
-  for (int c0 = threadIdx.x * 2; c0 < H0; c0 += 512) {
-    float a0 = 0.f, a1 = 0.f;
-    for (int y = ylo; y <= yhi; ++y) {
-      int y0, y1;
-      float wy;
-      bil_coord(y, s, h, y0, y1, wy);
-      const float cy = (y0 == py ? 1.f - wy : 0.f) + (y1 == py ? wy : 0.f);
-      if (cy == 0.f) continue;
-      for (int x = xlo; x <= xhi; ++x) {
-        int x0, x1;
-        float wx;
+  const int wy_n = yhi - ylo + 1, wx_n = xhi - xlo + 1;
+  const int C8 = H0 >> 3;
+  for (int pb = 0; pb < C8; pb += 256) {
+    const int npc = min(256, C8 - pb);
+    const int WL = 256 / npc;
+    const int piece = threadIdx.x % npc, wl = threadIdx.x / npc;
+    const int c0 = (pb + piece) * 8;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (wl < WL) {
+      for (int wi = wl; wi < wy_n * wx_n; wi += WL) {
+        const int y = ylo + wi / wx_n, x = xlo + wi % wx_n;
+        int y0, y1, x0, x1;
+        float wy, wx;
+        bil_coord(y, s, h, y0, y1, wy);
         bil_coord(x, s, h, x0, x1, wx);
+        const float cy = (y0 == py ? 1.f - wy : 0.f) + (y1 == py ? wy : 0.f);
         const float cx = (x0 == px ? 1.f - wx : 0.f) + (x1 == px ? wx : 0.f);
-        if (cx == 0.f) continue;
-        const half2_t v = *reinterpret_cast<const half2_t*>(dZ + ((size_t)row * h * h + y * h + x) * lddz + c0);
-        a0 += cy * cx * (float)v[0];
-        a1 += cy * cx * (float)v[1];
+        const float w = cy * cx;
+        if (w == 0.f) continue;
+        const half8_t v = ld_half8(dZ + ((size_t)row * h * h + y * h + x) * lddz + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += w * (float)v[j];
       }
     }
-    half2_t o = {(half_t)a0, (half_t)a1};
-    *reinterpret_cast<half2_t*>(dP + ((size_t)row * ss + np) * H0 + c0) = o;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = a[j];
+    __syncthreads();
+    if (threadIdx.x < npc) {
+      half8_t o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float t = 0.f;
+        for (int l = 0; l < WL; ++l) t += red[l * npc + threadIdx.x][j];
+        o[j] = (half_t)t;
+      }
+      st_half8(dP + ((size_t)row * ss + np) * H0 + c0, o);
+    }
   }
 }
 
@@ -446,15 +571,22 @@ inline int ew_grid(size_t total_items) {
 extern "C" int skg_lgp_layer0_gather(const SkgLgpTap* taps, int ntaps, const void* Wextra, int ldw,
                                      const void* bias0, const float* noise, float sigma, int samples, void* Z,
                                      int rows, int h, int H0, void* stream) {
-  SKG_REQUIRE(taps && ntaps > 0 && ntaps <= MAX_TAPS && Wextra && bias0 && noise && Z && rows > 0 && h > 0);
-  SKG_REQUIRE(H0 % 4 == 0 && ldw % 8 == 0 && skg_aligned(Wextra, 16) && skg_aligned(Z, 8) && samples > 0 &&
-              rows % samples == 0);
+  SKG_REQUIRE(taps && ntaps > 0 && ntaps <= MAX_TAPS && bias0 && noise && Z && rows > 0 && h > 0);
+  SKG_REQUIRE(H0 % 4 == 0 && skg_aligned(Z, 8) && samples > 0 && rows % samples == 0);
+  SKG_REQUIRE(Wextra ? (ldw % 8 == 0 && skg_aligned(Wextra, 16)) : (h % GT == 0 && H0 % GC == 0));
   TapArgs a{};
   a.n = ntaps;
   for (int i = 0; i < ntaps; ++i) {
     SKG_REQUIRE(taps[i].P && taps[i].s > 0 && h % taps[i].s == 0 && skg_aligned(taps[i].P, 16));
     a.P[i] = taps[i].P;
     a.s[i] = taps[i].s;
+  }
+  if (h % GT == 0 && H0 % GC == 0) {
+    hipLaunchKernelGGL(lgp_gather_tiled_kernel, dim3((h / GT) * (h / GT), rows, H0 / GC), dim3(256), 0,
+                       (hipStream_t)stream, a, (const half_t*)Wextra, ldw, (const half_t*)bias0, noise, sigma, samples,
+                       (half_t*)Z, rows, h, H0);
+    SKG_CHECK_LAUNCH("skg_lgp_layer0_gather");
+    return SKG_OK;
   }
   const size_t pixels = (size_t)rows * h * h;
   hipLaunchKernelGGL(lgp_gather_kernel, dim3((unsigned)((pixels + 1) / 2)), dim3(256), 0, (hipStream_t)stream, a,
@@ -465,7 +597,8 @@ extern "C" int skg_lgp_layer0_gather(const SkgLgpTap* taps, int ntaps, const voi
 
 extern "C" int skg_lgp_layer0_scatter(const void* dZ, int lddz, void* dP, int rows, int h, int s, int H0,
                                       void* stream) {
-  SKG_REQUIRE(dZ && dP && rows > 0 && h > 0 && s > 0 && h % s == 0 && H0 % 2 == 0 && lddz % 2 == 0);
+  SKG_REQUIRE(dZ && dP && rows > 0 && h > 0 && s > 0 && h % s == 0 && H0 % 8 == 0 && lddz % 8 == 0 &&
+              skg_aligned(dZ, 16) && skg_aligned(dP, 16));
   hipLaunchKernelGGL(lgp_scatter_kernel, dim3(rows * s * s), dim3(256), 0, (hipStream_t)stream, (const half_t*)dZ,
                      lddz, (half_t*)dP, rows, h, s, H0);
   SKG_CHECK_LAUNCH("skg_lgp_layer0_scatter");

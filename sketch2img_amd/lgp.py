@@ -45,6 +45,9 @@ class HipLGP:
         self.H0 = w0.shape[0]
         self.W0 = h16(w0)
         self.W0T = h16(w0[:, : self.E].t())                         # [E, H0] for the feature gradients
+        # the 40 noise-level / sinusoid columns, zero-padded to K = 64: their contribution is a GEMM whose fp32 result
+        # enters the gather as one more (s == h) tap
+        self.W0x = h16(torch.nn.functional.pad(w0[:, self.E:], (0, 64 - 40)))
         self.b = [h16(state_dict[f"layers.{i}.bias"]) for i in LIN]
         self.W = [self.W0] + [h16(state_dict[f"layers.{i}.weight"]) for i in LIN[1:]]
         self.WT = [None] + [h16(state_dict[f"layers.{i}.weight"].t()) for i in LIN[1:]]
@@ -72,7 +75,12 @@ class HipLGP:
             P.append(ops.gemm(F, self.W0[:, off:off + C], out_f32=True))
             sizes.append(s)
             off += C
-        Z = ops.lgp_layer0_gather(P, sizes, self.W0[:, self.E:], self.b[0], noise, sigma, S, h, self.H0)
+        if h % 8 == 0 and self.H0 % 128 == 0:
+            Ex = ops.lgp_extra_features(noise, sigma, S, 2 * S, h, 64)
+            Z = ops.lgp_layer0_gather(P + [ops.gemm(Ex, self.W0x, out_f32=True)], sizes + [h], None, self.b[0], noise,
+                                      sigma, S, h, self.H0)
+        else:
+            Z = ops.lgp_layer0_gather(P, sizes, self.W0[:, self.E:], self.b[0], noise, sigma, S, h, self.H0)
         zs, stats = [], []
         for l in range(4):
             if self.training:

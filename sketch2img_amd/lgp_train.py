@@ -86,7 +86,13 @@ class HipLGPTrainer:
             P.append(ops.gemm(F, W0[:, off:off + C], out_f32=True))
             sizes.append(s)
             off += C
-        Z = ops.lgp_layer0_gather(P, sizes, W0[:, self.E:], b0, noise_level, 1.0, B, h, self.H0, rows=B)
+        Ex = ops.lgp_extra_features(noise_level, 1.0, B, B, h, 64)               # [M, 64], 40 valid columns
+        if h % 8 == 0 and self.H0 % 128 == 0:
+            w0x = torch.nn.functional.pad(W0[:, self.E:], (0, 64 - 40)).contiguous()
+            Z = ops.lgp_layer0_gather(P + [ops.gemm(Ex, w0x, out_f32=True)], sizes + [h], None, b0, noise_level, 1.0, B,
+                                      h, self.H0, rows=B)
+        else:
+            Z = ops.lgp_layer0_gather(P, sizes, W0[:, self.E:], b0, noise_level, 1.0, B, h, self.H0, rows=B)
         zs, As, stats = [], [], []
         for l in range(4):
             st = ops.bn_stats(Z, 1, B, hw, 1e-5, self.running_mean[l], self.running_var[l])
@@ -138,7 +144,6 @@ class HipLGPTrainer:
             dP = ops.lgp_layer0_scatter(dZ, B, h, s, self.H0)                    # [B*s*s, H0]
             gW0[:, off:off + C].copy_(dweight(dP, F))
             off += C
-        Ex = ops.lgp_extra_features(noise_level, 1.0, B, B, h, 64)               # [M, 64], 40 valid columns
         gW0[:, self.E:].copy_(dweight(dZ, Ex)[:, :40])
         return loss, g
 

@@ -322,7 +322,7 @@ def lgp_layer0_gather(P: Sequence[torch.Tensor], sizes: Sequence[int], Wextra, b
         arr[i].P, arr[i].s = t.data_ptr(), s
     if out is None:
         out = torch.empty(rows * h * h, H0, device=noise.device, dtype=torch.float16)
-    check(lib.skg_lgp_layer0_gather(ctypes.addressof(arr), len(P), _p(Wextra), _ld(Wextra), _p(bias0),
+    check(lib.skg_lgp_layer0_gather(ctypes.addressof(arr), len(P), _p(Wextra), _ld(Wextra) if Wextra is not None else 0, _p(bias0),
                                     _p(noise), sigma, samples, _p(out), rows, h, H0, _stream()),
           "skg_lgp_layer0_gather")
     return out
@@ -330,6 +330,8 @@ def lgp_layer0_gather(P: Sequence[torch.Tensor], sizes: Sequence[int], Wextra, b
 
 def lgp_layer0_scatter(dZ, rows, h, s, H0):
     _f16(dZ)
+    if s == h and dZ.stride(0) == H0:          # the adjoint of an identity resize: no copy
+        return dZ
     out = torch.empty(rows * s * s, H0, device=dZ.device, dtype=torch.float16)
     check(lib.skg_lgp_layer0_scatter(_p(dZ), _ld(dZ), _p(out), rows, h, s, H0, _stream()),
           "skg_lgp_layer0_scatter")
