@@ -688,7 +688,9 @@ template <int MODE>
 void launch_mode(const GemmParams& p, hipStream_t st) {
   const TileCfg t = pick_tile(p.M, p.N, p.K);
   if (t.bm == 256) launch_cfg<256, 320, 2, 4, MODE>(p, st);
-  else if (t.bn == 160) launch_cfg<128, 160, 2, 2, MODE>(p, st);
+  else if (t.bn == 160) {
+    if (!skg_gemm4_try_launch(p, MODE, st)) launch_cfg<128, 160, 2, 2, MODE>(p, st);
+  }
   else if (t.bn == 128) launch_cfg<128, 128, 2, 2, MODE>(p, st);
   else launch_cfg<128, 64, 2, 2, MODE>(p, st);
 }

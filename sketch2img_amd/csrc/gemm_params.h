@@ -20,3 +20,5 @@ bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st);
 // column width of the tile v2 would use for an M x N output, or 0 if v2 does not take this shape
 int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode);
 void skg_gemm2_set_workspace(float* ws, size_t bytes);
+// v4 (gemm4.hip): persistent wave-specialised 128 x 160 kernel (DIRECT mode, plain epilogue); false = out of scope.
+bool skg_gemm4_try_launch(const GemmParams& p, int mode, hipStream_t st);

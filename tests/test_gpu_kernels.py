@@ -76,6 +76,16 @@ def test_forced_tiles(force, env):
     assert r.returncode == 0 and "ALL OK" in r.stdout
 
 
+@pytest.mark.parametrize("env", [{"SKG_GEMM4": "1"}, {}])
+def test_persistent_gemm(env):
+    """Large-M GEMMs (>= 256 tiles) through the opt-in persistent wave-specialised kernel and through the default."""
+    import os, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_gemm4_check.py")],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ALL OK" in r.stdout
+
+
 # ---------------------------------------------------------------------------------------------- conv
 def nhwc(x):   # [B,C,H,W] -> [B*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
