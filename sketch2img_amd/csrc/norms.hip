@@ -392,13 +392,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const half_t* __restrict__ 
   const int C8 = C >> 3;
   const float mean = stats[(size_t)row * 2], rstd = stats[(size_t)row * 2 + 1];
   float xh[LN_MAXP][8], dg[LN_MAXP][8];
+  half8_t rres[LN_MAXP];          // the residual is fetched with the other two streams, not after the reductions
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int q = 0; q < LN_MAXP; ++q) {
     const int pc = lane + q * 64;
+    rres[q] = zero_half8();
     if (pc < C8) {
       const half8_t x = ld_half8(X + (size_t)row * ldx + pc * 8);
       const half8_t d = ld_half8(dY + (size_t)row * lddy + pc * 8);
+      if (R) rres[q] = ld_half8(R + (size_t)row * ldr + pc * 8);
       const half8_t gv = ld_half8(gamma + pc * 8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -414,11 +417,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const half_t* __restrict__ 
   for (int q = 0; q < LN_MAXP; ++q) {
     const int pc = lane + q * 64;
     if (pc < C8) {
-      half8_t rv = zero_half8();
-      if (R) rv = ld_half8(R + (size_t)row * ldr + pc * 8);
       half8_t o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (half_t)(rstd * (dg[q][j] - m1 - xh[q][j] * m2) + (float)rv[j]);
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)(rstd * (dg[q][j] - m1 - xh[q][j] * m2) + (float)rres[q][j]);
       st_half8(dX + (size_t)row * lddx + pc * 8, o);
     }
   }
