@@ -140,6 +140,13 @@ int skg_geglu_bwd(const void* H, int ldh, const void* dY, int lddy, void* dH, in
 int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt,
                  void* O, int ldo, float* lse, int batch, int heads, int Nq, int Nkv,
                  int kv_stride, int dh, float scale, void* stream);
+/* Same with a causal mask: key j of a batch row is visible to query i only when j <= i (self-attention, Nq rows
+ * and kv_stride key slots per batch row).  dh in {16, 32, 64}.
+ * Replaces: the masked self-attention of transformers' CLIPTextModel, which the reference calls through
+ * StableDiffusionPipeline._encode_prompt (modules/pipeline.py:55-57). */
+int skg_attn_fwd_causal(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt,
+                        void* O, int ldo, float* lse, int batch, int heads, int Nq, int Nkv,
+                        int kv_stride, int dh, float scale, void* stream);
 /* backward.  delta[b][h][q] = sum_d dO*O (skg_attn_bwd_delta).  dQ kernel needs K, V row-major
  * (V [batch*kv_stride][..] ldv) and Kt (K transposed like Vt); dKV kernel needs Q, dO row-major
  * and their transposes Qt, dOt ([h*dh+d][b*Nq + q]).  Outputs row-major like their primals. */
@@ -173,6 +180,9 @@ int skg_silu_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, void* s
 /* Y = X * sigmoid(1.702 X): transformers' "quick_gelu", the MLP activation of the CLIP vision tower that
  * modules/clip_guided_inf.py:49-54,103 runs to produce the sketch tokens. */
 int skg_quick_gelu_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, void* stream);
+/* Y = X/2 (1 + erf(X / sqrt 2)): exact "gelu", the MLP activation of the OpenCLIP text encoder that SD 2.x
+ * checkpoints carry (transformers CLIPTextModel with hidden_act = "gelu"; modules/pipeline.py:55-57). */
+int skg_gelu_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, void* stream);
 /* adjoint of nearest 2x upsample: Y[b][y][x][c] = sum of the 2x2 block of X.  X [rows*2H*2W][C]. */
 int skg_sumpool2x2_f16(const void* X, int ldx, void* Y, int ldy, int rows, int H, int W, int C,
                        void* stream);

@@ -29,6 +29,7 @@ SIGNATURES = {
     "skg_geglu_fwd": ("i", "pipiiiip"),
     "skg_geglu_bwd": ("i", "pipipiiiip"),
     "skg_attn_fwd": ("i", "pipipipipiiiiiifp"),
+    "skg_attn_fwd_causal": ("i", "pipipipipiiiiiifp"),
     "skg_attn_bwd_delta": ("i", "pipipiiiip"),
     "skg_attn_bwd_dq": ("i", "pipipipipipppiiiiiiifp"),
     "skg_attn_bwd_dkv": ("i", "pipipipipipipppipiiiiiifp"),
@@ -37,6 +38,7 @@ SIGNATURES = {
     "skg_batch_copy_f16": ("i", "piipiiiiip"),
     "skg_silu_f16": ("i", "pipiiip"),
     "skg_quick_gelu_f16": ("i", "pipiiip"),
+    "skg_gelu_f16": ("i", "pipiiip"),
     "skg_sumpool2x2_f16": ("i", "pipiiiiip"),
     "skg_nchw_f32_to_nhwc_f16": ("i", "ppiiiip"),
     "skg_nhwc_f16_to_nchw_f32": ("i", "pipiiip"),

@@ -105,3 +105,25 @@ class CLIPVisionConfig:
 VIT_L_14 = CLIPVisionConfig()
 TINY_CLIP = CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
                              image_size=56, patch_size=14)
+
+
+# ------------------------------------------------------------------------------------------- CLIP text encoder
+@dataclass(frozen=True)
+class CLIPTextConfig:
+    """transformers CLIPTextModel, the ``text_encoder`` StableDiffusionPipeline._encode_prompt runs
+    (modules/pipeline.py:55-57).  SD 1.x: CLIP ViT-L/14 text tower; SD 2.x: OpenCLIP ViT-H, 23 of 24 layers, gelu."""
+    vocab_size: int = 49408
+    hidden_size: int = 768
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    max_position_embeddings: int = 77
+    hidden_act: str = "quick_gelu"
+    layer_norm_eps: float = 1e-5
+
+
+SD15_TEXT = CLIPTextConfig()
+SD21_TEXT = CLIPTextConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=23, num_attention_heads=16,
+                           hidden_act="gelu")
+TINY_TEXT = CLIPTextConfig(vocab_size=1000, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                           num_attention_heads=4)

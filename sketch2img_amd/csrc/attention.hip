@@ -206,7 +206,9 @@ __device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __rest
 // registers into LDS: the HBM/L2 latency of tile t+1 hides under the MFMA + VALU work of tile t.
 // Softmax arithmetic is kept to ~6 VALU per score: raw v_exp_f32 (arguments are <= 0, no range fix-up),
 // scale folded into one FMA, masking only on a ragged last tile.
-template <int KS, int ND, int QT>
+// CAUSAL (the CLIP text encoder, modules/pipeline.py:55-57 -> transformers CLIPTextModel): key j is visible to
+// query i only when j <= i; a separate instantiation so the UNet's kernels carry no extra test.
+template <int KS, int ND, int QT, bool CAUSAL = false>
 __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const AttnParams p) {
   // QT query tiles of 16 per wave: a workgroup covers 64 * QT queries, so every K / V^T fragment read from LDS
   // (and every byte of K/V streamed from L2) is used by QT MFMAs instead of one.
@@ -269,12 +271,14 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
     half8_t pb[QT][2];
 #pragma unroll
     for (int i = 0; i < QT; ++i) {
-      if (kv0 + 64 > p.Nkv) {          // ragged last tile only (wave-uniform)
+      if (CAUSAL || kv0 + 64 > p.Nkv) {          // ragged last tile only (wave-uniform)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (kv0 + 16 * t + 4 * g + r >= p.Nkv) s[i][t][r] = NEG_BIG;
+          for (int r = 0; r < 4; ++r) {
+            const int key = kv0 + 16 * t + 4 * g + r;
+            if (key >= p.Nkv || (CAUSAL && key > q[i])) s[i][t][r] = NEG_BIG;
+          }
       }
       float mx = fmaxf(fmaxf(s[i][0][0], s[i][0][1]), fmaxf(s[i][0][2], s[i][0][3]));
 #pragma unroll
@@ -677,15 +681,23 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
     default: return SKG_E_UNSUPPORTED;                                                                   \
   }
 
+#define SKG_ATTN_FWD_CAUSAL_DISPATCH(grid2)                                                               \
+  switch (p.dh) {                                                                                        \
+    case 16: hipLaunchKernelGGL((attn_fwd_kernel<1, 1, 2, true>), grid2, dim3(256), 0, st, p); break;    \
+    case 32: hipLaunchKernelGGL((attn_fwd_kernel<1, 2, 2, true>), grid2, dim3(256), 0, st, p); break;    \
+    case 64: hipLaunchKernelGGL((attn_fwd_kernel<2, 4, 2, true>), grid2, dim3(256), 0, st, p); break;    \
+    default: return SKG_E_UNSUPPORTED;                                                                   \
+  }
+
 inline bool common_ok(int batch, int heads, int Nq, int Nkv, int kv_stride, int dh) {
   return batch > 0 && heads > 0 && Nq > 0 && Nkv > 0 && kv_stride >= Nkv && kv_stride % 8 == 0 && dh % 8 == 0;
 }
 
 }  // namespace
 
-extern "C" int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O,
-                            int ldo, float* lse, int batch, int heads, int Nq, int Nkv, int kv_stride, int dh,
-                            float scale, void* stream) {
+static int attn_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O,
+                         int ldo, float* lse, int batch, int heads, int Nq, int Nkv, int kv_stride, int dh,
+                         float scale, bool causal, void* stream) {
   SKG_REQUIRE(Q && K && Vt && O && common_ok(batch, heads, Nq, Nkv, kv_stride, dh));
   SKG_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0);
   SKG_REQUIRE(skg_aligned(Q, 16) && skg_aligned(K, 16) && skg_aligned(Vt, 16) && skg_aligned(O, 8));
@@ -696,9 +708,26 @@ extern "C" int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, cons
   hipStream_t st = (hipStream_t)stream;
   p.nx = skg_cdiv(Nq, dh == 160 ? 64 : 128);       // query tiles per workgroup: see SKG_ATTN_FWD_DISPATCH
   dim3 grid((unsigned)p.nx * heads * batch);
-  SKG_ATTN_FWD_DISPATCH(grid, grid);
+  if (causal) {
+    SKG_REQUIRE(dh != 160);
+    SKG_ATTN_FWD_CAUSAL_DISPATCH(grid);
+  } else {
+    SKG_ATTN_FWD_DISPATCH(grid, grid);
+  }
   SKG_CHECK_LAUNCH("skg_attn_fwd");
   return SKG_OK;
+}
+
+extern "C" int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O,
+                            int ldo, float* lse, int batch, int heads, int Nq, int Nkv, int kv_stride, int dh,
+                            float scale, void* stream) {
+  return attn_fwd_impl(Q, ldq, K, ldk, Vt, ldvt, O, ldo, lse, batch, heads, Nq, Nkv, kv_stride, dh, scale, false, stream);
+}
+
+extern "C" int skg_attn_fwd_causal(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O,
+                                   int ldo, float* lse, int batch, int heads, int Nq, int Nkv, int kv_stride, int dh,
+                                   float scale, void* stream) {
+  return attn_fwd_impl(Q, ldq, K, ldk, Vt, ldvt, O, ldo, lse, batch, heads, Nq, Nkv, kv_stride, dh, scale, true, stream);
 }
 
 extern "C" int skg_attn_bwd_delta(const void* O, int ldo, const void* dO, int lddo, float* delta, int batch,

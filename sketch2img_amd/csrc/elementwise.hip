@@ -157,6 +157,25 @@ __global__ __launch_bounds__(256) void quick_gelu_kernel(const half_t* __restric
   }
 }
 
+// gelu(x) = x/2 (1 + erf(x / sqrt 2)): the MLP activation of the OpenCLIP text encoder SD 2.x ships (hidden_act "gelu")
+__global__ __launch_bounds__(256) void gelu_kernel(const half_t* __restrict__ X, int ldx, half_t* __restrict__ Y,
+                                                   int ldy, int M, int C) {
+  const int C8 = C >> 3;
+  const size_t total = (size_t)M * C8;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t m = i / C8;
+    const int c = (int)(i - m * C8) * 8;
+    const half8_t a = ld_half8(X + m * ldx + c);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (float)a[j];
+      o[j] = (half_t)(0.5f * x * (1.f + erff(x * 0.70710678118654752f)));
+    }
+    st_half8(Y + m * ldy + c, o);
+  }
+}
+
 __global__ __launch_bounds__(256) void silu_kernel(const half_t* __restrict__ X, int ldx, half_t* __restrict__ Y,
                                                    int ldy, int M, int C) {
   const int C8 = C >> 3;
@@ -442,6 +461,15 @@ extern "C" int skg_quick_gelu_f16(const void* X, int ldx, void* Y, int ldy, int 
   hipLaunchKernelGGL(quick_gelu_kernel, dim3(ew_grid((size_t)M * C / 8)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)X, ldx, (half_t*)Y, ldy, M, C);
   SKG_CHECK_LAUNCH("skg_quick_gelu_f16");
+  return SKG_OK;
+}
+
+extern "C" int skg_gelu_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, void* stream) {
+  SKG_REQUIRE(X && Y && M > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16));
+  hipLaunchKernelGGL(gelu_kernel, dim3(ew_grid((size_t)M * C / 8)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)X, ldx, (half_t*)Y, ldy, M, C);
+  SKG_CHECK_LAUNCH("skg_gelu_f16");
   return SKG_OK;
 }
 

@@ -9,7 +9,9 @@ UNet, the LGP and the guidance gradient run in libskg.so; there is no diffusers 
 Around the hot path:
   * ``vae``          ``sketch2img_amd.vae.AutoencoderKL`` decodes / encodes on the HIP kernels; any other object with
                      ``decode(latents) -> tensor | .sample`` (and ``encode`` for app.py:109) is used as a PyTorch module;
-  * ``text_encoder`` a callable ``(list[str]) -> (B, 77, D) tensor``; without one, prompts map to seeded
+  * ``text_encoder`` a callable ``(list[str]) -> (B, 77, D) tensor`` - ``sketch2img_amd.clip_text.PromptEncoder``
+                     (CLIP tokenizer + the text transformer on the HIP kernels) is picked up automatically when the
+                     checkpoint folder has ``tokenizer/`` and ``text_encoder/``; without one, prompts map to seeded
                      pseudo-embeddings (deterministic in the prompt text) so that the pipeline stays runnable
                      on a box with no CLIP weights.
 Schedulers: DDIM (the BASELINE metric) and DPM-Solver++ 2M (what app.py configures); see `sketch2img_amd.schedulers`.
@@ -128,12 +130,19 @@ class AntiGradientPipeline:
                         text_encoder=None, unet_config: Optional[UNetConfig] = None, **kwargs):
         cfg = unet_config or _config_from_folder(pretrained_model_name_or_path)
         sd = _load_unet_weights(pretrained_model_name_or_path, cfg)
+        root = pretrained_model_name_or_path
+        if text_encoder is None and root and os.path.isdir(os.path.join(root, "tokenizer")) \
+                and os.path.isdir(os.path.join(root, "text_encoder")):
+            from ..clip_text import PromptEncoder
+            text_encoder = PromptEncoder.from_pretrained(root)
         return cls(UNetFacade(cfg, sd, "cpu"), vae=vae, scheduler=scheduler, text_encoder=text_encoder)
 
     def to(self, device):
         self.unet.to(device)
         if self.vae is not None and hasattr(self.vae, "to"):
             self.vae.to(device)
+        if self.text_encoder is not None and hasattr(self.text_encoder, "to"):
+            self.text_encoder.to(device)
         return self
 
     @property

@@ -241,6 +241,15 @@ def quick_gelu(X, out=None):
     return out
 
 
+def gelu(X, out=None):
+    _f16(X)
+    M, C = X.shape
+    if out is None:
+        out = torch.empty(M, C, device=X.device, dtype=torch.float16)
+    check(lib.skg_gelu_f16(_p(X), _ld(X), _p(out), _ld(out), M, C, _stream()), "skg_gelu_f16")
+    return out
+
+
 def sumpool2x2(X, rows, H, W, out=None):
     """X [rows*2H*2W, C] -> [rows*H*W, C]."""
     _f16(X)
@@ -271,13 +280,14 @@ def nhwc_to_nchw(X: torch.Tensor, rows: int, C: int, H: int, W: int):
     return out
 
 
-def attn_fwd(Q, K, Vt, batch, heads, Nq, Nkv, kv_stride, dh, scale, out=None, want_lse=False):
+def attn_fwd(Q, K, Vt, batch, heads, Nq, Nkv, kv_stride, dh, scale, out=None, want_lse=False, causal=False):
     _f16(Q, K, Vt)
     if out is None:
         out = torch.empty(batch * Nq, heads * dh, device=Q.device, dtype=torch.float16)
     lse = torch.empty(batch, heads, Nq, device=Q.device, dtype=torch.float32) if want_lse else None
-    check(lib.skg_attn_fwd(_p(Q), _ld(Q), _p(K), _ld(K), _p(Vt), _ld(Vt), _p(out), _ld(out), _p(lse), batch,
-                           heads, Nq, Nkv, kv_stride, dh, scale, _stream()), "skg_attn_fwd")
+    fn = lib.skg_attn_fwd_causal if causal else lib.skg_attn_fwd
+    check(fn(_p(Q), _ld(Q), _p(K), _ld(K), _p(Vt), _ld(Vt), _p(out), _ld(out), _p(lse), batch,
+             heads, Nq, Nkv, kv_stride, dh, scale, _stream()), "skg_attn_fwd")
     return (out, lse) if want_lse else out
 
 

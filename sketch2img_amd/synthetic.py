@@ -295,3 +295,44 @@ def clip_vision_state_dict(cfg: CLIPVisionConfig, seed: int = CLIP_WEIGHT_SEED) 
             w = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(math.prod(shp[1:]))
         W[k] = w.half().float()
     return W
+
+
+# ---------------------------------------------------------------------------------------------- CLIP text encoder
+CLIP_TEXT_WEIGHT_SEED = 20261003
+
+
+def clip_text_param_shapes(cfg) -> "OrderedDict[str, tuple]":
+    """transformers CLIPTextModel state_dict keys (without the 4.x ``text_model.`` prefix) -> shapes."""
+    D, I = cfg.hidden_size, cfg.intermediate_size
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["embeddings.token_embedding.weight"] = (cfg.vocab_size, D)
+    s["embeddings.position_embedding.weight"] = (cfg.max_position_embeddings, D)
+    for l in range(cfg.num_hidden_layers):
+        p = f"encoder.layers.{l}"
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            s[f"{p}.self_attn.{n}.weight"] = (D, D); s[f"{p}.self_attn.{n}.bias"] = (D,)
+        s[f"{p}.layer_norm1.weight"] = (D,); s[f"{p}.layer_norm1.bias"] = (D,)
+        s[f"{p}.mlp.fc1.weight"] = (I, D); s[f"{p}.mlp.fc1.bias"] = (I,)
+        s[f"{p}.mlp.fc2.weight"] = (D, I); s[f"{p}.mlp.fc2.bias"] = (D,)
+        s[f"{p}.layer_norm2.weight"] = (D,); s[f"{p}.layer_norm2.bias"] = (D,)
+    s["final_layer_norm.weight"] = (D,); s["final_layer_norm.bias"] = (D,)
+    return s
+
+
+def clip_text_state_dict(cfg, seed: int = CLIP_TEXT_WEIGHT_SEED) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights, same recipe and draw order as oracle/clip_text.py init_weights."""
+    g = torch.Generator().manual_seed(seed)
+    W: Dict[str, torch.Tensor] = {}
+    for k, shp in clip_text_param_shapes(cfg).items():
+        if ("norm" in k) and k.endswith(".weight"):
+            w = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            w = 0.05 * torch.randn(shp, generator=g)
+        elif "token_embedding" in k:
+            w = 0.5 * torch.randn(shp, generator=g)
+        elif "position_embedding" in k:
+            w = 0.1 * torch.randn(shp, generator=g)
+        else:
+            w = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(math.prod(shp[1:]))
+        W[k] = w.half().float()
+    return W

@@ -397,3 +397,85 @@ def test_clip_vision_vit_l14_vs_oracle_and_feeds_satmixin():
     assert report("clip vision ViT-L/14 vs oracle", h.float().cpu(), ref)[0] < 5e-3
     state = torch.stack([torch.zeros_like(h[:1]), h[:1]]).squeeze(1)          # clip_guided_inf.py:105
     assert state.shape == (2, 257, 1024) and float(state[0].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ CLIP text encoder
+@pytest.mark.gpu
+@pytest.mark.parametrize("act", ["quick_gelu", "gelu"])
+def test_clip_text_tiny_matches_transformers_golden(act):
+    """HIP text encoder vs the output of transformers' own CLIPTextModel (committed golden vector) and vs the oracle."""
+    import dataclasses
+    import os
+    from oracle import clip_text as ot
+    from sketch2img_amd.clip_text import CLIPTextModel
+    from sketch2img_amd.config import TINY_TEXT
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_text_tiny.npz"))
+    W = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w.")}
+    m = CLIPTextModel(dataclasses.replace(TINY_TEXT, hidden_act=act))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 77, dtype=torch.long))                                # no CPU fallback
+    m.load_state_dict({"text_model." + k: v for k, v in W.items()})            # 4.x-style keys load
+    m.to(torch.device("cuda"))
+    ids = torch.from_numpy(d["input_ids"])
+    out = m(ids.to("cuda"))
+    h = out[0]
+    assert h is out.last_hidden_state and h.shape == (3, 77, 64) and h.dtype == torch.float16
+    ref = torch.from_numpy(d["last_hidden_state_" + act])
+    assert report(f"clip text tiny ({act}) vs transformers golden", h.float().cpu(), ref)[0] < 3e-3
+    ocfg = dataclasses.replace(ot.TINY_TEXT, hidden_act=act)
+    assert report(f"clip text tiny ({act}) vs oracle", h.float().cpu(), ot.last_hidden_state(ocfg, W, ids))[0] < 3e-3
+    # a shorter, non-multiple-of-8 sequence and causality on the device
+    ids2 = ids[:, :29].clone()
+    a = m(ids2.to("cuda"))[0]
+    assert report("clip text tiny L=29", a.float().cpu(), ot.last_hidden_state(ocfg, W, ids2))[0] < 3e-3
+    ids2[:, 20] = (ids2[:, 20] + 1) % 900
+    b = m(ids2.to("cuda"))[0]
+    assert torch.equal(a[:, :20], b[:, :20]) and not torch.equal(a[:, 20:], b[:, 20:])
+    with pytest.raises(ValueError):
+        m(torch.full((1, 77), 5000, dtype=torch.long))
+
+
+@pytest.mark.gpu
+def test_clip_text_sd15_vs_oracle_and_prompt_encoder_in_pipeline():
+    """The full SD 1.x text tower (123 060 480 parameters, 12 heads of 64) vs the CPU oracle; then PromptEncoder
+    (tokenizer + tower) stands where the pipeline's text_encoder is, as in modules/pipeline.py:55-57."""
+    from oracle import clip_text as ot
+    from sketch2img_amd.clip_text import CLIPTextModel, PromptEncoder
+    from sketch2img_amd.config import SD15_TEXT
+    m = CLIPTextModel(SD15_TEXT).to("cuda")
+    W = ot.init_weights(ot.SD15_TEXT)
+    assert all(torch.equal(m.state_dict()[k], W[k]) for k in W)
+    g = torch.Generator().manual_seed(4)
+    ids = torch.randint(0, 49406, (2, 77), generator=g)
+    ids[:, 0] = 49406
+    ids[0, 9:] = 49407
+    ids[1, 60:] = 49407
+    h = m(ids)[0]
+    assert h.shape == (2, 77, 768)
+    assert report("clip text SD1.5 vs oracle", h.float().cpu(), ot.last_hidden_state(ot.SD15_TEXT, W, ids))[0] < 5e-3
+
+    class Tok:                      # transformers' tokenizer call convention, with a toy word -> id table
+        model_max_length = 77
+
+        def __call__(self, prompts, padding=None, max_length=None, truncation=None, return_tensors=None):
+            assert padding == "max_length" and max_length == 77 and truncation and return_tensors == "pt"
+            out = torch.full((len(prompts), 77), 49407, dtype=torch.long)
+            for i, p in enumerate(prompts):
+                w = [49406] + [1000 + (sum(map(ord, t)) % 40000) for t in p.split()][:75]
+                out[i, :len(w)] = torch.tensor(w)
+            return {"input_ids": out}
+
+    enc = PromptEncoder(Tok(), m)
+    e = enc(["a cat on a mat", ""])
+    assert e.shape == (2, 77, 768) and e.dtype == torch.float16
+    ref = ot.last_hidden_state(ot.SD15_TEXT, W, Tok()(["a cat on a mat", ""], "max_length", 77, True, "pt")["input_ids"])
+    assert report("prompt encoder vs oracle", e.float().cpu(), ref)[0] < 5e-3
+
+    from sketch2img_amd.config import TINY
+    from sketch2img_amd.modules.pipeline import AntiGradientPipeline
+    import dataclasses
+    pipe = AntiGradientPipeline.from_pretrained(None, unet_config=dataclasses.replace(TINY, cross_attention_dim=768),
+                                                text_encoder=enc).to("cuda")
+    ehs = pipe._encode_prompt(["a cat on a mat"], "cuda", 2, True, None)
+    assert ehs.shape == (4, 77, 768)
+    assert torch.equal(ehs[0], e[1]) and torch.equal(ehs[2], e[0]) and torch.equal(ehs[3], e[0])

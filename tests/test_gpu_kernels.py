@@ -310,6 +310,26 @@ def test_attention_forward(ops, dh, heads, Nq, Nkv):
     assert report("attn lse", lse.cpu(), rl)[1] < 2e-3
 
 
+@pytest.mark.parametrize("dh,heads,N,Nkv", [(64, 12, 80, 77), (16, 4, 80, 77), (32, 3, 320, 320), (64, 2, 200, 197)])
+def test_attention_forward_causal(ops, dh, heads, N, Nkv):
+    """skg_attn_fwd_causal (the CLIP text encoder's masked self-attention): key j visible to query i iff j <= i;
+    several key tiles, ragged last tile, pad query rows past Nkv ignored."""
+    B, C = 2, heads * dh
+    q, k, v = rnd(B, N, C, seed=1), rnd(B, N, C, seed=2), rnd(B, N, C, seed=3)
+    scale = dh ** -0.5
+    d = dev()
+    Q, K, V = (t.reshape(B * N, C).to(d) for t in (q, k, v))
+    o, lse = ops.attn_fwd(Q, K, ops.transpose(V), B, heads, N, Nkv, N, dh, scale, want_lse=True, causal=True)
+    qh, kh, vh = (t.float().view(B, N, heads, dh).transpose(1, 2)[:, :, :Nkv] for t in (q, k, v))
+    sc = qh @ kh.transpose(-1, -2) * scale + torch.full((Nkv, Nkv), float("-inf")).triu(1)
+    ro = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B, Nkv, C)
+    assert report(f"attn causal dh{dh} {N}", o.float().cpu().view(B, N, C)[:, :Nkv], ro)[0] < 2e-3
+    assert report("attn causal lse", lse.cpu()[:, :, :Nkv], torch.logsumexp(sc, -1))[1] < 2e-3
+    assert torch.isfinite(o.float()).all()
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd(Q[:, :40], K[:, :40], ops.transpose(V[:, :40].contiguous()), B, 1, N, Nkv, N, 40, scale, causal=True)
+
+
 def test_attention_forward_strided_qkv_and_online_rescale(ops):
     """Q/K read as column slices of a fused [M, 3C] buffer; spiked keys force the running max to jump at a
     late tile (the online-softmax rescale branch)."""
@@ -517,6 +537,8 @@ def test_softmax_rows_and_quick_gelu(ops):
     h = rnd(777, 256, seed=2, scale=2.0)
     g = ops.quick_gelu(h.to(dev()))
     assert report("quick_gelu", g.float().cpu(), h.float() * torch.sigmoid(1.702 * h.float()))[0] < FP16_RND
+    e = ops.gelu(h.to(dev()))
+    assert report("gelu", e.float().cpu(), F.gelu(h.float()))[0] < FP16_RND
 
 
 def test_image_postprocess_and_gaussian_sample(ops):

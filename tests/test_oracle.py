@@ -362,3 +362,50 @@ def test_clip_vision_oracle_vs_live_transformers():
     with torch.no_grad():
         ref = model(x, output_hidden_states=True).last_hidden_state
     assert (oc.last_hidden_state(cfg, W, x) - ref).abs().max() < 5e-6
+
+
+# ------------------------------------------------------------------------------------------------ CLIP text encoder
+def test_clip_text_oracle_pinned_by_transformers_golden():
+    """tests/golden/clip_text_tiny.npz was produced by transformers' own CLIPTextModel (tools/gen_golden_clip_text.py),
+    the text_encoder diffusers' _encode_prompt runs for the reference at modules/pipeline.py:55-57."""
+    import dataclasses
+    import os
+    from oracle import clip_text as ot
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "clip_text_tiny.npz"))
+    W = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w.")}
+    assert list(W) == list(ot.param_shapes(ot.TINY_TEXT)) and all(torch.equal(W[k], v) for k, v in ot.init_weights(ot.TINY_TEXT).items())
+    ids = torch.from_numpy(d["input_ids"])
+    for act in ("quick_gelu", "gelu"):
+        out = ot.last_hidden_state(dataclasses.replace(ot.TINY_TEXT, hidden_act=act), W, ids)
+        ref = torch.from_numpy(d["last_hidden_state_" + act])
+        assert out.shape == ref.shape == (3, 77, 64)
+        assert (out - ref).abs().max() < 5e-6
+    assert ot.num_params(ot.SD15_TEXT) == 123_060_480           # CLIP ViT-L/14 text tower (SD 1.x)
+    assert ot.num_params(ot.SD21_TEXT) == 340_387_840           # OpenCLIP ViT-H text tower, 23 layers (SD 2.x)
+    assert list(ot.strip_prefix({"text_model." + k: v for k, v in W.items()})) == list(W)
+    # causality: changing a later token leaves every earlier position untouched
+    ids2 = ids.clone(); ids2[:, 30] = (ids2[:, 30] + 1) % 900
+    a, b = ot.last_hidden_state(ot.TINY_TEXT, W, ids), ot.last_hidden_state(ot.TINY_TEXT, W, ids2)
+    assert torch.equal(a[:, :30], b[:, :30]) and not torch.equal(a[:, 30:], b[:, 30:])
+
+
+def test_clip_text_oracle_vs_live_transformers():
+    """When transformers is importable (it is in this image): another configuration, fresh seed, short sequence."""
+    tr = pytest.importorskip("transformers")
+    from oracle import clip_text as ot
+    for act in ("quick_gelu", "gelu"):
+        cfg = ot.CLIPTextConfig(vocab_size=500, hidden_size=96, intermediate_size=160, num_hidden_layers=3,
+                                num_attention_heads=3, max_position_embeddings=40, hidden_act=act)
+        hf = tr.CLIPTextConfig(vocab_size=500, hidden_size=96, intermediate_size=160, num_hidden_layers=3,
+                               num_attention_heads=3, max_position_embeddings=40, hidden_act=act, eos_token_id=499,
+                               bos_token_id=498, pad_token_id=499)
+        model = tr.CLIPTextModel(hf).eval()
+        W = ot.init_weights(cfg, seed=78)
+        pre = "text_model." if any(k.startswith("text_model.") for k in model.state_dict()) else ""
+        res = model.load_state_dict({pre + k: v for k, v in W.items()}, strict=False)
+        assert not res.unexpected_keys and all("position_ids" in k for k in res.missing_keys)
+        ids = torch.randint(0, 498, (2, 33), generator=torch.Generator().manual_seed(1))
+        ids[:, -1] = 499
+        with torch.no_grad():
+            ref = model(ids)[0]
+        assert (ot.last_hidden_state(cfg, W, ids) - ref).abs().max() < 5e-6
