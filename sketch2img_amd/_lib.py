@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libskg.so")
+# SKG_LIB: another build of the same ABI (same-box A/B measurements of kernel variants); default = the in-tree library
+LIB_PATH = os.environ.get("SKG_LIB") or os.path.join(_HERE, "libskg.so")
 
 # spec letters: p = device/host pointer, i = int, f = float, u = unsigned, z = size_t (return only)
 SIGNATURES = {

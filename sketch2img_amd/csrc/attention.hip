@@ -60,6 +60,14 @@ __device__ __forceinline__ BlkMap attn_block_map(const AttnParams& p) {
 }
 
 constexpr float NEG_BIG = -1.0e30f;
+
+// max of three without the canonicalising v_max_f32 x, x, x that fmaxf() puts in front of every MFMA result (the
+// compiler cannot prove an MFMA output is not a signalling NaN): 16 scores reduce in 8 VALU instead of 31
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int TP = 72;   // pitch (halves) of the transposed tiles [d][64 + 8]
@@ -237,15 +245,28 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
       qf[i][ks] = (qok[i] && c < dh) ? ld_half8(p.Q + (size_t)(b * p.Nq + q[i]) * p.ldq + h * dh + c) : zero_half8();
     }
   }
+  // Q is pre-multiplied by scale * log2(e) (one fp16 rounding, the size of Q's own) and MINUS the reference maximum
+  // rides in as the C operand of the first QK^T MFMA, so a score leaves the matrix pipe as  s*sc - m  and the softmax
+  // is exp2 + max + pack per score: no FMA, no cross-lane traffic.  The reference m only has to stay within 2^8 of the
+  // true running maximum (p <= 256 is exact enough in fp16, O and the denominator share the reference), so it moves
+  // when a tile beats it by more than 8 (rare after the first tile) instead of on every new maximum.
+  const float sc = p.scale * LOG2E;
+#pragma unroll
+  for (int i = 0; i < QT; ++i)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[i][ks][j] = (half_t)((float)qf[i][ks][j] * sc);
   float4_t o[QT][ND];
-  float m[QT], l[QT];               // m: running max of the RAW scores times sc (log2 domain)
+  float4_t nm[QT];                  // minus the reference maximum (log2 domain), replicated: the MFMA C operand
+  float l[QT];
 #pragma unroll
   for (int i = 0; i < QT; ++i) {
-    m[i] = NEG_BIG; l[i] = 0.f;
+    nm[i] = float4_t{0.f, 0.f, 0.f, 0.f}; l[i] = 0.f;
 #pragma unroll
     for (int u = 0; u < ND; ++u) o[i][u] = float4_t{0.f, 0.f, 0.f, 0.f};
   }
-  const float sc = p.scale * LOG2E;
+  constexpr float REF_SLACK = 8.f;
   // <2, 3> is dispatched for d = 40 only: 8 spare rows in the 48-row V^T tile -> the denominator comes out of the
   // PV MFMA (row 40 of O^T) and the 16 adds per tile and query tile leave the VALU, which bounds this head size
   constexpr bool ONES = (KS == 2 && ND == 3);
@@ -254,52 +275,58 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
   const half_t* Vb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
   const int nt = (p.Nkv + 63) / 64;
 
-  // one 64-key tile: S^T = K Q^T, online softmax, O^T += V^T P^T   (for the wave's QT query tiles)
+  // one 64-key tile: S^T = K Q^T - m, online softmax, O^T += V^T P^T   (for the wave's QT query tiles)
   auto tile = [&](const half_t* __restrict__ Ks, const half_t* __restrict__ Vs, int kv0) {
     float4_t s[QT][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
-      for (int i = 0; i < QT; ++i) s[i][t] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const half8_t kf = ld_half8(Ks + (16 * t + l16) * KP + 32 * ks + 8 * g);
 #pragma unroll
-        for (int i = 0; i < QT; ++i) s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[i][ks], s[i][t], 0, 0, 0);
+        for (int i = 0; i < QT; ++i)
+          s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[i][ks], ks == 0 ? nm[i] : s[i][t], 0, 0, 0);
       }
     }
+    const bool first = kv0 == 0;          // the reference starts at 0: the first tile always re-bases it
     half8_t pb[QT][2];
 #pragma unroll
     for (int i = 0; i < QT; ++i) {
       if (CAUSAL || kv0 + 64 > p.Nkv) {          // ragged last tile only (wave-uniform)
+        // key = kv0 + 4g + (16t + r): compare the compile-time part against per-lane limits computed in here, so
+        // the full tiles carry no index arithmetic
+        const int lim = p.Nkv - kv0 - 4 * g;
+        const int qlim = CAUSAL ? q[i] - kv0 - 4 * g : 0;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kv0 + 16 * t + 4 * g + r;
-            if (key >= p.Nkv || (CAUSAL && key > q[i])) s[i][t][r] = NEG_BIG;
-          }
+          for (int r = 0; r < 4; ++r)
+            if (16 * t + r >= lim || (CAUSAL && 16 * t + r > qlim)) s[i][t][r] = NEG_BIG;
       }
-      float mx = fmaxf(fmaxf(s[i][0][0], s[i][0][1]), fmaxf(s[i][0][2], s[i][0][3]));
-#pragma unroll
-      for (int t = 1; t < 4; ++t) mx = fmaxf(fmaxf(mx, fmaxf(s[i][t][0], s[i][t][1])), fmaxf(s[i][t][2], s[i][t][3]));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m[i], mx * sc);
-      // rescale only when some query of this wave saw a new maximum (rare after the first tiles): wave-uniform
-      if (__builtin_amdgcn_ballot_w64(mn != m[i]) != 0) {
-        const float alpha = __builtin_amdgcn_exp2f(m[i] - mn);
-        m[i] = mn;
+      const float m0 = max3f(s[i][0][0], s[i][0][1], s[i][0][2]);
+      const float m1 = max3f(s[i][0][3], s[i][1][0], s[i][1][1]);
+      const float m2 = max3f(s[i][1][2], s[i][1][3], s[i][2][0]);
+      const float m3 = max3f(s[i][2][1], s[i][2][2], s[i][2][3]);
+      const float m4 = max3f(s[i][3][0], s[i][3][1], s[i][3][2]);
+      float mx = max3f(max3f(m0, m1, m2), max3f(m3, m4, s[i][3][3]), m0);
+      if (__builtin_amdgcn_ballot_w64(first || mx > REF_SLACK) != 0) {      // wave-uniform, rare after tile 0
+        mx = max3f(mx, __shfl_xor(mx, 16, 64), mx);
+        mx = max3f(mx, __shfl_xor(mx, 32, 64), mx);                         // the query's maximum over the tile
+        const float delta = (first || mx > REF_SLACK) ? mx : 0.f;
+        const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // (o, l are still zero in tile 0)
+        nm[i] -= delta;
         if (!ONES) l[i] *= alpha;
 #pragma unroll
         for (int u = 0; u < ND; ++u) o[i][u] *= alpha;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[i][t] -= delta;
       }
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(s[i][t][r], sc, -mn));
+          const float e = __builtin_amdgcn_exp2f(s[i][t][r]);
           s[i][t][r] = e;
           if (!ONES) ps += e;
         }
@@ -378,7 +405,7 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
           st_half4(orow + d, v);
         }
       }
-      if (p.lse && g == 0) p.lse[((size_t)b * p.heads + h) * p.Nq + q[i]] = (m[i] + log2f(li)) * LN2;
+      if (p.lse && g == 0) p.lse[((size_t)b * p.heads + h) * p.Nq + q[i]] = (log2f(li) - nm[i][0]) * LN2;
     }
   }
 }
