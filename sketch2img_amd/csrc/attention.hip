@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   int q[QT];
   bool qok[QT];
   half8_t qf[QT][KS], dof[QT][KS];
-  float lse2[QT], dl[QT];
+  float4_t nlse[QT], ndl[QT];
   float4_t dq[QT][ND];
 #pragma unroll
   for (int i = 0; i < QT; ++i) {
@@ -440,12 +440,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
       dof[i][ks] = ok ? ld_half8(p.dO + (size_t)(b * p.Nq + q[i]) * p.lddo + h * dh + c) : zero_half8();
     }
     const size_t sidx = ((size_t)b * p.heads + h) * p.Nq + (qok[i] ? q[i] : 0);
-    lse2[i] = qok[i] ? p.lse[sidx] * LOG2E : -NEG_BIG;
-    dl[i] = qok[i] ? p.delta[sidx] : 0.f;
+    // minus lse (log2 domain) and minus delta ride in as the C operands of the S and dP MFMAs (see the forward)
+    const float nl = qok[i] ? -p.lse[sidx] * LOG2E : NEG_BIG, nd = qok[i] ? -p.delta[sidx] : 0.f;
+    nlse[i] = float4_t{nl, nl, nl, nl};
+    ndl[i] = float4_t{nd, nd, nd, nd};
 #pragma unroll
     for (int u = 0; u < ND; ++u) dq[i][u] = float4_t{0.f, 0.f, 0.f, 0.f};
   }
   const float sc = p.scale * LOG2E;
+#pragma unroll
+  for (int i = 0; i < QT; ++i)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[i][ks][j] = (half_t)((float)qf[i][ks][j] * sc);   // same rounding as the forward
 
   const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
   const half_t* Vb = p.V + (size_t)b * p.kv_stride * p.ldv + h * dh;
@@ -469,37 +477,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
       rows_load<KS>(rv, Vb, p.ldv, kv0 + 64, p.kv_stride, dh);
       cols_load<ND>(rkt, Ktb, p.ldvt, kv0 + 64, p.kv_stride, dh);
     }
-    float4_t s[QT][4], dp[QT][4];
+    float4_t s[QT][4], dp[QT][4];      // s = S*sc - lse,  dp = dP - delta  straight out of the matrix pipe
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int i = 0; i < QT; ++i) {
-        s[i][t] = float4_t{0.f, 0.f, 0.f, 0.f};
-        dp[i][t] = float4_t{0.f, 0.f, 0.f, 0.f};
-      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int off = (16 * t + l16) * KP + 32 * ks + 8 * g;
         const half8_t kfr = ld_half8(Ks + off), vfr = ld_half8(Vr + off);
 #pragma unroll
         for (int i = 0; i < QT; ++i) {
-          s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr, qf[i][ks], s[i][t], 0, 0, 0);
-          dp[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr, dof[i][ks], dp[i][t], 0, 0, 0);
+          s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr, qf[i][ks], ks == 0 ? nlse[i] : s[i][t], 0, 0, 0);
+          dp[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr, dof[i][ks], ks == 0 ? ndl[i] : dp[i][t], 0, 0, 0);
         }
       }
     }
-    const bool ragged = kv0 + 64 > p.Nkv;      // wave-uniform
     half8_t sb[QT][2];
 #pragma unroll
     for (int i = 0; i < QT; ++i) {
+      if (kv0 + 64 > p.Nkv) {          // ragged last block only (wave-uniform)
+        const int lim = p.Nkv - kv0 - 4 * g;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (16 * t + r >= lim) s[i][t][r] = NEG_BIG;
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float pr = __builtin_amdgcn_exp2f(fmaf(s[i][t][r], sc, -lse2[i]));
-          if (ragged && kv0 + 16 * t + 4 * g + r >= p.Nkv) pr = 0.f;
-          s[i][t][r] = pr * (dp[i][t][r] - dl[i]);
-        }
+        for (int r = 0; r < 4; ++r) s[i][t][r] = __builtin_amdgcn_exp2f(s[i][t][r]) * dp[i][t][r];
       pack_p(s[i], sb[i]);
     }
 #pragma unroll
@@ -539,7 +545,7 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
   __shared__ __attribute__((aligned(16))) half_t Ds[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Qt[ND * 16 * TP];
   __shared__ __attribute__((aligned(16))) half_t Dt[ND * 16 * TP];
-  __shared__ float lse_s[64], del_s[64];
+  __shared__ __attribute__((aligned(16))) float lse_s[64], del_s[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, g = lane >> 4;
   const BlkMap bm = attn_block_map(p);
@@ -561,6 +567,12 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
     }
   }
   const float sc = p.scale * LOG2E;
+#pragma unroll
+  for (int i = 0; i < KT; ++i)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kf[i][ks][j] = (half_t)((float)kf[i][ks][j] * sc);   // S*sc out of the matrix pipe
   float4_t dk[KT][ND], dv[KT][ND];
 #pragma unroll
   for (int i = 0; i < KT; ++i)
@@ -586,8 +598,8 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
     cols_load<ND>(rdt, Dtb, p.lddot, q0, p.Nq, dh);
     if (threadIdx.x < 64) {
       const int qq = q0 + threadIdx.x;
-      r_lse = qq < p.Nq ? p.lse[sbase + qq] * LOG2E : -NEG_BIG;
-      r_del = qq < p.Nq ? p.delta[sbase + qq] : 0.f;
+      r_lse = qq < p.Nq ? -p.lse[sbase + qq] * LOG2E : NEG_BIG;      // stored NEGATED: they are MFMA C operands
+      r_del = qq < p.Nq ? -p.delta[sbase + qq] : 0.f;
     }
   };
   prefetch(0);
@@ -601,22 +613,18 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
     if (threadIdx.x < 64) { lse_s[threadIdx.x] = r_lse; del_s[threadIdx.x] = r_del; }
     __syncthreads();
     if (t0 + 1 < nt) prefetch(q0 + 64);
-    float4_t s[KT][4], dp[KT][4];
+    float4_t s[KT][4], dp[KT][4];      // s = S*sc - lse[q],  dp = dP - delta[q]  (rows 16t + 4g + r are queries)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int i = 0; i < KT; ++i) {
-        s[i][t] = float4_t{0.f, 0.f, 0.f, 0.f};
-        dp[i][t] = float4_t{0.f, 0.f, 0.f, 0.f};
-      }
+      const float4_t nl = *reinterpret_cast<const float4_t*>(lse_s + 16 * t + 4 * g);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int off = (16 * t + l16) * KP + 32 * ks + 8 * g;
         const half8_t qfr = ld_half8(Qs + off), dfr = ld_half8(Ds + off);
 #pragma unroll
         for (int i = 0; i < KT; ++i) {
-          s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qfr, kf[i][ks], s[i][t], 0, 0, 0);
-          dp[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dfr, vf[i][ks], dp[i][t], 0, 0, 0);
+          s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qfr, kf[i][ks], ks == 0 ? nl : s[i][t], 0, 0, 0);
+          dp[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dfr, vf[i][ks], ks == 0 ? float4_t{0.f, 0.f, 0.f, 0.f} : dp[i][t], 0, 0, 0);
         }
       }
     }
@@ -628,10 +636,9 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ql = 16 * t + 4 * g + r;
-          const float pr = __builtin_amdgcn_exp2f(fmaf(s[i][t][r], sc, -lse_s[ql]));
+          const float pr = __builtin_amdgcn_exp2f(s[i][t][r]);
           s[i][t][r] = pr;
-          ds[t][r] = pr * (dp[i][t][r] - del_s[ql]);
+          ds[t][r] = pr * (dp[i][t][r] + del_s[16 * t + 4 * g + r]);
         }
       pack_p(s[i], pb[i]);
       pack_p(ds, sb[i]);
