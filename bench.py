@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, separately reported) VAE decode")
+    ap.add_argument("--shape-report", default=None, help="write a per-shape table of the GEMM / conv launches of one batch")
     return ap.parse_args()
 
 
@@ -79,7 +80,9 @@ class LaunchTimer:
             out = self._gemm(A, B, *a, **k)
             e1.record()
             nbytes = 2.0 * (M * K + N * K + M * N * (2 if k.get("out_f32") else 1) + (M * N if k.get("residual") is not None else 0))
-            self.rec.append((kname(lib.skg_gemm_variant(M, N, K, 0, 0), "DIRECT"), 2.0 * M * N * K, e0, e1, nbytes))
+            tag = "+res" * (k.get("residual") is not None) + "+geglu" * bool(k.get("geglu")) + "+f32" * bool(k.get("out_f32"))
+            self.rec.append((kname(lib.skg_gemm_variant(M, N, K, 0, 0), "DIRECT"), 2.0 * M * N * K, e0, e1, nbytes,
+                             f"gemm M{M} N{N} K{K}{tag}"))
             return out
 
         def conv(X, Wp, rows, IH, IW, mode=0, *a, **k):
@@ -92,7 +95,8 @@ class LaunchTimer:
             e1.record()
             name = ("S1", "S2", "UP2", "S2T")[mode]
             nbytes = 2.0 * (X.shape[0] * Cin + Cout * 9 * Cin + M * Cout + (M * Cout if k.get("residual") is not None else 0))
-            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, 9 * Cin, Cin, 1 + mode), name), 2.0 * M * Cout * 9 * Cin, e0, e1, nbytes))
+            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, 9 * Cin, Cin, 1 + mode), name), 2.0 * M * Cout * 9 * Cin, e0, e1, nbytes,
+                             f"conv {name} M{M} Cin{Cin} Cout{Cout}" + "+res" * (k.get("residual") is not None)))
             return out
 
         ops.gemm, ops.conv3x3 = gemm, conv
@@ -104,10 +108,26 @@ class LaunchTimer:
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, e0, e1, nb in self.rec:
+        for name, fl, e0, e1, nb, _ in self.rec:
             a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += nb
         return agg
+
+    def shape_report(self, path):
+        """Per-shape table (launches, total ms, avg us, TFLOP/s, algorithmic TB/s), sorted by total time."""
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, e0, e1, nb, shape in self.rec:
+            a = agg.setdefault((shape, name), [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += nb
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
+        tot = sum(v[2] for _, v in rows)
+        with open(path, "w") as f:
+            f.write(f"GEMM / conv launches of one batch, HIP events around each launch: {tot * 1e3:.1f} ms in {len(self.rec)} launches\n")
+            f.write(f"{'shape':48s} {'kernel':36s} {'n':>6s} {'ms':>8s} {'avg us':>8s} {'TF/s':>7s} {'TB/s':>6s} {'%':>5s}\n")
+            for (shape, name), (n, fl, sec, nb) in rows:
+                f.write(f"{shape:48s} {name:36s} {n:6d} {sec * 1e3:8.2f} {sec / n * 1e6:8.1f} {fl / sec / 1e12:7.0f} "
+                        f"{nb / sec / 1e12:6.2f} {100 * sec / tot:5.1f}\n")
 
 
 def pmc_traffic(kernel_name):
@@ -234,6 +254,8 @@ def main():
         with LaunchTimer(ops) as lt:
             sampler.sample(lat0, target, T, tables=tab)
         agg = lt.summary()
+        if args.shape_report:
+            lt.shape_report(args.shape_report)
         name, (n, fl, sec, nb) = max(agg.items(), key=lambda kv: kv[1][2])
         tot_sec = sum(v[2] for v in agg.values())
         roof = dict(bound="mfma", kernel=name, achieved=fl / sec / 1e12, peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",

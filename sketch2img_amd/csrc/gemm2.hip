@@ -118,14 +118,17 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // ---- optional phase stamps (make PHASES=1; tools/gemm_phases.py): per workgroup s_memtime at tile start, before the
 // K loop, after it, after the first epilogue slab and at tile end, plus HW_ID / XCC_ID of wave 0 -------------------
 #ifdef SKG_PHASES
-__device__ unsigned long long g_phase[1 << 15][8];
+__device__ unsigned long long g_phase[1 << 15][16];
 #define SKG_PH(i) do { if (tid == 0 && vb < (1 << 15)) g_phase[vb][i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define SKG_PH(i) do { } while (0)
 #endif
 
-template <int BM, int BN, int WGM, int WGN, int MODE>
-__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
+// NS = pipeline stages.  2: two workgroups per CU cover each other's DMA waits.  3: for launches with at most ONE
+// workgroup per CU (<= 256 tiles) nothing else is resident, so the lone workgroup keeps two K tiles in flight instead
+// (110 KB of LDS) and waits with a counted vmcnt.
+template <int BM, int BN, int WGM, int WGN, int MODE, int NS = 2>
+__global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <= 80 * 1024) ? 2 : 1) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
                                                                   unsigned a_bytes, unsigned b_bytes,
                                                                   unsigned a_shift, int kt_per_split,
                                                                   float* __restrict__ ws) {
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
   static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && WM % 16 == 0 && WN % 16 == 0, "tile shape");
   constexpr int STAGE = (BM + BN) * BK;               // halves per stage: A tile then B tile
   constexpr bool AFFINE = (MODE == MODE_DIRECT || MODE == MODE_S1 || MODE == MODE_S2 || MODE == MODE_S2A);
-  __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) half_t smem[NS * STAGE + 2 * BN];     // the stages + the tile's fp32 bias slice
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -392,19 +395,44 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
 #pragma unroll
     for (int i = 0; i < ND; ++i) dma_one(d0, 0, i);
   }
-  for (int kt = kt_begin; kt < KT; kt += 2) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    lds_barrier();
-    step(kt + 1, 1, 0, KT);
-    if (kt + 1 < KT) {
+  if constexpr (NS == 2) {
+    for (int kt = kt_begin; kt < KT; kt += 2) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
-      step(kt + 2, 0, 1, KT);
+      step(kt + 1, 1, 0, KT);
+      if (kt + 1 < KT) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        step(kt + 2, 0, 1, KT);
+      }
+    }
+  } else {
+    static_assert(NS >= 3 && (NS - 2) * ND <= 63, "counted wait");
+#pragma unroll
+    for (int s = 1; s < NS - 1; ++s) {
+      const DmaStep d1 = dma_prepare(kt_begin + s, kt_begin + s < KT);
+#pragma unroll
+      for (int i = 0; i < ND; ++i) dma_one(d1, s, i);
+    }
+    // every step issues exactly ND DMA instructions per thread (dead ones are out-of-range zero fills) and loads
+    // retire in order, so "at most (NS-2)*ND outstanding" == the K tile about to be computed has landed
+    for (int kt = kt_begin; kt < KT; kt += NS) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        if (kt + s < KT) {
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * ND) : "memory");
+          lds_barrier();
+          step(kt + s + NS - 1, (s + NS - 1) % NS, s, KT);
+        }
+      }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last step's zero-fill DMA must not land in the staging area
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last steps' zero-fill DMA must not land in the staging area
 
   SKG_PH(2);
+#ifdef SKG_PHASES
+  if ((tid & 63) == 0 && vb < (1 << 15)) g_phase[vb][12 + (tid >> 6)] = __builtin_readcyclecounter();
+#endif
   // ---- epilogue: lane holds C[m = .. + l16][n = .. + 4g .. 4g+3] -----------------------------------
   // Outputs that cannot stay in the 32 MB of L2 anyway are stored non-temporally: a write-allocated 336 MB FF1 output
   // otherwise evicts the activation panel and the weights every other workgroup is still streaming (N = 2560, K = 320:
@@ -438,82 +466,92 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm2_kernel(const GemmPara
     constexpr int SLABS = BM / SROWS;
     static_assert(SROWS * OPF * 4 <= 2 * STAGE * 2, "staging slab must fit in the pipeline stages");
     constexpr int PPR = BN / 8;                // 8-column pieces per tile row
+    constexpr int TPR = NTHR / SROWS;          // threads per staged row (4 or 8): a thread keeps ONE row of the slab
+    constexpr int ITER = PPR / TPR;            // and walks pieces ec/8 + k * TPR of it (5, 4 or 2 of them)
+    static_assert(NTHR % SROWS == 0 && PPR % TPR == 0, "piece loop must have a compile-time trip count");
     float* const stg = reinterpret_cast<float*>(smem);
-    float* const bias_s = stg + SROWS * OPF;     // the tile's bias slice, fp32, read from LDS in phase 2
-    static_assert((SROWS * OPF + BN) * 4 <= 2 * STAGE * 2, "bias slice must fit behind the staging slab");
-    constexpr int ITER = SROWS * PPR / NTHR;     // pieces per thread per slab (5, 4 or 2)
-    static_assert(SROWS * PPR % NTHR == 0, "piece loop must have a compile-time trip count");
+    float* const bias_s = reinterpret_cast<float*>(smem + NS * STAGE);     // own area behind the stages
+    const int er = tid / TPR, ec = (tid % TPR) * 8;
+    const bool geglu = p.flags & SKG_EPI_GEGLU;
+    if (tid < BN) bias_s[tid] = bias_r;        // visible after the first barrier below
     // all residual loads of the tile are issued before the first store: vmcnt retires in order, so a load issued
     // behind a store could not be waited for without waiting for the store's acknowledgement too
     constexpr bool RES_UP_FRONT = SLABS * ITER <= 10;
     half8_t rv[SLABS][ITER];
+    const half_t* const rrow0 = p.res ? p.res + (size_t)(m0 + er) * p.ldr + n0 + ec : nullptr;
+    auto load_res = [&](int sl) {
+      const bool rowok = p.res && m0 + sl * SROWS + er < p.M;
+#pragma unroll
+      for (int k = 0; k < ITER; ++k)
+        rv[sl][k] = (rowok && n0 + ec + k * TPR * 8 < p.N)
+                        ? ld_half8(rrow0 + (size_t)sl * SROWS * p.ldr + k * TPR * 8) : zero_half8();
+    };
     if (RES_UP_FRONT) {
 #pragma unroll
-      for (int sl = 0; sl < SLABS; ++sl)
-#pragma unroll
-        for (int k = 0; k < ITER; ++k) {
-          const int pi = tid + k * NTHR;
-          const int r = pi / PPR, c = (pi - r * PPR) * 8;
-          const int m = m0 + sl * SROWS + r, n = n0 + c;
-          rv[sl][k] = (p.res && m < p.M && n < p.N) ? ld_half8(p.res + (size_t)m * p.ldr + n) : zero_half8();
-        }
+      for (int sl = 0; sl < SLABS; ++sl) load_res(sl);
     }
+    half_t* const crow0 = reinterpret_cast<half_t*>(p.C) + (size_t)(m0 + er) * p.ldc + (geglu ? ((n0 + ec) >> 1) : n0 + ec);
 #pragma unroll
     for (int sl = 0; sl < SLABS; ++sl) {
+      if (sl == 1) SKG_PH(11);
       lds_barrier();                           // stage reads (slab 0) / previous slab's reads are done
       if (sl == 1) SKG_PH(3);
-      if (sl == 0 && tid < BN) bias_s[tid] = bias_r;
-      if (wm == (sl * SROWS) / WM) {
+      if (sl == 0) SKG_PH(8);
+      if (wm == (sl * SROWS) / WM) {           // the bias joins the accumulators on their way into the staging slab
 #pragma unroll
-        for (int ii = 0; ii < SROWS / 16; ++ii) {
-          const int i = ((sl * SROWS) % WM) / 16 + ii;
+        for (int j = 0; j < NT; ++j) {
+          const float4_t b4 = *reinterpret_cast<const float4_t*>(&bias_s[wn * WN + j * 16 + g * 4]);
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            *reinterpret_cast<float4_t*>(&stg[(ii * 16 + l16) * OPF + wn * WN + j * 16 + g * 4]) = acc[i][j];
+          for (int ii = 0; ii < SROWS / 16; ++ii) {
+            const int i = ((sl * SROWS) % WM) / 16 + ii;
+            *reinterpret_cast<float4_t*>(&stg[(ii * 16 + l16) * OPF + wn * WN + j * 16 + g * 4]) = acc[i][j] + b4;
+          }
         }
       }
+      if (sl == 0) SKG_PH(9);
       lds_barrier();
-      if (!RES_UP_FRONT) {
+      if (sl == 0) SKG_PH(10);
+      if (!RES_UP_FRONT) load_res(sl);
+      if (m0 + sl * SROWS + er < p.M) {
+        const float* const srow = stg + er * OPF + ec;
+        half_t* const crow = crow0 + (size_t)sl * SROWS * p.ldc;
+        float4_t v0[ITER], v1[ITER];
 #pragma unroll
         for (int k = 0; k < ITER; ++k) {
-          const int pi = tid + k * NTHR;
-          const int r = pi / PPR, c = (pi - r * PPR) * 8;
-          const int m = m0 + sl * SROWS + r, n = n0 + c;
-          rv[sl][k] = (p.res && m < p.M && n < p.N) ? ld_half8(p.res + (size_t)m * p.ldr + n) : zero_half8();
+          v0[k] = *reinterpret_cast<const float4_t*>(srow + k * TPR * 8);
+          v1[k] = *reinterpret_cast<const float4_t*>(srow + k * TPR * 8 + 4);
         }
-      }
+        if (geglu) {
+          // interleaved FF1 pack: columns [a0 a1 g0 g1 | a2 a3 g2 g3] -> 4 outputs a * gelu(g) at column n/2
 #pragma unroll
-      for (int k = 0; k < ITER; ++k) {
-        const int pi = tid + k * NTHR;
-        const int r = pi / PPR, c = (pi - r * PPR) * 8;
-        const int m = m0 + sl * SROWS + r, n = n0 + c;
-        if (m < p.M && n < p.N) {
-          const float4_t v0 = *reinterpret_cast<const float4_t*>(&stg[r * OPF + c]);
-          const float4_t v1 = *reinterpret_cast<const float4_t*>(&stg[r * OPF + c + 4]);
-          const float4_t b0 = *reinterpret_cast<const float4_t*>(&bias_s[c]);
-          const float4_t b1 = *reinterpret_cast<const float4_t*>(&bias_s[c + 4]);
-          float v[8] = {v0[0] + b0[0], v0[1] + b0[1], v0[2] + b0[2], v0[3] + b0[3],
-                        v1[0] + b1[0], v1[1] + b1[1], v1[2] + b1[2], v1[3] + b1[3]};
-          if (p.flags & SKG_EPI_GEGLU) {
-            // interleaved FF1 pack: columns [a0 a1 g0 g1 | a2 a3 g2 g3] -> 4 outputs a * gelu(g) at column n/2
-            half4_t y = {(half_t)(v[0] * gelu_fast_f(v[2])), (half_t)(v[1] * gelu_fast_f(v[3])),
-                         (half_t)(v[4] * gelu_fast_f(v[6])), (half_t)(v[5] * gelu_fast_f(v[7]))};
-            half4_t* dst4 = reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + (n >> 1));
+          for (int k = 0; k < ITER; ++k) {
+            if (n0 + ec + k * TPR * 8 >= p.N) continue;
+            half4_t y = {(half_t)(v0[k][0] * gelu_fast_f(v0[k][2])), (half_t)(v0[k][1] * gelu_fast_f(v0[k][3])),
+                         (half_t)(v1[k][0] * gelu_fast_f(v1[k][2])), (half_t)(v1[k][1] * gelu_fast_f(v1[k][3]))};
+            half4_t* dst4 = reinterpret_cast<half4_t*>(crow + k * TPR * 4);
             if (stream_out) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst4), "v"(y) : "memory");
             else *dst4 = y;
-            continue;
           }
-          half8_t o;
+        } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float x = v[e] * p.alpha + (float)rv[sl][k][e];
-            if (relu) x = fmaxf(x, 0.f);
-            o[e] = (half_t)x;
+          for (int k = 0; k < ITER; ++k) {
+            if (n0 + ec + k * TPR * 8 >= p.N) continue;
+            float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              float x = v[e] * p.alpha + (float)rv[sl][k][e];
+              if (relu) x = fmaxf(x, 0.f);
+              o[e] = (half_t)x;
+            }
+            half8_t* dst8 = reinterpret_cast<half8_t*>(crow + k * TPR * 8);
+#ifdef SKG_PHASES
+            if (p.flags & 0x4000u) { if (o[0] == (half_t)12345.f) *dst8 = o; continue; }   // probe: epilogue without stores
+#endif
+            // (inline asm: hipcc merges an if/else pair of builtin stores into ONE plain store and drops the hint)
+            if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst8), "v"(o) : "memory");
+            else *dst8 = o;
           }
-          half8_t* dst8 = reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n);
-          // (inline asm: hipcc merges an if/else pair of builtin stores into ONE plain store and drops the hint)
-          if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst8), "v"(o) : "memory");
-          else *dst8 = o;
         }
       }
     }
@@ -587,7 +625,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 
 // number of K splits for a launch of `nwg` 128-row tiles over KT K-tiles (1 = no split)
 inline int pick_splits(long nwg, int KT, size_t slab_bytes) {
-  if (!g_ws || nwg >= 256 || KT < 16) return 1;
+  // nwg == 256 is ONE workgroup per CU: nothing overlaps its DMA waits.  Two K halves per CU (16x16-level convs,
+  // K >= 8192: 720 -> 990 TFLOP/s) beat the three-stage single workgroup (870) there; below that the fp32 slabs +
+  // reduce pass cost more than they hide and the launch takes the three-stage kernel instead
+  if (!g_ws || nwg > 256 || KT < (nwg == 256 ? 128 : 16)) return 1;
   int s = (int)((512 + nwg - 1) / nwg);
   if (s > 8) s = 8;
   while (s > 1 && KT / s < 8) --s;
@@ -668,7 +709,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   operand_bytes(p, MODE, a, b, s);
   const int KT = p.K / BK;
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
-  const int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
+  int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
   constexpr int NTHR = WGM * WGN * 64;
   if (splits > 1) {
     const int per = skg_cdiv(KT, splits);
@@ -679,6 +720,16 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p,
                        (const float*)g_ws, ns);
     return;
+  }
+  // three stages: the 128 x 160 tile when the launch has at most one workgroup per CU anyway (110 KB of LDS), the
+  // 128 x 64 tile always (74 KB: two workgroups per CU still fit)
+  if constexpr (BM == 128 && (BN == 160 || BN == 64) && (MODE == MODE_DIRECT || MODE == MODE_S1)) {
+    static const bool off = getenv("SKG_NO_NS3") != nullptr;        // A/B switch (tools/gemm_bench.py)
+    if (!off && KT >= 4 && (BN == 64 || ntiles <= 256)) {
+      hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 3>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles,
+                         (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
+      return;
+    }
   }
   hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles, NTHR)), dim3(NTHR), 0, st,
                      p, tiles_n, ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
@@ -724,6 +775,6 @@ bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
 
 #ifdef SKG_PHASES
 extern "C" int skg_debug_phases(void* host_out, int nblocks) {      // not part of the ABI: profiling builds only
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase), (size_t)nblocks * 8 * sizeof(unsigned long long));
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_phase), (size_t)nblocks * 16 * sizeof(unsigned long long));
 }
 #endif

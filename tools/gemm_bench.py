@@ -57,6 +57,10 @@ GROUPS = {
     "conv32": lambda: [conv_case(640, 640, 32), conv_case(1280, 640, 32), conv_case(1920, 640, 32)],
     "conv16": lambda: [conv_case(1280, 1280, 16), conv_case(2560, 1280, 16)],
     "conv8": lambda: [conv_case(1280, 1280, 8), conv_case(2560, 1280, 8), conv_case(1280, 1280, 8, rows=8)],
+    "small": lambda: [conv_case(1280, 1280, 16), conv_case(2560, 1280, 16), conv_case(1920, 1280, 16),
+                      conv_case(640, 1280, 16), conv_case(1280, 1280, 16, mode=2) if False else None,
+                      gemm_case(4096, 1280, 1280), gemm_case(4096, 1280, 5120), gemm_case(4096, 1280, 2560),
+                      gemm_case(4096, 3840, 1280), gemm_case(2048, 1280, 1280), gemm_case(8192, 640, 640)],
     "gemm": lambda: [gemm_case(65536, 320, 320), gemm_case(65536, 960, 320), gemm_case(65536, 2560, 320),
                      gemm_case(65536, 320, 1280), gemm_case(16384, 640, 640), gemm_case(16384, 5120, 640),
                      gemm_case(16384, 640, 2560), gemm_case(4096, 1280, 1280), gemm_case(4096, 10240, 1280),
