@@ -69,7 +69,8 @@ class LaunchTimer:
             """The name rocprofv3 prints for the instantiation that ran (template arguments spelled out)."""
             bn = variant % 1000
             if variant >= 2000:
-                return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}>"
+                stages = 3 if variant >= 10000 else 2
+                return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}, {stages}>"
             return f"gemm_kernel<{bn}, {MODES[mode]}>"
 
         def gemm(A, B, *a, **k):

@@ -750,10 +750,17 @@ void launch_mode(const GemmParams& p, hipStream_t st) {
 
 void skg_gemm2_set_workspace(float* ws, size_t bytes) { g_ws = ws; g_ws_bytes = bytes; }
 
+// tile width of the instantiation a plain (no fused GEGLU) launch of this shape runs, + 10000 when it is the
+// three-stage one (bench.py / tools spell the rocprofv3 kernel name from this)
 int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode) {
   if (K % BK != 0 || M < 1 || (mode != MODE_DIRECT && Cin % BK != 0)) return 0;
-  const int bn = pick_tile(M, N, K).bn;
-  return bn;
+  const TileCfg t = pick_tile(M, N, K);
+  const int KT = K / BK;
+  const long ntiles = (long)skg_cdiv(M, t.bm) * skg_cdiv(N, t.bn);
+  const bool three = t.bm == 128 && (t.bn == 160 || t.bn == 64) && (mode == MODE_DIRECT || mode == MODE_S1) &&
+                     !getenv("SKG_NO_NS3") && KT >= 4 && (t.bn == 64 || ntiles <= 256) &&
+                     pick_splits(ntiles, KT, (size_t)M * N * 4) == 1;
+  return t.bn + (three ? 10000 : 0);
 }
 
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
