@@ -217,7 +217,7 @@ __device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __rest
 // CAUSAL (the CLIP text encoder, modules/pipeline.py:55-57 -> transformers CLIPTextModel): key j is visible to
 // query i only when j <= i; a separate instantiation so the UNet's kernels carry no extra test.
 template <int KS, int ND, int QT, bool CAUSAL = false>
-__global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, (KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL) ? 4 : 2)) void attn_fwd_kernel(const AttnParams p) {
   // QT query tiles of 16 per wave: a workgroup covers 64 * QT queries, so every K / V^T fragment read from LDS
   // (and every byte of K/V streamed from L2) is used by QT MFMAs instead of one.
   constexpr int KP = KS * 32 + 8;
@@ -267,6 +267,10 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
     for (int u = 0; u < ND; ++u) o[i][u] = float4_t{0.f, 0.f, 0.f, 0.f};
   }
   constexpr float REF_SLACK = 8.f;
+  // (measured: requesting all fragments of a tile up front costs 14 VGPRs = the third wave per SIMD: 710 -> 767 us at
+  // d = 40; the compiler's read-as-you-go order with three resident waves is faster.  Kept for experiments.)
+  constexpr bool PRE = false && KS <= 2 && 4 * KS * QT >= 2 * ND;
+  constexpr int VREADS = 2;                                   // LDS instructions per V^T fragment (two ds_read_b64)
   // <2, 3> is dispatched for d = 40 only: 8 spare rows in the 48-row V^T tile -> the denominator comes out of the
   // PV MFMA (row 40 of O^T) and the 16 adds per tile and query tile leave the VALU, which bounds this head size
   constexpr bool ONES = (KS == 2 && ND == 3);
@@ -278,14 +282,44 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
   // one 64-key tile: S^T = K Q^T - m, online softmax, O^T += V^T P^T   (for the wave's QT query tiles)
   auto tile = [&](const half_t* __restrict__ Ks, const half_t* __restrict__ Vs, int kv0) {
     float4_t s[QT][4];
+    half8_t vf[ND][2];
+    if constexpr (PRE) {
+      // hipcc emits "2 ds_read -> s_waitcnt -> 4 MFMA" per 16 keys, i.e. one exposed LDS latency per group and the
+      // V^T reads after the softmax.  Here every K fragment of the tile is requested up front and the V^T fragments
+      // are requested under the QK^T MFMAs, so they land while the matrix pipe and then the softmax VALU work.
+      half8_t kf[4][KS];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const half8_t kf = ld_half8(Ks + (16 * t + l16) * KP + 32 * ks + 8 * g);
+        for (int ks = 0; ks < KS; ++ks) kf[t][ks] = ld_half8(Ks + (16 * t + l16) * KP + 32 * ks + 8 * g);
 #pragma unroll
-        for (int i = 0; i < QT; ++i)
-          s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[i][ks], ks == 0 ? nm[i] : s[i][t], 0, 0, 0);
+      for (int u = 0; u < ND; ++u)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) vf[u][k2] = tfrag(Vs, u, k2, l16, g);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+          for (int i = 0; i < QT; ++i)
+            s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t][ks], qf[i][ks], ks == 0 ? nm[i] : s[i][t], 0, 0, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 * KS, 0);            // all K fragment reads
+#pragma unroll
+      for (int r = 0; r < 2 * ND; ++r) {                                  // V^T reads woven under the first MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, VREADS, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * KS * QT - 2 * ND, 0);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const half8_t kf = ld_half8(Ks + (16 * t + l16) * KP + 32 * ks + 8 * g);
+#pragma unroll
+          for (int i = 0; i < QT; ++i)
+            s[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[i][ks], ks == 0 ? nm[i] : s[i][t], 0, 0, 0);
+        }
       }
     }
     const bool first = kv0 == 0;          // the reference starts at 0: the first tile always re-bases it
@@ -295,8 +329,9 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
       if (CAUSAL || kv0 + 64 > p.Nkv) {          // ragged last tile only (wave-uniform)
         // key = kv0 + 4g + (16t + r): compare the compile-time part against per-lane limits computed in here, so
         // the full tiles carry no index arithmetic
-        const int lim = p.Nkv - kv0 - 4 * g;
-        const int qlim = CAUSAL ? q[i] - kv0 - 4 * g : 0;
+        int lim = p.Nkv - kv0 - 4 * g;
+        int qlim = CAUSAL ? q[i] - kv0 - 4 * g : 0;
+        asm volatile("" : "+v"(lim), "+v"(qlim));      // keeps the 16 compares inside this (rare) branch
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -337,16 +372,16 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_fwd_kernel(const 
     for (int u = 0; u < ND; ++u)
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        const half8_t vf = tfrag(Vs, u, k2, l16, g);
+        if constexpr (!PRE) vf[u][k2] = tfrag(Vs, u, k2, l16, g);
 #pragma unroll
-        for (int i = 0; i < QT; ++i) o[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[i][k2], o[i][u], 0, 0, 0);
+        for (int i = 0; i < QT; ++i) o[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[u][k2], pb[i][k2], o[i][u], 0, 0, 0);
       }
   };
 
   // Two LDS stages (+ two register sets when they fit): tile t computes from stage t&1 while tile t+1 sits in
   // registers on its way to the other stage and tile t+2 is in flight from L2/HBM, ONE barrier per tile.
   // Invariant at the top of the (unrolled-by-2) loop, t even: stage 0 = tile t, r0 = tile t+1, r1 = tile t+2.
-  constexpr bool DEEP = KS < 5;      // d = 160: a second register set would not fit 2 waves / SIMD
+  constexpr bool DEEP = KS < 5 && !(KS == 2 && ND == 3);      // d = 160: a second register set would not fit 2 waves / SIMD; d = 40: four waves / SIMD instead
   KVRegs<KS, ND> r0;
   kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, 0, p.kv_stride, dh);
   kv_store<KS, ND>(r0, Ks0, Vs0);
