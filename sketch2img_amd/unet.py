@@ -192,7 +192,7 @@ class HipUNet:
         self.ctx = ctx
 
     # ------------------------------------------------------------------ modules, forward
-    def _res_fwd(self, p, x, rows, H, tb, stash: Optional[Stash]):
+    def _res_fwd(self, p, x, rows, H, tb, stash: Optional[Stash], out=None):
         cfg, W = self.cfg, self.W
         G, HW = cfg.norm_groups, H * H
         n1, st1 = ops.groupnorm(x, rows, HW, G, 1e-5, W[p + ".norm1.weight"], W[p + ".norm1.bias"], True)
@@ -202,12 +202,12 @@ class HipUNet:
             sc = ops.gemm(x, W[p + ".conv_shortcut.weight"], bias=W[p + ".conv_shortcut.bias"])
         else:
             sc = x
-        out = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, bias=W[p + ".conv2.bias"], residual=sc)
+        out = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out, bias=W[p + ".conv2.bias"], residual=sc)
         if stash is not None:
             stash.res[p] = dict(x=x, st1=st1, h1=h1, st2=st2, H=H)
         return out
 
-    def _tr_fwd(self, p, x, rows, H, heads, stash: Optional[Stash]):
+    def _tr_fwd(self, p, x, rows, H, heads, stash: Optional[Stash], out=None):
         cfg, W = self.cfg, self.W
         HW = H * H
         C = x.shape[1]
@@ -247,7 +247,7 @@ class HipUNet:
             gg = ops.geglu(f, interleaved=True)
             f = f[(rows // 2) * HW:]
         p3 = ops.gemm(gg, W[t + ".ff.net.2.weight"], bias=W[t + ".ff.net.2.bias"], residual=p2)
-        out = ops.gemm(p3, W[p + ".proj_out.weight"], bias=W[p + ".proj_out.bias"], residual=x)
+        out = ops.gemm(p3, W[p + ".proj_out.weight"], out, bias=W[p + ".proj_out.bias"], residual=x)
         if keep:
             stash.tr[p] = dict(x=x, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1, st2=st2, q2=q2,
                                o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads)
@@ -264,19 +264,41 @@ class HipUNet:
         tb = self.tbias[int(t)]
         boc = cfg.block_out_channels
         nb = len(boc)
-        h = ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, bias=W["conv_in.bias"])
-        skips = [h]
+        # torch.cat((h, skip)) of the up path without copies: the buffer [h | skip] of every up resnet exists from the
+        # start; the down-path layer that produces a skip writes it straight into the right-hand columns (and keeps
+        # using that strided view as its own output), the up-path layer that produces h into the left-hand ones.
+        lpb1 = cfg.layers_per_block + 1
+        rev = list(reversed(boc))
+        n_skips = 1 + sum(cfg.layers_per_block + (1 if i < nb - 1 else 0) for i in range(nb))
+        cats: List[Optional[torch.Tensor]] = [None] * (nb * lpb1)
+        ch_h = [rev[0] if u == 0 else (rev[u // lpb1 - 1] if u % lpb1 == 0 else rev[u // lpb1]) for u in range(nb * lpb1)]
+
+        def skip_slot(ch_s: int, size: int):
+            """Right-hand columns of the concat buffer that will consume the skip produced next."""
+            u = n_skips - 1 - len(skips)
+            if down_only:
+                return None
+            cats[u] = torch.empty(rows * size * size, ch_h[u] + ch_s, device=self.dev, dtype=torch.float16)
+            return cats[u][:, ch_h[u]:]
+
+        skips: List[torch.Tensor] = []
+        h = ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, out=skip_slot(boc[0], H), bias=W["conv_in.bias"])
+        skips.append(h)
         taps_down = []
         cur = H
         for i in range(nb):
             for j in range(cfg.layers_per_block):
-                h = self._res_fwd(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, stash)
                 if i < nb - 1:
-                    h = self._tr_fwd(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i], stash)
+                    h = self._res_fwd(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, stash)
+                    h = self._tr_fwd(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i], stash,
+                                     out=skip_slot(boc[i], cur))
+                else:
+                    h = self._res_fwd(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, stash, out=skip_slot(boc[i], cur))
                 skips.append(h)
             if i < nb - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
-                h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_S2, bias=W[p + ".bias"])
+                h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_S2, out=skip_slot(boc[i], cur // 2),
+                                bias=W[p + ".bias"])
                 cur //= 2
                 skips.append(h)
             if i < 3:
@@ -295,7 +317,7 @@ class HipUNet:
         tap_r0 = (h, cur)
         h = self._tr_fwd("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash)
         tap_at = (h, cur)
-        h = self._res_fwd("mid_block.resnets.1", h, rows, cur, tb, stash)
+        h = self._res_fwd("mid_block.resnets.1", h, rows, cur, tb, stash, out=cats[0][:, :ch_h[0]])
         tap_r1 = (h, cur)
         taps_up = []
         rev_heads = tuple(reversed(cfg.num_heads))
@@ -303,18 +325,22 @@ class HipUNet:
         for i in range(nb):
             if i > last_needed:
                 break
-            for j in range(cfg.layers_per_block + 1):
-                sk = skips.pop()
-                ch, cs = h.shape[1], sk.shape[1]
-                cat = torch.empty(h.shape[0], ch + cs, device=self.dev, dtype=torch.float16)
-                ops.axpby(h, out=cat[:, :ch])
-                ops.axpby(sk, out=cat[:, ch:])
-                h = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash)
+            for j in range(lpb1):
+                u = i * lpb1 + j
+                skips.pop()                                   # already sits in cats[u][:, ch_h[u]:]
+                cat = cats[u]
+                # where this layer's output goes: the next concat buffer of the same block, else a fresh tensor
+                nxt = cats[u + 1][:, :ch_h[u + 1]] if j < lpb1 - 1 else None
                 if i > 0:
-                    h = self._tr_fwd(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], stash)
+                    h = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash)
+                    h = self._tr_fwd(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], stash, out=nxt)
+                else:
+                    h = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash, out=nxt)
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
-                h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, bias=W[p + ".bias"])
+                u = (i + 1) * lpb1
+                h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=cats[u][:, :ch_h[u]],
+                                bias=W[p + ".bias"])
                 cur *= 2
             if i < 3:
                 taps_up.append((h, cur))
