@@ -182,8 +182,20 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
   const int ntiles = ws ? nwg / ((p.K / BK + kt_per_split - 1) / kt_per_split) : nwg;
   const int split = lid / ntiles;
   lid -= split * ntiles;
-  const int tile_m = lid / tiles_n;
-  const int tile_n = lid - tile_m * tiles_n;
+  int tile_m = lid / tiles_n;
+  int tile_n = lid - tile_m * tiles_n;
+  // Weight-heavy launches (16x16 / 8x8 levels: W = 30-60 MB, A = 10-20 MB): with the plain order every XCD walks all
+  // column panels, so each of the 8 L2s pulls the WHOLE weight matrix through the fabric.  The host then picks an
+  // gm x gn arrangement of the XCDs over the tile grid (flags bits 20-23 = gn; only when everything divides evenly):
+  // XCD (xm, xn) owns row block xm and column block xn, fabric traffic ~ gn * A + gm * W.
+  if (const int gn = (p.flags >> 20) & 0xf) {
+    const int per = nwg >> 3, tmb = (nwg / tiles_n) / (8 / gn), tnb = tiles_n / gn;
+    const int xr = lid / per, r = lid - xr * per;
+    const int xm = xr / gn, xn = xr - xm * gn;
+    const int rm = r / tnb;
+    tile_m = xm * tmb + rm;
+    tile_n = xn * tnb + (r - rm * tnb);
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- per-lane DMA source description ---------------------------------------------------------------
@@ -711,6 +723,19 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
   int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
   constexpr int NTHR = WGM * WGN * 64;
+  if (splits == 1 && ntiles % 8 == 0) {
+    static const bool off = getenv("SKG_NO_XGRID") != nullptr;        // A/B switch (tools/gemm_bench.py)
+    const int tiles_m = ntiles / tiles_n;
+    const double a_mb = (double)p.M * (MODE == MODE_DIRECT ? p.K : p.Cin) * 2.0, w_mb = (double)p.N * p.K * 2.0;
+    int best = 1;
+    double cost = a_mb + 8.0 * w_mb;
+    for (int gn = 2; gn <= 8; gn *= 2) {
+      if (tiles_n % gn != 0 || tiles_m % (8 / gn) != 0) continue;
+      const double c = gn * a_mb + (8 / gn) * w_mb;
+      if (c < 0.9 * cost) { cost = c; best = gn; }
+    }
+    if (!off && best > 1) p.flags |= (unsigned)best << 20;
+  }
   if (splits > 1) {
     const int per = skg_cdiv(KT, splits);
     const int ns = skg_cdiv(KT, per);            // every split non-empty
