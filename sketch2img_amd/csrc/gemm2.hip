@@ -468,6 +468,76 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
   }
   const bool staged = !f32out && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                       (!p.res || ((p.ldr % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
+  if (staged && !p.res) {
+    // No residual: bias, alpha and ReLU are applied in registers and the value is rounded to fp16 (its final rounding;
+    // for the fused GEGLU the same rounding the unfused path and the reference apply to the FF1 output) BEFORE it
+    // goes through LDS - half the staging bytes, all 128 rows in one slab, every wave writes at once, two barriers
+    // instead of four; phase 2 is then a plain 16-byte LDS read + 16-byte store per piece.
+    constexpr int OPH = BN + 8;                // staging pitch (halves)
+    constexpr int HROWS = 128;
+    constexpr int HSLABS = BM / HROWS;
+    constexpr int PPR = BN / 8;
+    constexpr int TPR2 = NTHR / 64;            // threads per staged row (4 or 8): 64-byte runs per row and store
+    constexpr int IT2 = PPR / TPR2;            // instruction (32-byte runs - two threads per row - store at half the rate)
+    constexpr int RPT = HROWS / 64;            // rows per thread: er, er + 64
+    static_assert(HROWS * OPH * 2 <= 2 * STAGE * 2 && NTHR % 64 == 0 && PPR % TPR2 == 0, "fp16 staging slab");
+    half_t* const hst = smem;
+    float* const bias_s = reinterpret_cast<float*>(smem + NS * STAGE);
+    const int er = tid / TPR2, ec = (tid % TPR2) * 8;
+    const bool geglu = p.flags & SKG_EPI_GEGLU;
+    if (tid < BN) bias_s[tid] = bias_r;
+    half_t* const crow0 = reinterpret_cast<half_t*>(p.C) + (size_t)(m0 + er) * p.ldc + (geglu ? ((n0 + ec) >> 1) : n0 + ec);
+#pragma unroll
+    for (int sl = 0; sl < HSLABS; ++sl) {
+      lds_barrier();
+      if (sl == 0) SKG_PH(8);
+      if (WM < HROWS || wm == sl) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float4_t b4 = *reinterpret_cast<const float4_t*>(&bias_s[wn * WN + j * 16 + g * 4]);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            float4_t v = (acc[i][j] + b4) * p.alpha;
+            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+            const int row = (WM < HROWS ? wm * WM : 0) + i * 16 + l16;
+            *reinterpret_cast<half4_t*>(&hst[row * OPH + wn * WN + j * 16 + g * 4]) = h;
+          }
+        }
+      }
+      if (sl == 0) SKG_PH(9);
+      lds_barrier();
+      if (sl == 0) { SKG_PH(10); SKG_PH(11); SKG_PH(3); }
+#pragma unroll
+      for (int hr = 0; hr < RPT; ++hr) {
+        if (m0 + sl * HROWS + hr * 64 + er >= p.M) continue;
+        const half_t* const srow = hst + (hr * 64 + er) * OPH + ec;
+        half_t* const crow = crow0 + (size_t)(sl * HROWS + hr * 64) * p.ldc;
+        half8_t hv[IT2];
+#pragma unroll
+        for (int k = 0; k < IT2; ++k) hv[k] = ld_half8(srow + k * TPR2 * 8);
+#pragma unroll
+        for (int k = 0; k < IT2; ++k) {
+          if (n0 + ec + k * TPR2 * 8 >= p.N) continue;
+          if (geglu) {
+            // interleaved FF1 pack: columns [a0 a1 g0 g1 | a2 a3 g2 g3] -> 4 outputs a * gelu(g) at column n/2
+            const half8_t a = hv[k];
+            half4_t y = {(half_t)((float)a[0] * gelu_fast_f((float)a[2])), (half_t)((float)a[1] * gelu_fast_f((float)a[3])),
+                         (half_t)((float)a[4] * gelu_fast_f((float)a[6])), (half_t)((float)a[5] * gelu_fast_f((float)a[7]))};
+            half4_t* dst4 = reinterpret_cast<half4_t*>(crow + k * TPR2 * 4);
+            if (stream_out) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst4), "v"(y) : "memory");
+            else *dst4 = y;
+          } else {
+            half8_t* dst8 = reinterpret_cast<half8_t*>(crow + k * TPR2 * 8);
+            if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst8), "v"(hv[k]) : "memory");
+            else *dst8 = hv[k];
+          }
+        }
+      }
+    }
+    SKG_PH(4);
+    continue;
+  }
   if (staged) {
     // The raw fp32 accumulators go through LDS (the pipeline stages are dead now), 64 tile rows at a time:
     // phase 1 is branch-free register -> LDS traffic; phase 2 walks whole output rows with 16-byte residual
