@@ -486,7 +486,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
     const int er = tid / TPR2, ec = (tid % TPR2) * 8;
     const bool geglu = p.flags & SKG_EPI_GEGLU;
     if (tid < BN) bias_s[tid] = bias_r;
-    half_t* const crow0 = reinterpret_cast<half_t*>(p.C) + (size_t)(m0 + er) * p.ldc + (geglu ? ((n0 + ec) >> 1) : n0 + ec);
+    half_t* const crow0 = reinterpret_cast<half_t*>(p.C) + (size_t)(m0 + er) * p.ldc + n0 + ec;
 #pragma unroll
     for (int sl = 0; sl < HSLABS; ++sl) {
       lds_barrier();
@@ -508,6 +508,49 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
       if (sl == 0) SKG_PH(9);
       lds_barrier();
       if (sl == 0) { SKG_PH(10); SKG_PH(11); SKG_PH(3); }
+      if (geglu && TPR2 >= 8) {
+        // eight threads per row: 8-byte outputs already form 64-byte runs (the 256 x 320 tile)
+#pragma unroll
+        for (int hr = 0; hr < RPT; ++hr) {
+          if (m0 + sl * HROWS + hr * 64 + er >= p.M) continue;
+          const half_t* const srow = hst + (hr * 64 + er) * OPH + ec;
+          half_t* const crow = reinterpret_cast<half_t*>(p.C) + (size_t)(m0 + sl * HROWS + hr * 64 + er) * p.ldc + ((n0 + ec) >> 1);
+#pragma unroll
+          for (int k = 0; k < IT2; ++k) {
+            if (n0 + ec + k * TPR2 * 8 >= p.N) continue;
+            const half8_t a = ld_half8(srow + k * TPR2 * 8);
+            half4_t y = {(half_t)((float)a[0] * gelu_fast_f((float)a[2])), (half_t)((float)a[1] * gelu_fast_f((float)a[3])),
+                         (half_t)((float)a[4] * gelu_fast_f((float)a[6])), (half_t)((float)a[5] * gelu_fast_f((float)a[7]))};
+            half4_t* dst4 = reinterpret_cast<half4_t*>(crow + k * TPR2 * 4);
+            if (stream_out) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst4), "v"(y) : "memory");
+            else *dst4 = y;
+          }
+        }
+        continue;
+      }
+      if (geglu) {
+        // interleaved FF1 pack: 16 staged columns [a0 a1 g0 g1 | a2 a3 g2 g3] x 2 -> 8 outputs a * gelu(g) = ONE
+        // 16-byte store; consecutive lanes take consecutive 16-byte pieces of an output row (whole-row runs - the
+        // 8-byte-per-thread form left 32-byte runs per row and instruction, which store at half the rate)
+        constexpr int QPR = PPR / 2;               // 16-byte output pieces per tile row
+        static_assert(HROWS * QPR % NTHR == 0, "GEGLU piece loop");
+#pragma unroll
+        for (int k = 0; k < HROWS * QPR / NTHR; ++k) {
+          const int pi = tid + k * NTHR;
+          const int row = pi / QPR, pp = pi - row * QPR;
+          if (m0 + sl * HROWS + row >= p.M || n0 + pp * 16 >= p.N) continue;
+          const half8_t a = ld_half8(hst + row * OPH + pp * 16), b = ld_half8(hst + row * OPH + pp * 16 + 8);
+          half8_t y = {(half_t)((float)a[0] * gelu_fast_f((float)a[2])), (half_t)((float)a[1] * gelu_fast_f((float)a[3])),
+                       (half_t)((float)a[4] * gelu_fast_f((float)a[6])), (half_t)((float)a[5] * gelu_fast_f((float)a[7])),
+                       (half_t)((float)b[0] * gelu_fast_f((float)b[2])), (half_t)((float)b[1] * gelu_fast_f((float)b[3])),
+                       (half_t)((float)b[4] * gelu_fast_f((float)b[6])), (half_t)((float)b[5] * gelu_fast_f((float)b[7]))};
+          half8_t* dst8 = reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(p.C) + (size_t)(m0 + sl * HROWS + row) * p.ldc +
+                                                     (n0 >> 1) + pp * 8);
+          if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst8), "v"(y) : "memory");
+          else *dst8 = y;
+        }
+        continue;
+      }
 #pragma unroll
       for (int hr = 0; hr < RPT; ++hr) {
         if (m0 + sl * HROWS + hr * 64 + er >= p.M) continue;
@@ -519,19 +562,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
 #pragma unroll
         for (int k = 0; k < IT2; ++k) {
           if (n0 + ec + k * TPR2 * 8 >= p.N) continue;
-          if (geglu) {
-            // interleaved FF1 pack: columns [a0 a1 g0 g1 | a2 a3 g2 g3] -> 4 outputs a * gelu(g) at column n/2
-            const half8_t a = hv[k];
-            half4_t y = {(half_t)((float)a[0] * gelu_fast_f((float)a[2])), (half_t)((float)a[1] * gelu_fast_f((float)a[3])),
-                         (half_t)((float)a[4] * gelu_fast_f((float)a[6])), (half_t)((float)a[5] * gelu_fast_f((float)a[7]))};
-            half4_t* dst4 = reinterpret_cast<half4_t*>(crow + k * TPR2 * 4);
-            if (stream_out) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst4), "v"(y) : "memory");
-            else *dst4 = y;
-          } else {
-            half8_t* dst8 = reinterpret_cast<half8_t*>(crow + k * TPR2 * 8);
-            if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst8), "v"(hv[k]) : "memory");
-            else *dst8 = hv[k];
-          }
+          half8_t* dst8 = reinterpret_cast<half8_t*>(crow + k * TPR2 * 8);
+          if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst8), "v"(hv[k]) : "memory");
+          else *dst8 = hv[k];
         }
       }
     }
@@ -554,7 +587,6 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
     float* const stg = reinterpret_cast<float*>(smem);
     float* const bias_s = reinterpret_cast<float*>(smem + NS * STAGE);     // own area behind the stages
     const int er = tid / TPR, ec = (tid % TPR) * 8;
-    const bool geglu = p.flags & SKG_EPI_GEGLU;
     if (tid < BN) bias_s[tid] = bias_r;        // visible after the first barrier below
     // all residual loads of the tile are issued before the first store: vmcnt retires in order, so a load issued
     // behind a store could not be waited for without waiting for the store's acknowledgement too
@@ -572,7 +604,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
 #pragma unroll
       for (int sl = 0; sl < SLABS; ++sl) load_res(sl);
     }
-    half_t* const crow0 = reinterpret_cast<half_t*>(p.C) + (size_t)(m0 + er) * p.ldc + (geglu ? ((n0 + ec) >> 1) : n0 + ec);
+    half_t* const crow0 = reinterpret_cast<half_t*>(p.C) + (size_t)(m0 + er) * p.ldc + n0 + ec;
 #pragma unroll
     for (int sl = 0; sl < SLABS; ++sl) {
       if (sl == 1) SKG_PH(11);
@@ -603,18 +635,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
           v0[k] = *reinterpret_cast<const float4_t*>(srow + k * TPR * 8);
           v1[k] = *reinterpret_cast<const float4_t*>(srow + k * TPR * 8 + 4);
         }
-        if (geglu) {
-          // interleaved FF1 pack: columns [a0 a1 g0 g1 | a2 a3 g2 g3] -> 4 outputs a * gelu(g) at column n/2
-#pragma unroll
-          for (int k = 0; k < ITER; ++k) {
-            if (n0 + ec + k * TPR * 8 >= p.N) continue;
-            half4_t y = {(half_t)(v0[k][0] * gelu_fast_f(v0[k][2])), (half_t)(v0[k][1] * gelu_fast_f(v0[k][3])),
-                         (half_t)(v1[k][0] * gelu_fast_f(v1[k][2])), (half_t)(v1[k][1] * gelu_fast_f(v1[k][3]))};
-            half4_t* dst4 = reinterpret_cast<half4_t*>(crow + k * TPR * 4);
-            if (stream_out) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst4), "v"(y) : "memory");
-            else *dst4 = y;
-          }
-        } else {
+        {
 #pragma unroll
           for (int k = 0; k < ITER; ++k) {
             if (n0 + ec + k * TPR * 8 >= p.N) continue;
