@@ -847,6 +847,14 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
       return;
     }
   }
+#ifdef SKG_PHASES
+  static const char* solo = getenv("SKG_SOLO");      // probe: pad the LDS request so that ONE workgroup fits per CU
+  if (solo) {
+    hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(ntiles), dim3(NTHR), 48 * 1024, st,
+                       p, tiles_n, ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
+    return;
+  }
+#endif
   hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles, NTHR)), dim3(NTHR), 0, st,
                      p, tiles_n, ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
 }
