@@ -58,6 +58,27 @@ def test_gemm_epilogue_and_views(ops):
     assert o32.dtype == torch.float32 and r < 2e-6 * math.sqrt(K) + 1e-6
 
 
+@pytest.mark.parametrize("M,N,K,tag", [
+    (777, 320, 128, "fp16-staged epilogue, ragged rows, strided output"),
+    (2048, 5120, 640, "XCD grid 1 x 8 (weight-heavy: every L2 owns one column block)"),
+    (4096, 1280, 1280, "three-stage pipeline, exactly 256 tiles"),
+    (4096, 1280, 8192, "split-K at exactly 256 tiles"),
+    (2048, 1280, 1280, "128 x 64 tile, three stages"),
+    (512, 10240, 1280, "256 x 320 tile, two fp16 slabs")])
+def test_gemm_residual_free_epilogue_and_launch_variants(ops, M, N, K, tag):
+    """No residual -> the fp16-staged epilogue (bias, alpha, ReLU in registers, one rounding) on every launch variant
+    the host can pick: result == round(relu(alpha * (A B^T + bias))) up to the fp32 summation order."""
+    A, B, bias = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=K ** -0.5), rnd(N, seed=13)
+    out = torch.zeros(M, N + 16, device=dev(), dtype=torch.float16)
+    ops.gemm(A.to(dev()), B.to(dev()), out=out[:, 8:8 + N], bias=bias.to(dev()), alpha=0.75, relu=True)
+    ref = torch.relu(0.75 * (A.float() @ B.float().t() + bias.float()))
+    assert report(f"gemm {tag}", out[:, 8:8 + N].float().cpu(), ref)[0] < FP16_RND
+    assert out[:, :8].abs().max() == 0 and out[:, 8 + N:].abs().max() == 0      # no stray writes
+    res = rnd(M, N, seed=14)
+    o2 = ops.gemm(A.to(dev()), B.to(dev()), bias=bias.to(dev()), residual=res.to(dev()))
+    assert report(f"gemm +res {tag}", o2.float().cpu(), A.float() @ B.float().t() + bias.float() + res.float())[0] < FP16_RND
+
+
 def test_gemm_rejects_bad_args(ops):
     from sketch2img_amd._lib import SkgError
     A, B = rnd(16, 24).to(dev()), rnd(8, 24).to(dev())        # K % 32 != 0
