@@ -492,18 +492,33 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
       lds_barrier();
       if (sl == 0) SKG_PH(8);
       if (WM < HROWS || wm == sl) {
+        // (a lone wave issues one VALU instruction per ~8 cycles - tools/ubench/valu_rate.hip - so this block is
+        // priced by its instruction count: one packed FMA per two values, ReLU behind a REAL branch; written as a
+        // select hipcc emits 2 x 80 v_max_f32 for every launch)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const float4_t b4 = *reinterpret_cast<const float4_t*>(&bias_s[wn * WN + j * 16 + g * 4]);
+          const float4_t b4 = *reinterpret_cast<const float4_t*>(&bias_s[wn * WN + j * 16 + g * 4]) * p.alpha;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) acc[i][j] = acc[i][j] * p.alpha + b4;
+        }
+        if (relu) {
+          asm volatile("" ::: "memory");           // not if-convertible
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int i = 0; i < MT; ++i) {
-            float4_t v = (acc[i][j] + b4) * p.alpha;
-            if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            const float4_t v = acc[i][j];
             const half4_t h = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
             const int row = (WM < HROWS ? wm * WM : 0) + i * 16 + l16;
             *reinterpret_cast<half4_t*>(&hst[row * OPH + wn * WN + j * 16 + g * 4]) = h;
           }
-        }
       }
       if (sl == 0) SKG_PH(9);
       lds_barrier();
@@ -642,11 +657,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
             float v[8] = {v0[k][0], v0[k][1], v0[k][2], v0[k][3], v1[k][0], v1[k][1], v1[k][2], v1[k][3]};
             half8_t o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              float x = v[e] * p.alpha + (float)rv[sl][k][e];
-              if (relu) x = fmaxf(x, 0.f);
-              o[e] = (half_t)x;
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + (float)rv[sl][k][e];
+            if (relu) {
+              asm volatile("" ::: "memory");       // a real (wave-uniform) branch instead of 8 selects per piece
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
             half8_t* dst8 = reinterpret_cast<half8_t*>(crow + k * TPR * 8);
 #ifdef SKG_PHASES
             if (p.flags & 0x4000u) { if (o[0] == (half_t)12345.f) *dst8 = o; continue; }   // probe: epilogue without stores
