@@ -188,8 +188,11 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
   // column panels, so each of the 8 L2s pulls the WHOLE weight matrix through the fabric.  The host then picks an
   // gm x gn arrangement of the XCDs over the tile grid (flags bits 20-23 = gn; only when everything divides evenly):
   // XCD (xm, xn) owns row block xm and column block xn, fabric traffic ~ gn * A + gm * W.
+  // Split-K launches: a K slice spans G = 8 / splits XCDs (flags bits 24-27, 0 = all 8) and the arrangement is made
+  // inside that group - `lid` is already the index inside the slice.
   if (const int gn = (p.flags >> 20) & 0xf) {
-    const int per = nwg >> 3, tmb = (nwg / tiles_n) / (8 / gn), tnb = tiles_n / gn;
+    const int G = ((p.flags >> 24) & 0xf) ? (int)((p.flags >> 24) & 0xf) : 8;
+    const int per = ntiles / G, tmb = (ntiles / tiles_n) / (G / gn), tnb = tiles_n / gn;
     const int xr = lid / per, r = lid - xr * per;
     const int xm = xr / gn, xn = xr - xm * gn;
     const int rm = r / tnb;
@@ -832,18 +835,21 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
   int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
   constexpr int NTHR = WGM * WGN * 64;
-  if (splits == 1 && ntiles % 8 == 0) {
+  // XCDs per K slice: all 8 without split-K; 8 / ns when the slices line up with XCD boundaries
+  const int ns_eff = splits > 1 ? skg_cdiv(KT, skg_cdiv(KT, splits)) : 1;
+  const int G = (8 % ns_eff == 0) ? 8 / ns_eff : 0;
+  if (G >= 2 && ntiles % G == 0) {
     static const bool off = getenv("SKG_NO_XGRID") != nullptr;        // A/B switch (tools/gemm_bench.py)
     const int tiles_m = ntiles / tiles_n;
     const double a_mb = (double)p.M * (MODE == MODE_DIRECT ? p.K : p.Cin) * 2.0, w_mb = (double)p.N * p.K * 2.0;
     int best = 1;
-    double cost = a_mb + 8.0 * w_mb;
-    for (int gn = 2; gn <= 8; gn *= 2) {
-      if (tiles_n % gn != 0 || tiles_m % (8 / gn) != 0) continue;
-      const double c = gn * a_mb + (8 / gn) * w_mb;
+    double cost = a_mb + G * w_mb;
+    for (int gn = 2; gn <= G; gn *= 2) {
+      if (tiles_n % gn != 0 || tiles_m % (G / gn) != 0) continue;
+      const double c = gn * a_mb + (G / gn) * w_mb;
       if (c < 0.9 * cost) { cost = c; best = gn; }
     }
-    if (!off && best > 1) p.flags |= (unsigned)best << 20;
+    if (!off && best > 1) p.flags |= ((unsigned)best << 20) | ((unsigned)(G == 8 ? 0 : G) << 24);
   }
   if (splits > 1) {
     const int per = skg_cdiv(KT, splits);
