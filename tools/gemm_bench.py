@@ -52,6 +52,16 @@ def gemm_case(M, N, K, iters=20):
     print(f"gemm M={M:6d} N={N:5d} K={K:5d}  variant {v}  {t * 1e6:9.1f} us  {2.0 * M * N * K / t / 1e12:7.1f} TF/s", flush=True)
 
 
+def gemm_res_case(M, N, K, iters=20):
+    a = torch.randn(M, K, device=DEV).half()
+    w = (torch.randn(N, K, device=DEV) * K ** -0.5).half()
+    b = torch.randn(N, device=DEV).half()
+    r = torch.randn(M, N, device=DEV).half()
+    out = torch.empty(M, N, device=DEV, dtype=torch.float16)
+    t = timeit(lambda: ops.gemm(a, w, out, bias=b, residual=r), iters)
+    print(f"gemm+res M={M:6d} N={N:5d} K={K:5d}  {t * 1e6:9.1f} us  {2.0 * M * N * K / t / 1e12:7.1f} TF/s", flush=True)
+
+
 GROUPS = {
     "conv64": lambda: [conv_case(320, 320, 64), conv_case(640, 320, 64), conv_case(960, 320, 64)],
     "conv32": lambda: [conv_case(640, 640, 32), conv_case(1280, 640, 32), conv_case(1920, 640, 32)],
@@ -61,6 +71,8 @@ GROUPS = {
                       conv_case(640, 1280, 16), conv_case(1280, 1280, 16, mode=2) if False else None,
                       gemm_case(4096, 1280, 1280), gemm_case(4096, 1280, 5120), gemm_case(4096, 1280, 2560),
                       gemm_case(4096, 3840, 1280), gemm_case(2048, 1280, 1280), gemm_case(8192, 640, 640)],
+    "res": lambda: [gemm_res_case(65536, 320, 320), gemm_res_case(65536, 320, 1280), gemm_res_case(16384, 640, 640),
+                    gemm_res_case(16384, 640, 2560), gemm_res_case(4096, 1280, 1280), gemm_res_case(4096, 1280, 5120)],
     "gemm": lambda: [gemm_case(65536, 320, 320), gemm_case(65536, 960, 320), gemm_case(65536, 2560, 320),
                      gemm_case(65536, 320, 1280), gemm_case(16384, 640, 640), gemm_case(16384, 5120, 640),
                      gemm_case(16384, 640, 2560), gemm_case(4096, 1280, 1280), gemm_case(4096, 10240, 1280),
