@@ -61,6 +61,16 @@ __device__ __forceinline__ BlkMap attn_block_map(const AttnParams& p) {
 
 constexpr float NEG_BIG = -1.0e30f;
 
+#ifdef SKG_PHASES
+// profiling build only (make phases; tools/attn_phases.py): per-wave cycle sums of the forward kernel's phases
+__device__ unsigned long long g_attn_phase[1 << 16][8];
+#define ATT_T(x) const unsigned long long x = __builtin_readcyclecounter()
+#define ATT_ACC(i, a, b) att_acc[i] += (b) - (a)
+#else
+#define ATT_T(x) do { } while (0)
+#define ATT_ACC(i, a, b) do { } while (0)
+#endif
+
 // max of three without the canonicalising v_max_f32 x, x, x that fmaxf() puts in front of every MFMA result (the
 // compiler cannot prove an MFMA output is not a signalling NaN): 16 scores reduce in 8 VALU instead of 31
 __device__ __forceinline__ float max3f(float a, float b, float c) {
@@ -279,8 +289,12 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL)
   const half_t* Vb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
   const int nt = (p.Nkv + 63) / 64;
 
+#ifdef SKG_PHASES
+  unsigned long long att_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
   // one 64-key tile: S^T = K Q^T - m, online softmax, O^T += V^T P^T   (for the wave's QT query tiles)
   auto tile = [&](const half_t* __restrict__ Ks, const half_t* __restrict__ Vs, int kv0) {
+    ATT_T(ta);
     float4_t s[QT][4];
     half8_t vf[ND][2];
     if constexpr (PRE) {
@@ -322,6 +336,8 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL)
         }
       }
     }
+    ATT_T(tb);
+    ATT_ACC(0, ta, tb);                   // K fragment reads + QK^T MFMA issue
     const bool first = kv0 == 0;          // the reference starts at 0: the first tile always re-bases it
     half8_t pb[QT][2];
 #pragma unroll
@@ -368,6 +384,8 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL)
       if (!ONES) l[i] += ps;
       pack_p(s[i], pb[i]);
     }
+    ATT_T(tc);
+    ATT_ACC(1, tb, tc);                   // wait for the scores + softmax VALU
 #pragma unroll
     for (int u = 0; u < ND; ++u)
 #pragma unroll
@@ -376,6 +394,8 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL)
 #pragma unroll
         for (int i = 0; i < QT; ++i) o[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[u][k2], pb[i][k2], o[i][u], 0, 0, 0);
       }
+    ATT_T(td);
+    ATT_ACC(2, tc, td);                   // V^T fragment reads + PV MFMA issue
   };
 
   // Two LDS stages (+ two register sets when they fit): tile t computes from stage t&1 while tile t+1 sits in
@@ -405,18 +425,37 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL)
   } else {
     // one register set: r0 = tile t+1 while tile t computes (prefetch distance one tile)
     __syncthreads();
+    ATT_T(tl0);
     for (int t0 = 0; t0 < nt; t0 += 2) {
       tile(Ks0, Vs0, t0 * 64);
+      ATT_T(t1);
       if (t0 + 1 < nt) kv_store<KS, ND>(r0, Ks1, Vs1);
+      ATT_T(t2);
       __syncthreads();
+      ATT_T(t3);
+      ATT_ACC(3, t1, t2);                 // staging the next tile (waits for its global loads)
+      ATT_ACC(4, t2, t3);                 // barrier
       if (t0 + 1 < nt) {
         if (t0 + 2 < nt) kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 2) * 64, p.kv_stride, dh);
         tile(Ks1, Vs1, (t0 + 1) * 64);
+        ATT_T(t4);
         if (t0 + 2 < nt) kv_store<KS, ND>(r0, Ks0, Vs0);
         if (t0 + 3 < nt) kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 3) * 64, p.kv_stride, dh);
+        ATT_T(t5);
         __syncthreads();
+        ATT_T(t6);
+        ATT_ACC(3, t4, t5);
+        ATT_ACC(4, t5, t6);
       }
     }
+    ATT_T(tl1);
+    ATT_ACC(5, tl0, tl1);                 // whole loop
+#ifdef SKG_PHASES
+    if (lane == 0 && blockIdx.x < (1 << 14)) {
+      for (int j = 0; j < 6; ++j) g_attn_phase[blockIdx.x * 4 + wave][j] = att_acc[j];
+      g_attn_phase[blockIdx.x * 4 + wave][6] = nt;
+    }
+#endif
   }
 #pragma unroll
   for (int i = 0; i < QT; ++i) {
@@ -870,3 +909,9 @@ extern "C" int skg_attn_bwd_dkv(const void* Q, int ldq, const void* Qt, int ldqt
   SKG_CHECK_LAUNCH("skg_attn_bwd_dkv");
   return SKG_OK;
 }
+
+#ifdef SKG_PHASES
+extern "C" int skg_debug_attn_phases(void* host_out, int nwaves) {      // not part of the ABI: profiling builds only
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_phase), (size_t)nwaves * 8 * sizeof(unsigned long long));
+}
+#endif
