@@ -430,7 +430,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
       for (int i = 0; i < ND; ++i) dma_one(d1, s, i);
     }
     // every step issues exactly ND DMA instructions per thread (dead ones are out-of-range zero fills) and loads
-    // retire in order, so "at most (NS-2)*ND outstanding" == the K tile about to be computed has landed
+    // retire in order, so "at most (NS-2)*ND outstanding" == the K tile about to be computed has landed.  The counting
+    // starts from a drained queue (the bias load and the first NS-1 tiles), so that only DMA loads are ever counted.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int kt = kt_begin; kt < KT; kt += NS) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) {

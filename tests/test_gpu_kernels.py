@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.util import report
+from tests.util import rel_err, report
 
 pytestmark = pytest.mark.gpu
 
@@ -77,6 +77,19 @@ def test_gemm_residual_free_epilogue_and_launch_variants(ops, M, N, K, tag):
     res = rnd(M, N, seed=14)
     o2 = ops.gemm(A.to(dev()), B.to(dev()), bias=bias.to(dev()), residual=res.to(dev()))
     assert report(f"gemm +res {tag}", o2.float().cpu(), A.float() @ B.float().t() + bias.float() + res.float())[0] < FP16_RND
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 320, 960), (4096, 640, 960), (6144, 320, 448)])
+def test_gemm_three_stage_tile_with_two_workgroups_per_cu_is_repeatable(ops, M, K, N):
+    """The 128 x 64 three-stage instantiation with more tiles than CUs (two co-resident workgroups, counted vmcnt):
+    ten launches each with and without residual, every one of them correct."""
+    x, Wt, b, r = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5), rnd(N, seed=33), rnd(M, N, seed=34)
+    d = dev()
+    xd, wd, bd, rd = x.to(d), Wt.to(d), b.to(d), r.to(d)
+    ref = x.float() @ Wt.float().t() + b.float()
+    for _ in range(10):
+        assert rel_err(ops.gemm(xd, wd, bias=bd).float().cpu(), ref) < FP16_RND
+        assert rel_err(ops.gemm(xd, wd, bias=bd, residual=rd).float().cpu(), ref + r.float()) < FP16_RND
 
 
 def test_gemm_rejects_bad_args(ops):
