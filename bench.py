@@ -296,7 +296,7 @@ def main():
             "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: SD1.5 architecture (synthetic seeded weights), "
                                    f"{S} independent samples per GPU, 512x512 (64x64 latents), {T} DDIM steps, "
-                                   "CFG 7.5, LGP sketch guidance on steps 0..25 (beta 1.6)",
+                                   f"CFG 7.5, LGP sketch guidance on steps 0..{int(0.5 * T)} (beta 1.6)",
                        "samples_per_gpu": S, "global_batch": world * S, "ddim_steps": T,
                        "parallelism": f"replicas x{world} (samples sharded, weights broadcast, latents gathered)"},
             "achieved_tflops_per_gpu": value / world * f_img_tflop(T),
