@@ -479,3 +479,28 @@ def test_clip_text_sd15_vs_oracle_and_prompt_encoder_in_pipeline():
     ehs = pipe._encode_prompt(["a cat on a mat"], "cuda", 2, True, None)
     assert ehs.shape == (4, 77, 768)
     assert torch.equal(ehs[0], e[1]) and torch.equal(ehs[2], e[0]) and torch.equal(ehs[3], e[0])
+
+
+# ------------------------------------------------------------------------------------------------ bench contract
+@pytest.mark.gpu
+def test_bench_prints_one_contract_line():
+    """`python bench.py` (reduced flags) prints exactly one JSON line with the driver's keys, the roofline object and
+    a finite positive value."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--ddim-steps", "4",
+                        "--samples-per-gpu", "1", "--no-cpu-baseline", "--no-vae"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["value"] > 0 and d["unit"] == "images/s" and d["outputs_finite"]
+    roof = d["roofline"]
+    assert roof["bound"] in ("mfma", "hbm") and 0 < roof["frac"] < 1 and roof["unit"] == "TFLOP/s" and "gemm" in roof["kernel"]
+    assert "workload" in d["config"] and "model" not in d["config"]
