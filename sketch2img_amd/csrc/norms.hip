@@ -469,6 +469,58 @@ extern "C" int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int
   return SKG_OK;
 }
 
+// Small maps (16x16 / 8x8 levels): ONE workgroup per (row, group) keeps the group's whole slice in registers - X is
+// read once, mean and the CENTRED variance come from two block reductions, the statistics are published for the
+// backward pass.  The chunked path is launch-latency bound there (two launches, 14-20 us for 2.6-10 MB).
+template <int NP>   // 16-byte pieces per thread
+__global__ __launch_bounds__(256) void gn_small_kernel(const half_t* __restrict__ X, int ldx, half_t* __restrict__ Y,
+                                                       int ldy, int HW, int C, int groups,
+                                                       const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                       int silu, float eps, float* __restrict__ stats) {
+  __shared__ float red[8];
+  const int g = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / groups, ppp = cpg >> 3;              // channels per group, pieces per pixel
+  const int npieces = HW * ppp;
+  const half_t* xb = X + (size_t)row * HW * ldx + g * cpg;
+  half_t* yb = Y + (size_t)row * HW * ldy + g * cpg;
+  half8_t v[NP];
+  int off[NP];                                             // pixel * ld is recomputed for the store; keep (px, pc)
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int pi = tid + k * 256;
+    const int px = pi / ppp, pc = pi - px * ppp;
+    off[k] = pi < npieces ? (px << 8) | pc : -1;           // ppp <= 255
+    v[k] = pi < npieces ? ld_half8(xb + (size_t)px * ldx + pc * 8) : zero_half8();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)v[k][j];
+  }
+  const float inv_n = 1.f / ((float)HW * cpg);
+  const float mean = block_sum<256>(s, red) * inv_n;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k)
+    if (off[k] >= 0)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)v[k][j] - mean; s2 += d * d; }
+  const float rstd = rsqrtf(block_sum<256>(s2, red) * inv_n + eps);
+  if (tid == 0) { stats[((size_t)row * groups + g) * 2] = mean; stats[((size_t)row * groups + g) * 2 + 1] = rstd; }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    if (off[k] < 0) continue;
+    const int px = off[k] >> 8, pc = off[k] & 255;
+    const half8_t gv = ld_half8(gamma + g * cpg + pc * 8), bv = ld_half8(beta + g * cpg + pc * 8);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = ((float)v[k][j] - mean) * rstd * (float)gv[j] + (float)bv[j];
+      if (silu) y = silu_f(y);
+      o[j] = (half_t)y;
+    }
+    st_half8(yb + (size_t)px * ldy + pc * 8, o);
+  }
+}
+
 extern "C" int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
                                  float eps, const void* gamma, const void* beta, int silu, float* stats,
                                  float* partial, void* stream) {
@@ -477,6 +529,21 @@ extern "C" int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int r
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
   hipStream_t st = (hipStream_t)stream;
+  const int cpg = C / groups;
+  if (cpg % 8 == 0 && (cpg >> 3) <= 255 && (long)HW * (cpg >> 3) <= 2560) {      // the slice fits 256 threads' registers
+    const int np = skg_cdiv(HW * (cpg >> 3), 256);
+    const dim3 grid(groups, rows);
+#define SKG_GN_SMALL(NP)                                                                                          \
+    hipLaunchKernelGGL((gn_small_kernel<NP>), grid, dim3(256), 0, st, (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, \
+                       groups, (const half_t*)gamma, (const half_t*)beta, silu, eps, stats)
+    if (np <= 2) SKG_GN_SMALL(2);
+    else if (np <= 3) SKG_GN_SMALL(3);
+    else if (np <= 5) SKG_GN_SMALL(5);
+    else SKG_GN_SMALL(10);
+#undef SKG_GN_SMALL
+    SKG_CHECK_LAUNCH("skg_groupnorm_fwd (small)");
+    return SKG_OK;
+  }
   const int nch = gn_chunks(HW);
   hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(nch, rows), dim3(256), 0, st, (const half_t*)X, ldx,
                      (const half_t*)nullptr, 0, HW, C, groups, (const float*)nullptr, (const half_t*)nullptr,

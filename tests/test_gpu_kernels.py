@@ -203,7 +203,8 @@ def test_conv_in_out_padding_paths(ops):
 
 # ---------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("B,C,H,G,silu", [(2, 320, 8, 32, True), (3, 960, 16, 32, True), (2, 64, 64, 8, False),
-                                          (1, 2560, 8, 32, True)])
+                                          (1, 2560, 8, 32, True), (2, 1280, 16, 32, True), (2, 2560, 16, 32, False),
+                                          (3, 1280, 8, 32, True), (2, 1920, 16, 32, True)])
 def test_groupnorm_fwd_bwd(ops, B, C, H, G, silu):
     x = rnd(B, C, H, H, seed=1) + 0.3
     ga, be = (1 + 0.2 * rnd(C, seed=2).float()).half(), (0.2 * rnd(C, seed=3).float()).half()

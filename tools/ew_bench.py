@@ -48,7 +48,17 @@ f = torch.empty(M, 4 * C, device=D).half()
 line("geglu_fwd M 65536 F 1280", timeit(lambda: ops.geglu(h, out=f, interleaved=True)), M * C * 24)
 v = torch.randn(M, C, device=D).half()
 line("transpose M 65536 C 320", timeit(lambda: ops.transpose(v)), 2 * M * C * 2)
-for rows, hw, C in ((16, 4096, 320), (16, 1024, 640), (16, 256, 1280), (16, 64, 1280)):
+def gn_fused(x, rows, hw, G, eps, g, b, silu, y):
+    """skg_groupnorm_fwd (partial + apply that folds the partials) regardless of the HW threshold in ops.groupnorm"""
+    from sketch2img_amd._lib import lib, check
+    st = torch.empty(rows, G, 2, device=x.device, dtype=torch.float32)
+    check(lib.skg_groupnorm_fwd(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), rows, hw, x.shape[1], G, eps,
+                                g.data_ptr(), b.data_ptr(), int(silu), st.data_ptr(),
+                                ops._gn_scratch(rows, G, x.device).data_ptr(), torch.cuda.current_stream().cuda_stream), "gn")
+    return st
+
+
+for rows, hw, C in ((16, 4096, 320), (16, 4096, 640), (16, 4096, 960), (8, 4096, 320), (8, 4096, 640), (16, 1024, 640), (16, 256, 1280), (16, 64, 1280)):
     x = torch.randn(rows * hw, C, device=D).half()
     g, b = torch.ones(C, device=D).half(), torch.zeros(C, device=D).half()
     y = torch.empty_like(x)
@@ -57,4 +67,4 @@ for rows, hw, C in ((16, 4096, 320), (16, 1024, 640), (16, 256, 1280), (16, 64, 
         st = ops.groupnorm_stats(x, rows, hw, 32, 1e-5)
         ops.groupnorm_apply(x, rows, hw, 32, st, g, b, True, y)
     line(f"gn fwd 3 launches rows {rows} hw {hw} C {C}", timeit(split), 3 * x.numel() * 2)
-    line(f"gn fwd fused      rows {rows} hw {hw} C {C}", timeit(lambda: ops.groupnorm(x, rows, hw, 32, 1e-5, g, b, True, y)), 3 * x.numel() * 2)
+    line(f"gn fwd fused      rows {rows} hw {hw} C {C}", timeit(lambda: gn_fused(x, rows, hw, 32, 1e-5, g, b, True, y)), 3 * x.numel() * 2)
