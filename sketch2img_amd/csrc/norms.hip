@@ -521,6 +521,61 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const half_t* __restrict_
   }
 }
 
+// backward of the same: dx = rstd * (d - mean(d) - xhat * mean(d * xhat)) + residual,  d = dy * silu'(.) * gamma
+template <int NP>
+__global__ __launch_bounds__(256) void gn_bwd_small_kernel(
+    const half_t* __restrict__ X, int ldx, const half_t* __restrict__ dY, int lddy, half_t* __restrict__ dX, int lddx,
+    const half_t* __restrict__ R, int ldr, int HW, int C, int groups, const float* __restrict__ stats,
+    const half_t* __restrict__ gamma, const half_t* __restrict__ beta, int silu) {
+  __shared__ float red[8];
+  const int g = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / groups, ppp = cpg >> 3;
+  const int npieces = HW * ppp;
+  const size_t r0 = (size_t)row * HW;
+  const float mean = stats[((size_t)row * groups + g) * 2], rstd = stats[((size_t)row * groups + g) * 2 + 1];
+  half8_t xv[NP];
+  float d[NP][8];
+  int off[NP];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int pi = tid + k * 256;
+    const int px = pi / ppp, pc = pi - px * ppp;
+    const bool ok = pi < npieces;
+    off[k] = ok ? (px << 8) | pc : -1;
+    const int c0 = g * cpg + pc * 8;
+    xv[k] = ok ? ld_half8(X + (r0 + px) * ldx + c0) : zero_half8();
+    const half8_t dv = ok ? ld_half8(dY + (r0 + px) * lddy + c0) : zero_half8();
+    const half8_t gv = ok ? ld_half8(gamma + c0) : zero_half8(), bv = ok ? ld_half8(beta + c0) : zero_half8();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = ((float)xv[k][j] - mean) * rstd;
+      float t = (float)dv[j];
+      if (silu) t *= silu_grad_f(xh * (float)gv[j] + (float)bv[j]);
+      t *= (float)gv[j];
+      d[k][j] = t;
+      s1 += t; s2 += t * xh;
+    }
+  }
+  const float inv_n = 1.f / ((float)HW * cpg);
+  const float m1 = block_sum<256>(s1, red) * inv_n;
+  const float m2 = block_sum<256>(s2, red) * inv_n;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    if (off[k] < 0) continue;
+    const int px = off[k] >> 8, pc = off[k] & 255;
+    const int c0 = g * cpg + pc * 8;
+    const half8_t rv = R ? ld_half8(R + (r0 + px) * ldr + c0) : zero_half8();
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = ((float)xv[k][j] - mean) * rstd;
+      o[j] = (half_t)(rstd * (d[k][j] - m1 - xh * m2) + (float)rv[j]);
+    }
+    st_half8(dX + (r0 + px) * lddx + c0, o);
+  }
+}
+
 extern "C" int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
                                  float eps, const void* gamma, const void* beta, int silu, float* stats,
                                  float* partial, void* stream) {
@@ -566,6 +621,22 @@ extern "C" int skg_groupnorm_bwd(const void* X, int ldx, const void* dY, int ldd
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(dY, 16) && skg_aligned(dX, 16) && skg_aligned(gamma, 16) &&
               skg_aligned(beta, 16) && (!residual || skg_aligned(residual, 16)));
   hipStream_t st = (hipStream_t)stream;
+  const int cpg = C / groups;
+  if (cpg % 8 == 0 && (cpg >> 3) <= 255 && (long)HW * (cpg >> 3) <= 2560) {      // one launch: see gn_small_kernel
+    const int np = skg_cdiv(HW * (cpg >> 3), 256);
+    const dim3 grid(groups, rows);
+#define SKG_GN_BWD_SMALL(NP)                                                                                         \
+    hipLaunchKernelGGL((gn_bwd_small_kernel<NP>), grid, dim3(256), 0, st, (const half_t*)X, ldx, (const half_t*)dY,   \
+                       lddy, (half_t*)dX, lddx, (const half_t*)residual, ldr, HW, C, groups, stats,                   \
+                       (const half_t*)gamma, (const half_t*)beta, silu)
+    if (np <= 2) SKG_GN_BWD_SMALL(2);
+    else if (np <= 3) SKG_GN_BWD_SMALL(3);
+    else if (np <= 5) SKG_GN_BWD_SMALL(5);
+    else SKG_GN_BWD_SMALL(10);
+#undef SKG_GN_BWD_SMALL
+    SKG_CHECK_LAUNCH("skg_groupnorm_bwd (small)");
+    return SKG_OK;
+  }
   const int nch = gn_chunks(HW);
   float* sums = partial + (size_t)rows * GN_MAX_CHUNKS * groups * 2;
   hipLaunchKernelGGL((gn_partial_kernel<1>), dim3(nch, rows), dim3(256), 0, st, (const half_t*)X, ldx,
