@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
-"""Benchmark of the sketch-guided sampler hot path (BASELINE.json metric, config[1]).
+"""Benchmark of the sketch-guided sampler hot path (BASELINE.json metric).
 
-One "step" = one complete pass of the hot path over one batch: 8 independent sketch-guided samples per
-GPU, SD1.5 architecture (synthetic seeded weights), 512x512 (64x64 latents), 50 DDIM steps, CFG 7.5, LGP
-guidance on steps 0..25.  Inputs (weights, text embeddings, sketch targets, initial latents) are resident
-in HBM before the timed region.  N > 1: one process per GPU (torch.distributed / RCCL), rank 0's weights
-are broadcast once, every rank samples its own 8 images (weak scaling, no per-step collective) and the
-final latents are gathered on rank 0 inside the timed region.
+One "step" = one complete pass of the hot path over one batch of independent samples on every GPU:
+50 DDIM steps (CFG 7.5) from resident latents to decoded uint8 images (VAE decode on the rank that sampled,
+then - N > 1 - the gather of the decoded images on rank 0).  ``--config`` picks the BASELINE.json workload:
+
+    2 (default)  configs[1]: SD1.5, 8 samples per GPU, 512x512, LGP sketch guidance on steps 0..25
+                 (configs[2] is the same workload at --gpus 8)
+    4            configs[3]: SD1.5, 8 samples per GPU, 512x512, sketch_guided_attn injection, no LGP gradient
+    5            configs[4]: SD2.1 architecture, 4 samples per GPU, 768x768, clip_guided_attn injection
+
+Weights, text embeddings, sketch inputs and initial latents are synthetic (seeded) and resident in HBM before
+the timed region.  N > 1: one process per GPU (torch.distributed / RCCL), rank 0's weights are broadcast
+once, every rank samples its own images (weak scaling, no per-step collective).
 
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 ... bench.py --gpus 8
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP-event
-timed in an extra instrumented pass) and `cpu_baseline` (the CPU oracle timed on this box's host cores on a
-bounded sample of the same workload; baseline only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant contraction kernel,
+HIP-event timed in an extra instrumented pass; `rocprof` = the committed rocprofv3 average of the same
+kernel on the same command, when profiles/ holds one) and `cpu_baseline` (the CPU oracle timed on this box's
+host cores on a bounded sample; baseline only).
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import re
 import sys
 import time
 
@@ -27,15 +37,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-F_IMG_TFLOP = 107.65          # algorithmic TFLOP per image at 50 steps / 26 guided, SURVEY.md section 8(d)
-
-
-def f_img_tflop(T):
-    """SURVEY 8(d) per-image work for T DDIM steps: UNet fwd 2 rows/step, + per guided step (i <= 0.5*T) the
-    cond-row UNet backward and the LGP forward (2 rows) + backward (1 row).  T = 50 -> 107.65."""
-    guided = sum(1 for i in range(T) if not (i > 0.5 * T))
-    return (T * 2 * 803.27 + guided * (929.33 + 3 * 40.50)) / 1e3
 PEAK_FP16_TFLOPS = 2500.0     # dense fp16 MFMA peak, MI355X_MICROARCH.md
+
+# algorithmic GFLOP per UNet row evaluation
+GF_SD15_FWD, GF_SD15_BWD, GF_LGP = 803.27, 929.33, 40.50
+GF_C4_ROW = 803.27 + 186.46       # + sketch_guided_attn injection
+GF_C5_ROW = 2149.1 + 852.8        # SD2.1 @ 96x96 + clip_guided_attn injection
+
+
+def f_img_tflop(config: int, T: int) -> float:
+    """Algorithmic TFLOP per image.  Config 2, T = 50 -> 107.65; config 4 -> 98.97; config 5 -> 300.19."""
+    if config == 2:
+        guided = sum(1 for i in range(T) if not (i > 0.5 * T))
+        return (T * 2 * GF_SD15_FWD + guided * (GF_SD15_BWD + 3 * GF_LGP)) / 1e3
+    return T * 2 * (GF_C4_ROW if config == 4 else GF_C5_ROW) / 1e3
+
+
+WORKLOADS = {
+    2: "BASELINE.json configs[1]: SD1.5 architecture (synthetic seeded weights), {S} independent samples per GPU, "
+       "512x512 (64x64 latents), {T} {sched} steps, CFG 7.5, LGP sketch guidance on steps 0..{G} (beta 1.6)",
+    4: "BASELINE.json configs[3]: SD1.5 architecture (synthetic seeded weights), {S} independent samples per GPU, "
+       "512x512 (64x64 latents), {T} {sched} steps, CFG 7.5, sketch_guided_attn injection (scale 1.0, synthetic "
+       "res_samples), no LGP gradient",
+    5: "BASELINE.json configs[4]: SD2.1 architecture (head_dim 64, 1024-wide context, synthetic seeded weights), {S} "
+       "independent samples per GPU, 768x768 (96x96 latents), {T} {sched} steps, CFG 7.5, clip_guided_attn injection on "
+       "[zeros; 257 CLIP tokens] (scale 1.0)",
+}
 
 
 def parse():
@@ -43,21 +70,32 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--samples-per-gpu", type=int, default=8)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5))
+    ap.add_argument("--samples-per-gpu", type=int, default=None, help="default 8 (configs 2, 4) / 4 (config 5)")
     ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--scheduler", default="ddim", choices=("ddim", "dpm"),
+                    help="dpm = DPM-Solver++ 2M as app.py:13-25 ships (the BASELINE metric is DDIM)")
+    ap.add_argument("--gather", default="images", choices=("images", "latents"),
+                    help="images (default): VAE decode on-rank + gather of uint8 images inside the timed region, as "
+                         "north_star states; latents: gather the fp32 latents, no decode (round-1 behaviour)")
+    ap.add_argument("--graph", action="store_true", help="replay the two step variants from captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, separately reported) VAE decode")
-    ap.add_argument("--shape-report", default=None, help="write a per-shape table of the GEMM / conv launches of one batch")
+    ap.add_argument("--shape-report", default=None, help="write a per-shape table of the GEMM / conv / attention launches of one batch")
+    ap.add_argument("--first-sample", type=int, default=0, help="global index of rank 0's first sample (seeds depend on the global index only)")
+    ap.add_argument("--dump-images", default=None, help="rank 0 saves the gathered result of the LAST timed batch (torch.save)")
     return ap.parse_args()
 
 
+ATTN_NAMES = {16: "1, 1, 2", 32: "1, 2, 2", 40: "2, 3, 2", 64: "2, 4, 2", 80: "3, 5, 2", 160: "5, 10, 1"}
+
+
 class LaunchTimer:
-    """Times every skg_gemm_f16 / skg_conv3x3_f16 launch with HIP events on the launch stream."""
+    """Times every skg_gemm_f16 / skg_conv3x3_f16 / skg_attn_fwd launch with HIP events on the launch stream."""
 
     def __init__(self, ops):
         self.ops, self.rec = ops, []
-        self._gemm, self._conv = ops.gemm, ops.conv3x3
+        self._gemm, self._conv, self._attn = ops.gemm, ops.conv3x3, ops.attn_fwd
 
     def __enter__(self):
         from sketch2img_amd._lib import lib
@@ -73,10 +111,13 @@ class LaunchTimer:
                 return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}, {stages}>"
             return f"gemm_kernel<{bn}, {MODES[mode]}>"
 
+        def ev():
+            return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
         def gemm(A, B, *a, **k):
             M, K = A.shape
             N = B.shape[0]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = ev()
             e0.record()
             out = self._gemm(A, B, *a, **k)
             e1.record()
@@ -90,7 +131,7 @@ class LaunchTimer:
             Cin, Cout = X.shape[1], Wp.shape[0]
             OH = IH if mode == 0 else (IH // 2 if mode == 1 else IH * 2)
             M = rows * OH * OH
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, e1 = ev()
             e0.record()
             out = self._conv(X, Wp, rows, IH, IW, mode, *a, **k)
             e1.record()
@@ -100,11 +141,22 @@ class LaunchTimer:
                              f"conv {name} M{M} Cin{Cin} Cout{Cout}" + "+res" * (k.get("residual") is not None)))
             return out
 
-        ops.gemm, ops.conv3x3 = gemm, conv
+        def attn(Q, K, Vt, batch, heads, Nq, Nkv, kv_stride, dh, scale, *a, **k):
+            e0, e1 = ev()
+            e0.record()
+            out = self._attn(Q, K, Vt, batch, heads, Nq, Nkv, kv_stride, dh, scale, *a, **k)
+            e1.record()
+            fl = 4.0 * batch * heads * Nq * Nkv * dh                      # QK^T + PV
+            nbytes = 2.0 * batch * heads * dh * (2 * Nq + 2 * Nkv)
+            self.rec.append((f"attn_fwd_kernel<{ATTN_NAMES.get(dh, '?')}, false>", fl, e0, e1, nbytes,
+                             f"attn B{batch} H{heads} Nq{Nq} Nkv{Nkv} d{dh}"))
+            return out
+
+        ops.gemm, ops.conv3x3, ops.attn_fwd = gemm, conv, attn
         return self
 
     def __exit__(self, *exc):
-        self.ops.gemm, self.ops.conv3x3 = self._gemm, self._conv
+        self.ops.gemm, self.ops.conv3x3, self.ops.attn_fwd = self._gemm, self._conv, self._attn
 
     def summary(self):
         torch.cuda.synchronize()
@@ -124,58 +176,177 @@ class LaunchTimer:
         rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
         tot = sum(v[2] for _, v in rows)
         with open(path, "w") as f:
-            f.write(f"GEMM / conv launches of one batch, HIP events around each launch: {tot * 1e3:.1f} ms in {len(self.rec)} launches\n")
+            f.write(f"GEMM / conv / attention launches of one batch, HIP events around each launch: {tot * 1e3:.1f} ms in {len(self.rec)} launches\n")
             f.write(f"{'shape':48s} {'kernel':36s} {'n':>6s} {'ms':>8s} {'avg us':>8s} {'TF/s':>7s} {'TB/s':>6s} {'%':>5s}\n")
             for (shape, name), (n, fl, sec, nb) in rows:
                 f.write(f"{shape:48s} {name:36s} {n:6d} {sec * 1e3:8.2f} {sec / n * 1e6:8.1f} {fl / sec / 1e12:7.0f} "
                         f"{nb / sec / 1e12:6.2f} {100 * sec / tot:5.1f}\n")
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 --pmc passes (profiles/
-    r01_hbm_counters.json: FETCH_SIZE and WRITE_SIZE collected in separate passes over the same workload).
-    Units are KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced reads (MI355X_MICROARCH.md
-    section HBM; re-checked here on GEGLU / GroupNorm-apply whose read:write byte ratio is known) -> doubled."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_counters.json")
-    if not os.path.exists(path):
-        return None
-    data = json.load(open(path))
-    for k, v in data.items():
-        if kernel_name in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+# ------------------------------------------------------------------------------- committed rocprofv3 evidence
+def _latest_profile(config: int, suffix: str):
+    """profiles/r<NN>_cfg<config>_<suffix> of the latest round that has one (round-1 files carry no cfg tag)."""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_cfg{config}_{suffix}")))
+    if not cands and config == 2:
+        legacy = {"hbm_counters.json": "r01_hbm_counters.json", "kernel_stats.csv": "r01_kernel_stats_final.csv"}
+        p = os.path.join(ROOT, "profiles", legacy.get(suffix, "-"))
+        cands = [p] if os.path.exists(p) else []
+    return cands[-1] if cands else None
+
+
+def _norm_kernel(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "")
+    m = re.match(r"^(void )?([\w:]+(<[^(]*>)?)", name)
+    return m.group(2) if m else name
+
+
+def pmc_traffic(config: int, kernel_name: str):
+    """HBM bytes per launch of `kernel_name` from the COMMITTED rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate passes over the same workload, tools/collect_profiles.sh).  Units are KiB; on gfx950
+    FETCH_SIZE counts half the bytes of wide coalesced reads (MI355X_MICROARCH.md section HBM; re-checked here on
+    GEGLU / GroupNorm-apply whose read:write byte ratio is known) -> doubled.  A constant of the committed
+    profile, not a measurement of this run."""
+    path = _latest_profile(config, "hbm_counters.json")
+    if path is None:
+        return None, None
+    for k, v in json.load(open(path)).items():
+        if kernel_name in k.replace("void ", "") and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             f, w = v["FETCH_SIZE"], v["WRITE_SIZE"]
-            return (2.0 * f["sum"] / f["launches"] + w["sum"] / w["launches"]) * 1024.0
+            return (2.0 * f["sum"] / f["launches"] + w["sum"] / w["launches"]) * 1024.0, os.path.relpath(path, ROOT)
+    return None, os.path.relpath(path, ROOT)
+
+
+def rocprof_duration(config: int, kernel_name: str):
+    """(average ns, launches, file) of `kernel_name` in the committed rocprofv3 --kernel-trace --stats summary."""
+    path = _latest_profile(config, "kernel_stats.csv")
+    if path is None:
+        return None
+    for r in csv.DictReader(open(path)):
+        if _norm_kernel(r["Name"]) == kernel_name:
+            return float(r["AverageNs"]), int(r["Calls"]), os.path.relpath(path, ROOT)
     return None
 
 
-def cpu_baseline(sd_unet, sd_lgp, ehs2, latent0, target0):
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(extrapolate_c2: bool = True):
     """The CPU oracle (a port of the reference's formulation: eager fp32, autograd through BOTH CFG rows,
-    materialised 9320-channel tensor) on a bounded sample of the same workload: ONE 512x512 sample, one
-    guided and one unguided DDIM step, extrapolated to 26 guided + 24 unguided steps."""
-    from oracle import ddim as oddim, guidance as og, unet as ounet
+    materialised 9320-channel tensor, modules/pipeline.py:83-161) on the host cores, as SURVEY 8(d) defines it:
+    BASELINE config[0] - one sketch, 256x256 (32x32 latents), 10 DDIM steps, guidance on steps 0..5 - 1 warm-up run +
+    3 timed runs.  Second, labelled figure: one guided + one unguided step of ONE config-2 sample (512x512) after a
+    warm-up evaluation, extrapolated to 26 + 24 steps."""
+    from oracle import ddim as oddim, guidance as og, lgp as olgp, unet as ounet
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import SD15
     # 32 threads is the fastest setting on the GPU box's 256-thread host for this eager fp32 graph (measured
     # with tools/cpu_sweep.py: 5.3 s / UNet eval at 32 threads, 7.2 s at 64, 11.1 s at 128)
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     cfg = ounet.SD15
-    tab = oddim.make_tables(50)
-    t = int(tab.timesteps[0])
-    x = latent0.clone()
-    times = {}
-    for guided in (True, False):
+    W = synthetic.unet_state_dict(SD15)
+    sd = synthetic.lgp_state_dict(synthetic.lgp_input_dim(SD15))
+    ehs = synthetic.text_embeddings(1)
+    h, T = 32, 10
+    x0, tgt = synthetic.initial_latents(0, 1, h), synthetic.sketch_targets(0, 1, h)
+    runs = []
+    for r in range(4):
         t0 = time.time()
-        x_in = torch.cat([x] * 2).requires_grad_(guided)
-        with torch.enable_grad() if guided else torch.no_grad():
-            eps, taps = ounet.unet_forward(cfg, sd_unet, x_in, t, ehs2)
-        eu, ec = eps.detach().chunk(2)
-        nxt = oddim.ddim_step(tab, eu + 7.5 * (ec - eu), t, x)
-        if guided:
-            nxt = og.apply_anti_gradient(taps, sd_lgp, tab.alphas_cumprod, x_in, nxt, latent0, t, target0, 1.6)
-        times[guided] = time.time() - t0
-    per_image = 26 * times[True] + 24 * times[False]
-    return dict(value=1.0 / per_image, unit="images/s", cores=cores, kind="port",
-                sample=f"1 sample 512x512, SD1.5 fp32 eager PyTorch on {cores} host threads: 1 guided step "
-                       f"({times[True]:.1f} s) + 1 unguided step ({times[False]:.1f} s) measured, extrapolated to "
-                       f"26 guided + 24 unguided = {per_image:.0f} s/image")
+        out = og.sample_one(cfg, W, dict(sd), ehs, x0, tgt, T)
+        runs.append(time.time() - t0)
+    assert torch.isfinite(out).all()
+    timed = runs[1:]
+    mean = sum(timed) / len(timed)
+    res = dict(value=1.0 / mean, unit="images/s", cores=cores, kind="port",
+               sample=f"BASELINE config[0] as SURVEY 8(d) defines the CPU baseline: 1 sketch, 256x256, {T} DDIM steps, "
+                      f"LGP guidance on steps 0..5, as-written formulation (autograd through both CFG rows), SD1.5 fp32 "
+                      f"eager PyTorch on {cores} host threads; 1 warm-up ({runs[0]:.1f} s) + 3 timed runs "
+                      f"({', '.join(f'{t:.1f}' for t in timed)} s), value = 1 / mean",
+               runs_s=timed, warmup_s=runs[0], tflop_per_image=6.11)
+    if extrapolate_c2:
+        h = 64
+        x, tgt = synthetic.initial_latents(0, 1, h), synthetic.sketch_targets(0, 1, h)
+        tab = oddim.make_tables(50)
+        t = int(tab.timesteps[0])
+        with torch.no_grad():
+            ounet.unet_forward(cfg, W, torch.cat([x] * 2), t, ehs)            # warm-up (first touch of the 64x64 buffers)
+        times = {}
+        for guided in (True, False):
+            t0 = time.time()
+            x_in = torch.cat([x] * 2).requires_grad_(guided)
+            with torch.enable_grad() if guided else torch.no_grad():
+                eps, taps = ounet.unet_forward(cfg, W, x_in, t, ehs)
+            eu, ec = eps.detach().chunk(2)
+            nxt = oddim.ddim_step(tab, eu + 7.5 * (ec - eu), t, x)
+            if guided:
+                nxt = og.apply_anti_gradient(taps, sd, tab.alphas_cumprod, x_in, nxt, x, t, tgt, 1.6)
+            times[guided] = time.time() - t0
+        per_image = 26 * times[True] + 24 * times[False]
+        res["config2_extrapolated"] = dict(
+            value=1.0 / per_image, unit="images/s",
+            sample=f"1 sample 512x512 after one warm-up evaluation: 1 guided step ({times[True]:.1f} s) + 1 unguided step "
+                   f"({times[False]:.1f} s) measured, extrapolated to 26 guided + 24 unguided = {per_image:.0f} s/image")
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------- workload
+def build_workload(args, rank, world, dev, dist):
+    """Everything resident in HBM: engines, inputs, tables.  Returns a dict with `one_batch()`."""
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import SD15, SD21, SD_VAE, tap_channels
+    from sketch2img_amd.dist import broadcast_state_dict, gather_images, gather_latents
+    from sketch2img_amd.inject import HipInjector
+    from sketch2img_amd.lgp import HipLGP
+    from sketch2img_amd.sampler import DDIMTables, DPMTables, HipSampler
+    from sketch2img_amd.unet import HipUNet
+    from sketch2img_amd.vae import HipVAEDecoder
+
+    C, T = args.config, args.ddim_steps
+    cfg = SD21 if C == 5 else SD15
+    h = 96 if C == 5 else 64
+    S = args.samples_per_gpu or (4 if C == 5 else 8)
+    first = args.first_sample + rank * S
+
+    def weights(make, shapes=None):
+        sd = make() if rank == 0 else None
+        return broadcast_state_dict(sd, shapes, dev, src=0) if world > 1 else sd
+
+    sd_unet = weights(lambda: synthetic.unet_state_dict(cfg), synthetic.unet_param_shapes(cfg))
+    net = HipUNet(cfg, sd_unet, dev, need_backward=(C == 2))
+    lgp, target, sd_lgp = None, None, None
+    if C == 2:
+        sd_lgp = weights(lambda: synthetic.lgp_state_dict(synthetic.lgp_input_dim(cfg)))
+        lgp = HipLGP(sd_lgp, tap_channels(cfg), dev)
+        target = synthetic.sketch_targets(first, S, h).to(dev)
+    else:
+        variant = "sketch" if C == 4 else "clip"
+        sd_sat = weights(lambda: synthetic.satmixin_state_dict(cfg, variant), synthetic.satmixin_param_shapes(cfg, variant))
+        inj = HipInjector(cfg, sd_sat, variant, dev)
+        inj.set_scale(1.0)
+        if C == 4:
+            inj.set_res_samples(synthetic.res_samples(cfg, first, S, h))
+        else:
+            inj.set_state(synthetic.sketch_state(first, S))
+        net.inject = inj
+    vae = None
+    if args.gather == "images":
+        sd_vae = weights(lambda: synthetic.vae_decoder_state_dict(SD_VAE), synthetic.vae_decoder_param_shapes(SD_VAE))
+        vae = HipVAEDecoder(SD_VAE, sd_vae, dev)
+    ehs = synthetic.text_embeddings(S, dim=cfg.cross_attention_dim)
+    net.prepare_context(ehs)
+    tab = DPMTables.make(T) if args.scheduler == "dpm" else DDIMTables.make(T)
+    net.prepare_timesteps(tab.timesteps.tolist())
+    lat0 = synthetic.initial_latents(first, S, h).to(dev)
+    sampler = HipSampler(net, lgp, use_graphs=args.graph)
+
+    def one_batch():
+        x = sampler.sample(lat0, target, T, tables=tab)
+        if vae is not None:
+            x = vae.decode_to_u8(x)                      # [S, 8h, 8h, 3] uint8: what the final gather carries
+        if world > 1:
+            got = (gather_images if vae is not None else gather_latents)(x, world, dst=0)
+            return x if got is None else torch.cat(got)
+        return x
+
+    return dict(one_batch=one_batch, sampler=sampler, net=net, vae=vae, S=S, h=h, T=T, tab=tab, lat0=lat0, target=target)
 
 
 def main():
@@ -199,42 +370,19 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from sketch2img_amd import ops, synthetic
-    from sketch2img_amd.config import SD15, tap_channels
-    from sketch2img_amd.dist import broadcast_state_dict, gather_latents
-    from sketch2img_amd.lgp import HipLGP
-    from sketch2img_amd.sampler import DDIMTables, HipSampler
-    from sketch2img_amd.unet import HipUNet
+    from sketch2img_amd import ops
 
-    S, h, T = args.samples_per_gpu, 64, args.ddim_steps
     t_setup = time.time()
-    sd_unet = synthetic.unet_state_dict(SD15) if rank == 0 else None
-    sd_lgp = synthetic.lgp_state_dict(synthetic.lgp_input_dim(SD15)) if rank == 0 else None
-    if world > 1:
-        sd_unet = broadcast_state_dict(sd_unet, synthetic.unet_param_shapes(SD15), dev, src=0)
-        sd_lgp = broadcast_state_dict(sd_lgp, None, dev, src=0)
-    net = HipUNet(SD15, sd_unet, dev)
-    lgp = HipLGP(sd_lgp, tap_channels(SD15), dev)
-    ehs = synthetic.text_embeddings(S)
-    net.prepare_context(ehs)
-    tab = DDIMTables.make(T)
-    net.prepare_timesteps(tab.timesteps.tolist())
-    lat0 = synthetic.initial_latents(rank * S, S, h).to(dev)
-    target = synthetic.sketch_targets(rank * S, S, h).to(dev)
-    sampler = HipSampler(net, lgp)
+    wl = build_workload(args, rank, world, dev, dist)
+    one_batch, S, T, C = wl["one_batch"], wl["S"], wl["T"], args.config
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
-
-    def one_batch():
-        x = sampler.sample(lat0, target, T, tables=tab)
-        if world > 1:
-            gather_latents(x, world, dst=0)
-        return x
 
     def barrier():
         if world > 1:
             dist.barrier()
 
+    out = None
     for _ in range(args.warmup):
         out = one_batch()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
@@ -247,65 +395,75 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    finite = bool(torch.isfinite(out).all())
+    lat_final = wl["sampler"].last_latents
+    finite = bool(torch.isfinite(lat_final).all())
+    if world > 1:
+        ft = torch.tensor([int(finite)], device=dev)
+        dist.all_reduce(ft, op=dist.ReduceOp.MIN)
+        finite = bool(int(ft))
     value = world * S * args.steps / dt
+    if rank == 0 and args.dump_images:
+        torch.save(dict(images=out.cpu(), latents=lat_final.cpu()), args.dump_images)
 
     roof, cpu = None, None
     if rank == 0 and not args.no_roofline:
         with LaunchTimer(ops) as lt:
-            sampler.sample(lat0, target, T, tables=tab)
+            wl["sampler"].sample(wl["lat0"], wl["target"], T, tables=wl["tab"], graphs=False)
+            if wl["vae"] is not None:
+                wl["vae"].decode_to_u8(wl["sampler"].last_latents)
         agg = lt.summary()
         if args.shape_report:
             lt.shape_report(args.shape_report)
         name, (n, fl, sec, nb) = max(agg.items(), key=lambda kv: kv[1][2])
         tot_sec = sum(v[2] for v in agg.values())
+        traffic, traffic_file = pmc_traffic(C, name)
         roof = dict(bound="mfma", kernel=name, achieved=fl / sec / 1e12, peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
-                    frac=fl / sec / 1e12 / PEAK_FP16_TFLOPS, traffic=pmc_traffic(name), algorithmic_bytes=nb / n,
-                    traffic_source="profiles/r01_hbm_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 10-step run; "
-                                   "bytes per launch = (2*FETCH + WRITE)*1024)", launches=n,
-                    avg_launch_us=sec / n * 1e6, avg_launch_gflop=fl / n / 1e9,
-                    all_gemm_conv_tflops=sum(v[1] for v in agg.values()) / tot_sec / 1e12,
-                    gemm_conv_share_of_step=tot_sec / (dt / args.steps),
+                    frac=fl / sec / 1e12 / PEAK_FP16_TFLOPS, traffic=traffic, algorithmic_bytes=nb / n,
+                    traffic_source=(f"from committed profile {traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes "
+                                    "per launch = (2*FETCH + WRITE)*1024), not measured in this run") if traffic_file else None,
+                    launches=n, avg_launch_us=sec / n * 1e6, avg_launch_gflop=fl / n / 1e9,
+                    timing="HIP events on the launch stream around every launch (includes the launch gap)",
+                    all_contraction_tflops=sum(v[1] for v in agg.values()) / tot_sec / 1e12,
+                    contraction_share_of_step=tot_sec / (dt / args.steps),
                     per_kernel={k: dict(launches=v[0], tflops=v[1] / v[2] / 1e12, seconds=v[2]) for k, v in
                                 sorted(agg.items(), key=lambda kv: -kv[1][2])})
+        rp = rocprof_duration(C, name)
+        if rp is not None:
+            avg_ns, calls, f = rp
+            roof["rocprof"] = dict(avg_launch_us=avg_ns / 1e3, launches=calls, achieved=fl / n / avg_ns / 1e3,
+                                   frac=fl / n / avg_ns / 1e3 / PEAK_FP16_TFLOPS,
+                                   source=f"committed {f} (rocprofv3 --kernel-trace --stats of this command)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(sd_unet, sd_lgp, ehs[[0, S]], lat0[:1].cpu(), target[:1].cpu())
-
-    vae_info = None
-    if rank == 0 and not args.no_vae:
-        # latents -> pixels (modules/pipeline.py:118) is outside the per-step path and outside `value` (SURVEY 8d:
-        # F_img excludes the 2.51 TFLOP VAE decode); timed separately on this rank's S final latents
-        from sketch2img_amd.config import SD_VAE
-        from sketch2img_amd.vae import AutoencoderKL
-        vae = AutoencoderKL(SD_VAE).to(dev)
-        img = vae.decode_latents(out)
-        torch.cuda.synchronize()
-        tv = time.perf_counter()
-        img = vae.decode_latents(out)
-        torch.cuda.synchronize()
-        tv = time.perf_counter() - tv
-        vae_info = {"ms_per_image": tv / S * 1e3, "tflops": 2.5145 * S / tv, "images": S, "out_shape": list(img.shape),
-                    "finite": bool(torch.isfinite(img).all()), "note": "SD VAE decoder on the HIP kernels, synthetic "
-                    "seeded weights; not included in value / ms_per_step"}
+        cpu = cpu_baseline()
 
     if rank == 0:
+        sched = "DPM-Solver++ 2M" if args.scheduler == "dpm" else "DDIM"
+        metric = "sketch-guided images/sec whole-node, SD1.5 512px 50-step DDIM"
+        if C == 5:
+            metric = "sketch-guided images/sec whole-node, SD2.1 768px 50-step DDIM (clip_guided_attn)"
         res = {
-            "metric": "sketch-guided images/sec whole-node, SD1.5 512px 50-step DDIM",
+            "metric": metric,
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: SD1.5 architecture (synthetic seeded weights), "
-                                   f"{S} independent samples per GPU, 512x512 (64x64 latents), {T} DDIM steps, "
-                                   f"CFG 7.5, LGP sketch guidance on steps 0..{int(0.5 * T)} (beta 1.6)",
-                       "samples_per_gpu": S, "global_batch": world * S, "ddim_steps": T,
-                       "parallelism": f"replicas x{world} (samples sharded, weights broadcast, latents gathered)"},
-            "achieved_tflops_per_gpu": value / world * f_img_tflop(T),
-            "outputs_finite": finite, "setup_s": t_setup,
-            "roofline": roof, "cpu_baseline": cpu, "vae_decode": vae_info,
+            "config": {"workload": WORKLOADS[C].format(S=S, T=T, G=int(0.5 * T), sched=sched),
+                       "baseline_config": C, "samples_per_gpu": S, "global_batch": world * S, "ddim_steps": T,
+                       "scheduler": args.scheduler, "hip_graphs": bool(args.graph),
+                       "output": ("decoded uint8 images [S, H, W, 3] (VAE decode on-rank, inside the timed region"
+                                  + (", gathered on rank 0)" if world > 1 else ")")) if args.gather == "images"
+                       else "fp32 latents (no decode)",
+                       "parallelism": f"replicas x{world} (samples sharded, weights broadcast, "
+                                      f"{'decoded images' if args.gather == 'images' else 'latents'} gathered)"},
+            "ms_per_image": dt / args.steps / S * 1e3,
+            "achieved_tflops_per_gpu": value / world * f_img_tflop(C, T) if args.scheduler == "ddim" else None,
+            "tflop_per_image": f_img_tflop(C, T), "outputs_finite": finite, "out_shape": list(out.shape),
+            "setup_s": t_setup, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
+    if not finite:
+        sys.exit("bench.py: non-finite latents - the throughput above is INVALID")
 
 
 if __name__ == "__main__":

@@ -287,6 +287,11 @@ int skg_softmax_rows_f16(const void* x, int ldx, void* y, int ldy, int M, int N,
 int skg_image_postprocess(const void* x, int ld, float* out, size_t pixels, int C, float scale, float shift,
                           void* stream);
 
+/* The same tail fused with numpy_to_pil's quantisation (modules/pipeline.py:125 -> diffusers numpy_to_pil:
+ * (images * 255).round().astype("uint8")): out[px][c] = rint(clamp(x*scale + shift, 0, 1) * 255), uint8 NHWC
+ * [pixels][C] - the (S, 512, 512, 3) payload a rank contributes to the final gather of decoded images. */
+int skg_image_to_u8(const void* x, int ld, void* out, size_t pixels, int C, float scale, float shift, void* stream);
+
 /* VAE encoder tail (app.py:109: vae.encode(img).latent_dist.sample() * 0.18215): from the fp16 NHWC moments
  * [samples*HW][ld] = (mean[0..L), logvar[L..2L)) to float NCHW [samples][L][HW]:
  *   out = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale;   noise NULL -> the mode (mean * scale).

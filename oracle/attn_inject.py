@@ -93,18 +93,21 @@ def route_res_samples(res_samples: Sequence[Sequence[torch.Tensor]]) -> List[tor
     return list(down + up[::-1] + mid)
 
 
+_r = lambda x: _unet._r(x)      # fp16-storage emulation (oracle/unet.py fp16_storage), identity by default
+
+
 def _attn_module(sd, n, x, ctx, heads):
-    q = F.linear(x, sd[f"{n}.sketch_attn.to_q.weight"])
-    k = F.linear(ctx, sd[f"{n}.sketch_attn.to_k.weight"])
-    v = F.linear(ctx, sd[f"{n}.sketch_attn.to_v.weight"])
+    q = _r(F.linear(x, sd[f"{n}.sketch_attn.to_q.weight"]))
+    k = _r(F.linear(ctx, sd[f"{n}.sketch_attn.to_k.weight"]))
+    v = _r(F.linear(ctx, sd[f"{n}.sketch_attn.to_v.weight"]))
     o = _unet.attention(q, k, v, heads)
-    return F.linear(o, sd[f"{n}.sketch_attn.to_out.0.weight"], sd[f"{n}.sketch_attn.to_out.0.bias"])
+    return _r(F.linear(o, sd[f"{n}.sketch_attn.to_out.0.weight"], sd[f"{n}.sketch_attn.to_out.0.bias"]))
 
 
 def _conv_scale_residual(sd, n, a, h, scale):
     a = a[:, : h.shape[1], : h.shape[2]].permute(0, 2, 1)
     a = scale * F.conv1d(a, sd[f"{n}.sketch_conv.weight"], sd[f"{n}.sketch_conv.bias"])
-    return a.permute(0, 2, 1) + h
+    return _r(a.permute(0, 2, 1) + h)
 
 
 def make_clip_inject(sd: Dict[str, torch.Tensor], sketch_state: torch.Tensor, scale: float = 1.0):
@@ -112,9 +115,9 @@ def make_clip_inject(sd: Dict[str, torch.Tensor], sketch_state: torch.Tensor, sc
     def inject(path, h, heads):
         n = module_name(path)
         c = h.shape[-1]
-        s = F.linear(sketch_state.to(h.dtype), sd[f"{n}.sketch_proj.weight"], sd[f"{n}.sketch_proj.bias"])
-        z = F.layer_norm(torch.cat([h, s], dim=1), (c,), sd[f"{n}.sketch_norm.weight"],
-                         sd[f"{n}.sketch_norm.bias"], 1e-5)
+        s = _r(F.linear(sketch_state.to(h.dtype), sd[f"{n}.sketch_proj.weight"], sd[f"{n}.sketch_proj.bias"]))
+        z = _r(F.layer_norm(torch.cat([h, s], dim=1), (c,), sd[f"{n}.sketch_norm.weight"],
+                            sd[f"{n}.sketch_norm.bias"], 1e-5))
         a = _attn_module(sd, n, z, z, heads)
         return _conv_scale_residual(sd, n, a, h, scale)
     return inject
@@ -128,7 +131,7 @@ def make_sketch_inject(cfg, sd: Dict[str, torch.Tensor], res_samples, scale: flo
     def inject(path, h, heads):
         n = module_name(path)
         c = h.shape[-1]
-        z = F.layer_norm(h, (c,), sd[f"{n}.sketch_norm.weight"], sd[f"{n}.sketch_norm.bias"], 1e-5)
+        z = _r(F.layer_norm(h, (c,), sd[f"{n}.sketch_norm.weight"], sd[f"{n}.sketch_norm.bias"], 1e-5))
         a = _attn_module(sd, n, z, table[path].to(h.dtype), heads)
         return _conv_scale_residual(sd, n, a, h, scale)
     return inject

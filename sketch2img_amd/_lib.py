@@ -60,6 +60,7 @@ SIGNATURES = {
     "skg_cfg_ddim_step": ("i", "ppipppiifffffp"),
     "skg_softmax_rows_f16": ("i", "pipiiip"),
     "skg_image_postprocess": ("i", "pipziffp"),
+    "skg_image_to_u8": ("i", "pipziffp"),
     "skg_gaussian_sample": ("i", "pippiiifp"),
     "skg_cfg_dpmpp2m_step": ("i", "ppippppiiffffffp"),
     "skg_guidance_update": ("i", "pipppiifp"),

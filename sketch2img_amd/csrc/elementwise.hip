@@ -306,6 +306,18 @@ __global__ __launch_bounds__(256) void image_post_kernel(const half_t* __restric
   }
 }
 
+// decode_latents tail + numpy_to_pil's quantisation (modules/pipeline.py:118,125): one thread per pixel,
+// u8[px][c] = rint(clamp(x*scale + shift, 0, 1) * 255)  (numpy's round = half to even = v_rndne)
+__global__ __launch_bounds__(256) void image_u8_kernel(const half_t* __restrict__ x, int ld, unsigned char* __restrict__ out,
+                                                       size_t pixels, int C, float scale, float shift) {
+  for (size_t px = (size_t)blockIdx.x * 256 + threadIdx.x; px < pixels; px += (size_t)gridDim.x * 256) {
+    const half_t* src = x + px * ld;
+    unsigned char* dst = out + px * C;
+    for (int c = 0; c < C; ++c)
+      dst[c] = (unsigned char)rintf(fminf(fmaxf((float)src[c] * scale + shift, 0.f), 1.f) * 255.f);
+  }
+}
+
 // DiagonalGaussianDistribution.sample() * scale from the encoder's moments: fp16 NHWC [px][ld] = (mean[0..L), logvar[L..2L))
 // -> float NCHW [S][L][HW]; logvar clamped to [-30, 20]; noise = caller-drawn N(0,1), NCHW (NULL: the mode = mean)
 __global__ __launch_bounds__(256) void gaussian_sample_kernel(const half_t* __restrict__ m, int ld,
@@ -527,6 +539,15 @@ extern "C" int skg_image_postprocess(const void* x, int ld, float* out, size_t p
   hipLaunchKernelGGL(image_post_kernel, dim3(ew_grid((size_t)pixels * C)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x, ld, out, (size_t)pixels, C, scale, shift);
   SKG_CHECK_LAUNCH("skg_image_postprocess");
+  return SKG_OK;
+}
+
+extern "C" int skg_image_to_u8(const void* x, int ld, void* out, size_t pixels, int C, float scale, float shift,
+                               void* stream) {
+  SKG_REQUIRE(x && out && pixels > 0 && C > 0 && ld >= C);
+  hipLaunchKernelGGL(image_u8_kernel, dim3(ew_grid((size_t)pixels)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x, ld, (unsigned char*)out, (size_t)pixels, C, scale, shift);
+  SKG_CHECK_LAUNCH("skg_image_to_u8");
   return SKG_OK;
 }
 

@@ -4,7 +4,8 @@ The sampler shards by SAMPLE: each trajectory is independent (the reference only
 there is no per-step collective.  Two collectives exist, both outside the per-step path:
   * broadcast_state_dict - rank 0's UNet / LGP weights to every rank, as a few large fp16 buckets
     (xGMI is point-to-point, ~153 GB/s per link: few large transfers, not one per tensor);
-  * gather_latents - the final latents of every rank to rank 0.
+  * gather_images - the decoded uint8 images of every rank (VAE decode runs on the rank that sampled) to rank 0;
+    gather_latents - the same for the fp32 latents, for callers that decode elsewhere.
 The reference has no multi-GPU inference path (app.py:45-46 is a single pipe.to("cuda")); its only
 collectives are the implicit DDP all-reduces of the training scripts (trainer.py:91), out of scope.
 """
@@ -71,10 +72,24 @@ def _numel(s) -> int:
 
 def gather_latents(x: torch.Tensor, world: int, dst: int = 0):
     """x [S,4,h,h] fp32 on every rank -> list of ``world`` tensors on rank dst (None elsewhere)."""
+    return _gather(x, world, dst)
+
+
+def _gather(x: torch.Tensor, world: int, dst: int):
     x = x.contiguous()
+    dev = x.device
+    if dist.get_backend() == "gloo" and x.is_cuda:       # CPU tests / several ranks on one GPU: stage through the host
+        x = x.cpu()
     bufs = [torch.empty_like(x) for _ in range(world)] if dist.get_rank() == dst else None
     dist.gather(x, bufs, dst=dst)
-    return bufs
+    return None if bufs is None else [b.to(dev) for b in bufs]
+
+
+def gather_images(img: torch.Tensor, world: int, dst: int = 0):
+    """img uint8 [S, H, W, 3] (decoded on the rank that sampled it: 786 432 B per 512x512 image) on every rank ->
+    list of ``world`` tensors on rank dst (None elsewhere).  The final gather north_star / SURVEY 8(e) describe."""
+    assert img.dtype == torch.uint8
+    return _gather(img, world, dst)
 
 
 def shard_range(total: int, rank: int, world: int):

@@ -34,8 +34,10 @@ class LatentEdgePredictor(nn.Module):
     def _engine(self, tap_channels, device):
         """HipLGP built from the current parameters (rebuilt when they, the mode or the tap split change)."""
         from ..lgp import HipLGP
+        # parameters AND BatchNorm buffers: version counters catch in-place edits (copy_, load_state_dict), data_ptr
+        # catches re-assignment (.to(), .half(), p.data = ...) which does not bump _version
         key = (tuple(tap_channels), str(device), self.training,
-               tuple(int(p._version) for p in self.layers.parameters()))
+               tuple((int(t._version), t.data_ptr()) for t in list(self.layers.parameters()) + list(self.layers.buffers())))
         if self._hip is None or self._hip_key != key:
             self._hip = HipLGP(self.state_dict(), tap_channels, device, training=self.training)
             self._hip_key = key
@@ -52,7 +54,11 @@ class LatentEdgePredictor(nn.Module):
                 bn.running_mean.copy_(self._hip.running_mean[l].to(bn.running_mean.dtype))
                 bn.running_var.copy_(self._hip.running_var[l].to(bn.running_var.dtype))
                 bn.num_batches_tracked.fill_(self._hip.num_batches_tracked[l])
-        self._hip_key = None if self._hip_key is None else self._hip_key
+        # the write-back above bumped the buffers' versions: re-key so the engine (which holds exactly these values)
+        # is not rebuilt, while any LATER edit of parameters or buffers by the user still is
+        if self._hip_key is not None:
+            self._hip_key = self._hip_key[:3] + (
+                tuple((int(t._version), t.data_ptr()) for t in list(self.layers.parameters()) + list(self.layers.buffers())),)
 
     def forward(self, x, t):
         """x (B, C, h, w) features, t (B, 4, h, w) noise level (the pipeline passes cat([nl] * 2)).

@@ -11,9 +11,10 @@ Around the hot path:
                      ``decode(latents) -> tensor | .sample`` (and ``encode`` for app.py:109) is used as a PyTorch module;
   * ``text_encoder`` a callable ``(list[str]) -> (B, 77, D) tensor`` - ``sketch2img_amd.clip_text.PromptEncoder``
                      (CLIP tokenizer + the text transformer on the HIP kernels) is picked up automatically when the
-                     checkpoint folder has ``tokenizer/`` and ``text_encoder/``; without one, prompts map to seeded
-                     pseudo-embeddings (deterministic in the prompt text) so that the pipeline stays runnable
-                     on a box with no CLIP weights.
+                     checkpoint folder has ``tokenizer/`` and ``text_encoder/``.  Seeded pseudo-embeddings
+                     (deterministic in the prompt text) and seeded synthetic UNet weights exist for boxes without
+                     checkpoints, but only behind the explicit opt-in ``from_pretrained(None)`` / ``synthetic=True``:
+                     a path that does not resolve to weights raises.
 Schedulers: DDIM (the BASELINE metric) and DPM-Solver++ 2M (what app.py configures); see `sketch2img_amd.schedulers`.
 """
 from __future__ import annotations
@@ -90,35 +91,101 @@ class UNetFacade:
         return SimpleNamespace(sample=ops.nhwc_to_nchw(eps, rows, self.cfg.out_channels, h, w))
 
 
-def _load_unet_weights(path: Optional[str], cfg: UNetConfig):
-    """diffusers-layout folder (``<path>/unet/diffusion_pytorch_model.safetensors`` or ``.bin``) if present,
-    else seeded synthetic weights (no checkpoints exist on the build / GPU boxes)."""
-    if path and os.path.isdir(os.path.join(path, "unet")):
-        d = os.path.join(path, "unet")
-        st = os.path.join(d, "diffusion_pytorch_model.safetensors")
-        if os.path.exists(st):
-            from safetensors.torch import load_file
-            return load_file(st)
-        pt = os.path.join(d, "diffusion_pytorch_model.bin")
-        if os.path.exists(pt):
-            return torch.load(pt, map_location="cpu")
+WEIGHT_FILES = ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.fp16.safetensors",
+                "diffusion_pytorch_model.bin", "diffusion_pytorch_model.fp16.bin")
+
+
+def load_diffusers_weights(folder: str, what: str):
+    """state_dict of a diffusers-layout sub-folder (``<root>/unet``, ``<root>/vae``): single-file or sharded
+    safetensors / .bin, plain or ``.fp16`` variant.  Raises FileNotFoundError when nothing loadable is there - a
+    path that does not resolve to weights must never fall through to random weights (a hub id such as
+    "runwayml/stable-diffusion-v1-5", which app.py:32 passes, is not a local folder: there is no network here)."""
+    if not os.path.isdir(folder):
+        raise FileNotFoundError(
+            f"{what}: {folder!r} is not a local diffusers-layout folder (hub ids cannot be resolved: no network). "
+            f"Pass a local checkpoint folder, or None / synthetic=True for seeded synthetic weights.")
+    for name in WEIGHT_FILES:
+        f = os.path.join(folder, name)
+        if os.path.exists(f):
+            if name.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                return load_file(f)
+            return torch.load(f, map_location="cpu")
+    for idx in ("diffusion_pytorch_model.safetensors.index.json", "diffusion_pytorch_model.bin.index.json"):
+        f = os.path.join(folder, idx)
+        if os.path.exists(f):
+            sd = {}
+            for shard in sorted(set(json.load(open(f))["weight_map"].values())):
+                sp = os.path.join(folder, shard)
+                if shard.endswith(".safetensors"):
+                    from safetensors.torch import load_file
+                    sd.update(load_file(sp))
+                else:
+                    sd.update(torch.load(sp, map_location="cpu"))
+            return sd
+    raise FileNotFoundError(f"{what}: no diffusion_pytorch_model.{{safetensors,bin}} (plain, .fp16 or sharded) in {folder!r}")
+
+
+def _load_unet_weights(path: Optional[str], cfg: UNetConfig, synthetic_ok: bool):
+    """``path`` None (or synthetic=True): seeded synthetic weights, the explicit opt-in used on boxes without
+    checkpoints.  Otherwise the folder MUST hold the weights, and their shapes must match ``cfg``."""
     from .. import synthetic
-    return synthetic.unet_state_dict(cfg)
+    if path is None or synthetic_ok and not os.path.isdir(os.path.join(str(path), "unet")):
+        return synthetic.unet_state_dict(cfg)
+    sd = load_diffusers_weights(os.path.join(path, "unet"), "AntiGradientPipeline.from_pretrained")
+    want = synthetic.unet_param_shapes(cfg)
+    missing = [k for k in want if k not in sd]
+    wrong = [k for k in want if k in sd and tuple(sd[k].shape) != tuple(want[k])
+             and tuple(sd[k].shape) != tuple(want[k]) + (1, 1) and tuple(sd[k].shape) + (1, 1) != tuple(want[k])]
+    if missing or wrong:
+        raise ValueError(f"unet checkpoint does not match the architecture {cfg}: {len(missing)} missing keys "
+                         f"(e.g. {missing[:3]}), {len(wrong)} shape mismatches (e.g. {wrong[:3]})")
+    return sd
 
 
 def _config_from_folder(path: Optional[str]) -> UNetConfig:
-    if path:
-        cj = os.path.join(path, "unet", "config.json")
-        if os.path.exists(cj):
-            c = json.load(open(cj))
-            if c.get("cross_attention_dim") == 1024:
-                return SD21
-    return SD15
+    """UNetConfig from ``<path>/unet/config.json``; every field that changes the graph is read and anything this
+    implementation does not cover is rejected instead of ignored."""
+    if not path:
+        return SD15
+    cj = os.path.join(path, "unet", "config.json")
+    if not os.path.exists(cj):
+        return SD15
+    c = json.load(open(cj))
+    boc = tuple(c.get("block_out_channels", SD15.block_out_channels))
+    ahd = c.get("attention_head_dim", 8)            # diffusers' "attention_head_dim" is a head COUNT for these models
+    heads = tuple(ahd) if isinstance(ahd, (list, tuple)) else (int(ahd),) * len(boc)
+    down = c.get("down_block_types", ["CrossAttnDownBlock2D"] * (len(boc) - 1) + ["DownBlock2D"])
+    up = c.get("up_block_types", ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * (len(boc) - 1))
+    unsupported = []
+    if list(down) != ["CrossAttnDownBlock2D"] * (len(boc) - 1) + ["DownBlock2D"] or \
+            list(up) != ["UpBlock2D"] + ["CrossAttnUpBlock2D"] * (len(boc) - 1):
+        unsupported.append(f"block types {down} / {up}")
+    for k, ok in (("act_fn", "silu"), ("center_input_sample", False), ("flip_sin_to_cos", True), ("freq_shift", 0),
+                  ("downsample_padding", 1), ("mid_block_scale_factor", 1), ("dual_cross_attention", False),
+                  ("only_cross_attention", False), ("class_embed_type", None), ("num_class_embeds", None),
+                  ("upcast_attention", None), ("resnet_time_scale_shift", "default")):
+        v = c.get(k, ok)
+        if k == "upcast_attention":
+            continue                                  # fp32 softmax statistics are what the flash kernel always does
+        if v != ok:
+            unsupported.append(f"{k}={v!r}")
+    if len(heads) != len(boc) or len(boc) != 4:
+        unsupported.append(f"block_out_channels {boc} / attention_head_dim {ahd}")
+    if unsupported:
+        raise NotImplementedError("unet/config.json asks for features outside the SD1.x / SD2.x UNet this package "
+                                  "implements: " + "; ".join(unsupported))
+    return UNetConfig(in_channels=c.get("in_channels", 4), out_channels=c.get("out_channels", 4), block_out_channels=boc,
+                      layers_per_block=c.get("layers_per_block", 2), cross_attention_dim=c.get("cross_attention_dim", 768),
+                      num_heads=heads, use_linear_projection=bool(c.get("use_linear_projection", False)),
+                      norm_groups=c.get("norm_num_groups", 32), sample_size=c.get("sample_size", 64))
 
 
 class AntiGradientPipeline:
-    def __init__(self, unet: UNetFacade, vae=None, scheduler=None, text_encoder: Optional[Callable] = None):
+    def __init__(self, unet: UNetFacade, vae=None, scheduler=None, text_encoder: Optional[Callable] = None,
+                 allow_pseudo_text: bool = False):
         self.unet, self.vae, self.scheduler, self.text_encoder = unet, vae, scheduler, text_encoder
+        self.allow_pseudo_text = allow_pseudo_text      # seeded pseudo text embeddings: synthetic pipelines only
         self.vae_scale_factor = 8
         self.lgp_model: Optional[LatentEdgePredictor] = None
         self.feature_blocks = None
@@ -127,15 +194,21 @@ class AntiGradientPipeline:
     # ------------------------------------------------------------------ construction (app.py:32-46,67-70)
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path=None, vae=None, torch_dtype=None, scheduler=None,
-                        text_encoder=None, unet_config: Optional[UNetConfig] = None, **kwargs):
-        cfg = unet_config or _config_from_folder(pretrained_model_name_or_path)
-        sd = _load_unet_weights(pretrained_model_name_or_path, cfg)
+                        text_encoder=None, unet_config: Optional[UNetConfig] = None, synthetic: bool = False, **kwargs):
+        """``pretrained_model_name_or_path``: a local diffusers-layout folder (``unet/``, optionally ``tokenizer/`` +
+        ``text_encoder/``).  ``None`` or ``synthetic=True`` is the explicit opt-in to seeded synthetic UNet weights and
+        seeded pseudo text embeddings (boxes without checkpoints, tests, bench.py); any other path that does not
+        resolve to weights raises FileNotFoundError instead of sampling noise from random weights."""
         root = pretrained_model_name_or_path
+        synthetic = synthetic or root is None
+        cfg = unet_config or _config_from_folder(root)
+        sd = _load_unet_weights(root, cfg, synthetic)
         if text_encoder is None and root and os.path.isdir(os.path.join(root, "tokenizer")) \
                 and os.path.isdir(os.path.join(root, "text_encoder")):
             from ..clip_text import PromptEncoder
             text_encoder = PromptEncoder.from_pretrained(root)
-        return cls(UNetFacade(cfg, sd, "cpu"), vae=vae, scheduler=scheduler, text_encoder=text_encoder)
+        return cls(UNetFacade(cfg, sd, "cpu"), vae=vae, scheduler=scheduler, text_encoder=text_encoder,
+                   allow_pseudo_text=synthetic)
 
     def to(self, device):
         self.unet.to(device)
@@ -175,6 +248,10 @@ class AntiGradientPipeline:
             negs = list(negative_prompt)
         if len(negs) != len(prompts):
             raise ValueError("`negative_prompt` and `prompt` must have the same batch size")
+        if self.text_encoder is None and not self.allow_pseudo_text:
+            raise RuntimeError("AntiGradientPipeline: no text encoder - the checkpoint folder has no tokenizer/ + "
+                               "text_encoder/; pass text_encoder=<callable (list[str]) -> (B, 77, D)>, or build the "
+                               "pipeline with synthetic=True to get seeded pseudo embeddings")
         enc = self.text_encoder or self._pseudo_text_encoder
         cond = enc(prompts).repeat_interleave(num_images_per_prompt, 0)
         if not do_classifier_free_guidance:
@@ -293,6 +370,15 @@ class AntiGradientPipeline:
         cfg = getattr(sch, "config", sch)
         get = lambda k, d: (cfg.get(k, d) if isinstance(cfg, dict) else getattr(cfg, k, d))
         name = type(sch).__name__
+        # options that change the arithmetic are rejected, never ignored (a diffusers scheduler object carries them)
+        if get("prediction_type", "epsilon") != "epsilon":
+            raise NotImplementedError(f"prediction_type={get('prediction_type', None)!r}: epsilon prediction only "
+                                      "(SD2.1-768 checkpoints are v-prediction)")
+        if get("beta_schedule", "scaled_linear") != "scaled_linear" or get("trained_betas", None) is not None:
+            raise NotImplementedError("scaled_linear betas (Stable Diffusion) only")
+        if "DDIM" in name and get("clip_sample", False):
+            raise NotImplementedError("DDIM clip_sample=True is not implemented (Stable Diffusion uses clip_sample=False; "
+                                      "note that diffusers' DDIMScheduler() default is True)")
         if "DPMSolverMultistep" in name or get("algorithm_type", None) is not None:
             if get("algorithm_type", "dpmsolver++") != "dpmsolver++" or get("solver_type", "midpoint") != "midpoint":
                 raise NotImplementedError("DPM-Solver: only algorithm_type='dpmsolver++', solver_type='midpoint'")

@@ -18,15 +18,22 @@ CONV_S1, CONV_S2, CONV_UP2, CONV_S2T, CONV_S2A = 0, 1, 2, 3, 4
 
 
 _workspace = {}
+_workspace_dev = None
 WORKSPACE_BYTES = 128 << 20
 
 
 def _stream() -> int:
-    """Current HIP stream; also hands libskg.so its split-K workspace the first time a device is used."""
+    """Current HIP stream; also hands libskg.so the split-K workspace of the CURRENT device (one slab per device; the
+    library holds one pointer, so it is re-pointed whenever the current device changes).  Launches are assumed to
+    come from one stream per device at a time: the slab and the cached scratch buffers below are shared by every
+    launch (the pipeline is not re-entrant, like the reference's module-level state - DESIGN.md 4)."""
+    global _workspace_dev
     dev = torch.cuda.current_device()
-    if dev not in _workspace:
-        _workspace[dev] = torch.empty(WORKSPACE_BYTES // 4, device=f"cuda:{dev}", dtype=torch.float32)
+    if dev != _workspace_dev:
+        if dev not in _workspace:
+            _workspace[dev] = torch.empty(WORKSPACE_BYTES // 4, device=f"cuda:{dev}", dtype=torch.float32)
         check(lib.skg_set_workspace(_workspace[dev].data_ptr(), WORKSPACE_BYTES), "skg_set_workspace")
+        _workspace_dev = dev
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -468,6 +475,14 @@ def image_postprocess(X, pixels: int, C: int, scale: float = 0.5, shift: float =
     out = torch.empty(pixels, C, device=X.device, dtype=torch.float32)
     check(lib.skg_image_postprocess(_p(X), _ld(X), _p(out), pixels, C, scale, shift, _stream()),
           "skg_image_postprocess")
+    return out
+
+
+def image_to_u8(X, pixels: int, C: int, scale: float = 0.5, shift: float = 0.5):
+    """fp16 NHWC rows -> uint8 [pixels, C] = rint(clamp(x*scale + shift, 0, 1) * 255) (numpy_to_pil's quantisation)."""
+    _f16(X)
+    out = torch.empty(pixels, C, device=X.device, dtype=torch.uint8)
+    check(lib.skg_image_to_u8(_p(X), _ld(X), _p(out), pixels, C, scale, shift, _stream()), "skg_image_to_u8")
     return out
 
 

@@ -107,11 +107,18 @@ def guided_step(i: int, T: int) -> bool:
 
 
 class HipSampler:
-    def __init__(self, unet: HipUNet, lgp: Optional[HipLGP] = None):
-        self.unet, self.lgp = unet, lgp
+    """``use_graphs``: replay every step of the schedule from a captured hipGraph (one graph per step index - the
+    per-step scalars and the per-timestep bias vectors are baked into the kernel arguments, the latents live in
+    static buffers).  The reference's real caller samples ONE image per call (app.py:113-123); at that size a step is
+    ~900 launches of a few microseconds each and the Python / ctypes launch path, not the GPU, sets the pace."""
+
+    def __init__(self, unet: HipUNet, lgp: Optional[HipLGP] = None, use_graphs: bool = False):
+        self.unet, self.lgp, self.use_graphs = unet, lgp, use_graphs
         self.last_aux: List[Optional[torch.Tensor]] = []
+        self.last_latents: Optional[torch.Tensor] = None
         self._x0_before: Optional[torch.Tensor] = None      # DPM-Solver++ history (one x0 prediction)
         self._seen = 0
+        self._graphs: dict = {}
 
     def reset_history(self):
         self._x0_before, self._seen = None, 0
@@ -152,7 +159,7 @@ class HipSampler:
     def sample(self, latents0: torch.Tensor, target: Optional[torch.Tensor], num_inference_steps: int = 50,
                guidance_scale: float = 7.5, beta: float = 1.6,
                callback: Optional[Callable[[int, int, torch.Tensor], None]] = None,
-               tables=None) -> torch.Tensor:
+               tables=None, graphs: Optional[bool] = None) -> torch.Tensor:
         dev = self.unet.dev
         tab = tables or DDIMTables.make(num_inference_steps)
         x = latents0.to(dev, torch.float32).contiguous()
@@ -161,9 +168,69 @@ class HipSampler:
         self.unet.prepare_timesteps(tab.timesteps.tolist())
         self.last_aux = []
         self.reset_history()
-        for i, t in enumerate(tab.timesteps.tolist()):
-            x, _, aux = self.step(x, noise, tgt, tab, i, guidance_scale, beta)
-            self.last_aux.append(aux)
-            if callback is not None:
-                callback(i, t, x)
+        if (self.use_graphs if graphs is None else graphs) and callback is None:
+            x = self._sample_graphed(x, tgt, tab, guidance_scale, beta)
+        else:
+            for i, t in enumerate(tab.timesteps.tolist()):
+                x, _, aux = self.step(x, noise, tgt, tab, i, guidance_scale, beta)
+                self.last_aux.append(aux)
+                if callback is not None:
+                    callback(i, t, x)
+        self.last_latents = x
         return x
+
+    # ------------------------------------------------------------------------------------------ hipGraph replay
+    def _sample_graphed(self, x: torch.Tensor, tgt: Optional[torch.Tensor], tab, guidance_scale: float, beta: float):
+        """Captures (first call for a given schedule / shape) and replays one hipGraph per step.  Every launch of a
+        step goes to torch's current stream, which is the capturing stream inside ``torch.cuda.graph``; nothing on the
+        step path allocates outside torch's (graph-private) pool or synchronises with the host."""
+        T = len(tab.timesteps)
+        key = (type(tab).__name__, tuple(int(t) for t in tab.timesteps), tuple(x.shape), tgt is None,
+               float(guidance_scale), float(beta), id(self.unet.inject), self.unet.ctx is not None and id(self.unet.ctx))
+        ent = self._graphs.get(key)
+        if ent is None:
+            xs, ns = torch.empty_like(x), torch.empty_like(x)
+            ts = None if tgt is None else torch.empty_like(tgt)
+            x0b = torch.zeros_like(x)
+            # one eager pass first: lazily created scratch / workspace buffers and the per-timestep bias vectors must
+            # exist before a capture (allocations inside a capture belong to the graph's pool)
+            xs.copy_(x); ns.copy_(x)
+            if ts is not None:
+                ts.copy_(tgt)
+            saved = None if self.lgp is None else [[r.clone() for r in self.lgp.running_mean], [r.clone() for r in self.lgp.running_var],
+                                                   list(self.lgp.num_batches_tracked)]
+            self._x0_before, self._seen = x0b, 0
+            w = xs.clone()
+            for i in range(T):
+                w, _, _ = self.step(w, ns, ts, tab, i, guidance_scale, beta)
+            if saved is not None:       # the warm-up pass is not part of the trajectory: undo its BatchNorm side effects
+                for l in range(4):
+                    self.lgp.running_mean[l].copy_(saved[0][l]); self.lgp.running_var[l].copy_(saved[1][l])
+                self.lgp.num_batches_tracked = saved[2]
+            torch.cuda.synchronize()
+            pool = torch.cuda.graph_pool_handle()
+            graphs, auxs = [], []
+            self._x0_before, self._seen = x0b, 0
+            for i in range(T):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    xn, _, aux = self.step(xs, ns, ts, tab, i, guidance_scale, beta)
+                    xs.copy_(xn)
+                graphs.append(g)
+                auxs.append(aux)
+            if saved is not None:       # captures do not execute, but keep the Python-side counters where they were
+                self.lgp.num_batches_tracked = list(saved[2])
+            ent = self._graphs[key] = dict(graphs=graphs, auxs=auxs, xs=xs, ns=ns, ts=ts, x0b=x0b)
+        ent["xs"].copy_(x); ent["ns"].copy_(x)
+        if tgt is not None:
+            ent["ts"].copy_(tgt)
+        ent["x0b"].zero_()
+        S = x.shape[0]
+        for i, g in enumerate(ent["graphs"]):
+            g.replay()
+            aux = ent["auxs"][i]
+            self.last_aux.append(None if aux is None else aux.clone())
+            if aux is not None and self.lgp is not None and self.lgp.training:
+                for l in range(4):
+                    self.lgp.num_batches_tracked[l] += S
+        return ent["xs"].clone()

@@ -159,6 +159,71 @@ def lgp_input_dim(cfg: UNetConfig) -> int:
     return sum(tap_channels(cfg)) + 4 + 36
 
 
+# ------------------------------------------------------------------------- injected attention (configs 4 / 5)
+SAT_WEIGHT_SEED = 20260930
+
+
+def satmixin_param_shapes(cfg: UNetConfig, variant: str) -> "OrderedDict[str, tuple]":
+    """SatMixin.state_dict() keys / shapes (modules/clip_guided_attn.py:14-27,52-63; sketch_guided_attn.py:52-70):
+    per BasicTransformerBlock, in unet.named_modules() order; variant 'clip' adds sketch_proj."""
+    from .inject import block_dims, module_name
+    m: "OrderedDict[str, tuple]" = OrderedDict()
+    for path, c, _ in block_dims(cfg):
+        n = module_name(path)
+        if variant == "clip":
+            m[f"{n}.sketch_proj.weight"] = (c, 1024)
+            m[f"{n}.sketch_proj.bias"] = (c,)
+        m[f"{n}.sketch_norm.weight"] = (c,)
+        m[f"{n}.sketch_norm.bias"] = (c,)
+        for q in ("to_q", "to_k", "to_v"):
+            m[f"{n}.sketch_attn.{q}.weight"] = (c, c)
+        m[f"{n}.sketch_attn.to_out.0.weight"] = (c, c)
+        m[f"{n}.sketch_attn.to_out.0.bias"] = (c,)
+        m[f"{n}.sketch_conv.weight"] = (c, c, 1)
+        m[f"{n}.sketch_conv.bias"] = (c,)
+    return m
+
+
+def satmixin_state_dict(cfg: UNetConfig, variant: str, seed: int = SAT_WEIGHT_SEED) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    man = satmixin_param_shapes(cfg, variant)
+    sd: Dict[str, torch.Tensor] = {}
+    for k, shp in man.items():
+        if ".sketch_norm." in k:
+            v = (torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)) + 0.1 * (torch.rand(shp, generator=g) - 0.5)
+        else:
+            wk = k[: -len("bias")] + "weight" if k.endswith("bias") else k
+            v = (torch.rand(shp, generator=g) * 2 - 1) / math.sqrt(math.prod(man[wk][1:]))
+        sd[k] = v.half().float()
+    return sd
+
+
+def res_samples(cfg: UNetConfig, first: int, count: int, h: int):
+    """Config 4 input: what ``SatMixin.set_res_samples`` takes (modules/sketch_guided_attn.py:29-40) - per
+    down block a tuple of NCHW tensors, here seeded per sample (seed 3000 + global sample index) and laid out in the
+    sampler's row order [uncond rows ; cond rows] with both CFG rows of a sample carrying the same features (the
+    SketchEncoder sees the same sketch for both)."""
+    boc, nb = cfg.block_out_channels, len(cfg.block_out_channels)
+    gens = [torch.Generator().manual_seed(3000 + i) for i in range(first, first + count)]
+    out = []
+    for i, c in enumerate(boc):
+        sizes = [h >> i] * cfg.layers_per_block + ([h >> (i + 1)] if i < nb - 1 else [])
+        blk = []
+        for s in sizes:
+            one = torch.stack([torch.randn(c, s, s, generator=g) for g in gens]).half().float()
+            blk.append(torch.cat([one, one]))
+        out.append(tuple(blk))
+    return out
+
+
+def sketch_state(first: int, count: int, tokens: int = 257, dim: int = 1024) -> torch.Tensor:
+    """Config 5 input: [zeros (uncond rows) ; CLIP-vision hidden states (cond rows)] as modules/clip_guided_inf.py:107
+    stacks them; the hidden states are seeded stand-ins, seed 9 + global sample index (seed 9)."""
+    hid = torch.stack([torch.randn(tokens, dim, generator=torch.Generator().manual_seed(9 + i))
+                       for i in range(first, first + count)]).half().float()
+    return torch.cat([torch.zeros_like(hid), hid])
+
+
 # ---------------------------------------------------------------------------------------------- VAE decoder
 VAE_WEIGHT_SEED = 20260930
 

@@ -41,6 +41,25 @@ class _HipVAEBlocks:
         W[a + ".qkv.weight"] = torch.cat([W.pop(f"{a}.{n}.weight") for n in ("query", "key", "value")]).contiguous()
         W[a + ".qkv.bias"] = torch.cat([W.pop(f"{a}.{n}.bias") for n in ("query", "key", "value")]).contiguous()
 
+    @staticmethod
+    def normalise_attention_keys(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """The VAE mid-block attention under either diffusers spelling: legacy AttentionBlock
+        (``query / key / value / proj_attn``, the 0.12-0.14 era the reference dates to) or the current Attention class
+        (``to_q / to_k / to_v / to_out.0``, e.g. sd-vae-ft-mse re-saves; Linear or 1x1-conv shaped) -> legacy names,
+        2-D weights."""
+        ren = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+        out = {}
+        for k, v in sd.items():
+            if ".attentions." in k:
+                for new, old in ren.items():
+                    if f".{new}." in k:
+                        k = k.replace(f".{new}.", f".{old}.")
+                        break
+                if k.endswith(".weight") and v.dim() == 4 and any(f".{o}." in k for o in ren.values()):
+                    v = v.reshape(v.shape[0], v.shape[1])
+            out[k] = v
+        return out
+
     # ------------------------------------------------------------------------------------------ blocks
     def _res(self, p, x, rows, H):
         W, G, HW = self.W, self.cfg.norm_groups, H * H
@@ -79,6 +98,7 @@ class HipVAEDecoder(_HipVAEBlocks):
 
     # ------------------------------------------------------------------------------------------ weights
     def _pack(self, sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        sd = self.normalise_attention_keys(sd)
         cfg, dev = self.cfg, self.dev
         sd = {k: v for k, v in sd.items() if k.startswith(("decoder.", "post_quant_conv."))}
         W: Dict[str, torch.Tensor] = {}
@@ -153,6 +173,19 @@ class HipVAEDecoder(_HipVAEBlocks):
         return torch.cat(outs)
 
 
+    @torch.no_grad()
+    def decode_to_u8(self, latents: torch.Tensor) -> torch.Tensor:
+        """decode_latents + numpy_to_pil's quantisation on the device: latents [S,4,h,h] -> uint8 [S, 8h, 8h, 3]
+        (what a rank hands to the final gather: 786 432 B per 512x512 image)."""
+        outs = []
+        for s0 in range(0, latents.shape[0], self.chunk):
+            z = latents[s0:s0 + self.chunk].to(self.dev, torch.float32) * (1.0 / self.cfg.scaling_factor)
+            y, H = self.decode_tokens(z)
+            n = y.shape[0] // (H * H)
+            outs.append(ops.image_to_u8(y, y.shape[0], self.cfg.out_channels).reshape(n, H, H, -1))
+        return torch.cat(outs)
+
+
 class HipVAEEncoder(_HipVAEBlocks):
     """AutoencoderKL.encode on the HIP kernels: float images [S, 3, H, W] in [-1, 1] -> fp16 NHWC moments."""
 
@@ -162,6 +195,7 @@ class HipVAEEncoder(_HipVAEBlocks):
         self.W = self._pack(state_dict)
 
     def _pack(self, sd):
+        sd = self.normalise_attention_keys(sd)
         cfg, dev = self.cfg, self.dev
         sd = {k: v.detach().float() for k, v in sd.items() if k.startswith(("encoder.", "quant_conv."))}
         W: Dict[str, torch.Tensor] = {}
@@ -291,16 +325,14 @@ class AutoencoderKL:
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path=None, subfolder: Optional[str] = None, torch_dtype=None,
                         config: Optional[VAEConfig] = None, **kwargs):
+        """``None``: seeded synthetic weights (explicit opt-in).  Any other path must resolve to a local diffusers-layout
+        folder with the weights, else FileNotFoundError - never a silent fall-through to random weights."""
         import os
         sd = None
-        if pretrained_model_name_or_path:
+        if pretrained_model_name_or_path is not None:
+            from .modules.pipeline import load_diffusers_weights
             d = os.path.join(pretrained_model_name_or_path, subfolder) if subfolder else pretrained_model_name_or_path
-            st, pt = os.path.join(d, "diffusion_pytorch_model.safetensors"), os.path.join(d, "diffusion_pytorch_model.bin")
-            if os.path.exists(st):
-                from safetensors.torch import load_file
-                sd = load_file(st)
-            elif os.path.exists(pt):
-                sd = torch.load(pt, map_location="cpu")
+            sd = load_diffusers_weights(d, "AutoencoderKL.from_pretrained")
         return cls(config or SD_VAE, sd)
 
     def state_dict(self):
@@ -332,6 +364,9 @@ class AutoencoderKL:
 
     def decode_latents(self, latents):
         return self.hip.decode_latents(latents)
+
+    def decode_to_u8(self, latents):
+        return self.hip.decode_to_u8(latents)
 
     def encode(self, x, return_dict: bool = True):
         self.hip

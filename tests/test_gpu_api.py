@@ -492,7 +492,7 @@ def test_bench_prints_one_contract_line():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--ddim-steps", "4",
-                        "--samples-per-gpu", "1", "--no-cpu-baseline", "--no-vae"], capture_output=True, text=True, timeout=600)
+                        "--samples-per-gpu", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -504,3 +504,4 @@ def test_bench_prints_one_contract_line():
     roof = d["roofline"]
     assert roof["bound"] in ("mfma", "hbm") and 0 < roof["frac"] < 1 and roof["unit"] == "TFLOP/s" and "gemm" in roof["kernel"]
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["out_shape"] == [1, 512, 512, 3] and d["config"]["baseline_config"] == 2

@@ -166,11 +166,12 @@ def test_unet_tiny_forward_vs_oracle(tiny):
     eps, taps = net.forward(ops.nchw_to_nhwc(xx.to(DEV), CIN_PAD), 501, 2 * S, h)
     with torch.no_grad():
         re, rt = ounet.unet_forward(tiny["cfg"], tiny["W"], xx, 501, tiny["ehs"])
-    # fp16 storage of ~150 intermediate tensors vs fp32 oracle: measured ~2e-3, bound 1e-2
-    assert report("unet tiny eps", ops.nhwc_to_nchw(eps, 2 * S, 4, h, h).cpu(), re)[0] < 1e-2
+    # fp16 storage of ~150 intermediate tensors vs the fp32 oracle.  Measured: eps rel 1.19e-3, taps 0.67 - 1.62e-3 - the
+    # same as the oracle's own fp16-storage mode costs (tests/test_gpu_configs.py decomposition); bounds = measured x 1.5
+    assert report("unet tiny eps", ops.nhwc_to_nchw(eps, 2 * S, 4, h, h).cpu(), re)[0] < 2e-3
     for i, ((tp, s), r) in enumerate(zip(taps, rt)):
         assert s == r.shape[2]
-        assert report(f"unet tiny tap{i}", from_nhwc(tp, 2 * S, s, s), r)[0] < 1e-2
+        assert report(f"unet tiny tap{i}", from_nhwc(tp, 2 * S, s, s), r)[0] < 2.5e-3
 
 
 def test_unet_tiny_backward_vs_oracle(tiny):
@@ -189,15 +190,15 @@ def test_unet_tiny_backward_vs_oracle(tiny):
     tot = sum((r[S:] * t).sum() for r, t in zip(rt, tg))
     gr = torch.autograd.grad(tot, xr, retain_graph=True)[0][S:]
     got = ops.nhwc_to_nchw(dx, S, 4, h, h).cpu()
-    # every backward activation is stored in fp16 and P / dS are fp16 MFMA operands: measured ~5e-3
-    assert report("unet tiny d/dx", got, gr)[0] < 2e-2
+    # every backward activation is stored in fp16 and P / dS are fp16 MFMA operands: measured 2.2e-3, bound = x 1.8
+    assert report("unet tiny d/dx", got, gr)[0] < 4e-3
     assert dx[:, 4:].abs().max() == 0
     # each tap on its own (catches a mis-routed skip / tap gradient that a sum could hide)
     for i in (0, 2, 3, 4, 5, 6, 8):
         one = [nhwc16(t if j == i else torch.zeros_like(t)) for j, t in enumerate(tg)]
         dxi = ops.nhwc_to_nchw(net.backward(stash, one), S, 4, h, h).cpu()
         gi = torch.autograd.grad((rt[i][S:] * tg[i]).sum(), xr, retain_graph=True)[0][S:]
-        assert report(f"unet tiny d/dx tap{i}", dxi, gi)[0] < 2e-2
+        assert report(f"unet tiny d/dx tap{i}", dxi, gi)[0] < 6e-3
 
 
 def test_sampler_tiny_vs_oracle(tiny):
@@ -227,7 +228,7 @@ def test_sampler_tiny_vs_oracle(tiny):
         xp, eps, aux = sampler.step(x_i.to(DEV).contiguous(), noise, target.to(DEV), tab, i, 7.5, 1.6, want_eps=True)
         for smp in range(S):
             tr = traces[smp][i]
-            assert report(f"sampler step{i} s{smp} eps", eps[smp:smp + 1].cpu(), tr["eps"])[0] < 1e-2
+            assert report(f"sampler step{i} s{smp} eps", eps[smp:smp + 1].cpu(), tr["eps"])[0] < 1.4e-2       # CFG eps: x 9.9
             if tr["aux"] is None:
                 assert aux is None
                 assert report(f"sampler step{i} s{smp} x_prev", xp[smp:smp + 1].cpu(), tr["latents"])[0] < 1e-2
@@ -279,11 +280,12 @@ def test_unet_sd15_forward_vs_oracle_full_size():
     eps, taps = net.forward(ops.nchw_to_nhwc(xx.to(DEV), CIN_PAD), 981, 2, 64)
     with torch.no_grad():
         re, rt = ounet.unet_forward(cfg, W, xx, 981, ehs)
-    assert report("unet sd15 eps", ops.nhwc_to_nchw(eps, 2, 4, 64, 64).cpu(), re)[0] < 1e-2
+    # measured: eps rel 1.09e-3 / max 1.94e-3, taps rel 0.65 - 1.58e-3; bounds = measured x 1.5.  The decomposition
+    # (HIP vs fp16-storage oracle vs fp32 oracle) is tests/test_gpu_configs.py::test_sd15_eps_error_decomposition_*
+    r, m = report("unet sd15 eps", ops.nhwc_to_nchw(eps, 2, 4, 64, 64).cpu(), re)
+    assert r < 2e-3 and m < 3e-3
     for i, ((tp, s), r) in enumerate(zip(taps, rt)):
-        assert report(f"unet sd15 tap{i}", from_nhwc(tp, 2, s, s), r)[0] < 1e-2
-    _, m = report("unet sd15 eps (abs)", ops.nhwc_to_nchw(eps, 2, 4, 64, 64).cpu(), re)
-    print(f"[parity] max |eps - eps_oracle| = {m:.3e} (north-star aspiration 1e-3 at fp16)")
+        assert report(f"unet sd15 tap{i}", from_nhwc(tp, 2, s, s), r)[0] < 2.5e-3
 
 
 def test_sd15_full_size_guided_step_and_backward_vs_oracle():
@@ -319,7 +321,8 @@ def test_sd15_full_size_guided_step_and_backward_vs_oracle():
     xr = xx.clone().requires_grad_(True)
     re, rt = ounet.unet_forward(cfg, W, xr, t, ehs)
     gr = torch.autograd.grad(sum((r[1:] * v).sum() for r, v in zip(rt, tg)), xr, retain_graph=True)[0][1:]
-    assert report("sd15 d/dx (random tap grads)", ops.nhwc_to_nchw(dx, 1, 4, h, h).cpu(), gr)[0] < 2e-2
+    # measured 2.2e-3 (every backward activation stored in fp16), bound = x 1.8
+    assert report("sd15 d/dx (random tap grads)", ops.nhwc_to_nchw(dx, 1, 4, h, h).cpu(), gr)[0] < 4e-3
     del stash, dx
     # ---- one full guided step
     sampler = HipSampler(net, HipLGP(sd, tap_channels(SD15), DEV))
@@ -329,7 +332,9 @@ def test_sd15_full_size_guided_step_and_backward_vs_oracle():
     e_ref = eu + 7.5 * (ec - eu)
     nxt = oddim.ddim_step(otab, e_ref, t, x0)
     new, oaux = og.apply_anti_gradient(rt, sd, otab.alphas_cumprod, xr, nxt, x0, t, target, 1.6, return_aux=True)
-    assert report("sd15 guided step eps", e_hip.cpu(), e_ref)[0] < 1e-2
+    # CFG-combined eps = eps_u + 7.5 (eps_c - eps_u): the combination amplifies the two rows' independent fp16 errors
+    # by ~sqrt(7.5^2 + 6.5^2) = 9.9 (measured 9.2e-3 = 8.4 x the single-row 1.09e-3); bound = measured x 1.5
+    assert report("sd15 guided step eps", e_hip.cpu(), e_ref)[0] < 1.4e-2
     upd_ref, upd = new - nxt, xp.cpu() - nxt
     nr = float(upd.norm() / upd_ref.norm())
     cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm()))

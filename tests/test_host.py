@@ -184,6 +184,15 @@ WORKER = textwrap.dedent("""
         assert torch.equal(allx, synthetic.initial_latents(0, total, 8) + 1.0), "gather"
     else:
         assert got is None
+    # the final gather of decoded images (uint8, the payload north_star names)
+    from sketch2img_amd.dist import gather_images
+    img = torch.full((2, 8, 8, 3), 10 * rank + 1, dtype=torch.uint8)
+    gi = gather_images(img, world, dst=0)
+    if rank == 0:
+        assert len(gi) == 2 and all(g.dtype == torch.uint8 for g in gi)
+        assert int(gi[0][0, 0, 0, 0]) == 1 and int(gi[1][0, 0, 0, 0]) == 11
+    else:
+        assert gi is None
     # the LGP-training collective: bucketed mean all-reduce of a flat gradient vector
     from sketch2img_amd.dist import allreduce_mean_
     g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
@@ -252,3 +261,81 @@ def test_dpm_tables_bit_exact_vs_oracle_and_scheduler_selection():
     p.scheduler = type("EulerDiscreteScheduler", (), {"config": SimpleNamespace()})()
     with pytest.raises(NotImplementedError):
         p._tables(25)
+
+
+# ---------------------------------------------------------------------------------------- loading: nothing silent
+def test_from_pretrained_never_falls_back_to_random_weights(tmp_path):
+    """A path that does not resolve to weights raises (a hub id, as app.py:32 passes, is not a local folder); seeded
+    synthetic weights / pseudo text embeddings need the explicit opt-in (None or synthetic=True)."""
+    import json
+    from sketch2img_amd.config import TINY
+    from sketch2img_amd.modules.pipeline import AntiGradientPipeline, _config_from_folder
+    from sketch2img_amd.vae import AutoencoderKL
+    with pytest.raises(FileNotFoundError):
+        AntiGradientPipeline.from_pretrained("runwayml/stable-diffusion-v1-5")
+    with pytest.raises(FileNotFoundError):
+        AutoencoderKL.from_pretrained("runwayml/stable-diffusion-v1-5", subfolder="vae")
+    (tmp_path / "unet").mkdir()
+    with pytest.raises(FileNotFoundError):                       # folder exists, weights do not
+        AntiGradientPipeline.from_pretrained(str(tmp_path))
+    p = AntiGradientPipeline.from_pretrained(None, unet_config=TINY)            # explicit opt-in
+    assert p.allow_pseudo_text and p._encode_prompt("a", "cpu", 1, True, None).shape == (2, 77, TINY.cross_attention_dim)
+    p.allow_pseudo_text = False
+    with pytest.raises(RuntimeError):
+        p._encode_prompt("a", "cpu", 1, True, None)
+    # a real (tiny) checkpoint folder loads, its config.json decides the architecture, a wrong one is rejected
+    from safetensors.torch import save_file
+    from sketch2img_amd import synthetic
+    sd = synthetic.unet_state_dict(TINY)
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / "unet" / "diffusion_pytorch_model.fp16.safetensors"))
+    cj = dict(block_out_channels=list(TINY.block_out_channels), attention_head_dim=list(TINY.num_heads), layers_per_block=2,
+              cross_attention_dim=TINY.cross_attention_dim, norm_num_groups=TINY.norm_groups, sample_size=32)
+    json.dump(cj, open(tmp_path / "unet" / "config.json", "w"))
+    assert _config_from_folder(str(tmp_path)) == TINY
+    q = AntiGradientPipeline.from_pretrained(str(tmp_path), text_encoder=lambda prompts: torch.zeros(len(prompts), 77, 64))
+    assert not q.allow_pseudo_text and q.unet.cfg == TINY and set(q.unet.state_dict()) == set(sd)
+    json.dump(dict(cj, block_out_channels=[32, 64, 128, 256]), open(tmp_path / "unet" / "config.json", "w"))
+    with pytest.raises(ValueError):                              # config and weights disagree
+        AntiGradientPipeline.from_pretrained(str(tmp_path))
+    json.dump(dict(cj, class_embed_type="timestep"), open(tmp_path / "unet" / "config.json", "w"))
+    with pytest.raises(NotImplementedError):
+        AntiGradientPipeline.from_pretrained(str(tmp_path))
+
+
+def test_scheduler_options_that_change_the_maths_are_rejected():
+    from types import SimpleNamespace
+    from sketch2img_amd.modules.pipeline import AntiGradientPipeline
+    p = AntiGradientPipeline.__new__(AntiGradientPipeline)
+    DDIM = type("DDIMScheduler", (), {})
+    for bad in (dict(prediction_type="v_prediction"), dict(clip_sample=True), dict(beta_schedule="linear"),
+                dict(trained_betas=[0.1, 0.2])):
+        s = DDIM()
+        s.config = SimpleNamespace(**bad)
+        p.scheduler = s
+        with pytest.raises(NotImplementedError):
+            p._tables(50)
+    s = DDIM()
+    s.config = SimpleNamespace(prediction_type="epsilon", clip_sample=False, steps_offset=1)
+    p.scheduler = s
+    assert p._tables(50).timesteps[0] == 981
+
+
+def test_vae_attention_keys_both_diffusers_spellings():
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import TINY_VAE
+    from sketch2img_amd.vae import _HipVAEBlocks
+    sd = dict(synthetic.vae_decoder_state_dict(TINY_VAE))
+    legacy = [k for k in sd if ".attentions." in k]
+    assert any(".query." in k for k in legacy) and any(".proj_attn." in k for k in legacy)
+    ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+    new = {}
+    for k, v in sd.items():
+        for old, nw in ren.items():
+            if f".{old}." in k and ".attentions." in k:
+                k = k.replace(f".{old}.", f".{nw}.")
+                if k.endswith(".weight"):
+                    v = v[:, :, None, None]                     # some re-saves keep the 1x1-conv shape
+        new[k] = v
+    back = _HipVAEBlocks.normalise_attention_keys(new)
+    assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
+    assert _HipVAEBlocks.normalise_attention_keys(sd).keys() == sd.keys()
