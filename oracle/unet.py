@@ -199,25 +199,31 @@ def init_weights(cfg: UNetConfig, seed: int = 20260929, dtype=torch.float32,
 #                                         fp16 P operand of the PV product, pre-scaled Q), and
 #     (fp16-storage oracle  vs  fp32)  = what ANY fp16 implementation, the reference's included, pays.
 # Autograd sees ``x.half().float()``: its backward rounds the gradient at the same boundaries.
+# Every rounding point carries a kind so that tools/eps_decompose.py can switch classes of tensors off one at a
+# time ("which stored tensors cost the accuracy"): "res" = the residual stream (ResnetBlock / attention / FF sums,
+# conv_in / resampling outputs), "norm" = GroupNorm(+SiLU) / LayerNorm outputs, "lin" = conv / Linear outputs that
+# feed a norm or an activation, "attn" = q / k / v and attention outputs, "temb" = the time-embedding path.
 _FP16_STORAGE = False
+_FP16_SKIP: frozenset = frozenset()
 
 
 class fp16_storage:
-    def __init__(self, on: bool = True):
-        self.on = on
+    def __init__(self, on: bool = True, skip=()):
+        self.on, self.skip = on, frozenset(skip)
 
     def __enter__(self):
-        global _FP16_STORAGE
-        self.prev, _FP16_STORAGE = _FP16_STORAGE, self.on
+        global _FP16_STORAGE, _FP16_SKIP
+        self.prev = (_FP16_STORAGE, _FP16_SKIP)
+        _FP16_STORAGE, _FP16_SKIP = self.on, self.skip
         return self
 
     def __exit__(self, *exc):
-        global _FP16_STORAGE
-        _FP16_STORAGE = self.prev
+        global _FP16_STORAGE, _FP16_SKIP
+        _FP16_STORAGE, _FP16_SKIP = self.prev
 
 
-def _r(x: torch.Tensor) -> torch.Tensor:
-    return x.half().to(x.dtype) if _FP16_STORAGE else x
+def _r(x: torch.Tensor, kind: str = "lin") -> torch.Tensor:
+    return x.half().to(x.dtype) if (_FP16_STORAGE and kind not in _FP16_SKIP) else x
 
 
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -233,15 +239,15 @@ def _gn(x, W, p, groups, eps):
 
 
 def resnet_forward(cfg, W, p, x, temb_act):
-    h = _r(F.silu(_gn(x, W, p + ".norm1", cfg.norm_groups, 1e-5)))
-    tproj = _r(F.linear(temb_act, W[p + ".time_emb_proj.weight"], W[p + ".time_emb_proj.bias"]))
-    tb = _r(tproj + W[p + ".conv1.bias"])
+    h = _r(F.silu(_gn(x, W, p + ".norm1", cfg.norm_groups, 1e-5)), "norm")
+    tproj = _r(F.linear(temb_act, W[p + ".time_emb_proj.weight"], W[p + ".time_emb_proj.bias"]), "temb")
+    tb = _r(tproj + W[p + ".conv1.bias"], "temb")
     h = _r(F.conv2d(h, W[p + ".conv1.weight"], None, padding=1) + tb[:, :, None, None])
-    h = _r(F.silu(_gn(h, W, p + ".norm2", cfg.norm_groups, 1e-5)))
+    h = _r(F.silu(_gn(h, W, p + ".norm2", cfg.norm_groups, 1e-5)), "norm")
     h = F.conv2d(h, W[p + ".conv2.weight"], W[p + ".conv2.bias"], padding=1)
     if (p + ".conv_shortcut.weight") in W:
         x = _r(F.conv2d(x, W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"]))
-    return _r(x + h)
+    return _r(x + h, "res")
 
 
 def attention(q, k, v, heads):
@@ -258,15 +264,15 @@ def attention(q, k, v, heads):
     else:
         s = torch.matmul(qh, kh.transpose(-1, -2)) * (d ** -0.5)
         o = torch.matmul(torch.softmax(s, dim=-1), vh)
-    return _r(o.transpose(1, 2).reshape(B, N, C))
+    return _r(o.transpose(1, 2).reshape(B, N, C), "attn")
 
 
 def cross_attention_module(W, p, x, ctx, heads):
     """diffusers CrossAttention: to_q/to_k/to_v without bias, to_out.0 with bias."""
     ctx = x if ctx is None else ctx
-    q = _r(F.linear(x, W[p + ".to_q.weight"]))
-    k = _r(F.linear(ctx, W[p + ".to_k.weight"]))
-    v = _r(F.linear(ctx, W[p + ".to_v.weight"]))
+    q = _r(F.linear(x, W[p + ".to_q.weight"]), "attn")
+    k = _r(F.linear(ctx, W[p + ".to_k.weight"]), "attn")
+    v = _r(F.linear(ctx, W[p + ".to_v.weight"]), "attn")
     o = attention(q, k, v, heads)
     return F.linear(o, W[p + ".to_out.0.weight"], W[p + ".to_out.0.bias"])      # caller adds the residual, then rounds
 
@@ -279,28 +285,28 @@ def transformer_block_forward(W, p, x, ehs, heads, inject: Optional[InjectFn] = 
     step 1.5 (modules/clip_guided_attn.py:111-125, modules/sketch_guided_attn.py:120-132),
     applied between self- and cross-attention; it returns the new hidden states."""
     c = x.shape[-1]
-    n = _r(F.layer_norm(x, (c,), W[p + ".norm1.weight"], W[p + ".norm1.bias"], 1e-5))
-    x = _r(cross_attention_module(W, p + ".attn1", n, None, heads) + x)
+    n = _r(F.layer_norm(x, (c,), W[p + ".norm1.weight"], W[p + ".norm1.bias"], 1e-5), "norm")
+    x = _r(cross_attention_module(W, p + ".attn1", n, None, heads) + x, "res")
     if inject is not None:
         x = inject(p, x, heads)
-    n = _r(F.layer_norm(x, (c,), W[p + ".norm2.weight"], W[p + ".norm2.bias"], 1e-5))
-    x = _r(cross_attention_module(W, p + ".attn2", n, ehs, heads) + x)
-    n = _r(F.layer_norm(x, (c,), W[p + ".norm3.weight"], W[p + ".norm3.bias"], 1e-5))
+    n = _r(F.layer_norm(x, (c,), W[p + ".norm2.weight"], W[p + ".norm2.bias"], 1e-5), "norm")
+    x = _r(cross_attention_module(W, p + ".attn2", n, ehs, heads) + x, "res")
+    n = _r(F.layer_norm(x, (c,), W[p + ".norm3.weight"], W[p + ".norm3.bias"], 1e-5), "norm")
     hcat = _r(F.linear(n, W[p + ".ff.net.0.proj.weight"], W[p + ".ff.net.0.proj.bias"]))
     hid, gate = hcat.chunk(2, dim=-1)
     ff = F.linear(_r(hid * F.gelu(gate)), W[p + ".ff.net.2.weight"], W[p + ".ff.net.2.bias"])
-    return _r(ff + x)
+    return _r(ff + x, "res")
 
 
 def transformer2d_forward(cfg, W, p, x, ehs, heads, inject=None):
     B, C, H, Wd = x.shape
     res = x
-    h = _r(_gn(x, W, p + ".norm", cfg.norm_groups, 1e-6))
+    h = _r(_gn(x, W, p + ".norm", cfg.norm_groups, 1e-6), "norm")
     if cfg.use_linear_projection:
         h = h.permute(0, 2, 3, 1).reshape(B, H * Wd, C)
-        h = _r(F.linear(h, W[p + ".proj_in.weight"], W[p + ".proj_in.bias"]))
+        h = _r(F.linear(h, W[p + ".proj_in.weight"], W[p + ".proj_in.bias"]), "res")
     else:
-        h = _r(F.conv2d(h, W[p + ".proj_in.weight"], W[p + ".proj_in.bias"]))
+        h = _r(F.conv2d(h, W[p + ".proj_in.weight"], W[p + ".proj_in.bias"]), "res")
         h = h.permute(0, 2, 3, 1).reshape(B, H * Wd, C)
     h = transformer_block_forward(W, p + ".transformer_blocks.0", h, ehs, heads, inject)
     if cfg.use_linear_projection:
@@ -309,7 +315,7 @@ def transformer2d_forward(cfg, W, p, x, ehs, heads, inject=None):
     else:
         h = h.reshape(B, H, Wd, C).permute(0, 3, 1, 2)
         h = F.conv2d(h, W[p + ".proj_out.weight"], W[p + ".proj_out.bias"])
-    return _r(h + res)
+    return _r(h + res, "res")
 
 
 def transformer_block_paths(cfg: UNetConfig) -> List[str]:
@@ -339,12 +345,12 @@ def unet_forward(cfg: UNetConfig, W: Dict[str, torch.Tensor], x: torch.Tensor, t
     nb = len(boc)
     B = x.shape[0]
     tt = torch.as_tensor(t).reshape(-1).expand(B)
-    temb = _r(timestep_embedding(tt, boc[0]).to(x.dtype))
-    temb = _r(F.linear(temb, W["time_embedding.linear_1.weight"], W["time_embedding.linear_1.bias"]))
-    temb = _r(F.linear(_r(F.silu(temb)), W["time_embedding.linear_2.weight"], W["time_embedding.linear_2.bias"]))
-    temb_act = _r(F.silu(temb))
+    temb = _r(timestep_embedding(tt, boc[0]).to(x.dtype), "temb")
+    temb = _r(F.linear(temb, W["time_embedding.linear_1.weight"], W["time_embedding.linear_1.bias"]), "temb")
+    temb = _r(F.linear(_r(F.silu(temb), "temb"), W["time_embedding.linear_2.weight"], W["time_embedding.linear_2.bias"]), "temb")
+    temb_act = _r(F.silu(temb), "temb")
 
-    h = _r(F.conv2d(_r(x), W["conv_in.weight"], W["conv_in.bias"], padding=1))
+    h = _r(F.conv2d(_r(x, "res"), W["conv_in.weight"], W["conv_in.bias"], padding=1), "res")
     skips = [h]
     taps_down, per_block = [], []
     for i in range(nb):
@@ -358,7 +364,7 @@ def unet_forward(cfg: UNetConfig, W: Dict[str, torch.Tensor], x: torch.Tensor, t
             blk_res.append(h)
         if i < nb - 1:
             p = f"down_blocks.{i}.downsamplers.0.conv"
-            h = _r(F.conv2d(h, W[p + ".weight"], W[p + ".bias"], stride=2, padding=1))
+            h = _r(F.conv2d(h, W[p + ".weight"], W[p + ".bias"], stride=2, padding=1), "res")
             skips.append(h)
             blk_res.append(h)
         per_block.append(tuple(blk_res))
@@ -386,11 +392,11 @@ def unet_forward(cfg: UNetConfig, W: Dict[str, torch.Tensor], x: torch.Tensor, t
         if i < nb - 1:
             p = f"up_blocks.{i}.upsamplers.0.conv"
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
-            h = _r(F.conv2d(h, W[p + ".weight"], W[p + ".bias"], padding=1))
+            h = _r(F.conv2d(h, W[p + ".weight"], W[p + ".bias"], padding=1), "res")
         if i < 3:
             taps_up.append(h)
-    h = _r(F.silu(_gn(h, W, "conv_norm_out", cfg.norm_groups, 1e-5)))
-    eps = _r(F.conv2d(h, W["conv_out.weight"], W["conv_out.bias"], padding=1))
+    h = _r(F.silu(_gn(h, W, "conv_norm_out", cfg.norm_groups, 1e-5)), "norm")
+    eps = _r(F.conv2d(h, W["conv_out.weight"], W["conv_out.bias"], padding=1), "res")
     taps = taps_down + [tap_mid_attn, tap_mid_r0, tap_mid_r1] + taps_up
     return eps, taps
 

@@ -198,7 +198,7 @@ class HipSampler:
             if ts is not None:
                 ts.copy_(tgt)
             saved = None if self.lgp is None else [[r.clone() for r in self.lgp.running_mean], [r.clone() for r in self.lgp.running_var],
-                                                   list(self.lgp.num_batches_tracked)]
+                                                   tuple(self.lgp.num_batches_tracked)]
             self._x0_before, self._seen = x0b, 0
             w = xs.clone()
             for i in range(T):
@@ -206,7 +206,7 @@ class HipSampler:
             if saved is not None:       # the warm-up pass is not part of the trajectory: undo its BatchNorm side effects
                 for l in range(4):
                     self.lgp.running_mean[l].copy_(saved[0][l]); self.lgp.running_var[l].copy_(saved[1][l])
-                self.lgp.num_batches_tracked = saved[2]
+                self.lgp.num_batches_tracked = list(saved[2])
             torch.cuda.synchronize()
             pool = torch.cuda.graph_pool_handle()
             graphs, auxs = [], []
