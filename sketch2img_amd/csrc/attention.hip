@@ -16,6 +16,7 @@
 // Block = 4 waves = 64 query rows (forward, dQ) or 64 key rows (dK/dV); KV / Q tiles of 64 rows are
 // staged in LDS (padded pitches: conflict-free ds_read_b128 / b64 fragment reads).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -226,8 +227,10 @@ __device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __rest
 // scale folded into one FMA, masking only on a ragged last tile.
 // CAUSAL (the CLIP text encoder, modules/pipeline.py:55-57 -> transformers CLIPTextModel): key j is visible to
 // query i only when j <= i; a separate instantiation so the UNet's kernels carry no extra test.
-template <int KS, int ND, int QT, bool CAUSAL = false>
-__global__ __launch_bounds__(256, (KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL) ? 4 : 2)) void attn_fwd_kernel(const AttnParams p) {
+// VAR (experiments / per-shape tuning): bit 0 = request every fragment of a tile up front (PRE), bit 1 = one register
+// prefetch set instead of two (frees 16 VGPRs), bits 2-3 = waves per SIMD the register allocation is bounded for (0 = default)
+template <int KS, int ND, int QT, bool CAUSAL = false, int VAR = 0>
+__global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL && QT == 2) ? 4 : 2)) void attn_fwd_kernel(const AttnParams p) {
   // QT query tiles of 16 per wave: a workgroup covers 64 * QT queries, so every K / V^T fragment read from LDS
   // (and every byte of K/V streamed from L2) is used by QT MFMAs instead of one.
   constexpr int KP = KS * 32 + 8;
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL)
   constexpr float REF_SLACK = 8.f;
   // (measured: requesting all fragments of a tile up front costs 14 VGPRs = the third wave per SIMD: 710 -> 767 us at
   // d = 40; the compiler's read-as-you-go order with three resident waves is faster.  Kept for experiments.)
-  constexpr bool PRE = false && KS <= 2 && 4 * KS * QT >= 2 * ND;
+  constexpr bool PRE = (VAR & 1) && KS <= 2 && 4 * KS * QT >= 2 * ND;
   constexpr int VREADS = 2;                                   // LDS instructions per V^T fragment (two ds_read_b64)
   // <2, 3> is dispatched for d = 40 only: 8 spare rows in the 48-row V^T tile -> the denominator comes out of the
   // PV MFMA (row 40 of O^T) and the 16 adds per tile and query tile leave the VALU, which bounds this head size
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL)
   // Two LDS stages (+ two register sets when they fit): tile t computes from stage t&1 while tile t+1 sits in
   // registers on its way to the other stage and tile t+2 is in flight from L2/HBM, ONE barrier per tile.
   // Invariant at the top of the (unrolled-by-2) loop, t even: stage 0 = tile t, r0 = tile t+1, r1 = tile t+2.
-  constexpr bool DEEP = KS < 5 && !(KS == 2 && ND == 3);      // d = 160: a second register set would not fit 2 waves / SIMD; d = 40: four waves / SIMD instead
+  constexpr bool DEEP = KS < 5 && !(KS == 2 && ND == 3) && !(VAR & 2);      // d = 160: a second register set would not fit 2 waves / SIMD; d = 40: four waves / SIMD instead
   KVRegs<KS, ND> r0;
   kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, 0, p.kv_stride, dh);
   kv_store<KS, ND>(r0, Ks0, Vs0);
@@ -777,13 +780,25 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
   }
 }
 
+// tuning variants of the d = 40 / d = 64 forward (SKG_ATTN_VAR, tools/attn_bench.py); 0 = shipped
+#define SKG_ATTN_VARIANTS(KS_, ND_, grid2)                                                                       \
+  switch (attn_var()) {                                                                                          \
+    case 1: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 1>), grid2, dim3(256), 0, st, p); break;       \
+    case 2: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 2 | (3 << 2)>), grid2, dim3(256), 0, st, p); break; \
+    case 3: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 1 | 2>), grid2, dim3(256), 0, st, p); break;   \
+    case 4: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, (2 << 2)>), grid2, dim3(256), 0, st, p); break; \
+    case 5: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, 1 | (2 << 2)>), grid2, dim3(256), 0, st, p); break; \
+    case 6: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 1 | (3 << 2)>), grid2, dim3(256), 0, st, p); break; \
+    default: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2>), grid2, dim3(256), 0, st, p); break;              \
+  }
+
 // forward: two query tiles per wave (128 queries per workgroup) except at d = 160 (register budget)
 #define SKG_ATTN_FWD_DISPATCH(grid1, grid2)                                                              \
   switch (p.dh) {                                                                                        \
     case 16: hipLaunchKernelGGL((attn_fwd_kernel<1, 1, 2>), grid2, dim3(256), 0, st, p); break;          \
     case 32: hipLaunchKernelGGL((attn_fwd_kernel<1, 2, 2>), grid2, dim3(256), 0, st, p); break;          \
-    case 40: hipLaunchKernelGGL((attn_fwd_kernel<2, 3, 2>), grid2, dim3(256), 0, st, p); break;          \
-    case 64: hipLaunchKernelGGL((attn_fwd_kernel<2, 4, 2>), grid2, dim3(256), 0, st, p); break;          \
+    case 40: SKG_ATTN_VARIANTS(2, 3, grid2); break;                                                      \
+    case 64: SKG_ATTN_VARIANTS(2, 4, grid2); break;                                                      \
     case 80: hipLaunchKernelGGL((attn_fwd_kernel<3, 5, 2>), grid2, dim3(256), 0, st, p); break;          \
     case 160: hipLaunchKernelGGL((attn_fwd_kernel<5, 10, 1>), grid1, dim3(256), 0, st, p); break;        \
     default: return SKG_E_UNSUPPORTED;                                                                   \
@@ -796,6 +811,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
     case 64: hipLaunchKernelGGL((attn_fwd_kernel<2, 4, 2, true>), grid2, dim3(256), 0, st, p); break;    \
     default: return SKG_E_UNSUPPORTED;                                                                   \
   }
+
+inline int attn_var() {
+  static const int v = getenv("SKG_ATTN_VAR") ? atoi(getenv("SKG_ATTN_VAR")) : 0;
+  return v;
+}
+inline int attn_var_qt() { return (attn_var() == 4 || attn_var() == 5) ? 4 : 2; }
 
 inline bool common_ok(int batch, int heads, int Nq, int Nkv, int kv_stride, int dh) {
   return batch > 0 && heads > 0 && Nq > 0 && Nkv > 0 && kv_stride >= Nkv && kv_stride % 8 == 0 && dh % 8 == 0;
@@ -815,6 +836,7 @@ static int attn_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const v
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
   p.nx = skg_cdiv(Nq, dh == 160 ? 64 : 128);       // query tiles per workgroup: see SKG_ATTN_FWD_DISPATCH
+  if (!causal && (dh == 40 || dh == 64)) p.nx = skg_cdiv(Nq, 64 * attn_var_qt());
   dim3 grid((unsigned)p.nx * heads * batch);
   if (causal) {
     SKG_REQUIRE(dh != 160);
