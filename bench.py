@@ -106,6 +106,8 @@ class LaunchTimer:
         def kname(variant, mode):
             """The name rocprofv3 prints for the instantiation that ran (template arguments spelled out)."""
             bn = variant % 1000
+            if variant == 8160:
+                return f"gemm8_kernel<{MODES[mode]}, 0>"
             if variant >= 2000:
                 stages = 3 if variant >= 10000 else 2
                 return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}, {stages}>"
@@ -148,7 +150,7 @@ class LaunchTimer:
             e1.record()
             fl = 4.0 * batch * heads * Nq * Nkv * dh                      # QK^T + PV
             nbytes = 2.0 * batch * heads * dh * (2 * Nq + 2 * Nkv)
-            self.rec.append((f"attn_fwd_kernel<{ATTN_NAMES.get(dh, '?')}, false>", fl, e0, e1, nbytes,
+            self.rec.append((f"attn_fwd_kernel<{ATTN_NAMES.get(dh, '?')}, false, {14 if dh == 64 else 0}>", fl, e0, e1, nbytes,
                              f"attn B{batch} H{heads} Nq{Nq} Nkv{Nkv} d{dh}"))
             return out
 

@@ -789,7 +789,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
     case 4: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, (2 << 2)>), grid2, dim3(256), 0, st, p); break; \
     case 5: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, 1 | (2 << 2)>), grid2, dim3(256), 0, st, p); break; \
     case 6: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 1 | (3 << 2)>), grid2, dim3(256), 0, st, p); break; \
-    default: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2>), grid2, dim3(256), 0, st, p); break;              \
+    case 7: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2>), grid2, dim3(256), 0, st, p); break;              \
+    default:                                                                                                     \
+      /* d = 64: one register prefetch set -> 162 VGPRs = three waves per SIMD instead of two (+8...15 %, */     \
+      /* tools/attn_var_bench.py); d = 40 already runs four waves per SIMD */                                    \
+      if (ND_ == 4) hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 2 | (3 << 2)>), grid2, dim3(256), 0, st, p); \
+      else hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2>), grid2, dim3(256), 0, st, p);                       \
+      break;                                                                                                     \
   }
 
 // forward: two query tiles per wave (128 queries per workgroup) except at d = 160 (register budget)

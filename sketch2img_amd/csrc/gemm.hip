@@ -180,6 +180,10 @@ inline bool use_wide(int M, int N) { return (N % 128 == 0) && ((long)skg_cdiv(M,
 
 template <int MODE>
 int launch(const GemmParams& p, hipStream_t st) {
+  if (skg_gemm8_try_launch(p, MODE, st)) {
+    SKG_CHECK_LAUNCH("skg_gemm (v8)");
+    return SKG_OK;
+  }
   if (skg_gemm2_try_launch(p, MODE, st)) {
     SKG_CHECK_LAUNCH("skg_gemm (v2)");
     return SKG_OK;
@@ -206,6 +210,11 @@ extern "C" int skg_set_workspace(void* ws, size_t bytes) {
 }
 
 extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
+  {   // v8 takes plain (fp16 out, no fused GEGLU) launches of eligible shapes
+    GemmParams q{};
+    q.M = M; q.N = N; q.K = K; q.Cin = Cin; q.lda = q.ldb = K; q.ldc = N; q.OH = q.OW = q.IH = q.IW = 1;
+    if (skg_gemm8_eligible(q, mode)) return 8160;
+  }
   const int v2 = skg_gemm2_tile_n(M, N, K, Cin, mode);
   return v2 ? 2000 + v2 : 1000 + (use_wide(M, N) ? 128 : 64);
 }

@@ -1,0 +1,364 @@
+// v8 fp16 MFMA GEMM / 3x3 implicit-GEMM convolution for gfx950: ONE 8-wave workgroup per CU on a 256 x 160 tile,
+// three LDS stages, and a PING-PONG schedule between the two waves that share a SIMD.
+//
+// Why: rocprofv3 counters put the matrix pipe of the v2 convolution kernel (two co-resident
+// 4-wave workgroups on 128 x 160 tiles) at 44 % busy at 2.17 GHz.  In v2 every wave interleaves LDS fragment reads,
+// LDS-DMA issue (each `buffer_load ... lds` occupies its wave for ~100 cycles) and MFMAs in one instruction stream,
+// and the only thing that covers a wave's non-MFMA time is whatever the co-resident workgroup happens to be doing.
+// Here the overlap is constructed instead of hoped for.  Waves w and w + 4 of a workgroup land on the same SIMD;
+// group 0 (waves 0-3) and group 1 (waves 4-7) run the SAME sequence of segments
+//        LOAD(j): 9 fragment reads of k-sub-step j + 3-4 LDS-DMA instructions of the tile two ahead -> s_barrier ->
+//        COMPUTE(j): 20 MFMAs out of registers at raised priority                                     -> s_barrier
+// but group 1 starts one barrier late, so on every SIMD one wave streams MFMAs while its partner reads and issues
+// DMA (the 8-phase idea of the CDNA4 GEMM playbook, cut to the two phases per 32-deep sub-step this tile needs).
+// A 256 x 160 tile moves 10 B of operands per kFLOP through the texture path instead of 14 (128 x 160).
+//
+// Pipeline bookkeeping (tile t = 64-deep K step, sub-step j = 2t + ks, stage = t % 3):
+//   * tile t + 2 is requested during LOAD(2t) (A rows) and LOAD(2t + 1) (B rows) into stage (t + 2) % 3 = (t - 1) % 3,
+//     whose last reader - group 1's LOAD(2t - 1) - finished two barriers earlier;
+//   * every wave issues exactly ND DMA instructions per tile (7 for waves 0-3, 6 for waves 4-7: 20 B chunks over 8
+//     waves; out-of-range ones are zero fills), so `s_waitcnt vmcnt(ND)` at the end of LOAD(2t + 1) means "tile t + 1
+//     has landed" for that wave, and the barrier that follows publishes it to the others before anyone reads it.
+// Scope: MODE_DIRECT and MODE_S1, K % 64 == 0 (conv: Cin % 64 == 0), N % 160 == 0, fp16 output, no fused GEGLU, no
+// split-K; everything else stays on gemm2.hip.  Epilogue: bias / alpha / residual / ReLU in fp32, one rounding.
+#include "gemm_params.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BM = 256, BN = 160, BK = 64, NS = 3, NW = 8, NTHR = 512;
+constexpr int WM = 64, WN = 80, MT = 4, NT = 5;
+constexpr int STAGE = (BM + BN) * BK;            // halves per stage: A tile then B tile (53 248 B)
+constexpr int ACH = 4, BCH = 3;
+constexpr unsigned OOB = 0x80000000u;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, half_t* lds_wave_base, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
+
+// EXP: probe builds (SKG_G8_EXP; compute on stale / missing data, timing only): 1 = no DMA in the loop, 2 = no
+// fragment reads in the loop, 4 = no priority raise, 8 = no stagger between the two groups
+template <int MODE, int EXP = 0>
+__global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int tiles_n, int nwg, unsigned a_bytes,
+                                                        unsigned b_bytes, unsigned a_shift) {
+  __shared__ __attribute__((aligned(16))) half_t smem[NS * STAGE + 512];     // + 1 KB sink for the idle DMA slot of waves 4-7
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                 // waves w and w + 4 share a SIMD: one of each group
+  const int wm = wave & 3, wn = wave >> 2;   // wave tile (64 rows x 80 columns) inside the 256 x 160 block
+  const int g = lane >> 4, l16 = lane & 15;
+
+  const __amdgpu_buffer_rsrc_t rA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - a_shift), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, b_bytes, 0x00020000);
+
+  // XCD-aware tile assignment (workgroup b -> XCD b % 8): every XCD owns a contiguous tile range, n fastest
+  int lid;
+  {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_m = lid / tiles_n, tile_n = lid - tile_m * tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-lane DMA source description (as gemm2.hip: one voffset per operand row, tap / k position in soffset) ----
+  const int lr = lane >> 3, lq = lane & 7;
+  unsigned a_voff[ACH], a_mask[ACH];
+#pragma unroll
+  for (int j = 0; j < ACH; ++j) {
+    const int r = (j * NW + wave) * 8 + lr;
+    const unsigned pk = (unsigned)(lq ^ ((r >> 1) & 7)) * 16u;
+    const int m = m0 + r;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
+    a_mask[j] = 0;
+    if (MODE == MODE_DIRECT) {
+      a_voff[j] = ok ? (unsigned)mm * (unsigned)p.lda * 2u + pk : OOB;
+    } else {
+      const int ohw = p.OH * p.OW;
+      const int b = mm / ohw;
+      const int rr = mm - b * ohw;
+      const int oy = rr / p.OW, ox = rr - oy * p.OW;
+      const unsigned img = (unsigned)b * (unsigned)(p.IH * p.IW);
+      a_voff[j] = ok ? ((img + (unsigned)(oy * p.IW + ox)) * (unsigned)p.lda) * 2u + pk : OOB;
+      unsigned mk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+        if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mk |= 1u << t;
+      }
+      a_mask[j] = mk;
+    }
+  }
+  unsigned b_voff[BCH];
+#pragma unroll
+  for (int j = 0; j < BCH; ++j) {
+    const int r = (j * NW + wave) * 8 + lr;
+    const unsigned pk = (unsigned)(lq ^ ((r >> 1) & 7)) * 16u;
+    const int n = n0 + r;
+    b_voff[j] = (r < BN && n < p.N) ? (unsigned)n * (unsigned)p.ldb * 2u + pk : OOB;
+  }
+  const bool has_b2 = wave < 4;              // B chunk 16 + wave exists for waves 0-3 only (20 chunks of 8 rows)
+
+  const int KT = p.K / BK;
+  // scalar description of K tile kt: A soffset, B soffset, filter tap (conv: channel block outermost, taps innermost)
+  auto ktile = [&](int kt, unsigned& soa, unsigned& sob, int& tap) {
+    if (MODE == MODE_DIRECT) {
+      soa = sob = (unsigned)kt * (BK * 2u);
+      tap = 0;
+    } else {
+      const int cb = kt / 9;
+      tap = kt - cb * 9;
+      const int c0 = cb * BK;
+      const int ky = tap / 3, kx = tap - ky * 3;
+      soa = (unsigned)((ky * p.IW + kx) * p.lda + c0) * 2u;
+      sob = (unsigned)(tap * p.Cin + c0) * 2u;
+    }
+  };
+  auto dma_a = [&](int kt, int buf) {        // the tile's A rows: ACH instructions
+    unsigned soa, sob;
+    int tap;
+    const bool live = kt < KT;
+    ktile(live ? kt : 0, soa, sob, tap);
+#pragma unroll
+    for (int j = 0; j < ACH; ++j) {
+      unsigned v = a_voff[j];
+      if (MODE != MODE_DIRECT) v = ((a_mask[j] >> tap) & 1u) ? v : OOB;
+      dma16(rA, &smem[buf * STAGE + (j * NW + wave) * 8 * BK], live ? v : OOB, soa);
+    }
+  };
+  auto dma_b = [&](int kt, int buf) {        // the tile's B rows: 3 (waves 0-3) / 2 (waves 4-7) instructions
+    unsigned soa, sob;
+    int tap;
+    const bool live = kt < KT;
+    ktile(live ? kt : 0, soa, sob, tap);
+#pragma unroll
+    for (int j = 0; j < BCH; ++j) {
+      // chunk 16 + wave exists for waves 0-3 only; waves 4-7 zero-fill the sink instead (keeps the stream branch-free
+      // and every wave's DMA count at ND = 7: b_voff is out of range for them)
+      half_t* dst = (j == BCH - 1 && !has_b2) ? &smem[NS * STAGE] : &smem[buf * STAGE + BM * BK + (j * NW + wave) * 8 * BK];
+      dma16(rB, dst, live ? b_voff[j] : OOB, sob);
+    }
+  };
+  // "the tile before the newest one has landed": ND outstanding instructions allowed (the newest tile's)
+  auto wait_older = [&]() { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); };
+
+  float4_t acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read addresses (halves) inside a stage for k-sub-step 0 / 1; slot = piece ^ ((row >> 1) & 7)
+  int a_ad[MT][2], b_ad[NT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int row = wm * WM + i * 16 + l16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) a_ad[i][ks] = row * BK + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 3);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = wn * WN + j * 16 + l16;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) b_ad[j][ks] = BM * BK + row * BK + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 3);
+  }
+
+  half8_t xf[MT], wf[NT];
+  // one sub-step of one wave: LOAD segment, barrier, COMPUTE segment, barrier
+  auto substep = [&](int t, int stg, int ks) {        // stg, ks: compile-time constants at every call site
+    const half_t* sb = &smem[stg * STAGE];
+    if (!(EXP & 2) || t == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = ld_half8(sb + b_ad[j][ks]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) xf[i] = ld_half8(sb + a_ad[i][ks]);
+    }
+    const int nbuf = stg == 0 ? 2 : stg - 1;          // (stg + 2) % 3
+    constexpr bool DIC = (EXP & 16) != 0;             // DMA issued from the COMPUTE segment, woven between the MFMAs
+    if (!(EXP & 1) && !DIC) {
+      if (ks == 0) dma_a(t + 2, nbuf);
+      else dma_b(t + 2, nbuf);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ks == 1 && !(EXP & 1)) {
+      // tile t + 1 must have landed before anyone's LOAD(2t + 2).  DMA in LOAD: all of tile t + 2 is in flight (ND).
+      // DMA in COMPUTE: only its A part (issued in COMPUTE(2t)) is - the B part follows in COMPUTE(2t + 1).
+      if (DIC) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else wait_older();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bar();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(EXP & 4)) __builtin_amdgcn_s_setprio(1);
+    if (DIC && !(EXP & 1)) {
+      if (ks == 0) dma_a(t + 2, nbuf);
+      else dma_b(t + 2, nbuf);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    if (DIC) {      // issue order: 4 MFMAs, one DMA instruction, ... (the B part has 3 or 2: the plan covers the longer)
+      constexpr int NDMA = 4;               // (ks == 1: three - the fourth slot of the plan stays empty)
+#pragma unroll
+      for (int q = 0; q < NDMA; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - 4 * NDMA, 0);
+    }
+    if (!(EXP & 4)) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    bar();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // prologue: tiles 0 and 1 in flight, tile 0 landed and published
+  dma_a(0, 0); dma_b(0, 0);
+  dma_a(1, 1); dma_b(1, 1);
+  wait_older();
+  bar();
+  if (EXP & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (grp == 1 && !(EXP & 8)) bar();                   // group 1 runs one barrier behind group 0
+  for (int t = 0; t < KT; t += 3) {
+    substep(t, 0, 0);
+    substep(t, 0, 1);
+    if (t + 1 < KT) {
+      substep(t + 1, 1, 0);
+      substep(t + 1, 1, 1);
+    }
+    if (t + 2 < KT) {
+      substep(t + 2, 2, 0);
+      substep(t + 2, 2, 1);
+    }
+  }
+  if (grp == 0 && !(EXP & 8)) bar();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last tiles' zero-fill DMA
+
+  // ---- epilogue: lane holds C[m = .. + l16][n = .. + 4g .. 4g + 3] --------------------------------------------------
+  // Every load is issued before the first use (conditions hoisted out of the element loops: a per-element
+  // "load or not" select makes hipcc wait vmcnt(0) after each load - 40 serial round trips).  Rows beyond M read row
+  // M - 1 and are not stored; N is a multiple of the tile width.
+  const bool relu = p.flags & SKG_EPI_RELU;
+  float4_t bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bv[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const half4_t b = ld_half4(p.bias + n0 + wn * WN + j * 16 + g * 4);
+      bv[j] = float4_t{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+    }
+  }
+  const int mrow = m0 + wm * WM + l16;
+  if (p.res) {
+    half4_t rv[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = min(mrow + i * 16, p.M - 1);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) rv[i][j] = ld_half4(p.res + (size_t)m * p.ldr + n0 + wn * WN + j * 16 + g * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const half4_t r = rv[i][j];
+        acc[i][j] = (acc[i][j] + bv[j]) * p.alpha + float4_t{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (acc[i][j] + bv[j]) * p.alpha;
+  }
+  if (relu) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = mrow + i * 16;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float4_t v = acc[i][j];
+      const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+      st_half4(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n0 + wn * WN + j * 16 + g * 4, o);
+    }
+  }
+}
+
+inline bool operand_bytes(const GemmParams& p, int mode, unsigned long long& a, unsigned long long& b,
+                          unsigned long long& shift) {
+  b = ((unsigned long long)(p.N - 1) * p.ldb + p.K) * 2ull;
+  if (mode == MODE_DIRECT) {
+    shift = 0;
+    a = ((unsigned long long)(p.M - 1) * p.lda + p.K) * 2ull;
+  } else {
+    const unsigned long long rows = (unsigned long long)p.M / ((unsigned long long)p.OH * p.OW);
+    shift = (unsigned long long)(p.IW + 1) * p.lda * 2ull;
+    a = rows * p.IH * p.IW * p.lda * 2ull + shift + (unsigned long long)(2 * p.IW + 2) * p.lda * 2ull;
+  }
+  return a < 0x7fffffffull && b < 0x7fffffffull;
+}
+
+}  // namespace
+
+// 0 = off, 1 = on for eligible shapes (SKG_GEMM8, read once)
+static int gemm8_mode() {
+  static const int v = getenv("SKG_GEMM8") ? atoi(getenv("SKG_GEMM8")) : 0;
+  return v;
+}
+
+bool skg_gemm8_eligible(const GemmParams& p, int mode) {
+  if (!gemm8_mode()) return false;
+  if (mode != MODE_DIRECT && mode != MODE_S1) return false;
+  if (p.K % BK != 0 || p.K < 2 * BK || p.N % BN != 0 || p.M < 1) return false;
+  if (mode == MODE_S1 && p.Cin % BK != 0) return false;
+  if (p.flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) return false;
+  if (p.ldc % 4 != 0 || (p.res && p.ldr % 4 != 0)) return false;
+  const long tiles = (long)skg_cdiv(p.M, BM) * (p.N / BN);
+  if (tiles < 224) return false;                 // fewer workgroups than CUs: the 128-row tiles fill the chip better
+  unsigned long long a, b, s;
+  return operand_bytes(p, mode, a, b, s);
+}
+
+bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st) {
+  if (!skg_gemm8_eligible(p, mode)) return false;
+  unsigned long long a, b, s;
+  operand_bytes(p, mode, a, b, s);
+  const int tiles_n = p.N / BN;
+  const int ntiles = skg_cdiv(p.M, BM) * tiles_n;
+  static const int exp = getenv("SKG_G8_EXP") ? atoi(getenv("SKG_G8_EXP")) : 0;
+#define G8_LAUNCH(M_, E_) hipLaunchKernelGGL((gemm8_kernel<M_, E_>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles, \
+                                             (unsigned)a, (unsigned)b, (unsigned)s)
+  if (mode == MODE_DIRECT) {
+    G8_LAUNCH(MODE_DIRECT, 0);
+  } else {
+    switch (exp) {
+      case 1: G8_LAUNCH(MODE_S1, 1); break;
+      case 2: G8_LAUNCH(MODE_S1, 2); break;
+      case 3: G8_LAUNCH(MODE_S1, 3); break;
+      case 4: G8_LAUNCH(MODE_S1, 4); break;
+      case 8: G8_LAUNCH(MODE_S1, 8); break;
+      case 11: G8_LAUNCH(MODE_S1, 11); break;
+      case 16: G8_LAUNCH(MODE_S1, 16); break;
+      case 20: G8_LAUNCH(MODE_S1, 20); break;
+      default: G8_LAUNCH(MODE_S1, 0); break;
+    }
+  }
+  return true;
+}

@@ -22,3 +22,6 @@ int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode);
 void skg_gemm2_set_workspace(float* ws, size_t bytes);
 // v4 (gemm4.hip): persistent wave-specialised 128 x 160 kernel (DIRECT mode, plain epilogue); false = out of scope.
 bool skg_gemm4_try_launch(const GemmParams& p, int mode, hipStream_t st);
+// v8 (gemm8.hip): 256 x 160 tiles, one 8-wave workgroup per CU, ping-pong schedule (DIRECT / S1, plain epilogue).
+bool skg_gemm8_eligible(const GemmParams& p, int mode);
+bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st);

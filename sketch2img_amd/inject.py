@@ -10,10 +10,11 @@ projected + normalised sketch tokens and, for the feature variant, the K / V pro
 samples.  LayerNorm is per token, so LayerNorm(cat([h, s])) == cat(LayerNorm(h), LayerNorm(s)): the sketch
 tokens are normalised once and copied into the tail of the per-step token buffer.
 
-Buffers, CLIP variant, per block: tokens [rows][N + T_pad][C] with T = 257 sketch tokens padded to a multiple
-of 8; the first N slots of every batch row are refreshed each step (skg_batch_copy_f16), the attention runs
-over all slots as queries (the T_pad sketch-query outputs are never read: 6 % extra work at N = 4096, no
-extra kernels) with the last padding keys masked by Nkv < kv_stride.
+Buffers, CLIP variant, per block: K / V [rows][N + T_pad][2C] with T = 257 sketch tokens padded to a multiple of 8.
+The sketch tokens' K / V rows do not depend on the latent and are written once per image; each step the image
+tokens' K / V go straight into the first N slots of every batch row (one GEMM per row, no copy), the queries are
+the N image tokens only (the reference slices the sketch-query outputs away, clip_guided_attn.py:119) and the
+last padding keys are masked by Nkv < kv_stride.
 """
 from __future__ import annotations
 
@@ -110,7 +111,8 @@ class HipInjector:
         st = sketch_state.to(self.dev, torch.float16).reshape(rows * T, D).contiguous()
         for path, w in self.W.items():
             s = ops.gemm(st, w["wp"], bias=w["bp"])
-            self.per_image[path] = dict(zs=ops.layernorm(s, w["ng"], w["nb"]), rows=rows, T=T, bufs={})
+            zs = ops.layernorm(s, w["ng"], w["nb"])
+            self.per_image[path] = dict(kvs=ops.gemm(zs, w["wkv"]), rows=rows, T=T, bufs={})
 
     def set_res_samples(self, res_samples: Optional[Sequence[Sequence[torch.Tensor]]]):
         """Feature variant.  res_samples: per down block a tuple of NCHW tensors [rows, C, h, w]."""
@@ -141,21 +143,19 @@ class HipInjector:
             a = ops.attn_fwd(q, pi["K"], pi["Vt"], rows, heads, N, N, N, dh, scale)
             o = ops.gemm(a, w["wo"], bias=w["bo"])
             return ops.gemm(o, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)
-        # CLIP variant: self-attention over [N image tokens ; T sketch tokens]
+        # CLIP variant: self-attention of the N image-token queries over [N image tokens ; T sketch tokens]
         assert pi["rows"] == rows
         T = pi["T"]
         L = (N + T + 7) // 8 * 8
-        buf = pi["bufs"].get(N)
-        if buf is None:
-            z = torch.zeros(rows * L, C, device=self.dev, dtype=torch.float16)
-            ops.batch_copy(pi["zs"], T, z[N:], L, rows, T)      # normalised sketch tokens, once per image
-            buf = pi["bufs"][N] = z
+        kvbuf = pi["bufs"].get(N)
+        if kvbuf is None:
+            kvbuf = torch.zeros(rows * L, 2 * C, device=self.dev, dtype=torch.float16)
+            ops.batch_copy(pi["kvs"], T, kvbuf[N:], L, rows, T)     # K / V of the normalised sketch tokens, once per image
+            pi["bufs"][N] = kvbuf
         zh = ops.layernorm(h, w["ng"], w["nb"])
-        ops.batch_copy(zh, N, buf, L, rows, N)
-        q = ops.gemm(buf, w["wq"])
-        kv = ops.gemm(buf, w["wkv"])
-        a = ops.attn_fwd(q, kv[:, :C], ops.transpose(kv[:, C:]), rows, heads, L, N + T, L, dh, scale)
+        q = ops.gemm(zh, w["wq"])
+        for b in range(rows):
+            ops.gemm(zh[b * N:(b + 1) * N], w["wkv"], out=kvbuf[b * L:b * L + N])
+        a = ops.attn_fwd(q, kvbuf[:, :C], ops.transpose(kvbuf[:, C:]), rows, heads, N, N + T, L, dh, scale)
         o = ops.gemm(a, w["wo"], bias=w["bo"])
-        on = torch.empty(rows * N, C, device=self.dev, dtype=torch.float16)
-        ops.batch_copy(o, L, on, N, rows, N)                    # [:, :N] (clip_guided_attn.py:119)
-        return ops.gemm(on, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)
+        return ops.gemm(o, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)

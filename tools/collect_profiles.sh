@@ -45,3 +45,5 @@ python tools/pmc_agg.py ${OUT}_pmc_MFMA > profiles/${TAG}_cfg${CFG}_mfma_counter
 python tools/mfma_report.py profiles/${TAG}_cfg${CFG}_mfma_counters.json profiles/${TAG}_cfg${CFG}_kernel_stats.csv \
   profiles/${TAG}_cfg${CFG}_hbm_counters.json > profiles/${TAG}_cfg${CFG}_mfma_counters.txt
 cat profiles/${TAG}_cfg${CFG}_mfma_counters.txt
+# gpurun only merges gpurun_out/ back: leave copies there (copy them into profiles/ in the build container)
+mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_cfg${CFG}_* gpurun_out/profiles_out/

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Per-kernel matrix-pipe utilisation from the committed counter passes (tools/collect_profiles.sh).
 
-  MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE)
-    SQ_VALU_MFMA_BUSY_CYCLES sums, over the chip's 256 CUs x 4 SIMDs, the cycles a SIMD's matrix pipe is busy
-    (16 per v_mfma_f32_16x16x32_f16, 32 per 32x32x16: MI355X_MICROARCH.md, per-instruction constants);
-    GRBM_GUI_ACTIVE = shader clock cycles the dispatch was active.
-  effective clock   = GRBM_GUI_ACTIVE / dispatch duration (the chip clocks to its power budget: DVFS give-back)
+  MFMA busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD)
+    = rocprofiler-sdk's MfmaUtil for gfx950 (counter_defs.yaml: reduce(SQ_VALU_MFMA_BUSY_CYCLES,sum) /
+    (reduce(GRBM_GUI_ACTIVE,max) * SIMD_NUM)).  SQ_VALU_MFMA_BUSY_CYCLES sums, over the chip's 256 CUs x 4 SIMDs, the
+    cycles a SIMD's matrix pipe is busy (16 per v_mfma_f32_16x16x32_f16: MI355X_MICROARCH.md per-instruction constants);
+    GRBM_GUI_ACTIVE has one instance per XCD and the CSV carries their SUM, so the per-XCD value (what `max` picks, the
+    instances agree to < 1 %) is sum / 8.
+  effective clock   = GRBM_GUI_ACTIVE per XCD / dispatch duration (the chip clocks to its power budget: DVFS give-back;
+    counter passes serialise the dispatches, so the chip runs cooler and faster here than in the un-profiled bench)
   HBM MB / launch   = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts half of wide coalesced reads)
 Usage: mfma_report.py mfma_counters.json kernel_stats.csv [hbm_counters.json]"""
 import csv
@@ -29,7 +32,7 @@ for k, v in mf.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" not in v or "GRBM_GUI_ACTIVE" not in v:
         continue
     n = v["GRBM_GUI_ACTIVE"]["launches"]
-    gui = v["GRBM_GUI_ACTIVE"]["sum"] / n
+    gui = v["GRBM_GUI_ACTIVE"]["sum"] / n / 8.0          # per XCD
     busy = v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / v["SQ_VALU_MFMA_BUSY_CYCLES"]["launches"]
     sqb = v.get("SQ_BUSY_CYCLES", {"sum": 0, "launches": 1})
     sqb = sqb["sum"] / max(1, sqb["launches"])
