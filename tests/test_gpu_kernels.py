@@ -142,6 +142,15 @@ def test_persistent_gemm(env):
     assert r.returncode == 0 and "ALL OK" in r.stdout
 
 
+def test_gemm8_pingpong_kernel():
+    """The opt-in 256 x 160 ping-pong kernel (gemm8.hip, SKG_GEMM8=1; DESIGN.md 3b records why it stays opt-in)."""
+    import os, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "_gemm8_check.py")],
+                       env=dict(os.environ, SKG_GEMM8="1"), capture_output=True, text=True, timeout=600)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "ALL OK" in r.stdout
+
+
 # ---------------------------------------------------------------------------------------------- conv
 def nhwc(x):   # [B,C,H,W] -> [B*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
