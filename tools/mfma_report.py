@@ -26,7 +26,7 @@ def norm(name):
 mf = json.load(open(sys.argv[1]))
 dur = {norm(r["Name"]): (float(r["AverageNs"]), int(r["Calls"]), float(r["Percentage"])) for r in csv.DictReader(open(sys.argv[2]))}
 hbm = json.load(open(sys.argv[3])) if len(sys.argv) > 3 else {}
-print(f"{'kernel':58s} {'% time':>6s} {'avg us':>8s} {'MFMA busy':>9s} {'SQ busy':>8s} {'clock GHz':>9s} {'HBM MB/launch':>13s}")
+print(f"{'kernel':58s} {'% time':>6s} {'avg us':>8s} {'MFMA busy':>9s} {'clock GHz':>9s} {'HBM MB/launch':>13s}")
 rows = []
 for k, v in mf.items():
     if "SQ_VALU_MFMA_BUSY_CYCLES" not in v or "GRBM_GUI_ACTIVE" not in v:
@@ -44,5 +44,5 @@ for k, v in mf.items():
         mb = (2 * hb["FETCH_SIZE"]["sum"] / hb["FETCH_SIZE"]["launches"] + hb["WRITE_SIZE"]["sum"] / hb["WRITE_SIZE"]["launches"]) * 1024 / 1e6
     rows.append((pct, k, avg_ns, busy / (1024.0 * gui) if gui else 0.0, sqb / gui if gui else 0.0, gui / ns if ns else None, mb))
 for pct, k, avg_ns, util, sq, clk, mb in sorted(rows, reverse=True)[:24]:
-    print(f"{k[:58]:58s} {pct:6.2f} {(avg_ns or 0) / 1e3:8.1f} {util:9.3f} {sq:8.2f} "
+    print(f"{k[:58]:58s} {pct:6.2f} {(avg_ns or 0) / 1e3:8.1f} {util:9.3f} "
           f"{(f'{clk:9.2f}' if clk else '        -')} {(f'{mb:13.1f}' if mb is not None else '            -')}")
