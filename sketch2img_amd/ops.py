@@ -18,23 +18,30 @@ CONV_S1, CONV_S2, CONV_UP2, CONV_S2T, CONV_S2A = 0, 1, 2, 3, 4
 
 
 _workspace = {}
-_workspace_dev = None
+_workspace_key = None
 WORKSPACE_BYTES = 128 << 20
 
 
 def _stream() -> int:
-    """Current HIP stream; also hands libskg.so the split-K workspace of the CURRENT device (one slab per device; the
-    library holds one pointer, so it is re-pointed whenever the current device changes).  Launches are assumed to
-    come from one stream per device at a time: the slab and the cached scratch buffers below are shared by every
-    launch (the pipeline is not re-entrant, like the reference's module-level state - DESIGN.md 4)."""
-    global _workspace_dev
-    dev = torch.cuda.current_device()
-    if dev != _workspace_dev:
-        if dev not in _workspace:
-            _workspace[dev] = torch.empty(WORKSPACE_BYTES // 4, device=f"cuda:{dev}", dtype=torch.float32)
-        check(lib.skg_set_workspace(_workspace[dev].data_ptr(), WORKSPACE_BYTES), "skg_set_workspace")
-        _workspace_dev = dev
-    return torch.cuda.current_stream().cuda_stream
+    """Current HIP stream; also hands libskg.so the split-K workspace of the CURRENT (device, stream): one slab per
+    stream, because launches on different streams may run concurrently (several pipelines in one process, a graph
+    capture stream next to the eager stream); the library holds one pointer that it reads at
+    launch time, so it is re-pointed whenever the (device, stream) of the caller changes.  Launches on ONE stream are
+    ordered, so they can share their stream's slab and scratch buffers."""
+    global _workspace_key
+    st = torch.cuda.current_stream()
+    key = (st.device.index, st.cuda_stream)
+    if key != _workspace_key:
+        if key not in _workspace:
+            _workspace[key] = torch.empty(WORKSPACE_BYTES // 4, device=st.device, dtype=torch.float32)
+        check(lib.skg_set_workspace(_workspace[key].data_ptr(), WORKSPACE_BYTES), "skg_set_workspace")
+        _workspace_key = key
+    return st.cuda_stream
+
+
+def _skey(dev):
+    """Scratch-buffer key part: device + current stream (see _stream)."""
+    return (str(dev), torch.cuda.current_stream().cuda_stream)
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -97,7 +104,7 @@ _scratch = {}
 
 def _gn_scratch(rows: int, groups: int, dev) -> torch.Tensor:
     n = lib.skg_groupnorm_scratch_floats(rows, groups)
-    key = ("gn", dev, n)
+    key = ("gn", _skey(dev), n)
     if key not in _scratch:
         _scratch[key] = torch.empty(n, device=dev, dtype=torch.float32)
     return _scratch[key]
@@ -357,7 +364,7 @@ def lgp_layer0_scatter(dZ, rows, h, s, H0):
 
 def _bn_scratch(samples, C, dev):
     n = lib.skg_bn_scratch_floats(samples, C)
-    key = ("bn", dev, n)
+    key = ("bn", _skey(dev), n)
     if key not in _scratch:
         _scratch[key] = torch.empty(n, device=dev, dtype=torch.float32)
     return _scratch[key]
@@ -416,7 +423,7 @@ def colsum(X, scale: float = 1.0):
     _f16(X)
     M, C = X.shape
     out = torch.empty(C, device=X.device, dtype=torch.float32)
-    key = ("colsum", X.device, C)
+    key = ("colsum", _skey(X.device), C)
     if key not in _scratch:
         _scratch[key] = torch.empty(lib.skg_colsum_scratch_floats(C), device=X.device, dtype=torch.float32)
     check(lib.skg_colsum_f16(_p(X), _ld(X), M, C, scale, _p(out), _p(_scratch[key]), _stream()), "skg_colsum_f16")
