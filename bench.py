@@ -38,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0     # dense fp16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_TBS = 8.0            # HBM3E peak (spec), MI355X_MICROARCH.md
 
 # algorithmic GFLOP per UNet row evaluation
 GF_SD15_FWD, GF_SD15_BWD, GF_LGP = 803.27, 929.33, 40.50
@@ -161,11 +162,15 @@ class LaunchTimer:
         self.ops.gemm, self.ops.conv3x3, self.ops.attn_fwd = self._gemm, self._conv, self._attn
 
     def summary(self):
+        """per kernel: [launches, flops, seconds, algorithmic bytes, roofline seconds, seconds of HBM-bound launches];
+        a launch's roofline time = max(flops / MFMA peak, algorithmic bytes / HBM peak)."""
         torch.cuda.synchronize()
         agg = {}
         for name, fl, e0, e1, nb, _ in self.rec:
-            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
-            a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += nb
+            a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0, 0.0])
+            t = e0.elapsed_time(e1) * 1e-3
+            t_m, t_h = fl / (PEAK_FP16_TFLOPS * 1e12), nb / (PEAK_HBM_TBS * 1e12)
+            a[0] += 1; a[1] += fl; a[2] += t; a[3] += nb; a[4] += max(t_m, t_h); a[5] += t if t_h > t_m else 0.0
         return agg
 
     def shape_report(self, path):
@@ -416,7 +421,7 @@ def main():
         agg = lt.summary()
         if args.shape_report:
             lt.shape_report(args.shape_report)
-        name, (n, fl, sec, nb) = max(agg.items(), key=lambda kv: kv[1][2])
+        name, (n, fl, sec, nb, _, _) = max(agg.items(), key=lambda kv: kv[1][2])
         tot_sec = sum(v[2] for v in agg.values())
         traffic, traffic_file = pmc_traffic(C, name)
         roof = dict(bound="mfma", kernel=name, achieved=fl / sec / 1e12, peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
@@ -427,8 +432,13 @@ def main():
                     timing="HIP events on the launch stream around every launch (includes the launch gap)",
                     all_contraction_tflops=sum(v[1] for v in agg.values()) / tot_sec / 1e12,
                     contraction_share_of_step=tot_sec / (dt / args.steps),
-                    per_kernel={k: dict(launches=v[0], tflops=v[1] / v[2] / 1e12, seconds=v[2]) for k, v in
-                                sorted(agg.items(), key=lambda kv: -kv[1][2])})
+                    # every launch against ITS OWN bound, max(flops / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s): the short-K
+                    # projections (K = 320: 320 flop per output byte against a machine balance of 312) are HBM-bound launches
+                    # of the same instantiation that runs the MFMA-bound ones
+                    all_contraction_frac_of_own_roofline=sum(v[4] for v in agg.values()) / tot_sec,
+                    per_kernel={k: dict(launches=v[0], tflops=v[1] / v[2] / 1e12, seconds=v[2],
+                                        frac_of_own_roofline=v[4] / v[2], hbm_bound_share_of_time=v[5] / v[2])
+                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])})
         rp = rocprof_duration(C, name)
         if rp is not None:
             avg_ns, calls, f = rp

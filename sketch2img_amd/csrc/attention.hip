@@ -14,7 +14,10 @@
 // V^T (and K^T, Q^T, dO^T for the backward kernels) are produced by skg_transpose_f16.
 //
 // Block = 4 waves = 64 query rows (forward, dQ) or 64 key rows (dK/dV); KV / Q tiles of 64 rows are
-// staged in LDS (padded pitches: conflict-free ds_read_b128 / b64 fragment reads).
+// staged in LDS.  Pitches: row tiles [64][32 KS + 16] (ds_read_b128 is served in four NON-contiguous 16-lane groups,
+// MI355X_MICROARCH.md section LDS: a pitch of 16 or 48 mod 64 halves puts each group on 16 distinct 16-byte slots; the
+// round-1 pitch 32 KS + 8 was 2-way conflicted - SQ_LDS_BANK_CONFLICT = 42 % of SQ_LDS_IDX_ACTIVE), transposed tiles
+// [d][72] read with ds_read_b64 pairs (two 32-lane groups: conflict-free at 72).
 #include "common.h"
 #include <stdlib.h>
 
@@ -87,7 +90,7 @@ constexpr int TP = 72;   // pitch (halves) of the transposed tiles [d][64 + 8]
 template <int KS>
 __device__ __forceinline__ void stage_rows(half_t* __restrict__ dst, const half_t* __restrict__ src, int ld,
                                            int r0, int rlim, int dh) {
-  constexpr int KP = KS * 32 + 8;
+  constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
   constexpr int PPR = KS * 4;
   for (int pi = threadIdx.x; pi < 64 * PPR; pi += 256) {
     const int r = pi / PPR, pc = (pi - r * PPR) * 8;
@@ -142,7 +145,7 @@ __device__ __forceinline__ void rows_load(RowRegs<KS>& r, const half_t* __restri
 }
 template <int KS>
 __device__ __forceinline__ void rows_store(const RowRegs<KS>& r, half_t* __restrict__ dst) {
-  constexpr int KP = KS * 32 + 8;
+  constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
   constexpr int PPR = KS * 4;
 #pragma unroll
   for (int q = 0; q < KS; ++q) {
@@ -205,7 +208,7 @@ __device__ __forceinline__ void kv_load(KVRegs<KS, ND>& r, const half_t* __restr
 
 template <int KS, int ND>
 __device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __restrict__ Ks, half_t* __restrict__ Vs) {
-  constexpr int KP = KS * 32 + 8;
+  constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
   constexpr int PPR = KS * 4;
 #pragma unroll
   for (int q = 0; q < KVRegs<KS, ND>::NK; ++q) {
@@ -217,6 +220,117 @@ __device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __rest
   for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) {
     const int pi = threadIdx.x + q * 256;
     if (pi < ND * 128) st_half8(Vs + (pi >> 3) * TP + (pi & 7) * 8, r.v[q]);
+  }
+}
+
+// The same prefetch through buffer descriptors: every per-lane source offset is loop-invariant (row / column inside the
+// tile, or an out-of-range constant for the zero-padded head-dim columns / rows), the tile position is a wave-uniform
+// soffset and the descriptor's range check supplies the zeros behind the last key row - a prefetch is 2 * (KS + NV)
+// instructions instead of ~15 VALU + 8 SALU per load of compare / select / zero-fill / exec masking (the round-2 counters:
+// 140 VALU instructions per tile and wave of which only 32 + 16 + 20 are the softmax; VALU time ~ MFMA time at d = 40).
+constexpr unsigned ATT_OOB = 0x80000000u;
+template <int KS, int ND>
+struct KVSrc {
+  __amdgpu_buffer_rsrc_t rk, rv;
+  unsigned ko[KVRegs<KS, ND>::NK], vo[KVRegs<KS, ND>::NV];
+  int vcol[KVRegs<KS, ND>::NV];            // first key column of the lane's piece (ragged last tile only)
+  unsigned ones;                           // bit q: piece q of this lane is the all-ones row (ONES)
+};
+template <int KS, int ND, bool ONES>
+__device__ __forceinline__ KVSrc<KS, ND> kv_src(const half_t* Kb, int ldk, const half_t* Vb, int ldvt, int kvlim, int dh) {
+  KVSrc<KS, ND> s;
+  // K: rows of THIS batch row only (the next row's keys start right behind: the size is what cuts them off)
+  s.rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (unsigned)(((size_t)(kvlim - 1) * ldk + dh) * 2), 0x00020000);
+  s.rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (unsigned)(((size_t)(dh - 1) * ldvt + kvlim) * 2), 0x00020000);
+  constexpr int PPR = KS * 4;
+  s.ones = 0;
+#pragma unroll
+  for (int q = 0; q < KVRegs<KS, ND>::NK; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    const int row = pi / PPR, pc = (pi - row * PPR) * 8;
+    s.ko[q] = pc < dh ? (unsigned)(row * ldk + pc) * 2u : ATT_OOB;
+  }
+#pragma unroll
+  for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    const int d = pi >> 3, pc = (pi & 7) * 8;
+    s.vo[q] = (pi < ND * 128 && d < dh) ? (unsigned)(d * ldvt + pc) * 2u : ATT_OOB;
+    s.vcol[q] = pc;
+    if (ONES && d == dh) s.ones |= 1u << q;
+  }
+  return s;
+}
+__device__ __forceinline__ half8_t buf_half8(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+  return __builtin_bit_cast(half8_t, v);
+}
+template <int KS, int ND, bool ONES>
+__device__ __forceinline__ void kv_load_buf(KVRegs<KS, ND>& r, const KVSrc<KS, ND>& s, int kv0, int ldk, int kvlim) {
+  const unsigned sk = (unsigned)kv0 * (unsigned)ldk * 2u, sv = (unsigned)kv0 * 2u;
+#pragma unroll
+  for (int q = 0; q < KVRegs<KS, ND>::NK; ++q) r.k[q] = buf_half8(s.rk, s.ko[q], sk);
+  if (kv0 + 64 <= kvlim) {                 // wave-uniform
+#pragma unroll
+    for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) r.v[q] = buf_half8(s.rv, s.vo[q], sv);
+  } else {                                 // ragged last tile: key columns behind this batch row's keys read as zero
+#pragma unroll
+    for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) r.v[q] = buf_half8(s.rv, kv0 + s.vcol[q] < kvlim ? s.vo[q] : ATT_OOB, sv);
+  }
+  if (ONES) {
+    const half_t one = (half_t)1.f;
+#pragma unroll
+    for (int q = 0; q < KVRegs<KS, ND>::NV; ++q)
+      if ((s.ones >> q) & 1u) r.v[q] = half8_t{one, one, one, one, one, one, one, one};
+  }
+}
+
+// The backward kernels' row / transposed tiles through the same descriptors (see KVSrc)
+template <int KS>
+struct RowSrc { __amdgpu_buffer_rsrc_t r; unsigned o[KS]; };
+template <int KS>
+__device__ __forceinline__ RowSrc<KS> row_src(const half_t* src, int ld, int rlim, int dh) {
+  RowSrc<KS> s;
+  s.r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)(((size_t)(rlim - 1) * ld + dh) * 2), 0x00020000);
+  constexpr int PPR = KS * 4;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    const int row = pi / PPR, pc = (pi - row * PPR) * 8;
+    s.o[q] = pc < dh ? (unsigned)(row * ld + pc) * 2u : ATT_OOB;
+  }
+  return s;
+}
+template <int KS>
+__device__ __forceinline__ void rows_load_buf(RowRegs<KS>& r, const RowSrc<KS>& s, int ld, int r0) {
+  const unsigned so = (unsigned)r0 * (unsigned)ld * 2u;
+#pragma unroll
+  for (int q = 0; q < KS; ++q) r.v[q] = buf_half8(s.r, s.o[q], so);
+}
+template <int ND>
+struct ColSrc { __amdgpu_buffer_rsrc_t r; unsigned o[(ND + 1) / 2]; int col[(ND + 1) / 2]; };
+template <int ND>
+__device__ __forceinline__ ColSrc<ND> col_src(const half_t* src, int ld, int clim, int dh) {
+  ColSrc<ND> s;
+  s.r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)(((size_t)(dh - 1) * ld + clim) * 2), 0x00020000);
+#pragma unroll
+  for (int q = 0; q < (ND + 1) / 2; ++q) {
+    const int pi = threadIdx.x + q * 256;
+    const int d = pi >> 3, pc = (pi & 7) * 8;
+    s.o[q] = (pi < ND * 128 && d < dh) ? (unsigned)(d * ld + pc) * 2u : ATT_OOB;
+    s.col[q] = pc;
+  }
+  return s;
+}
+template <int ND>
+__device__ __forceinline__ void cols_load_buf(ColRegs<ND>& r, const ColSrc<ND>& s, int c0, int clim) {
+  const unsigned so = (unsigned)c0 * 2u;
+  if (c0 + 64 <= clim) {
+#pragma unroll
+    for (int q = 0; q < (ND + 1) / 2; ++q) r.v[q] = buf_half8(s.r, s.o[q], so);
+  } else {
+#pragma unroll
+    for (int q = 0; q < (ND + 1) / 2; ++q) r.v[q] = buf_half8(s.r, c0 + s.col[q] < clim ? s.o[q] : ATT_OOB, so);
   }
 }
 
@@ -233,7 +347,7 @@ template <int KS, int ND, int QT, bool CAUSAL = false, int VAR = 0>
 __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL && QT == 2) ? 4 : 2)) void attn_fwd_kernel(const AttnParams p) {
   // QT query tiles of 16 per wave: a workgroup covers 64 * QT queries, so every K / V^T fragment read from LDS
   // (and every byte of K/V streamed from L2) is used by QT MFMAs instead of one.
-  constexpr int KP = KS * 32 + 8;
+  constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
   constexpr int KSZ = 64 * KP, VSZ = ND * 16 * TP;
   __shared__ __attribute__((aligned(16))) half_t lds[2 * (KSZ + VSZ)];      // two (K, V^T) stages
   half_t* const Ks0 = lds;
@@ -405,23 +519,24 @@ __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS =
   // registers on its way to the other stage and tile t+2 is in flight from L2/HBM, ONE barrier per tile.
   // Invariant at the top of the (unrolled-by-2) loop, t even: stage 0 = tile t, r0 = tile t+1, r1 = tile t+2.
   constexpr bool DEEP = KS < 5 && !(KS == 2 && ND == 3) && !(VAR & 2);      // d = 160: a second register set would not fit 2 waves / SIMD; d = 40: four waves / SIMD instead
+  const KVSrc<KS, ND> src = kv_src<KS, ND, ONES>(Kb, p.ldk, Vb, p.ldvt, p.kv_stride, dh);
   KVRegs<KS, ND> r0;
-  kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, 0, p.kv_stride, dh);
+  kv_load_buf<KS, ND, ONES>(r0, src, 0, p.ldk, p.kv_stride);
   kv_store<KS, ND>(r0, Ks0, Vs0);
-  if (nt > 1) kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, 64, p.kv_stride, dh);
+  if (nt > 1) kv_load_buf<KS, ND, ONES>(r0, src, 64, p.ldk, p.kv_stride);
   if constexpr (DEEP) {
     KVRegs<KS, ND> r1;
-    if (nt > 2) kv_load<KS, ND, ONES>(r1, Kb, p.ldk, Vb, p.ldvt, 128, p.kv_stride, dh);
+    if (nt > 2) kv_load_buf<KS, ND, ONES>(r1, src, 128, p.ldk, p.kv_stride);
     __syncthreads();
     for (int t0 = 0; t0 < nt; t0 += 2) {
       tile(Ks0, Vs0, t0 * 64);
       if (t0 + 1 < nt) kv_store<KS, ND>(r0, Ks1, Vs1);
-      if (t0 + 3 < nt) kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 3) * 64, p.kv_stride, dh);
+      if (t0 + 3 < nt) kv_load_buf<KS, ND, ONES>(r0, src, (t0 + 3) * 64, p.ldk, p.kv_stride);
       __syncthreads();
       if (t0 + 1 < nt) {
         tile(Ks1, Vs1, (t0 + 1) * 64);
         if (t0 + 2 < nt) kv_store<KS, ND>(r1, Ks0, Vs0);
-        if (t0 + 4 < nt) kv_load<KS, ND, ONES>(r1, Kb, p.ldk, Vb, p.ldvt, (t0 + 4) * 64, p.kv_stride, dh);
+        if (t0 + 4 < nt) kv_load_buf<KS, ND, ONES>(r1, src, (t0 + 4) * 64, p.ldk, p.kv_stride);
         __syncthreads();
       }
     }
@@ -439,11 +554,11 @@ __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS =
       ATT_ACC(3, t1, t2);                 // staging the next tile (waits for its global loads)
       ATT_ACC(4, t2, t3);                 // barrier
       if (t0 + 1 < nt) {
-        if (t0 + 2 < nt) kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 2) * 64, p.kv_stride, dh);
+        if (t0 + 2 < nt) kv_load_buf<KS, ND, ONES>(r0, src, (t0 + 2) * 64, p.ldk, p.kv_stride);
         tile(Ks1, Vs1, (t0 + 1) * 64);
         ATT_T(t4);
         if (t0 + 2 < nt) kv_store<KS, ND>(r0, Ks0, Vs0);
-        if (t0 + 3 < nt) kv_load<KS, ND, ONES>(r0, Kb, p.ldk, Vb, p.ldvt, (t0 + 3) * 64, p.kv_stride, dh);
+        if (t0 + 3 < nt) kv_load_buf<KS, ND, ONES>(r0, src, (t0 + 3) * 64, p.ldk, p.kv_stride);
         ATT_T(t5);
         __syncthreads();
         ATT_T(t6);
@@ -491,7 +606,7 @@ __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS =
 template <int KS, int ND, int QT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
   // QT query tiles of 16 per wave (64 * QT queries per workgroup): each K / V / K^T fragment read feeds QT MFMAs
-  constexpr int KP = KS * 32 + 8;
+  constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
   __shared__ __attribute__((aligned(16))) half_t Ks[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Vr[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Kt[ND * 16 * TP];
@@ -539,9 +654,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   // register prefetch: the three tiles of key block t+1 are loaded while block t computes
   RowRegs<KS> rk, rv;
   ColRegs<ND> rkt;
-  rows_load<KS>(rk, Kb, p.ldk, 0, p.kv_stride, dh);
-  rows_load<KS>(rv, Vb, p.ldv, 0, p.kv_stride, dh);
-  cols_load<ND>(rkt, Ktb, p.ldvt, 0, p.kv_stride, dh);
+  const RowSrc<KS> sk = row_src<KS>(Kb, p.ldk, p.kv_stride, dh), sv = row_src<KS>(Vb, p.ldv, p.kv_stride, dh);
+  const ColSrc<ND> skt = col_src<ND>(Ktb, p.ldvt, p.kv_stride, dh);
+  rows_load_buf<KS>(rk, sk, p.ldk, 0);
+  rows_load_buf<KS>(rv, sv, p.ldv, 0);
+  cols_load_buf<ND>(rkt, skt, 0, p.kv_stride);
   for (int t0 = 0; t0 < nt; ++t0) {
     const int kv0 = t0 * 64;
     __syncthreads();                     // everyone is done reading the previous block
@@ -550,9 +667,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     cols_store<ND>(rkt, Kt);
     __syncthreads();
     if (t0 + 1 < nt) {
-      rows_load<KS>(rk, Kb, p.ldk, kv0 + 64, p.kv_stride, dh);
-      rows_load<KS>(rv, Vb, p.ldv, kv0 + 64, p.kv_stride, dh);
-      cols_load<ND>(rkt, Ktb, p.ldvt, kv0 + 64, p.kv_stride, dh);
+      rows_load_buf<KS>(rk, sk, p.ldk, kv0 + 64);
+      rows_load_buf<KS>(rv, sv, p.ldv, kv0 + 64);
+      cols_load_buf<ND>(rkt, skt, kv0 + 64, p.kv_stride);
     }
     float4_t s[QT][4], dp[QT][4];      // s = S*sc - lse,  dp = dP - delta  straight out of the matrix pipe
 #pragma unroll
@@ -617,7 +734,7 @@ template <int KS, int ND, int KT>
 __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(const AttnParams p) {
   // KT key tiles of 16 per wave: a workgroup owns 64 * KT keys, so every Q / dO / Q^T / dO^T fragment read from LDS
   // (and every byte of those panels streamed from L2) feeds KT MFMAs instead of one (same idea as QT in the forward).
-  constexpr int KP = KS * 32 + 8;
+  constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
   __shared__ __attribute__((aligned(16))) half_t Qs[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Ds[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Qt[ND * 16 * TP];
@@ -668,11 +785,13 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
   RowRegs<KS> rq, rd;
   ColRegs<ND> rqt, rdt;
   float r_lse = 0.f, r_del = 0.f;
+  const RowSrc<KS> sq = row_src<KS>(Qb, p.ldq, p.Nq, dh), sd = row_src<KS>(Db, p.lddo, p.Nq, dh);
+  const ColSrc<ND> sqt = col_src<ND>(Qtb, p.ldqt, p.Nq, dh), sdt = col_src<ND>(Dtb, p.lddot, p.Nq, dh);
   auto prefetch = [&](int q0) {
-    rows_load<KS>(rq, Qb, p.ldq, q0, p.Nq, dh);
-    rows_load<KS>(rd, Db, p.lddo, q0, p.Nq, dh);
-    cols_load<ND>(rqt, Qtb, p.ldqt, q0, p.Nq, dh);
-    cols_load<ND>(rdt, Dtb, p.lddot, q0, p.Nq, dh);
+    rows_load_buf<KS>(rq, sq, p.ldq, q0);
+    rows_load_buf<KS>(rd, sd, p.lddo, q0);
+    cols_load_buf<ND>(rqt, sqt, q0, p.Nq);
+    cols_load_buf<ND>(rdt, sdt, q0, p.Nq);
     if (threadIdx.x < 64) {
       const int qq = q0 + threadIdx.x;
       r_lse = qq < p.Nq ? -p.lse[sbase + qq] * LOG2E : NEG_BIG;      // stored NEGATED: they are MFMA C operands

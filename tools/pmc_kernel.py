@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""One kernel shape, a few launches - the target of `rocprofv3 --pmc ...` passes (tools/pmc_kernels.sh).
+    python tools/pmc_kernel.py attn40 | attn64 | conv | gemm_short | gemm_ff1"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sketch2img_amd import ops  # noqa: E402
+
+dev = "cuda:0"
+what = sys.argv[1]
+g = torch.Generator().manual_seed(1)
+if what.startswith("attn"):
+    B, H, N, Nkv, d = (16, 8, 4096, 4096, 40) if what == "attn40" else (8, 5, 9216, 9473, 64)
+    kvs = (Nkv + 7) // 8 * 8
+    q = torch.randn(B * N, H * d, generator=g).half().to(dev)
+    k = torch.randn(B * kvs, H * d, generator=g).half().to(dev)
+    v = torch.randn(B * kvs, H * d, generator=g).half().to(dev)
+    vt = ops.transpose(v)
+    fn = lambda: ops.attn_fwd(q, k, vt, B, H, N, Nkv, kvs, d, d ** -0.5)
+elif what == "conv":
+    rows, hw, cin, cout = 16, 32, 1920, 640
+    x = torch.randn(rows * hw * hw, cin, generator=g).half().to(dev)
+    w = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(dev)
+    fn = lambda: ops.conv3x3(x, w, rows, hw, hw, 0)
+else:
+    M, N, K = (65536, 320, 320) if what == "gemm_short" else (65536, 2560, 320)
+    a = torch.randn(M, K, generator=g).half().to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev)
+    fn = lambda: ops.gemm(a, w)
+for _ in range(6):
+    fn()
+torch.cuda.synchronize()
