@@ -47,3 +47,5 @@ python tools/mfma_report.py profiles/${TAG}_cfg${CFG}_mfma_counters.json profile
 cat profiles/${TAG}_cfg${CFG}_mfma_counters.txt
 # gpurun only merges gpurun_out/ back: leave copies there (copy them into profiles/ in the build container)
 mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_cfg${CFG}_* gpurun_out/profiles_out/
+# the raw traces are tens of MB per config and gpurun_out/ may carry 64 MiB back: keep the summaries only
+rm -rf ${OUT}_trace ${OUT}_pmc_FETCH_SIZE ${OUT}_pmc_WRITE_SIZE ${OUT}_pmc_MFMA
