@@ -8,6 +8,13 @@ from __future__ import annotations
 import ctypes
 import os
 
+# Load order matters: PyTorch-ROCm ships its own libamdhip64 under torch/lib, libskg.so is linked against the SONAME
+# libamdhip64.so.7.  Whichever is loaded first decides which HIP runtime the process gets; if libskg.so came first, its
+# kernels would be launched through a second runtime instance that never saw torch's device / streams
+# ("no ROCm-capable device is detected" at the first launch).  Importing torch first makes libskg.so bind to the runtime
+# torch already loaded - the one that owns the tensors and streams every launch uses.
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SKG_LIB: another build of the same ABI (same-box A/B measurements of kernel variants); default = the in-tree library
 LIB_PATH = os.environ.get("SKG_LIB") or os.path.join(_HERE, "libskg.so")
