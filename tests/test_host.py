@@ -339,3 +339,13 @@ def test_vae_attention_keys_both_diffusers_spellings():
     back = _HipVAEBlocks.normalise_attention_keys(new)
     assert set(back) == set(sd) and all(torch.equal(back[k], sd[k]) for k in sd)
     assert _HipVAEBlocks.normalise_attention_keys(sd).keys() == sd.keys()
+
+
+def test_binding_loads_torch_before_libskg():
+    """libskg.so must bind to the HIP runtime torch ships (one runtime per process): importing the binding alone has to
+    import torch first.  (build() followed by smoke() in one process used to launch through a second runtime.)"""
+    r = subprocess.run([sys.executable, "-c",
+                        "import sys; sys.path.insert(0, %r); import sketch2img_amd._lib as L; "
+                        "ks = list(sys.modules); assert ks.index('torch') < ks.index('sketch2img_amd._lib'); print('order ok')" % ROOT],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "order ok" in r.stdout, r.stderr[-1500:]
