@@ -248,6 +248,40 @@ def test_graph_replay_is_bit_identical_to_eager(sched):
     assert lg.num_batches_tracked == [2 * n for n in eager.lgp.num_batches_tracked]
 
 
+@pytest.mark.parametrize("variant", ["clip", "sketch"])
+def test_graph_replay_with_injected_attention_is_bit_identical(variant):
+    """bench.py --graph is allowed with configs 4 / 5: the injectors' per-image buffers are created by the eager
+    warm-up pass, the captured steps only read / refresh them."""
+    from oracle import unet as ounet
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import TINY
+    from sketch2img_amd.inject import HipInjector
+    from sketch2img_amd.sampler import DDIMTables, HipSampler
+    from sketch2img_amd.unet import HipUNet
+    W = ounet.init_weights(ounet.TINY)
+    g = torch.Generator().manual_seed(4)
+    h, T, S = 32, 4, 2
+    x0 = torch.randn(S, 4, h, h, generator=g)
+    ehs = torch.randn(2 * S, 77, TINY.cross_attention_dim, generator=g).half().float()
+    net = HipUNet(TINY, W, DEV, need_backward=False)
+    net.prepare_context(ehs)
+    inj = HipInjector(TINY, synthetic.satmixin_state_dict(TINY, variant), variant, DEV)
+    if variant == "clip":
+        inj.set_state(synthetic.sketch_state(0, S))
+    else:
+        inj.set_res_samples(synthetic.res_samples(TINY, 0, S, h))
+    net.inject = inj
+    tab = DDIMTables.make(T)
+    a = HipSampler(net, None).sample(x0, None, T, tables=tab).clone()
+    gs = HipSampler(net, None, use_graphs=True)
+    b = gs.sample(x0, None, T, tables=tab).clone()
+    c = gs.sample(x0, None, T, tables=tab).clone()
+    assert torch.equal(a, b) and torch.equal(a, c)
+    net.inject = None
+    plain = HipSampler(net, None).sample(x0, None, T, tables=tab)
+    assert not torch.equal(plain, a)
+
+
 # ------------------------------------------------------------------------------------- N > 1 on real hardware
 def _bench(args, env=None, nproc=1, port=29611):
     cmd = [sys.executable]
