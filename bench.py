@@ -344,16 +344,22 @@ def build_workload(args, rank, world, dev, dist):
     lat0 = synthetic.initial_latents(first, S, h).to(dev)
     sampler = HipSampler(net, lgp, use_graphs=args.graph)
 
+    decode_events = []
+
     def one_batch():
         x = sampler.sample(lat0, target, T, tables=tab)
         if vae is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             x = vae.decode_to_u8(x)                      # [S, 8h, 8h, 3] uint8: what the final gather carries
+            e1.record()
+            decode_events.append((e0, e1))
         if world > 1:
             got = (gather_images if vae is not None else gather_latents)(x, world, dst=0)
             return x if got is None else torch.cat(got)
         return x
 
-    return dict(one_batch=one_batch, sampler=sampler, net=net, vae=vae, S=S, h=h, T=T, tab=tab, lat0=lat0, target=target)
+    return dict(one_batch=one_batch, sampler=sampler, net=net, decode_events=decode_events, vae=vae, S=S, h=h, T=T, tab=tab, lat0=lat0, target=target)
 
 
 def main():
@@ -393,6 +399,7 @@ def main():
     for _ in range(args.warmup):
         out = one_batch()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    wl["decode_events"].clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = one_batch()
@@ -409,6 +416,9 @@ def main():
         dist.all_reduce(ft, op=dist.ReduceOp.MIN)
         finite = bool(int(ft))
     value = world * S * args.steps / dt
+    # the VAE decode's share of the timed region on this rank (HIP events), and the throughput with round 1's definition
+    # of a step (stops at the latents: SURVEY 8d keeps the 2.51 TFLOP decode out of F_img)
+    decode_s = sum(a.elapsed_time(b) for a, b in wl["decode_events"]) * 1e-3
     if rank == 0 and args.dump_images:
         torch.save(dict(images=out.cpu(), latents=lat_final.cpu()), args.dump_images)
 
@@ -467,6 +477,8 @@ def main():
                        "parallelism": f"replicas x{world} (samples sharded, weights broadcast, "
                                       f"{'decoded images' if args.gather == 'images' else 'latents'} gathered)"},
             "ms_per_image": dt / args.steps / S * 1e3,
+            "decode_ms_per_step": decode_s / args.steps * 1e3 if wl["decode_events"] else None,
+            "value_excluding_decode": world * S * args.steps / (dt - decode_s) if wl["decode_events"] and world == 1 else None,
             "achieved_tflops_per_gpu": value / world * f_img_tflop(C, T) if args.scheduler == "ddim" else None,
             "tflop_per_image": f_img_tflop(C, T), "outputs_finite": finite, "out_shape": list(out.shape),
             "setup_s": t_setup, "roofline": roof, "cpu_baseline": cpu,
