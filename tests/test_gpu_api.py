@@ -329,6 +329,15 @@ def test_pipeline_decodes_with_hip_vae(pipe):
         assert isinstance(imgs, list) and len(imgs) == 2 and imgs[0].size == (8 * h, 8 * h) and imgs[0].mode == "RGB"
         arr = pipe(["a cat", "a dog"], height=8 * h, width=8 * h, num_inference_steps=2, latents=lat, output_type="np.array")
         assert arr.shape == (2, 8 * h, 8 * h, 3) and arr.dtype == "float32" and 0.0 <= arr.min() and arr.max() <= 1.0
+        # the fused decode + numpy_to_pil quantisation (what a rank hands to the gather of decoded images) equals
+        # numpy_to_pil applied to the float image, bit for bit (round half to even on the same fp32 values)
+        import numpy as np
+        z = torch.randn(2, 4, h, h, generator=torch.Generator().manual_seed(9)) * 0.18215
+        u8 = pipe.vae.decode_to_u8(z.to("cuda")).cpu().numpy()
+        f32 = pipe.vae.decode_latents(z.to("cuda")).cpu().numpy()
+        assert u8.dtype == np.uint8 and u8.shape == (2, 8 * h, 8 * h, 3)
+        assert np.array_equal(u8, (f32 * 255).round().astype("uint8"))
+        assert np.array_equal(np.asarray(pipe.numpy_to_pil(f32)[1]), u8[1])
     finally:
         pipe.vae = old
 
