@@ -899,23 +899,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
   }
 }
 
-// tuning variants of the d = 40 / d = 64 forward (SKG_ATTN_VAR, tools/attn_bench.py); 0 = shipped
+// d = 40 / d = 64 forward.  d = 64 ships with ONE register prefetch set: 152 VGPRs = three waves per SIMD instead of two
+// (+8...15 %); d = 40 already runs four waves per SIMD.  SKG_ATTN_VAR=7 launches the two-set form for A/B runs
+// (tools/attn_var_bench.py; the other variants measured in round 2 - all fragments of a tile requested up front, four
+// query tiles per wave - lost and are not instantiated: profiles/r02_attn_variants.txt).
 #define SKG_ATTN_VARIANTS(KS_, ND_, grid2)                                                                       \
-  switch (attn_var()) {                                                                                          \
-    case 1: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 1>), grid2, dim3(256), 0, st, p); break;       \
-    case 2: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 2 | (3 << 2)>), grid2, dim3(256), 0, st, p); break; \
-    case 3: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 1 | 2>), grid2, dim3(256), 0, st, p); break;   \
-    case 4: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, (2 << 2)>), grid2, dim3(256), 0, st, p); break; \
-    case 5: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, 1 | (2 << 2)>), grid2, dim3(256), 0, st, p); break; \
-    case 6: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 1 | (3 << 2)>), grid2, dim3(256), 0, st, p); break; \
-    case 7: hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2>), grid2, dim3(256), 0, st, p); break;              \
-    default:                                                                                                     \
-      /* d = 64: one register prefetch set -> 162 VGPRs = three waves per SIMD instead of two (+8...15 %, */     \
-      /* tools/attn_var_bench.py); d = 40 already runs four waves per SIMD */                                    \
-      if (ND_ == 4) hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 2 | (3 << 2)>), grid2, dim3(256), 0, st, p); \
-      else hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2>), grid2, dim3(256), 0, st, p);                       \
-      break;                                                                                                     \
-  }
+  if (ND_ == 4 && attn_var() != 7)                                                                               \
+    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 2 | (3 << 2)>), grid2, dim3(256), 0, st, p);         \
+  else                                                                                                           \
+    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2>), grid2, dim3(256), 0, st, p)
 
 // forward: two query tiles per wave (128 queries per workgroup) except at d = 160 (register budget)
 #define SKG_ATTN_FWD_DISPATCH(grid1, grid2)                                                              \
@@ -941,7 +933,6 @@ inline int attn_var() {
   static const int v = getenv("SKG_ATTN_VAR") ? atoi(getenv("SKG_ATTN_VAR")) : 0;
   return v;
 }
-inline int attn_var_qt() { return (attn_var() == 4 || attn_var() == 5) ? 4 : 2; }
 
 inline bool common_ok(int batch, int heads, int Nq, int Nkv, int kv_stride, int dh) {
   return batch > 0 && heads > 0 && Nq > 0 && Nkv > 0 && kv_stride >= Nkv && kv_stride % 8 == 0 && dh % 8 == 0;
@@ -961,7 +952,6 @@ static int attn_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const v
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
   p.nx = skg_cdiv(Nq, dh == 160 ? 64 : 128);       // query tiles per workgroup: see SKG_ATTN_FWD_DISPATCH
-  if (!causal && (dh == 40 || dh == 64)) p.nx = skg_cdiv(Nq, 64 * attn_var_qt());
   dim3 grid((unsigned)p.nx * heads * batch);
   if (causal) {
     SKG_REQUIRE(dh != 160);

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of the forward-attention tuning variants (SKG_ATTN_VAR, attention.hip) on the config-2 / config-5 shapes: one
+"""A/B of the forward-attention variants (SKG_ATTN_VAR, attention.hip: 0 = shipped, 7 = two register prefetch sets at d = 64; the
+round-2 sweep over five more variants is recorded in profiles/r02_attn_variants.txt) on the config-2 / config-5 shapes: one
 subprocess per variant (the variant is read once per process), interleaved rounds, correctness of every variant checked
 against an fp32 torch reference on two (row, head) pairs.   python tools/attn_var_bench.py [variants...]"""
 import os
@@ -54,7 +55,7 @@ if __name__ == "__main__":
     if os.environ.get("SKG_ATTN_WORKER"):
         worker()
     else:
-        for v in (sys.argv[1:] or ["0", "1", "2", "3", "4", "5", "6", "0"]):
+        for v in (sys.argv[1:] or ["0", "7", "0", "7"]):
             r = subprocess.run([sys.executable, __file__], env=dict(os.environ, SKG_ATTN_VAR=v, SKG_ATTN_WORKER="1"),
                                capture_output=True, text=True)
             print(r.stdout, r.stderr[-800:] if r.returncode else "", flush=True)
