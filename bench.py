@@ -107,8 +107,8 @@ class LaunchTimer:
         def kname(variant, mode):
             """The name rocprofv3 prints for the instantiation that ran (template arguments spelled out)."""
             bn = variant % 1000
-            if variant == 8160:
-                return f"gemm8_kernel<{MODES[mode]}, 0>"
+            if variant in (8160, 8320):
+                return f"gemm8_kernel<{variant - 8000}, {MODES[mode]}, 0>"
             if variant >= 2000:
                 stages = 3 if variant >= 10000 else 2
                 return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}, {stages}>"

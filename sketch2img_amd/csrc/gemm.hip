@@ -213,7 +213,7 @@ extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
   {   // v8 takes plain (fp16 out, no fused GEGLU) launches of eligible shapes
     GemmParams q{};
     q.M = M; q.N = N; q.K = K; q.Cin = Cin; q.lda = q.ldb = K; q.ldc = N; q.OH = q.OW = q.IH = q.IW = 1;
-    if (skg_gemm8_eligible(q, mode)) return 8160;
+    if (const int bn8 = skg_gemm8_tile_n(q, mode)) return 8000 + bn8;
   }
   const int v2 = skg_gemm2_tile_n(M, N, K, Cin, mode);
   return v2 ? 2000 + v2 : 1000 + (use_wide(M, N) ? 128 : 64);

@@ -19,6 +19,10 @@
 //   * every wave issues exactly ND DMA instructions per tile (7 for waves 0-3, 6 for waves 4-7: 20 B chunks over 8
 //     waves; out-of-range ones are zero fills), so `s_waitcnt vmcnt(ND)` at the end of LOAD(2t + 1) means "tile t + 1
 //     has landed" for that wave, and the barrier that follows publishes it to the others before anyone reads it.
+// Two tiles: 256 x 160 (wave grid 4 x 2, three stages, prefetch distance two tiles) and 256 x 320 (wave grid 2 x 4, wave
+// tile 128 x 80, TWO stages of 73.7 KB: the whole next tile is requested in LOAD(2t) and waited for with vmcnt(0) at the
+// end of LOAD(2t + 1); 7 B of operands per kFLOP) - the latter only where one workgroup per CU still fills the chip,
+// i.e. the 64 x 64 level at 16 rows.
 // Scope: MODE_DIRECT and MODE_S1, K % 64 == 0 (conv: Cin % 64 == 0), N % 160 == 0, fp16 output, no fused GEGLU, no
 // split-K; everything else stays on gemm2.hip.  Epilogue: bias / alpha / residual / ReLU in fp32, one rounding.
 #include "gemm_params.h"
@@ -26,10 +30,8 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 160, BK = 64, NS = 3, NW = 8, NTHR = 512;
-constexpr int WM = 64, WN = 80, MT = 4, NT = 5;
-constexpr int STAGE = (BM + BN) * BK;            // halves per stage: A tile then B tile (53 248 B)
-constexpr int ACH = 4, BCH = 3;
+constexpr int BM = 256, BK = 64, NW = 8, NTHR = 512;
+constexpr int NT = 5, ACH = 4;                   // every wave tile is 80 columns wide; 32 A chunks of 8 rows over 8 waves
 constexpr unsigned OOB = 0x80000000u;
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -41,15 +43,23 @@ __device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); 
 
 // EXP: probe builds (SKG_G8_EXP; compute on stale / missing data, timing only): 1 = no DMA in the loop, 2 = no
 // fragment reads in the loop, 4 = no priority raise, 8 = no stagger between the two groups
-template <int MODE, int EXP = 0>
+template <int BN, int MODE, int EXP = 0>
 __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int tiles_n, int nwg, unsigned a_bytes,
                                                         unsigned b_bytes, unsigned a_shift) {
-  __shared__ __attribute__((aligned(16))) half_t smem[NS * STAGE + 512];     // + 1 KB sink for the idle DMA slot of waves 4-7
+  constexpr int NS = BN == 160 ? 3 : 2;            // LDS stages
+  constexpr int WGN = BN / 80, WGM = NW / WGN;     // wave grid: 4 x 2 (BN = 160) or 2 x 4 (BN = 320)
+  constexpr int WM = BM / WGM, WN = 80, MT = WM / 16;
+  constexpr int BCH = (BN / 8 + NW - 1) / NW;      // B chunks of 8 rows per wave: 3 (20 chunks: the last slot is idle
+                                                   // for waves 4-7) or 5 (40 chunks)
+  constexpr int ND = ACH + BCH;
+  constexpr int STAGE = (BM + BN) * BK;            // halves per stage: A tile then B tile
+  constexpr bool SINK = (BN / 8) % NW != 0;
+  __shared__ __attribute__((aligned(16))) half_t smem[NS * STAGE + (SINK ? 512 : 0)];   // + 1 KB sink for an idle DMA slot
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;                 // waves w and w + 4 share a SIMD: one of each group
-  const int wm = wave & 3, wn = wave >> 2;   // wave tile (64 rows x 80 columns) inside the 256 x 160 block
+  const int grp = wave >> 2;                       // waves w and w + 4 share a SIMD: one of each group
+  const int wm = WGN == 2 ? (wave & 3) : (wave >> 2), wn = WGN == 2 ? (wave >> 2) : (wave & 3);
   const int g = lane >> 4, l16 = lane & 15;
 
   const __amdgpu_buffer_rsrc_t rA =
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
     const int n = n0 + r;
     b_voff[j] = (r < BN && n < p.N) ? (unsigned)n * (unsigned)p.ldb * 2u + pk : OOB;
   }
-  const bool has_b2 = wave < 4;              // B chunk 16 + wave exists for waves 0-3 only (20 chunks of 8 rows)
+  const bool last_b_idle = SINK && wave >= (BN / 8) % NW;      // this wave's last B slot has no chunk: it zero-fills the sink
 
   const int KT = p.K / BK;
   // scalar description of K tile kt: A soffset, B soffset, filter tap (conv: channel block outermost, taps innermost)
@@ -133,21 +143,17 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
       dma16(rA, &smem[buf * STAGE + (j * NW + wave) * 8 * BK], live ? v : OOB, soa);
     }
   };
-  auto dma_b = [&](int kt, int buf) {        // the tile's B rows: 3 (waves 0-3) / 2 (waves 4-7) instructions
+  auto dma_b = [&](int kt, int buf) {        // the tile's B rows: BCH instructions (an idle slot zero-fills the sink)
     unsigned soa, sob;
     int tap;
     const bool live = kt < KT;
     ktile(live ? kt : 0, soa, sob, tap);
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
-      // chunk 16 + wave exists for waves 0-3 only; waves 4-7 zero-fill the sink instead (keeps the stream branch-free
-      // and every wave's DMA count at ND = 7: b_voff is out of range for them)
-      half_t* dst = (j == BCH - 1 && !has_b2) ? &smem[NS * STAGE] : &smem[buf * STAGE + BM * BK + (j * NW + wave) * 8 * BK];
+      half_t* dst = (j == BCH - 1 && last_b_idle) ? &smem[NS * STAGE] : &smem[buf * STAGE + BM * BK + (j * NW + wave) * 8 * BK];
       dma16(rB, dst, live ? b_voff[j] : OOB, sob);
     }
   };
-  // "the tile before the newest one has landed": ND outstanding instructions allowed (the newest tile's)
-  auto wait_older = [&]() { asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); };
 
   float4_t acc[MT][NT];
 #pragma unroll
@@ -155,19 +161,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
 
-  // fragment read addresses (halves) inside a stage for k-sub-step 0 / 1; slot = piece ^ ((row >> 1) & 7)
-  int a_ad[MT][2], b_ad[NT][2];
+  // fragment read addresses (halves) inside a stage for k-sub-step 0 / 1; slot = piece ^ ((row >> 1) & 7).  Every wave
+  // tile starts at a multiple of 16 rows and fragment i starts 16 i rows further, so the swizzle key is (l16 >> 1) & 7
+  // for all of them: ONE address per operand and sub-step, the fragment index is an immediate offset.
+  const int key = (l16 >> 1) & 7;
+  int a_base[2], b_base[2];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int row = wm * WM + i * 16 + l16;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) a_ad[i][ks] = row * BK + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 3);
-  }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int row = wn * WN + j * 16 + l16;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) b_ad[j][ks] = BM * BK + row * BK + (((ks * 4 + g) ^ ((row >> 1) & 7)) << 3);
+  for (int ks = 0; ks < 2; ++ks) {
+    a_base[ks] = (wm * WM + l16) * BK + (((ks * 4 + g) ^ key) << 3);
+    b_base[ks] = BM * BK + (wn * WN + l16) * BK + (((ks * 4 + g) ^ key) << 3);
   }
 
   half8_t xf[MT], wf[NT];
@@ -176,66 +178,61 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
     const half_t* sb = &smem[stg * STAGE];
     if (!(EXP & 2) || t == 0) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = ld_half8(sb + b_ad[j][ks]);
+      for (int j = 0; j < NT; ++j) wf[j] = ld_half8(sb + b_base[ks] + j * 16 * BK);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) xf[i] = ld_half8(sb + a_ad[i][ks]);
+      for (int i = 0; i < MT; ++i) xf[i] = ld_half8(sb + a_base[ks] + i * 16 * BK);
     }
-    const int nbuf = stg == 0 ? 2 : stg - 1;          // (stg + 2) % 3
-    constexpr bool DIC = (EXP & 16) != 0;             // DMA issued from the COMPUTE segment, woven between the MFMAs
-    if (!(EXP & 1) && !DIC) {
-      if (ks == 0) dma_a(t + 2, nbuf);
-      else dma_b(t + 2, nbuf);
+    if (!(EXP & 1)) {
+      if (NS == 3) {          // tile t + 2 into stage (stg + 2) % 3, whose last reader finished two barriers ago
+        const int nbuf = stg == 0 ? 2 : stg - 1;
+        if (ks == 0) dma_a(t + 2, nbuf);
+        else dma_b(t + 2, nbuf);
+      } else if (ks == 0) {   // tile t + 1 into the other stage: its last reader was group 1's LOAD(2t - 1), one barrier ago
+        dma_a(t + 1, stg ^ 1);
+        dma_b(t + 1, stg ^ 1);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (ks == 1 && !(EXP & 1)) {
-      // tile t + 1 must have landed before anyone's LOAD(2t + 2).  DMA in LOAD: all of tile t + 2 is in flight (ND).
-      // DMA in COMPUTE: only its A part (issued in COMPUTE(2t)) is - the B part follows in COMPUTE(2t + 1).
-      if (DIC) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else wait_older();
+      // the tile that LOAD(2t + 2) reads must have landed before the barrier below.  Three stages: the newest tile's
+      // ND instructions may stay in flight.  Two stages: the tile requested in LOAD(2t) is the one - drain.
+      if (NS == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
     bar();
     __builtin_amdgcn_sched_barrier(0);
     if (!(EXP & 4)) __builtin_amdgcn_s_setprio(1);
-    if (DIC && !(EXP & 1)) {
-      if (ks == 0) dma_a(t + 2, nbuf);
-      else dma_b(t + 2, nbuf);
-    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[i], acc[i][j], 0, 0, 0);
-    if (DIC) {      // issue order: 4 MFMAs, one DMA instruction, ... (the B part has 3 or 2: the plan covers the longer)
-      constexpr int NDMA = 4;               // (ks == 1: three - the fourth slot of the plan stays empty)
-#pragma unroll
-      for (int q = 0; q < NDMA; ++q) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, MT * NT - 4 * NDMA, 0);
-    }
     if (!(EXP & 4)) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     bar();
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // prologue: tiles 0 and 1 in flight, tile 0 landed and published
+  // prologue: the first NS - 1 tiles in flight, tile 0 landed and published
   dma_a(0, 0); dma_b(0, 0);
-  dma_a(1, 1); dma_b(1, 1);
-  wait_older();
+  if (NS == 3) {
+    dma_a(1, 1); dma_b(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   bar();
   if (EXP & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (grp == 1 && !(EXP & 8)) bar();                   // group 1 runs one barrier behind group 0
-  for (int t = 0; t < KT; t += 3) {
+  for (int t = 0; t < KT; t += NS) {
     substep(t, 0, 0);
     substep(t, 0, 1);
     if (t + 1 < KT) {
       substep(t + 1, 1, 0);
       substep(t + 1, 1, 1);
     }
-    if (t + 2 < KT) {
+    if (NS == 3 && t + 2 < KT) {
       substep(t + 2, 2, 0);
       substep(t + 2, 2, 1);
     }
@@ -245,7 +242,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
 
   // ---- epilogue: lane holds C[m = .. + l16][n = .. + 4g .. 4g + 3] --------------------------------------------------
   // Every load is issued before the first use (conditions hoisted out of the element loops: a per-element
-  // "load or not" select makes hipcc wait vmcnt(0) after each load - 40 serial round trips).  Rows beyond M read row
+  // "load or not" select makes hipcc wait vmcnt(0) after each load - 40 serial round trips); four 16-row groups at a
+  // time so that the residual registers stay within what the dead fragment registers free.  Rows beyond M read row
   // M - 1 and are not stored; N is a multiple of the tile width.
   const bool relu = p.flags & SKG_EPI_RELU;
   float4_t bv[NT];
@@ -259,44 +257,47 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
     }
   }
   const int mrow = m0 + wm * WM + l16;
-  if (p.res) {
-    half4_t rv[MT][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int m = min(mrow + i * 16, p.M - 1);
+  for (int i0 = 0; i0 < MT; i0 += 4) {
+    if (p.res) {
+      half4_t rv[4][NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) rv[i][j] = ld_half4(p.res + (size_t)m * p.ldr + n0 + wn * WN + j * 16 + g * 4);
+      for (int ii = 0; ii < 4; ++ii) {
+        const int m = min(mrow + (i0 + ii) * 16, p.M - 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rv[ii][j] = ld_half4(p.res + (size_t)m * p.ldr + n0 + wn * WN + j * 16 + g * 4);
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const half4_t r = rv[ii][j];
+          acc[i0 + ii][j] = (acc[i0 + ii][j] + bv[j]) * p.alpha + float4_t{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        }
+    } else {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i0 + ii][j] = (acc[i0 + ii][j] + bv[j]) * p.alpha;
+    }
+    if (relu) {
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i0 + ii][j][e] = fmaxf(acc[i0 + ii][j][e], 0.f);
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int ii = 0; ii < 4; ++ii) {
+      const int m = mrow + (i0 + ii) * 16;
+      if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const half4_t r = rv[i][j];
-        acc[i][j] = (acc[i][j] + bv[j]) * p.alpha + float4_t{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+        const float4_t v = acc[i0 + ii][j];
+        const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        st_half4(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n0 + wn * WN + j * 16 + g * 4, o);
       }
-  } else {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = (acc[i][j] + bv[j]) * p.alpha;
-  }
-  if (relu) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[i][j][e] = fmaxf(acc[i][j][e], 0.f);
-  }
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int m = mrow + i * 16;
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const float4_t v = acc[i][j];
-      const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-      st_half4(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n0 + wn * WN + j * 16 + g * 4, o);
     }
   }
 }
@@ -315,35 +316,46 @@ inline bool operand_bytes(const GemmParams& p, int mode, unsigned long long& a, 
   return a < 0x7fffffffull && b < 0x7fffffffull;
 }
 
-}  // namespace
-
-// 0 = off, 1 = on for eligible shapes (SKG_GEMM8, read once)
-static int gemm8_mode() {
-  static const int v = getenv("SKG_GEMM8") ? atoi(getenv("SKG_GEMM8")) : 0;
+// SKG_GEMM8 (read once): 0 = off; 1 = both tiles for every eligible shape (experiments); 2 = the 256 x 320 tile for
+// long-K launches (K >= 1024) of both modes; unset = what ships: the 256 x 320 tile for 3x3 convolutions only - same
+// box, interleaved (tools/gemm8_bench.py, profiles/r02_gemm8_320.txt): conv 640->320 @ 64x64 213-221 -> 199 us, 960->320
+// 306-327 -> 275-292 us (1.24-1.32 PFLOP/s), 320->320 124-127 -> 121 us; the FF2 GEMM (K = 1280) is 5 % SLOWER with the
+// direct-store epilogue and stays on gemm2.hip, like every shape the 256 x 160 tile would take.
+int gemm8_mode() {
+  static const int v = getenv("SKG_GEMM8") ? atoi(getenv("SKG_GEMM8")) : 3;
   return v;
 }
 
-bool skg_gemm8_eligible(const GemmParams& p, int mode) {
-  if (!gemm8_mode()) return false;
-  if (mode != MODE_DIRECT && mode != MODE_S1) return false;
-  if (p.K % BK != 0 || p.K < 2 * BK || p.N % BN != 0 || p.M < 1) return false;
-  if (mode == MODE_S1 && p.Cin % BK != 0) return false;
-  if (p.flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) return false;
-  if (p.ldc % 4 != 0 || (p.res && p.ldr % 4 != 0)) return false;
-  const long tiles = (long)skg_cdiv(p.M, BM) * (p.N / BN);
-  if (tiles < 224) return false;                 // fewer workgroups than CUs: the 128-row tiles fill the chip better
+// tile width v8 would use for this launch (0 = not taken)
+int gemm8_tile(const GemmParams& p, int mode) {
+  const int md = gemm8_mode();
+  if (!md) return 0;
+  if (mode != MODE_DIRECT && mode != MODE_S1) return 0;
+  if (p.K % BK != 0 || p.K < 2 * BK || p.M < 1) return 0;
+  if (mode == MODE_S1 && p.Cin % BK != 0) return 0;
+  if (p.flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) return 0;
+  if (p.ldc % 4 != 0 || (p.res && p.ldr % 4 != 0)) return 0;
   unsigned long long a, b, s;
-  return operand_bytes(p, mode, a, b, s);
+  if (!operand_bytes(p, mode, a, b, s)) return 0;
+  const long tm = skg_cdiv(p.M, BM);
+  // 256 x 320 where one workgroup per CU fills the chip in whole rounds; else 256 x 160 (mode 1 only)
+  if (md == 3 && mode != MODE_S1) return 0;
+  if (p.N % 320 == 0 && (md == 1 || p.K >= 1024)) {
+    const long t = tm * (p.N / 320);
+    if (t >= 224 && (t <= 256 || t >= 480)) return 320;
+  }
+  if (md == 1 && p.N % 160 == 0 && tm * (p.N / 160) >= 224) return 160;
+  return 0;
 }
 
-bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st) {
-  if (!skg_gemm8_eligible(p, mode)) return false;
+template <int BN>
+void launch8(const GemmParams& p, int mode, hipStream_t st) {
   unsigned long long a, b, s;
   operand_bytes(p, mode, a, b, s);
   const int tiles_n = p.N / BN;
   const int ntiles = skg_cdiv(p.M, BM) * tiles_n;
   static const int exp = getenv("SKG_G8_EXP") ? atoi(getenv("SKG_G8_EXP")) : 0;
-#define G8_LAUNCH(M_, E_) hipLaunchKernelGGL((gemm8_kernel<M_, E_>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles, \
+#define G8_LAUNCH(M_, E_) hipLaunchKernelGGL((gemm8_kernel<BN, M_, E_>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles, \
                                              (unsigned)a, (unsigned)b, (unsigned)s)
   if (mode == MODE_DIRECT) {
     G8_LAUNCH(MODE_DIRECT, 0);
@@ -354,11 +366,21 @@ bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st) {
       case 3: G8_LAUNCH(MODE_S1, 3); break;
       case 4: G8_LAUNCH(MODE_S1, 4); break;
       case 8: G8_LAUNCH(MODE_S1, 8); break;
-      case 11: G8_LAUNCH(MODE_S1, 11); break;
-      case 16: G8_LAUNCH(MODE_S1, 16); break;
-      case 20: G8_LAUNCH(MODE_S1, 20); break;
       default: G8_LAUNCH(MODE_S1, 0); break;
     }
   }
+#undef G8_LAUNCH
+}
+
+}  // namespace
+
+bool skg_gemm8_eligible(const GemmParams& p, int mode) { return gemm8_tile(p, mode) != 0; }
+int skg_gemm8_tile_n(const GemmParams& p, int mode) { return gemm8_tile(p, mode); }
+
+bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st) {
+  const int bn = gemm8_tile(p, mode);
+  if (!bn) return false;
+  if (bn == 320) launch8<320>(p, mode, st);
+  else launch8<160>(p, mode, st);
   return true;
 }

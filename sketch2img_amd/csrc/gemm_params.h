@@ -24,4 +24,5 @@ void skg_gemm2_set_workspace(float* ws, size_t bytes);
 bool skg_gemm4_try_launch(const GemmParams& p, int mode, hipStream_t st);
 // v8 (gemm8.hip): 256 x 160 tiles, one 8-wave workgroup per CU, ping-pong schedule (DIRECT / S1, plain epilogue).
 bool skg_gemm8_eligible(const GemmParams& p, int mode);
+int skg_gemm8_tile_n(const GemmParams& p, int mode);      // 160 / 320, or 0 when v8 does not take the launch
 bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st);
