@@ -190,6 +190,22 @@ class LaunchTimer:
                         f"{nb / sec / 1e12:6.2f} {100 * sec / tot:5.1f}\n")
 
 
+def by_operator(agg):
+    """{operator: launches, seconds, TFLOP/s, fraction of the MFMA peak} from the per-instantiation table."""
+    def op(name):
+        if name.startswith("attn"):
+            return "attention_fwd"
+        args = name[name.index("<") + 1:-1].split(", ")
+        mode = int(args[4]) if name.startswith("gemm2") else int(args[1])
+        return {0: "gemm", 1: "conv3x3"}.get(mode, "conv3x3_resample")
+    out = {}
+    for k, v in agg.items():
+        o = out.setdefault(op(k), [0, 0.0, 0.0, []])
+        o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3].append(k)
+    return {k: dict(launches=v[0], seconds=v[2], tflops=v[1] / v[2] / 1e12, frac=v[1] / v[2] / 1e12 / PEAK_FP16_TFLOPS,
+                    kernels=sorted(v[3])) for k, v in sorted(out.items(), key=lambda kv: -kv[1][2])}
+
+
 # ------------------------------------------------------------------------------- committed rocprofv3 evidence
 def _latest_profile(config: int, suffix: str):
     """profiles/r<NN>_cfg<config>_<suffix> of the latest round that has one (round-1 files carry no cfg tag)."""
@@ -446,6 +462,9 @@ def main():
                     # projections (K = 320: 320 flop per output byte against a machine balance of 312) are HBM-bound launches
                     # of the same instantiation that runs the MFMA-bound ones
                     all_contraction_frac_of_own_roofline=sum(v[4] for v in agg.values()) / tot_sec,
+                    # the same launches grouped by OPERATOR (an operator may run on several instantiations: the 3x3
+                    # convolution on gemm2_kernel<..., 1, ...> and, for the 64x64 level, on gemm8_kernel<320, 1, 0>)
+                    by_operator=by_operator(agg),
                     per_kernel={k: dict(launches=v[0], tflops=v[1] / v[2] / 1e12, seconds=v[2],
                                         frac_of_own_roofline=v[4] / v[2], hbm_bound_share_of_time=v[5] / v[2])
                                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])})

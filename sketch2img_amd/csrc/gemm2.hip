@@ -886,37 +886,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
 }
 
 template <int MODE>
-void launch_mode(const GemmParams& p, hipStream_t st);
-
-// Tail quantisation of long-K convolutions: with 512 workgroup slots (two per CU) a launch of e.g. 1 152 tiles (config 5,
-// 96 x 96 latents: 8 rows x 72 x 2) runs THREE rounds for 2.25 rounds of work.  The images of the partial round are split
-// off into their own launch, which then has few enough tiles to take split-K: 2 rounds + a quarter-length round.
-template <int MODE>
-bool try_split_tail(const GemmParams& p, hipStream_t st) {
-  if (MODE != MODE_S1) return false;
-  static const bool off = getenv("SKG_NO_TAIL_SPLIT") != nullptr;        // A/B switch
-  const int ohw = p.OH * p.OW;
-  if (off || ohw % 128 != 0 || p.M % ohw != 0 || p.N % 160 != 0 || p.K / BK < 32) return false;
-  const long per_img = (long)(ohw / 128) * (p.N / 160);
-  const long imgs = p.M / ohw, nt = imgs * per_img;
-  const long full = nt / 512 * 512, rest = nt - full;
-  if (nt <= 1024 || rest == 0 || rest > 224) return false;
-  const long head = full / per_img, tail = imgs - head;
-  if (head < 1 || tail < 1 || tail * per_img > 256) return false;
-  GemmParams a = p, b = p;
-  a.M = (int)(head * ohw);
-  b.M = (int)(tail * ohw);
-  b.A = p.A + (size_t)head * p.IH * p.IW * p.lda;
-  b.C = (void*)((char*)p.C + (size_t)head * ohw * p.ldc * ((p.flags & SKG_EPI_OUT_F32) ? 4 : 2));
-  if (p.res) b.res = p.res + (size_t)head * ohw * p.ldr;
-  launch_mode<MODE>(a, st);
-  launch_mode<MODE>(b, st);
-  return true;
-}
-
-template <int MODE>
 void launch_mode(const GemmParams& p, hipStream_t st) {
-  if (try_split_tail<MODE>(p, st)) return;
   const TileCfg t = pick_tile(p.M, p.N, p.K);
   if (t.bm == 256) launch_cfg<256, 320, 2, 4, MODE>(p, st);
   else if (t.bn == 160) {
