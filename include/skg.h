@@ -140,6 +140,12 @@ int skg_geglu_bwd(const void* H, int ldh, const void* dY, int lddy, void* dH, in
 int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt,
                  void* O, int ldo, float* lse, int batch, int heads, int Nq, int Nkv,
                  int kv_stride, int dh, float scale, void* stream);
+/* Same with V handed over ROW-MAJOR: V [batch*kv_stride][ldv], head h at columns h*dh.. (e.g. the third column block
+ * of a fused QKV projection, ldv = 3C).  The kernel reads its V fragments through the gfx950 LDS transpose read
+ * (ds_read_b64_tr_b16), so no transposed copy of V is written.  Same replaced reference calls as skg_attn_fwd. */
+int skg_attn_fwd_rowv(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                      void* O, int ldo, float* lse, int batch, int heads, int Nq, int Nkv,
+                      int kv_stride, int dh, float scale, void* stream);
 /* Same with a causal mask: key j of a batch row is visible to query i only when j <= i (self-attention, Nq rows
  * and kv_stride key slots per batch row).  dh in {16, 32, 64}.
  * Replaces: the masked self-attention of transformers' CLIPTextModel, which the reference calls through
@@ -147,17 +153,19 @@ int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, const void* Vt,
 int skg_attn_fwd_causal(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt,
                         void* O, int ldo, float* lse, int batch, int heads, int Nq, int Nkv,
                         int kv_stride, int dh, float scale, void* stream);
-/* backward.  delta[b][h][q] = sum_d dO*O (skg_attn_bwd_delta).  dQ kernel needs K, V row-major
- * (V [batch*kv_stride][..] ldv) and Kt (K transposed like Vt); dKV kernel needs Q, dO row-major
- * and their transposes Qt, dOt ([h*dh+d][b*Nq + q]).  Outputs row-major like their primals. */
+/* backward.  delta[b][h][q] = sum_d dO*O (skg_attn_bwd_delta).  All operands row-major like their primals (Q, dO
+ * [batch*Nq][..], K, V [batch*kv_stride][..]); the transposed fragments the dQ / dK / dV products need (K^T, Q^T, dO^T)
+ * are read from the row tiles in LDS through ds_read_b64_tr_b16 - no transposed copies in HBM.  Outputs row-major.
+ * Replaces: torch autograd through xformers memory_efficient_attention / CrossAttention, triggered by
+ * torch.autograd.grad at modules/pipeline.py:159. */
 int skg_attn_bwd_delta(const void* O, int ldo, const void* dO, int lddo, float* delta, int batch,
                        int heads, int Nq, int dh, void* stream);
 int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
-                    const void* Kt, int ldkt, const void* dO, int lddo, const float* lse,
+                    const void* dO, int lddo, const float* lse,
                     const float* delta, void* dQ, int lddq, int batch, int heads, int Nq, int Nkv,
                     int kv_stride, int dh, float scale, void* stream);
-int skg_attn_bwd_dkv(const void* Q, int ldq, const void* Qt, int ldqt, const void* K, int ldk,
-                     const void* V, int ldv, const void* dO, int lddo, const void* dOt, int lddot,
+int skg_attn_bwd_dkv(const void* Q, int ldq, const void* K, int ldk,
+                     const void* V, int ldv, const void* dO, int lddo,
                      const float* lse, const float* delta, void* dK, int lddk, void* dV, int lddv,
                      int batch, int heads, int Nq, int Nkv, int dh, float scale, void* stream);
 

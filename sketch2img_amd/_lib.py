@@ -38,9 +38,10 @@ SIGNATURES = {
     "skg_geglu_bwd": ("i", "pipipiiiip"),
     "skg_attn_fwd": ("i", "pipipipipiiiiiifp"),
     "skg_attn_fwd_causal": ("i", "pipipipipiiiiiifp"),
+    "skg_attn_fwd_rowv": ("i", "pipipipipiiiiiifp"),
     "skg_attn_bwd_delta": ("i", "pipipiiiip"),
-    "skg_attn_bwd_dq": ("i", "pipipipipipppiiiiiiifp"),
-    "skg_attn_bwd_dkv": ("i", "pipipipipipipppipiiiiiifp"),
+    "skg_attn_bwd_dq": ("i", "pipipipipppiiiiiiifp"),
+    "skg_attn_bwd_dkv": ("i", "pipipipipppipiiiiiifp"),
     "skg_transpose_f16": ("i", "pipiiip"),
     "skg_axpby_f16": ("i", "pipipiiiffp"),
     "skg_batch_copy_f16": ("i", "piipiiiiip"),

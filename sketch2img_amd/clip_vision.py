@@ -94,8 +94,7 @@ class HipCLIPVision:
             p = f"encoder.layers.{l}"
             h = ops.layernorm(x, W[p + ".layer_norm1.weight"], W[p + ".layer_norm1.bias"], cfg.layer_norm_eps)
             qkv = ops.gemm(h, W[p + ".qkv.weight"], bias=W[p + ".qkv.bias"])
-            vt = ops.transpose(qkv[:, 2 * D:])
-            a = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], vt, B, H, Lp, N, Lp, d, scale)
+            a = ops.attn_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], B, H, Lp, N, Lp, d, scale, v_rows=True)
             x = ops.gemm(a, W[p + ".self_attn.out_proj.weight"], bias=W[p + ".self_attn.out_proj.bias"], residual=x)
             h = ops.layernorm(x, W[p + ".layer_norm2.weight"], W[p + ".layer_norm2.bias"], cfg.layer_norm_eps)
             f = ops.gemm(h, W[p + ".mlp.fc1.weight"], bias=W[p + ".mlp.fc1.bias"])

@@ -27,10 +27,8 @@ struct AttnParams {
   const half_t* Q; int ldq;
   const half_t* K; int ldk;
   const half_t* V; int ldv;       // row-major V (backward)
-  const half_t* Vt; int ldvt;     // forward: V^T; dq: K^T
-  const half_t* Qt; int ldqt;     // dkv: Q^T
+  const half_t* Vt; int ldvt;     // forward: V^T (skg_attn_fwd, _causal) or the row-major V and its pitch (skg_attn_fwd_rowv)
   const half_t* dO; int lddo;
-  const half_t* dOt; int lddot;   // dkv: dO^T
   half_t* O; int ldo;             // fwd: O; dq: dQ; dkv: dK
   half_t* O2; int ldo2;           // dkv: dV
   float* lse;                     // [batch][heads][Nq]
@@ -86,31 +84,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 constexpr int TP = 72;   // pitch (halves) of the transposed tiles [d][64 + 8]
 
-// stage a [64][dh] row-major tile (rows r0.., zero rows >= rlim, zero cols >= dh) into LDS [64][KP]
-template <int KS>
-__device__ __forceinline__ void stage_rows(half_t* __restrict__ dst, const half_t* __restrict__ src, int ld,
-                                           int r0, int rlim, int dh) {
-  constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
-  constexpr int PPR = KS * 4;
-  for (int pi = threadIdx.x; pi < 64 * PPR; pi += 256) {
-    const int r = pi / PPR, pc = (pi - r * PPR) * 8;
-    half8_t v = zero_half8();
-    if (r0 + r < rlim && pc < dh) v = ld_half8(src + (size_t)(r0 + r) * ld + pc);
-    st_half8(dst + r * KP + pc, v);
-  }
-}
-// stage a transposed tile: rows d (0..dh-1 valid, up to ND*16 zero), cols c0..c0+63 (valid < clim)
-template <int ND>
-__device__ __forceinline__ void stage_cols(half_t* __restrict__ dst, const half_t* __restrict__ src, int ld,
-                                           int c0, int clim, int dh) {
-  for (int pi = threadIdx.x; pi < ND * 16 * 8; pi += 256) {
-    const int d = pi >> 3, pc = (pi & 7) * 8;
-    half8_t v = zero_half8();
-    if (d < dh && c0 + pc < clim) v = ld_half8(src + (size_t)d * ld + c0 + pc);
-    st_half8(dst + d * TP + pc, v);
-  }
-}
-
 // A-operand fragment of a transposed tile for k-step s: head-dim row (16 u + l16), keys by the map above
 __device__ __forceinline__ half8_t tfrag(const half_t* tile, int u, int s, int l16, int g) {
   const half_t* p = tile + (u * 16 + l16) * TP + 32 * s + 4 * g;
@@ -118,6 +91,24 @@ __device__ __forceinline__ half8_t tfrag(const half_t* tile, int u, int s, int l
   half8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return f;
 }
+// The same fragment out of a ROW-MAJOR tile [key][VP] through the gfx950 transpose read: in a 16-lane group lane i hands
+// in the address of 4 contiguous halves - row i >> 2, columns 4 (i & 3) .. + 3 of a [4][16] block - and receives column
+// i of that block, rows 0 .. 3 (tools/ubench/tr_probe.hip).  Group g of fragment (u, s) takes the block of keys
+// 32 s + 16 hh + 4 g .. + 3 x head-dim columns 16 u .. + 15, hh = 0 / 1: exactly the k <-> key map above, so V (and K, Q,
+// dO in the backward kernels) needs no transposed copy in HBM.  `base` = tile + (4 g + (l16 >> 2)) * VP + 4 (l16 & 3).
+// Banks: 8 key rows x 32 bytes per 32-lane group are conflict-free when VP = 16 (mod 32) halves.
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ half4_t tr_read(const half_t* p) {
+  const fp16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(p));
+  return __builtin_bit_cast(half4_t, r);
+}
+template <int VP>
+__device__ __forceinline__ half8_t tfrag_rows(const half_t* base, int u, int s) {
+  const half4_t lo = tr_read(base + (32 * s) * VP + 16 * u), hi = tr_read(base + (32 * s + 16) * VP + 16 * u);
+  half8_t f = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return f;
+}
+constexpr int vrow_pitch(int nd) { return nd * 16 + ((nd & 1) ? 0 : 16); }      // = 16 (mod 32) halves, >= 16 nd
 // pack score-layout registers (4 tiles x 4) into the two B-operand fragments
 __device__ __forceinline__ void pack_p(const float4_t (&s)[4], half8_t (&pb)[2]) {
 #pragma unroll
@@ -129,20 +120,7 @@ __device__ __forceinline__ void pack_p(const float4_t (&s)[4], half8_t (&pb)[2])
 // register staging of [64][dh] row tiles and [dh][64] transposed tiles (global -> VGPR now, VGPR -> LDS later)
 template <int KS>
 struct RowRegs { half8_t v[KS]; };               // 64 * KS*4 pieces / 256 threads
-template <int ND>
-struct ColRegs { half8_t v[(ND + 1) / 2]; };     // ND*16*8 pieces / 256 threads
 
-template <int KS>
-__device__ __forceinline__ void rows_load(RowRegs<KS>& r, const half_t* __restrict__ src, int ld, int r0, int rlim,
-                                          int dh) {
-  constexpr int PPR = KS * 4;
-#pragma unroll
-  for (int q = 0; q < KS; ++q) {
-    const int pi = threadIdx.x + q * 256;
-    const int row = pi / PPR, pc = (pi - row * PPR) * 8;
-    r.v[q] = (r0 + row < rlim && pc < dh) ? ld_half8(src + (size_t)(r0 + row) * ld + pc) : zero_half8();
-  }
-}
 template <int KS>
 __device__ __forceinline__ void rows_store(const RowRegs<KS>& r, half_t* __restrict__ dst) {
   constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
@@ -154,25 +132,6 @@ __device__ __forceinline__ void rows_store(const RowRegs<KS>& r, half_t* __restr
     st_half8(dst + row * KP + pc, r.v[q]);
   }
 }
-template <int ND>
-__device__ __forceinline__ void cols_load(ColRegs<ND>& r, const half_t* __restrict__ src, int ld, int c0, int clim,
-                                          int dh) {
-#pragma unroll
-  for (int q = 0; q < (ND + 1) / 2; ++q) {
-    const int pi = threadIdx.x + q * 256;
-    const int d = pi >> 3, pc = (pi & 7) * 8;
-    r.v[q] = (pi < ND * 128 && d < dh && c0 + pc < clim) ? ld_half8(src + (size_t)d * ld + c0 + pc) : zero_half8();
-  }
-}
-template <int ND>
-__device__ __forceinline__ void cols_store(const ColRegs<ND>& r, half_t* __restrict__ dst) {
-#pragma unroll
-  for (int q = 0; q < (ND + 1) / 2; ++q) {
-    const int pi = threadIdx.x + q * 256;
-    if (pi < ND * 128) st_half8(dst + (pi >> 3) * TP + (pi & 7) * 8, r.v[q]);
-  }
-}
-
 // -------------------------------------------------------------------------------------------------
 // register staging of one K tile ([64][dh] rows) and one transposed V tile ([dh][64]) per workgroup
 template <int KS, int ND>
@@ -182,31 +141,7 @@ struct KVRegs {
   half8_t k[NK], v[NV];
 };
 
-// ONES: V^T row `dh` (the first padding row of the last 16-row tile) is filled with 1.0, so that row of
-// O^T = V^T P^T accumulates the softmax denominator sum_k p[k] on the matrix pipe instead of the VALU.
-template <int KS, int ND, bool ONES = false>
-__device__ __forceinline__ void kv_load(KVRegs<KS, ND>& r, const half_t* __restrict__ Kb, int ldk,
-                                        const half_t* __restrict__ Vb, int ldvt, int kv0, int kvlim, int dh) {
-  constexpr int PPR = KS * 4;
-#pragma unroll
-  for (int q = 0; q < KVRegs<KS, ND>::NK; ++q) {
-    const int pi = threadIdx.x + q * 256;
-    const int row = pi / PPR, pc = (pi - row * PPR) * 8;
-    r.k[q] = (kv0 + row < kvlim && pc < dh) ? ld_half8(Kb + (size_t)(kv0 + row) * ldk + pc) : zero_half8();
-  }
-#pragma unroll
-  for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) {
-    const int pi = threadIdx.x + q * 256;
-    const int d = pi >> 3, pc = (pi & 7) * 8;
-    r.v[q] = (pi < ND * 128 && d < dh && kv0 + pc < kvlim) ? ld_half8(Vb + (size_t)d * ldvt + kv0 + pc) : zero_half8();
-    if (ONES && d == dh) {
-      const half_t one = (half_t)1.f;
-      r.v[q] = half8_t{one, one, one, one, one, one, one, one};
-    }
-  }
-}
-
-template <int KS, int ND>
+template <int KS, int ND, bool VROW = false>
 __device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __restrict__ Ks, half_t* __restrict__ Vs) {
   constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
   constexpr int PPR = KS * 4;
@@ -219,7 +154,12 @@ __device__ __forceinline__ void kv_store(const KVRegs<KS, ND>& r, half_t* __rest
 #pragma unroll
   for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) {
     const int pi = threadIdx.x + q * 256;
-    if (pi < ND * 128) st_half8(Vs + (pi >> 3) * TP + (pi & 7) * 8, r.v[q]);
+    if constexpr (VROW) {      // row-major V tile [64][VP]: 2 ND pieces per key row (a dense image when VP = 16 ND)
+      constexpr int VP = vrow_pitch(ND);
+      if (pi < ND * 128) st_half8(Vs + (pi / (2 * ND)) * VP + (pi % (2 * ND)) * 8, r.v[q]);
+    } else {
+      if (pi < ND * 128) st_half8(Vs + (pi >> 3) * TP + (pi & 7) * 8, r.v[q]);
+    }
   }
 }
 
@@ -236,12 +176,13 @@ struct KVSrc {
   int vcol[KVRegs<KS, ND>::NV];            // first key column of the lane's piece (ragged last tile only)
   unsigned ones;                           // bit q: piece q of this lane is the all-ones row (ONES)
 };
-template <int KS, int ND, bool ONES>
+template <int KS, int ND, bool ONES, bool VROW = false>
 __device__ __forceinline__ KVSrc<KS, ND> kv_src(const half_t* Kb, int ldk, const half_t* Vb, int ldvt, int kvlim, int dh) {
   KVSrc<KS, ND> s;
   // K: rows of THIS batch row only (the next row's keys start right behind: the size is what cuts them off)
   s.rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (unsigned)(((size_t)(kvlim - 1) * ldk + dh) * 2), 0x00020000);
-  s.rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (unsigned)(((size_t)(dh - 1) * ldvt + kvlim) * 2), 0x00020000);
+  s.rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (unsigned)((VROW ? (size_t)(kvlim - 1) * ldvt + dh
+                                                                           : (size_t)(dh - 1) * ldvt + kvlim) * 2), 0x00020000);
   constexpr int PPR = KS * 4;
   s.ones = 0;
 #pragma unroll
@@ -253,10 +194,17 @@ __device__ __forceinline__ KVSrc<KS, ND> kv_src(const half_t* Kb, int ldk, const
 #pragma unroll
   for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) {
     const int pi = threadIdx.x + q * 256;
-    const int d = pi >> 3, pc = (pi & 7) * 8;
-    s.vo[q] = (pi < ND * 128 && d < dh) ? (unsigned)(d * ldvt + pc) * 2u : ATT_OOB;
-    s.vcol[q] = pc;
-    if (ONES && d == dh) s.ones |= 1u << q;
+    if constexpr (VROW) {      // ldvt is V's row pitch here; rows behind the last key read as zero by the range check
+      const int row = pi / (2 * ND), pc = (pi % (2 * ND)) * 8;
+      s.vo[q] = (pi < ND * 128 && pc < dh) ? (unsigned)(row * ldvt + pc) * 2u : ATT_OOB;
+      s.vcol[q] = 0;
+      if (ONES && pi < ND * 128 && pc == dh) s.ones |= 1u << q;      // column dh of every key row = 1.0
+    } else {
+      const int d = pi >> 3, pc = (pi & 7) * 8;
+      s.vo[q] = (pi < ND * 128 && d < dh) ? (unsigned)(d * ldvt + pc) * 2u : ATT_OOB;
+      s.vcol[q] = pc;
+      if (ONES && d == dh) s.ones |= 1u << q;
+    }
   }
   return s;
 }
@@ -265,12 +213,13 @@ __device__ __forceinline__ half8_t buf_half8(__amdgpu_buffer_rsrc_t r, unsigned 
   const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
   return __builtin_bit_cast(half8_t, v);
 }
-template <int KS, int ND, bool ONES>
-__device__ __forceinline__ void kv_load_buf(KVRegs<KS, ND>& r, const KVSrc<KS, ND>& s, int kv0, int ldk, int kvlim) {
-  const unsigned sk = (unsigned)kv0 * (unsigned)ldk * 2u, sv = (unsigned)kv0 * 2u;
+template <int KS, int ND, bool ONES, bool VROW = false>
+__device__ __forceinline__ void kv_load_buf(KVRegs<KS, ND>& r, const KVSrc<KS, ND>& s, int kv0, int ldk, int kvlim,
+                                            int ldv = 0) {
+  const unsigned sk = (unsigned)kv0 * (unsigned)ldk * 2u, sv = VROW ? (unsigned)kv0 * (unsigned)ldv * 2u : (unsigned)kv0 * 2u;
 #pragma unroll
   for (int q = 0; q < KVRegs<KS, ND>::NK; ++q) r.k[q] = buf_half8(s.rk, s.ko[q], sk);
-  if (kv0 + 64 <= kvlim) {                 // wave-uniform
+  if (VROW || kv0 + 64 <= kvlim) {         // wave-uniform
 #pragma unroll
     for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) r.v[q] = buf_half8(s.rv, s.vo[q], sv);
   } else {                                 // ragged last tile: key columns behind this batch row's keys read as zero
@@ -278,10 +227,10 @@ __device__ __forceinline__ void kv_load_buf(KVRegs<KS, ND>& r, const KVSrc<KS, N
     for (int q = 0; q < KVRegs<KS, ND>::NV; ++q) r.v[q] = buf_half8(s.rv, kv0 + s.vcol[q] < kvlim ? s.vo[q] : ATT_OOB, sv);
   }
   if (ONES) {
-    const half_t one = (half_t)1.f;
+    const half_t one = (half_t)1.f, zr = (half_t)0.f;
 #pragma unroll
     for (int q = 0; q < KVRegs<KS, ND>::NV; ++q)
-      if ((s.ones >> q) & 1u) r.v[q] = half8_t{one, one, one, one, one, one, one, one};
+      if ((s.ones >> q) & 1u) r.v[q] = VROW ? half8_t{one, zr, zr, zr, zr, zr, zr, zr} : half8_t{one, one, one, one, one, one, one, one};
   }
 }
 
@@ -307,33 +256,6 @@ __device__ __forceinline__ void rows_load_buf(RowRegs<KS>& r, const RowSrc<KS>& 
 #pragma unroll
   for (int q = 0; q < KS; ++q) r.v[q] = buf_half8(s.r, s.o[q], so);
 }
-template <int ND>
-struct ColSrc { __amdgpu_buffer_rsrc_t r; unsigned o[(ND + 1) / 2]; int col[(ND + 1) / 2]; };
-template <int ND>
-__device__ __forceinline__ ColSrc<ND> col_src(const half_t* src, int ld, int clim, int dh) {
-  ColSrc<ND> s;
-  s.r = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (unsigned)(((size_t)(dh - 1) * ld + clim) * 2), 0x00020000);
-#pragma unroll
-  for (int q = 0; q < (ND + 1) / 2; ++q) {
-    const int pi = threadIdx.x + q * 256;
-    const int d = pi >> 3, pc = (pi & 7) * 8;
-    s.o[q] = (pi < ND * 128 && d < dh) ? (unsigned)(d * ld + pc) * 2u : ATT_OOB;
-    s.col[q] = pc;
-  }
-  return s;
-}
-template <int ND>
-__device__ __forceinline__ void cols_load_buf(ColRegs<ND>& r, const ColSrc<ND>& s, int c0, int clim) {
-  const unsigned so = (unsigned)c0 * 2u;
-  if (c0 + 64 <= clim) {
-#pragma unroll
-    for (int q = 0; q < (ND + 1) / 2; ++q) r.v[q] = buf_half8(s.r, s.o[q], so);
-  } else {
-#pragma unroll
-    for (int q = 0; q < (ND + 1) / 2; ++q) r.v[q] = buf_half8(s.r, c0 + s.col[q] < clim ? s.o[q] : ATT_OOB, so);
-  }
-}
-
 // Forward.  Per 64-key tile: issue the global loads of the NEXT tile into registers, run S^T = K Q^T,
 // online softmax and O^T += V^T P^T on the current LDS tile, then (barrier) spill the prefetched
 // registers into LDS: the HBM/L2 latency of tile t+1 hides under the MFMA + VALU work of tile t.
@@ -343,12 +265,13 @@ __device__ __forceinline__ void cols_load_buf(ColRegs<ND>& r, const ColSrc<ND>& 
 // query i only when j <= i; a separate instantiation so the UNet's kernels carry no extra test.
 // VAR (experiments / per-shape tuning): bit 0 = request every fragment of a tile up front (PRE), bit 1 = one register
 // prefetch set instead of two (frees 16 VGPRs), bits 2-3 = waves per SIMD the register allocation is bounded for (0 = default)
-template <int KS, int ND, int QT, bool CAUSAL = false, int VAR = 0>
+template <int KS, int ND, int QT, bool CAUSAL = false, int VAR = 0, bool VROW = false>
 __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS == 2 && ND == 3 && !CAUSAL && QT == 2) ? 4 : 2)) void attn_fwd_kernel(const AttnParams p) {
   // QT query tiles of 16 per wave: a workgroup covers 64 * QT queries, so every K / V^T fragment read from LDS
   // (and every byte of K/V streamed from L2) is used by QT MFMAs instead of one.
   constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
-  constexpr int KSZ = 64 * KP, VSZ = ND * 16 * TP;
+  constexpr int VP = vrow_pitch(ND);    // VROW: p.Vt / p.ldvt are the ROW-MAJOR V and its pitch; the tile is kept [64][VP] and read transposing
+  constexpr int KSZ = 64 * KP, VSZ = VROW ? 64 * VP : ND * 16 * TP;
   __shared__ __attribute__((aligned(16))) half_t lds[2 * (KSZ + VSZ)];      // two (K, V^T) stages
   half_t* const Ks0 = lds;
   half_t* const Vs0 = lds + KSZ;
@@ -403,7 +326,9 @@ __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS =
   constexpr bool ONES = (KS == 2 && ND == 3);
 
   const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
-  const half_t* Vb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
+  const half_t* Vb = VROW ? p.Vt + (size_t)b * p.kv_stride * p.ldvt + h * dh
+                          : p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
+  const int vlane = (4 * g + (l16 >> 2)) * VP + 4 * (l16 & 3);      // VROW: the lane's corner of every [4][16] block
   const int nt = (p.Nkv + 63) / 64;
 
 #ifdef SKG_PHASES
@@ -426,7 +351,7 @@ __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS =
 #pragma unroll
       for (int u = 0; u < ND; ++u)
 #pragma unroll
-        for (int k2 = 0; k2 < 2; ++k2) vf[u][k2] = tfrag(Vs, u, k2, l16, g);
+        for (int k2 = 0; k2 < 2; ++k2) vf[u][k2] = VROW ? tfrag_rows<VP>(Vs + vlane, u, k2) : tfrag(Vs, u, k2, l16, g);
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -507,7 +432,7 @@ __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS =
     for (int u = 0; u < ND; ++u)
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        if constexpr (!PRE) vf[u][k2] = tfrag(Vs, u, k2, l16, g);
+        if constexpr (!PRE) vf[u][k2] = VROW ? tfrag_rows<VP>(Vs + vlane, u, k2) : tfrag(Vs, u, k2, l16, g);
 #pragma unroll
         for (int i = 0; i < QT; ++i) o[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[u][k2], pb[i][k2], o[i][u], 0, 0, 0);
       }
@@ -519,24 +444,24 @@ __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS =
   // registers on its way to the other stage and tile t+2 is in flight from L2/HBM, ONE barrier per tile.
   // Invariant at the top of the (unrolled-by-2) loop, t even: stage 0 = tile t, r0 = tile t+1, r1 = tile t+2.
   constexpr bool DEEP = KS < 5 && !(KS == 2 && ND == 3) && !(VAR & 2);      // d = 160: a second register set would not fit 2 waves / SIMD; d = 40: four waves / SIMD instead
-  const KVSrc<KS, ND> src = kv_src<KS, ND, ONES>(Kb, p.ldk, Vb, p.ldvt, p.kv_stride, dh);
+  const KVSrc<KS, ND> src = kv_src<KS, ND, ONES, VROW>(Kb, p.ldk, Vb, p.ldvt, p.kv_stride, dh);
   KVRegs<KS, ND> r0;
-  kv_load_buf<KS, ND, ONES>(r0, src, 0, p.ldk, p.kv_stride);
-  kv_store<KS, ND>(r0, Ks0, Vs0);
-  if (nt > 1) kv_load_buf<KS, ND, ONES>(r0, src, 64, p.ldk, p.kv_stride);
+  kv_load_buf<KS, ND, ONES, VROW>(r0, src, 0, p.ldk, p.kv_stride, p.ldvt);
+  kv_store<KS, ND, VROW>(r0, Ks0, Vs0);
+  if (nt > 1) kv_load_buf<KS, ND, ONES, VROW>(r0, src, 64, p.ldk, p.kv_stride, p.ldvt);
   if constexpr (DEEP) {
     KVRegs<KS, ND> r1;
-    if (nt > 2) kv_load_buf<KS, ND, ONES>(r1, src, 128, p.ldk, p.kv_stride);
+    if (nt > 2) kv_load_buf<KS, ND, ONES, VROW>(r1, src, 128, p.ldk, p.kv_stride, p.ldvt);
     __syncthreads();
     for (int t0 = 0; t0 < nt; t0 += 2) {
       tile(Ks0, Vs0, t0 * 64);
-      if (t0 + 1 < nt) kv_store<KS, ND>(r0, Ks1, Vs1);
-      if (t0 + 3 < nt) kv_load_buf<KS, ND, ONES>(r0, src, (t0 + 3) * 64, p.ldk, p.kv_stride);
+      if (t0 + 1 < nt) kv_store<KS, ND, VROW>(r0, Ks1, Vs1);
+      if (t0 + 3 < nt) kv_load_buf<KS, ND, ONES, VROW>(r0, src, (t0 + 3) * 64, p.ldk, p.kv_stride, p.ldvt);
       __syncthreads();
       if (t0 + 1 < nt) {
         tile(Ks1, Vs1, (t0 + 1) * 64);
-        if (t0 + 2 < nt) kv_store<KS, ND>(r1, Ks0, Vs0);
-        if (t0 + 4 < nt) kv_load_buf<KS, ND, ONES>(r1, src, (t0 + 4) * 64, p.ldk, p.kv_stride);
+        if (t0 + 2 < nt) kv_store<KS, ND, VROW>(r1, Ks0, Vs0);
+        if (t0 + 4 < nt) kv_load_buf<KS, ND, ONES, VROW>(r1, src, (t0 + 4) * 64, p.ldk, p.kv_stride, p.ldvt);
         __syncthreads();
       }
     }
@@ -547,18 +472,18 @@ __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS =
     for (int t0 = 0; t0 < nt; t0 += 2) {
       tile(Ks0, Vs0, t0 * 64);
       ATT_T(t1);
-      if (t0 + 1 < nt) kv_store<KS, ND>(r0, Ks1, Vs1);
+      if (t0 + 1 < nt) kv_store<KS, ND, VROW>(r0, Ks1, Vs1);
       ATT_T(t2);
       __syncthreads();
       ATT_T(t3);
       ATT_ACC(3, t1, t2);                 // staging the next tile (waits for its global loads)
       ATT_ACC(4, t2, t3);                 // barrier
       if (t0 + 1 < nt) {
-        if (t0 + 2 < nt) kv_load_buf<KS, ND, ONES>(r0, src, (t0 + 2) * 64, p.ldk, p.kv_stride);
+        if (t0 + 2 < nt) kv_load_buf<KS, ND, ONES, VROW>(r0, src, (t0 + 2) * 64, p.ldk, p.kv_stride, p.ldvt);
         tile(Ks1, Vs1, (t0 + 1) * 64);
         ATT_T(t4);
-        if (t0 + 2 < nt) kv_store<KS, ND>(r0, Ks0, Vs0);
-        if (t0 + 3 < nt) kv_load_buf<KS, ND, ONES>(r0, src, (t0 + 3) * 64, p.ldk, p.kv_stride);
+        if (t0 + 2 < nt) kv_store<KS, ND, VROW>(r0, Ks0, Vs0);
+        if (t0 + 3 < nt) kv_load_buf<KS, ND, ONES, VROW>(r0, src, (t0 + 3) * 64, p.ldk, p.kv_stride, p.ldvt);
         ATT_T(t5);
         __syncthreads();
         ATT_T(t6);
@@ -609,7 +534,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
   constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
   __shared__ __attribute__((aligned(16))) half_t Ks[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Vr[64 * KP];
-  __shared__ __attribute__((aligned(16))) half_t Kt[ND * 16 * TP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, g = lane >> 4;
   const BlkMap bm = attn_block_map(p);
@@ -649,27 +573,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
 
   const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
   const half_t* Vb = p.V + (size_t)b * p.kv_stride * p.ldv + h * dh;
-  const half_t* Ktb = p.Vt + (size_t)h * dh * p.ldvt + (size_t)b * p.kv_stride;
   const int nt = (p.Nkv + 63) / 64;
-  // register prefetch: the three tiles of key block t+1 are loaded while block t computes
+  // register prefetch: the two tiles of key block t+1 are loaded while block t computes.  K^T fragments (the A operand
+  // of dQ^T += K^T dS^T) come out of the SAME row-major K tile through the LDS transpose read (tfrag_rows).
   RowRegs<KS> rk, rv;
-  ColRegs<ND> rkt;
   const RowSrc<KS> sk = row_src<KS>(Kb, p.ldk, p.kv_stride, dh), sv = row_src<KS>(Vb, p.ldv, p.kv_stride, dh);
-  const ColSrc<ND> skt = col_src<ND>(Ktb, p.ldvt, p.kv_stride, dh);
+  const int tlane = (4 * g + (l16 >> 2)) * KP + 4 * (l16 & 3);
   rows_load_buf<KS>(rk, sk, p.ldk, 0);
   rows_load_buf<KS>(rv, sv, p.ldv, 0);
-  cols_load_buf<ND>(rkt, skt, 0, p.kv_stride);
   for (int t0 = 0; t0 < nt; ++t0) {
     const int kv0 = t0 * 64;
     __syncthreads();                     // everyone is done reading the previous block
     rows_store<KS>(rk, Ks);
     rows_store<KS>(rv, Vr);
-    cols_store<ND>(rkt, Kt);
     __syncthreads();
     if (t0 + 1 < nt) {
       rows_load_buf<KS>(rk, sk, p.ldk, kv0 + 64);
       rows_load_buf<KS>(rv, sv, p.ldv, kv0 + 64);
-      cols_load_buf<ND>(rkt, skt, kv0 + 64, p.kv_stride);
     }
     float4_t s[QT][4], dp[QT][4];      // s = S*sc - lse,  dp = dP - delta  straight out of the matrix pipe
 #pragma unroll
@@ -706,7 +626,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     for (int u = 0; u < ND; ++u)
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        const half8_t ktf = tfrag(Kt, u, k2, l16, g);
+        const half8_t ktf = tfrag_rows<KP>(Ks + tlane, u, k2);
 #pragma unroll
         for (int i = 0; i < QT; ++i) dq[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ktf, sb[i][k2], dq[i][u], 0, 0, 0);
       }
@@ -737,8 +657,6 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
   constexpr int KP = KS * 32 + 16;      // pitch = 16 or 48 (mod 64) halves: conflict-free for the 4 x 16-lane groups of ds_read_b128 (+ 8 is 2-way)
   __shared__ __attribute__((aligned(16))) half_t Qs[64 * KP];
   __shared__ __attribute__((aligned(16))) half_t Ds[64 * KP];
-  __shared__ __attribute__((aligned(16))) half_t Qt[ND * 16 * TP];
-  __shared__ __attribute__((aligned(16))) half_t Dt[ND * 16 * TP];
   __shared__ __attribute__((aligned(16))) float lse_s[64], del_s[64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l16 = lane & 15, g = lane >> 4;
@@ -777,21 +695,17 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
     }
   const half_t* Qb = p.Q + (size_t)b * p.Nq * p.ldq + h * dh;
   const half_t* Db = p.dO + (size_t)b * p.Nq * p.lddo + h * dh;
-  const half_t* Qtb = p.Qt + (size_t)h * dh * p.ldqt + (size_t)b * p.Nq;
-  const half_t* Dtb = p.dOt + (size_t)h * dh * p.lddot + (size_t)b * p.Nq;
   const size_t sbase = ((size_t)b * p.heads + h) * p.Nq;
   const int nt = (p.Nq + 63) / 64;
-  // register prefetch of query block t+1 (Q, dO row tiles, their transposes, lse, delta) under block t's math
+  // register prefetch of query block t+1 (Q, dO row tiles, lse, delta) under block t's math; the Q^T / dO^T fragments
+  // of dK^T += Q^T dS, dV^T += dO^T P are read from the same row tiles through the LDS transpose read
   RowRegs<KS> rq, rd;
-  ColRegs<ND> rqt, rdt;
   float r_lse = 0.f, r_del = 0.f;
   const RowSrc<KS> sq = row_src<KS>(Qb, p.ldq, p.Nq, dh), sd = row_src<KS>(Db, p.lddo, p.Nq, dh);
-  const ColSrc<ND> sqt = col_src<ND>(Qtb, p.ldqt, p.Nq, dh), sdt = col_src<ND>(Dtb, p.lddot, p.Nq, dh);
+  const int tlane = (4 * g + (l16 >> 2)) * KP + 4 * (l16 & 3);
   auto prefetch = [&](int q0) {
     rows_load_buf<KS>(rq, sq, p.ldq, q0);
     rows_load_buf<KS>(rd, sd, p.lddo, q0);
-    cols_load_buf<ND>(rqt, sqt, q0, p.Nq);
-    cols_load_buf<ND>(rdt, sdt, q0, p.Nq);
     if (threadIdx.x < 64) {
       const int qq = q0 + threadIdx.x;
       r_lse = qq < p.Nq ? -p.lse[sbase + qq] * LOG2E : NEG_BIG;      // stored NEGATED: they are MFMA C operands
@@ -804,8 +718,6 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
     __syncthreads();
     rows_store<KS>(rq, Qs);
     rows_store<KS>(rd, Ds);
-    cols_store<ND>(rqt, Qt);
-    cols_store<ND>(rdt, Dt);
     if (threadIdx.x < 64) { lse_s[threadIdx.x] = r_lse; del_s[threadIdx.x] = r_del; }
     __syncthreads();
     if (t0 + 1 < nt) prefetch(q0 + 64);
@@ -843,7 +755,7 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 1 : 2)) void attn_bwd_dkv_kernel(co
     for (int u = 0; u < ND; ++u)
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        const half8_t dtf = tfrag(Dt, u, k2, l16, g), qtf = tfrag(Qt, u, k2, l16, g);
+        const half8_t dtf = tfrag_rows<KP>(Ds + tlane, u, k2), qtf = tfrag_rows<KP>(Qs + tlane, u, k2);
 #pragma unroll
         for (int i = 0; i < KT; ++i) {
           dv[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(dtf, pb[i][k2], dv[i][u], 0, 0, 0);
@@ -903,22 +815,22 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
 // (+8...15 %); d = 40 already runs four waves per SIMD.  SKG_ATTN_VAR=7 launches the two-set form for A/B runs
 // (tools/attn_var_bench.py; the other variants measured in round 2 - all fragments of a tile requested up front, four
 // query tiles per wave - lost and are not instantiated: profiles/r02_attn_variants.txt).
-#define SKG_ATTN_VARIANTS(KS_, ND_, grid2)                                                                       \
+#define SKG_ATTN_VARIANTS(KS_, ND_, grid2, VROW_)                                                                \
   if (ND_ == 4 && attn_var() != 7)                                                                               \
-    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 2 | (3 << 2)>), grid2, dim3(256), 0, st, p);         \
+    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 2 | (3 << 2), VROW_>), grid2, dim3(256), 0, st, p);  \
   else                                                                                                           \
-    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2>), grid2, dim3(256), 0, st, p)
+    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 0, VROW_>), grid2, dim3(256), 0, st, p)
 
 // forward: two query tiles per wave (128 queries per workgroup) except at d = 160 (register budget)
-#define SKG_ATTN_FWD_DISPATCH(grid1, grid2)                                                              \
-  switch (p.dh) {                                                                                        \
-    case 16: hipLaunchKernelGGL((attn_fwd_kernel<1, 1, 2>), grid2, dim3(256), 0, st, p); break;          \
-    case 32: hipLaunchKernelGGL((attn_fwd_kernel<1, 2, 2>), grid2, dim3(256), 0, st, p); break;          \
-    case 40: SKG_ATTN_VARIANTS(2, 3, grid2); break;                                                      \
-    case 64: SKG_ATTN_VARIANTS(2, 4, grid2); break;                                                      \
-    case 80: hipLaunchKernelGGL((attn_fwd_kernel<3, 5, 2>), grid2, dim3(256), 0, st, p); break;          \
-    case 160: hipLaunchKernelGGL((attn_fwd_kernel<5, 10, 1>), grid1, dim3(256), 0, st, p); break;        \
-    default: return SKG_E_UNSUPPORTED;                                                                   \
+#define SKG_ATTN_FWD_DISPATCH(grid1, grid2, VROW_)                                                                 \
+  switch (p.dh) {                                                                                                  \
+    case 16: hipLaunchKernelGGL((attn_fwd_kernel<1, 1, 2, false, 0, VROW_>), grid2, dim3(256), 0, st, p); break;   \
+    case 32: hipLaunchKernelGGL((attn_fwd_kernel<1, 2, 2, false, 0, VROW_>), grid2, dim3(256), 0, st, p); break;   \
+    case 40: SKG_ATTN_VARIANTS(2, 3, grid2, VROW_); break;                                                         \
+    case 64: SKG_ATTN_VARIANTS(2, 4, grid2, VROW_); break;                                                         \
+    case 80: hipLaunchKernelGGL((attn_fwd_kernel<3, 5, 2, false, 0, VROW_>), grid2, dim3(256), 0, st, p); break;   \
+    case 160: hipLaunchKernelGGL((attn_fwd_kernel<5, 10, 1, false, 0, VROW_>), grid1, dim3(256), 0, st, p); break; \
+    default: return SKG_E_UNSUPPORTED;                                                                             \
   }
 
 #define SKG_ATTN_FWD_CAUSAL_DISPATCH(grid2)                                                               \
@@ -942,7 +854,7 @@ inline bool common_ok(int batch, int heads, int Nq, int Nkv, int kv_stride, int 
 
 static int attn_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O,
                          int ldo, float* lse, int batch, int heads, int Nq, int Nkv, int kv_stride, int dh,
-                         float scale, bool causal, void* stream) {
+                         float scale, bool causal, void* stream, bool vrow = false) {
   SKG_REQUIRE(Q && K && Vt && O && common_ok(batch, heads, Nq, Nkv, kv_stride, dh));
   SKG_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 4 == 0);
   SKG_REQUIRE(skg_aligned(Q, 16) && skg_aligned(K, 16) && skg_aligned(Vt, 16) && skg_aligned(O, 8));
@@ -954,10 +866,12 @@ static int attn_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const v
   p.nx = skg_cdiv(Nq, dh == 160 ? 64 : 128);       // query tiles per workgroup: see SKG_ATTN_FWD_DISPATCH
   dim3 grid((unsigned)p.nx * heads * batch);
   if (causal) {
-    SKG_REQUIRE(dh != 160);
+    SKG_REQUIRE(dh != 160 && !vrow);
     SKG_ATTN_FWD_CAUSAL_DISPATCH(grid);
+  } else if (vrow) {
+    SKG_ATTN_FWD_DISPATCH(grid, grid, true);
   } else {
-    SKG_ATTN_FWD_DISPATCH(grid, grid);
+    SKG_ATTN_FWD_DISPATCH(grid, grid, false);
   }
   SKG_CHECK_LAUNCH("skg_attn_fwd");
   return SKG_OK;
@@ -967,6 +881,14 @@ extern "C" int skg_attn_fwd(const void* Q, int ldq, const void* K, int ldk, cons
                             int ldo, float* lse, int batch, int heads, int Nq, int Nkv, int kv_stride, int dh,
                             float scale, void* stream) {
   return attn_fwd_impl(Q, ldq, K, ldk, Vt, ldvt, O, ldo, lse, batch, heads, Nq, Nkv, kv_stride, dh, scale, false, stream);
+}
+
+// V handed over ROW-MAJOR ([batch * kv_stride][ldv], e.g. the third column block of a fused QKV projection): the kernel
+// reads its fragments through the LDS transpose read, no V^T copy is needed
+extern "C" int skg_attn_fwd_rowv(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
+                                 int ldo, float* lse, int batch, int heads, int Nq, int Nkv, int kv_stride, int dh,
+                                 float scale, void* stream) {
+  return attn_fwd_impl(Q, ldq, K, ldk, V, ldv, O, ldo, lse, batch, heads, Nq, Nkv, kv_stride, dh, scale, false, stream, true);
 }
 
 extern "C" int skg_attn_fwd_causal(const void* Q, int ldq, const void* K, int ldk, const void* Vt, int ldvt, void* O,
@@ -987,16 +909,15 @@ extern "C" int skg_attn_bwd_delta(const void* O, int ldo, const void* dO, int ld
 }
 
 extern "C" int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
-                               const void* Kt, int ldkt, const void* dO, int lddo, const float* lse,
+                               const void* dO, int lddo, const float* lse,
                                const float* delta, void* dQ, int lddq, int batch, int heads, int Nq, int Nkv,
                                int kv_stride, int dh, float scale, void* stream) {
-  SKG_REQUIRE(Q && K && V && Kt && dO && lse && delta && dQ && common_ok(batch, heads, Nq, Nkv, kv_stride, dh));
-  SKG_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldkt % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0);
-  SKG_REQUIRE(skg_aligned(Q, 16) && skg_aligned(K, 16) && skg_aligned(V, 16) && skg_aligned(Kt, 16) &&
-              skg_aligned(dO, 16) && skg_aligned(dQ, 8));
+  SKG_REQUIRE(Q && K && V && dO && lse && delta && dQ && common_ok(batch, heads, Nq, Nkv, kv_stride, dh));
+  SKG_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0);
+  SKG_REQUIRE(skg_aligned(Q, 16) && skg_aligned(K, 16) && skg_aligned(V, 16) && skg_aligned(dO, 16) && skg_aligned(dQ, 8));
   AttnParams p{};
   p.Q = (const half_t*)Q; p.ldq = ldq; p.K = (const half_t*)K; p.ldk = ldk; p.V = (const half_t*)V; p.ldv = ldv;
-  p.Vt = (const half_t*)Kt; p.ldvt = ldkt; p.dO = (const half_t*)dO; p.lddo = lddo;
+  p.dO = (const half_t*)dO; p.lddo = lddo;
   p.lse = const_cast<float*>(lse); p.delta = delta; p.O = (half_t*)dQ; p.ldo = lddq;
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
@@ -1015,20 +936,18 @@ extern "C" int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, c
   return SKG_OK;
 }
 
-extern "C" int skg_attn_bwd_dkv(const void* Q, int ldq, const void* Qt, int ldqt, const void* K, int ldk,
-                                const void* V, int ldv, const void* dO, int lddo, const void* dOt, int lddot,
+extern "C" int skg_attn_bwd_dkv(const void* Q, int ldq, const void* K, int ldk,
+                                const void* V, int ldv, const void* dO, int lddo,
                                 const float* lse, const float* delta, void* dK, int lddk, void* dV, int lddv,
                                 int batch, int heads, int Nq, int Nkv, int dh, float scale, void* stream) {
-  SKG_REQUIRE(Q && Qt && K && V && dO && dOt && lse && delta && dK && dV && common_ok(batch, heads, Nq, Nkv, Nkv, dh));
-  SKG_REQUIRE(Nq % 8 == 0);   // transposed tiles are read in 16-byte pieces along q (self-attention: Nkv == kv_stride)
-  SKG_REQUIRE(ldq % 8 == 0 && ldqt % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddot % 8 == 0 &&
-              lddk % 4 == 0 && lddv % 4 == 0);
-  SKG_REQUIRE(skg_aligned(Q, 16) && skg_aligned(Qt, 16) && skg_aligned(K, 16) && skg_aligned(V, 16) &&
-              skg_aligned(dO, 16) && skg_aligned(dOt, 16) && skg_aligned(dK, 8) && skg_aligned(dV, 8));
+  SKG_REQUIRE(Q && K && V && dO && lse && delta && dK && dV && common_ok(batch, heads, Nq, Nkv, Nkv, dh));
+  SKG_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddk % 4 == 0 && lddv % 4 == 0);
+  SKG_REQUIRE(skg_aligned(Q, 16) && skg_aligned(K, 16) && skg_aligned(V, 16) &&
+              skg_aligned(dO, 16) && skg_aligned(dK, 8) && skg_aligned(dV, 8));
   AttnParams p{};
-  p.Q = (const half_t*)Q; p.ldq = ldq; p.Qt = (const half_t*)Qt; p.ldqt = ldqt; p.K = (const half_t*)K; p.ldk = ldk;
-  p.V = (const half_t*)V; p.ldv = ldv; p.dO = (const half_t*)dO; p.lddo = lddo; p.dOt = (const half_t*)dOt;
-  p.lddot = lddot; p.lse = const_cast<float*>(lse); p.delta = delta; p.O = (half_t*)dK; p.ldo = lddk;
+  p.Q = (const half_t*)Q; p.ldq = ldq; p.K = (const half_t*)K; p.ldk = ldk;
+  p.V = (const half_t*)V; p.ldv = ldv; p.dO = (const half_t*)dO; p.lddo = lddo;
+  p.lse = const_cast<float*>(lse); p.delta = delta; p.O = (half_t*)dK; p.ldo = lddk;
   p.O2 = (half_t*)dV; p.ldo2 = lddv;
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = Nkv; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;

@@ -125,7 +125,7 @@ class HipInjector:
             assert C == w["C"]
             tok = r.to(self.dev, torch.float16).permute(0, 2, 3, 1).reshape(rows * hh * ww, C).contiguous()
             kv = ops.gemm(tok, w["wkv"])                       # res_sample is used un-normalised (:127)
-            self.per_image[path] = dict(K=kv[:, :C], V=kv[:, C:], Vt=ops.transpose(kv[:, C:]), rows=rows, N=hh * ww)
+            self.per_image[path] = dict(K=kv[:, :C], V=kv[:, C:], rows=rows, N=hh * ww)
 
     # ---- per UNet evaluation ------------------------------------------------------------------------------
     def __call__(self, path: str, h: torch.Tensor, rows: int, N: int, heads: int) -> torch.Tensor:
@@ -140,7 +140,7 @@ class HipInjector:
             assert pi["rows"] == rows and pi["N"] == N
             z = ops.layernorm(h, w["ng"], w["nb"])
             q = ops.gemm(z, w["wq"])
-            a = ops.attn_fwd(q, pi["K"], pi["Vt"], rows, heads, N, N, N, dh, scale)
+            a = ops.attn_fwd(q, pi["K"], pi["V"], rows, heads, N, N, N, dh, scale, v_rows=True)
             o = ops.gemm(a, w["wo"], bias=w["bo"])
             return ops.gemm(o, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)
         # CLIP variant: self-attention of the N image-token queries over [N image tokens ; T sketch tokens]
@@ -156,6 +156,6 @@ class HipInjector:
         q = ops.gemm(zh, w["wq"])
         for b in range(rows):
             ops.gemm(zh[b * N:(b + 1) * N], w["wkv"], out=kvbuf[b * L:b * L + N])
-        a = ops.attn_fwd(q, kvbuf[:, :C], ops.transpose(kvbuf[:, C:]), rows, heads, N, N + T, L, dh, scale)
+        a = ops.attn_fwd(q, kvbuf[:, :C], kvbuf[:, C:], rows, heads, N, N + T, L, dh, scale, v_rows=True)
         o = ops.gemm(a, w["wo"], bias=w["bo"])
         return ops.gemm(o, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)

@@ -294,12 +294,15 @@ def nhwc_to_nchw(X: torch.Tensor, rows: int, C: int, H: int, W: int):
     return out
 
 
-def attn_fwd(Q, K, Vt, batch, heads, Nq, Nkv, kv_stride, dh, scale, out=None, want_lse=False, causal=False):
+def attn_fwd(Q, K, Vt, batch, heads, Nq, Nkv, kv_stride, dh, scale, out=None, want_lse=False, causal=False,
+             v_rows=False):
+    """v_rows=True: `Vt` is the row-major V ([batch*kv_stride, heads*dh] view, any row pitch) instead of its transpose."""
     _f16(Q, K, Vt)
+    assert not (causal and v_rows)
     if out is None:
         out = torch.empty(batch * Nq, heads * dh, device=Q.device, dtype=torch.float16)
     lse = torch.empty(batch, heads, Nq, device=Q.device, dtype=torch.float32) if want_lse else None
-    fn = lib.skg_attn_fwd_causal if causal else lib.skg_attn_fwd
+    fn = lib.skg_attn_fwd_causal if causal else lib.skg_attn_fwd_rowv if v_rows else lib.skg_attn_fwd
     check(fn(_p(Q), _ld(Q), _p(K), _ld(K), _p(Vt), _ld(Vt), _p(out), _ld(out), _p(lse), batch,
              heads, Nq, Nkv, kv_stride, dh, scale, _stream()), "skg_attn_fwd")
     return (out, lse) if want_lse else out
@@ -313,24 +316,24 @@ def attn_bwd_delta(O, dO, batch, heads, Nq, dh):
     return delta
 
 
-def attn_bwd_dq(Q, K, V, Kt, dO, lse, delta, batch, heads, Nq, Nkv, kv_stride, dh, scale, out=None):
-    _f16(Q, K, V, Kt, dO)
+def attn_bwd_dq(Q, K, V, dO, lse, delta, batch, heads, Nq, Nkv, kv_stride, dh, scale, out=None):
+    _f16(Q, K, V, dO)
     if out is None:
         out = torch.empty(batch * Nq, heads * dh, device=Q.device, dtype=torch.float16)
-    check(lib.skg_attn_bwd_dq(_p(Q), _ld(Q), _p(K), _ld(K), _p(V), _ld(V), _p(Kt), _ld(Kt), _p(dO), _ld(dO),
+    check(lib.skg_attn_bwd_dq(_p(Q), _ld(Q), _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO),
                               _p(lse), _p(delta), _p(out), _ld(out), batch, heads, Nq, Nkv, kv_stride, dh,
                               scale, _stream()), "skg_attn_bwd_dq")
     return out
 
 
-def attn_bwd_dkv(Q, Qt, K, V, dO, dOt, lse, delta, batch, heads, Nq, Nkv, dh, scale, dK=None, dV=None):
-    _f16(Q, Qt, K, V, dO, dOt)
+def attn_bwd_dkv(Q, K, V, dO, lse, delta, batch, heads, Nq, Nkv, dh, scale, dK=None, dV=None):
+    _f16(Q, K, V, dO)
     if dK is None:
         dK = torch.empty(batch * Nkv, heads * dh, device=Q.device, dtype=torch.float16)
     if dV is None:
         dV = torch.empty(batch * Nkv, heads * dh, device=Q.device, dtype=torch.float16)
-    check(lib.skg_attn_bwd_dkv(_p(Q), _ld(Q), _p(Qt), _ld(Qt), _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO),
-                               _p(dOt), _ld(dOt), _p(lse), _p(delta), _p(dK), _ld(dK), _p(dV), _ld(dV), batch,
+    check(lib.skg_attn_bwd_dkv(_p(Q), _ld(Q), _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO),
+                               _p(lse), _p(delta), _p(dK), _ld(dK), _p(dV), _ld(dV), batch,
                                heads, Nq, Nkv, dh, scale, _stream()), "skg_attn_bwd_dkv")
     return dK, dV
 

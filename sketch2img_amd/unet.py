@@ -185,10 +185,7 @@ class HipUNet:
                     wv = torch.nn.functional.pad(wv, (0, Dp - D)).contiguous()
                 Kc = ops.gemm(x, wk)                     # padded token rows are exactly zero (zero input, no bias)
                 Vc = ops.gemm(x, wv)
-                blk = dict(K=Kc, V=Vc, Vt=ops.transpose(Vc))
-                if self.need_backward:
-                    blk["Kt_c"] = ops.transpose(Kc[S * Lp:])
-                ctx["blocks"][p] = blk
+                ctx["blocks"][p] = dict(K=Kc, V=Vc)
         self.ctx = ctx
 
     # ------------------------------------------------------------------ modules, forward
@@ -219,16 +216,17 @@ class HipUNet:
         pin = ops.gemm(g, W[p + ".proj_in.weight"], bias=W[p + ".proj_in.bias"])
         a1, st1 = ops.layernorm(pin, W[t + ".norm1.weight"], W[t + ".norm1.bias"], want_stats=True)
         qkv = ops.gemm(a1, W[t + ".attn1.qkv"])
-        vt = ops.transpose(qkv[:, 2 * C:])
-        o1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], vt, rows, heads, HW, HW, HW, dh, scale, want_lse=True)
+        # V straight out of the fused projection (row-major; the kernel's LDS transpose read replaces the V^T copy)
+        o1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], rows, heads, HW, HW, HW, dh, scale,
+                                want_lse=True, v_rows=True)
         p1 = ops.gemm(o1, W[t + ".attn1.to_out.0.weight"], bias=W[t + ".attn1.to_out.0.bias"], residual=pin)
         if self.inject is not None:
             p1 = self.inject(t, p1, rows, HW, heads)
         a2, st2 = ops.layernorm(p1, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
         q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"])
         cb = self.ctx["blocks"][t + ".attn2"]
-        o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["Vt"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
-                                want_lse=True)
+        o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
+                                want_lse=True, v_rows=True)
         p2 = ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], bias=W[t + ".attn2.to_out.0.bias"], residual=p1)
         a3, st3 = ops.layernorm(p2, W[t + ".norm3.weight"], W[t + ".norm3.bias"], want_stats=True)
         if not keep and C % 64 == 0:        # no backward will follow: gate inside the GEMM epilogue (half the bytes)
@@ -391,7 +389,7 @@ class HipUNet:
         cb = self.ctx["blocks"][t + ".attn2"]
         L, Lp = self.ctx["L"], self.ctx["Lp"]
         delta2 = ops.attn_bwd_delta(c(st["o2"]), do2, S, heads, HW, dh)
-        dq2 = ops.attn_bwd_dq(c(st["q2"]), cb["K"][S * Lp:], cb["V"][S * Lp:], cb["Kt_c"], do2, st["lse2"][S:],
+        dq2 = ops.attn_bwd_dq(c(st["q2"]), cb["K"][S * Lp:], cb["V"][S * Lp:], do2, st["lse2"][S:],
                               delta2, S, heads, HW, L, Lp, dh, scale)
         da2 = ops.gemm(dq2, W[t + ".attn2.to_q.weight:T"])
         dp1 = ops.layernorm_bwd(c(st["p1"]), da2, W[t + ".norm2.weight"], c(st["st2"]), residual=dp2)
@@ -402,10 +400,8 @@ class HipUNet:
         delta1 = ops.attn_bwd_delta(c(st["o1"]), do1, S, heads, HW, dh)
         lse1 = st["lse1"][S:]
         dqkv = torch.empty(M0, 3 * C, device=self.dev, dtype=torch.float16)
-        ops.attn_bwd_dq(Q, K, V, ops.transpose(K), do1, lse1, delta1, S, heads, HW, HW, HW, dh, scale,
-                        out=dqkv[:, :C])
-        ops.attn_bwd_dkv(Q, ops.transpose(Q), K, V, do1, ops.transpose(do1), lse1, delta1, S, heads, HW, HW, dh,
-                         scale, dK=dqkv[:, C:2 * C], dV=dqkv[:, 2 * C:])
+        ops.attn_bwd_dq(Q, K, V, do1, lse1, delta1, S, heads, HW, HW, HW, dh, scale, out=dqkv[:, :C])
+        ops.attn_bwd_dkv(Q, K, V, do1, lse1, delta1, S, heads, HW, HW, dh, scale, dK=dqkv[:, C:2 * C], dV=dqkv[:, 2 * C:])
         da1 = ops.gemm(dqkv, W[t + ".attn1.qkv:T"])
         dpin = ops.layernorm_bwd(c(st["pin"]), da1, W[t + ".norm1.weight"], c(st["st1"]), residual=dp1)
         dg = ops.gemm(dpin, W[p + ".proj_in.weight:T"])

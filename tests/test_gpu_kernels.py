@@ -374,6 +374,10 @@ def test_attention_forward(ops, dh, heads, Nq, Nkv):
     # P is rounded to fp16 before the PV product (like every fp16 flash kernel): ~1e-3 relative
     assert r < 2e-3
     assert report("attn lse", lse.cpu(), rl)[1] < 2e-3
+    # V handed over row-major (skg_attn_fwd_rowv: fragments through ds_read_b64_tr_b16): the same products in the same
+    # order, so the result is the transposed-copy path's bit for bit
+    o2, lse2 = ops.attn_fwd(Q, K, V, B, heads, Nq, Nkv, kvs, dh, scale, want_lse=True, v_rows=True)
+    assert torch.equal(o2, o) and torch.equal(lse2, lse)
 
 
 @pytest.mark.parametrize("dh,heads,N,Nkv", [(64, 12, 80, 77), (16, 4, 80, 77), (32, 3, 320, 320), (64, 2, 200, 197)])
@@ -410,6 +414,8 @@ def test_attention_forward_strided_qkv_and_online_rescale(ops):
     q, k, v = (qkv[:, i * C:(i + 1) * C].float().view(B, N, C) for i in range(3))
     ro, _ = ref_attention(q, k, v, heads, dh ** -0.5)
     assert report("attn fwd strided+spike", o.float().cpu().view(B, N, C), ro)[0] < 2e-3
+    o2 = ops.attn_fwd(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], B, heads, N, N, N, dh, dh ** -0.5, v_rows=True)
+    assert torch.equal(o2, o)                        # V as the third column block of the fused buffer, no transpose
 
 
 @pytest.mark.parametrize("dh,heads,Nq,Nkv,cross", [(40, 8, 256, 256, False), (80, 8, 64, 64, False),
@@ -432,12 +438,11 @@ def test_attention_backward(ops, dh, heads, Nq, Nkv, cross):
     dO = do.reshape(B * Nq, C).to(d)
     o, lse = ops.attn_fwd(Q, K, ops.transpose(V), B, heads, Nq, Nkv, kvs, dh, scale, want_lse=True)
     delta = ops.attn_bwd_delta(o, dO, B, heads, Nq, dh)
-    dq = ops.attn_bwd_dq(Q, K, V, ops.transpose(K), dO, lse, delta, B, heads, Nq, Nkv, kvs, dh, scale)
+    dq = ops.attn_bwd_dq(Q, K, V, dO, lse, delta, B, heads, Nq, Nkv, kvs, dh, scale)
     # tolerance: P and dS are rounded to fp16 before their MFMA products, delta uses the fp16 O
     assert report(f"attn dq dh{dh}", dq.float().cpu().view(B, Nq, C), qf.grad)[0] < 4e-3
     if not cross:
-        dk, dv = ops.attn_bwd_dkv(Q, ops.transpose(Q), K, V, dO, ops.transpose(dO), lse, delta, B, heads, Nq, Nkv,
-                                  dh, scale)
+        dk, dv = ops.attn_bwd_dkv(Q, K, V, dO, lse, delta, B, heads, Nq, Nkv, dh, scale)
         assert report(f"attn dk dh{dh}", dk.float().cpu().view(B, Nkv, C), kf.grad)[0] < 4e-3
         assert report(f"attn dv dh{dh}", dv.float().cpu().view(B, Nkv, C), vf.grad)[0] < 4e-3
 

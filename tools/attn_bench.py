@@ -35,22 +35,19 @@ def case(B, heads, N, dh, Nkv=None, bwd=True):
     else:
         kv = torch.randn(B * kvs, 2 * C, device=DEV).half()
         k, v = kv[:, :C], kv[:, C:]
-    vt = ops.transpose(v)
     scale = dh ** -0.5
-    t = timeit(lambda: ops.attn_fwd(q, k, vt, B, heads, N, Nkv, kvs, dh, scale, want_lse=True))
+    t = timeit(lambda: ops.attn_fwd(q, k, v, B, heads, N, Nkv, kvs, dh, scale, want_lse=True, v_rows=True))
     fl = 4.0 * B * heads * N * Nkv * dh
     print(f"attn fwd  B{B:2d} h{heads} N{N:5d} kv{Nkv:5d} d{dh:3d}: {t * 1e6:8.1f} us  {fl / t / 1e12:6.1f} TF/s", flush=True)
     if not bwd:
         return
-    o, lse = ops.attn_fwd(q, k, vt, B, heads, N, Nkv, kvs, dh, scale, want_lse=True)
+    o, lse = ops.attn_fwd(q, k, v, B, heads, N, Nkv, kvs, dh, scale, want_lse=True, v_rows=True)
     do = torch.randn(B * N, C, device=DEV).half()
     delta = ops.attn_bwd_delta(o, do, B, heads, N, dh)
-    kt = ops.transpose(k)
-    t = timeit(lambda: ops.attn_bwd_dq(q, k, v, kt, do, lse, delta, B, heads, N, Nkv, kvs, dh, scale))
+    t = timeit(lambda: ops.attn_bwd_dq(q, k, v, do, lse, delta, B, heads, N, Nkv, kvs, dh, scale))
     print(f"attn dq   B{B:2d} h{heads} N{N:5d} kv{Nkv:5d} d{dh:3d}: {t * 1e6:8.1f} us  {1.5 * fl / t / 1e12:6.1f} TF/s", flush=True)
     if Nkv == N:
-        qt, dot = ops.transpose(q), ops.transpose(do)
-        t = timeit(lambda: ops.attn_bwd_dkv(q, qt, k, v, do, dot, lse, delta, B, heads, N, Nkv, dh, scale))
+        t = timeit(lambda: ops.attn_bwd_dkv(q, k, v, do, lse, delta, B, heads, N, Nkv, dh, scale))
         print(f"attn dkv  B{B:2d} h{heads} N{N:5d} kv{Nkv:5d} d{dh:3d}: {t * 1e6:8.1f} us  {2.0 * fl / t / 1e12:6.1f} TF/s", flush=True)
 
 
