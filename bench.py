@@ -151,7 +151,8 @@ class LaunchTimer:
             e1.record()
             fl = 4.0 * batch * heads * Nq * Nkv * dh                      # QK^T + PV
             nbytes = 2.0 * batch * heads * dh * (2 * Nq + 2 * Nkv)
-            self.rec.append((f"attn_fwd_kernel<{ATTN_NAMES.get(dh, '?')}, false, {14 if dh == 64 else 0}>", fl, e0, e1, nbytes,
+            vrow = "true" if k.get("v_rows") else "false"         # row-major V through the LDS transpose read
+            self.rec.append((f"attn_fwd_kernel<{ATTN_NAMES.get(dh, '?')}, false, {14 if dh == 64 else 0}, {vrow}>", fl, e0, e1, nbytes,
                              f"attn B{batch} H{heads} Nq{Nq} Nkv{Nkv} d{dh}"))
             return out
 

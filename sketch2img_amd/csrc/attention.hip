@@ -9,9 +9,11 @@
 // For the second product O^T = V^T P^T the probabilities are used straight from those registers as
 // the B operand: element i of lane (q, g) is declared to be k-slot (g, i) <-> key
 // 32 s + 16 (i >> 2) + 4 g + (i & 3); the MFMA only needs A and B to agree on the k <-> key map, so
-// the A operand (V^T rows = head-dim index, from an LDS tile that is stored transposed) is read with
-// the same map as two 8-byte LDS reads.  No P round trip through LDS, no cross-lane transposes.
-// V^T (and K^T, Q^T, dO^T for the backward kernels) are produced by skg_transpose_f16.
+// the A operand (V^T rows = head-dim index) is read with the same map: two ds_read_b64_tr_b16 per fragment out of
+// the ROW-MAJOR V tile (skg_attn_fwd_rowv; tfrag_rows below), or two 8-byte reads out of a tile stored transposed
+// when the caller hands over V^T (skg_attn_fwd, _causal).  No P round trip through LDS, no cross-lane transposes.
+// The backward kernels read K^T, Q^T and dO^T fragments the same way from the row tiles they stage anyway, so
+// nothing on the UNet path needs skg_transpose_f16 any more.
 //
 // Block = 4 waves = 64 query rows (forward, dQ) or 64 key rows (dK/dV); KV / Q tiles of 64 rows are
 // staged in LDS.  Pitches: row tiles [64][32 KS + 16] (ds_read_b128 is served in four NON-contiguous 16-lane groups,
@@ -117,7 +119,7 @@ __device__ __forceinline__ void pack_p(const float4_t (&s)[4], half8_t (&pb)[2])
     for (int i = 0; i < 8; ++i) pb[k2][i] = (half_t)s[2 * k2 + (i >> 2)][i & 3];
 }
 
-// register staging of [64][dh] row tiles and [dh][64] transposed tiles (global -> VGPR now, VGPR -> LDS later)
+// register staging of [64][dh] row tiles (global -> VGPR now, VGPR -> LDS later)
 template <int KS>
 struct RowRegs { half8_t v[KS]; };               // 64 * KS*4 pieces / 256 threads
 
@@ -133,7 +135,9 @@ __device__ __forceinline__ void rows_store(const RowRegs<KS>& r, half_t* __restr
   }
 }
 // -------------------------------------------------------------------------------------------------
-// register staging of one K tile ([64][dh] rows) and one transposed V tile ([dh][64]) per workgroup
+// register staging of one K tile ([64][dh] rows) and one V tile (transposed [dh][64], or row-major [64][VP] with VROW)
+// per workgroup.  ONES (d = 40): the first padding row of V^T / column dh of the row-major tile is 1.0, so row dh of
+// O^T = V^T P^T accumulates the softmax denominator sum_k p[k] on the matrix pipe instead of the VALU.
 template <int KS, int ND>
 struct KVRegs {
   static constexpr int NK = KS;                 // 64 * KS*4 pieces / 256 threads
