@@ -104,14 +104,16 @@ class LaunchTimer:
 
         MODES = {"DIRECT": 0, "S1": 1, "S2": 2, "UP2": 3, "S2T": 4}
 
-        def kname(variant, mode):
-            """The name rocprofv3 prints for the instantiation that ran (template arguments spelled out)."""
+        def kname(variant, mode, gn=False):
+            """The name rocprofv3 prints for the instantiation that ran (template arguments spelled out); gn: the one
+            whose epilogue also writes the GroupNorm partial sums of the output."""
             bn = variant % 1000
+            g = "true" if gn else "false"
             if variant in (8160, 8320):
-                return f"gemm8_kernel<{variant - 8000}, {MODES[mode]}, 0>"
+                return f"gemm8_kernel<{variant - 8000}, {MODES[mode]}, 0, {g}>"
             if variant >= 2000:
                 stages = 3 if variant >= 10000 else 2
-                return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}, {stages}>"
+                return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}, {stages}, {g}>"
             return f"gemm_kernel<{bn}, {MODES[mode]}>"
 
         def ev():
@@ -126,7 +128,9 @@ class LaunchTimer:
             e1.record()
             nbytes = 2.0 * (M * K + N * K + M * N * (2 if k.get("out_f32") else 1) + (M * N if k.get("residual") is not None else 0))
             tag = "+res" * (k.get("residual") is not None) + "+geglu" * bool(k.get("geglu")) + "+f32" * bool(k.get("out_f32"))
-            self.rec.append((kname(lib.skg_gemm_variant(M, N, K, 0, 0), "DIRECT"), 2.0 * M * N * K, e0, e1, nbytes,
+            gs = k.get("gn_stats")
+            gn = gs is not None and bool(lib.skg_gemm_gn_fused(M, N, K, 0, 0, gs[0], gs[1]))
+            self.rec.append((kname(lib.skg_gemm_variant(M, N, K, 0, 0), "DIRECT", gn), 2.0 * M * N * K, e0, e1, nbytes,
                              f"gemm M{M} N{N} K{K}{tag}"))
             return out
 
@@ -140,7 +144,9 @@ class LaunchTimer:
             e1.record()
             name = ("S1", "S2", "UP2", "S2T")[mode]
             nbytes = 2.0 * (X.shape[0] * Cin + Cout * 9 * Cin + M * Cout + (M * Cout if k.get("residual") is not None else 0))
-            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, 9 * Cin, Cin, 1 + mode), name), 2.0 * M * Cout * 9 * Cin, e0, e1, nbytes,
+            gg = k.get("gn_groups")
+            gn = gg is not None and bool(lib.skg_gemm_gn_fused(M, Cout, 9 * Cin, Cin, 1 + mode, OH * OH, gg))
+            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, 9 * Cin, Cin, 1 + mode), name, gn), 2.0 * M * Cout * 9 * Cin, e0, e1, nbytes,
                              f"conv {name} M{M} Cin{Cin} Cout{Cout}" + "+res" * (k.get("residual") is not None)))
             return out
 

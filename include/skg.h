@@ -101,6 +101,26 @@ int skg_groupnorm_stats(const void* X, int ldx, int rows, int HW, int C, int gro
  * skg_groupnorm_bwd): what the UNet / VAE forward use. */
 int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups, float eps,
                       const void* gamma, const void* beta, int silu, float* stats, float* partial, void* stream);
+/* GroupNorm whose statistics pass is done by the PRODUCER of X.  skg_gemm_f16_gn / skg_conv3x3_f16_gn are
+ * skg_gemm_f16 / skg_conv3x3_f16 that additionally leave, per (sample b, 128-row chunk c, group g), sum(y) and sum(y^2)
+ * of the fp16 outputs in gn_partial[((b * (HW / 128) + c) * groups + g) * 2 + {0, 1}] (HW = rows of C per sample, a
+ * multiple of 128; fp16 output, no fused GEGLU).  The sums come out of the kernel's own epilogue when the tile that runs
+ * can produce them (256 x 320 and 128 x 160 tiles, whole tiles, groups inside a tile - every 64 x 64 / 32 x 32-level
+ * layer of the UNet), otherwise from the stand-alone statistics pass: the result is the same either way, in a fixed
+ * summation order.  skg_groupnorm_from_partial folds `nch` chunks per (sample, group), publishes (mean, rstd) to `stats`
+ * and applies - X is read once instead of twice.  Same replaced reference calls as skg_groupnorm_fwd. */
+int skg_gemm_f16_gn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                    const void* bias, const void* residual, int ldr, float alpha, unsigned flags,
+                    float* gn_partial, int HW, int groups, void* stream);
+int skg_conv3x3_f16_gn(const void* X, int ldx, const void* Wp, void* Y, int ldy, int rows, int IH, int IW,
+                       int Cin, int Cout, int mode, const void* bias, const void* residual, int ldr,
+                       float alpha, unsigned flags, float* gn_partial, int groups, void* stream);
+/* 1 when the _gn launch of this shape gets its partial sums from the kernel's own epilogue (mode as in
+ * skg_gemm_variant: 0 = GEMM, 1 + SKG_CONV_*), 0 when the stand-alone statistics pass follows. */
+int skg_gemm_gn_fused(int M, int N, int K, int Cin, int mode, int HW, int groups);
+int skg_groupnorm_from_partial(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
+                               float eps, const void* gamma, const void* beta, int silu, float* stats,
+                               const float* partial, int nch, void* stream);
 int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C,
                         int groups, const float* stats, const void* gamma, const void* beta,
                         int silu, void* stream);

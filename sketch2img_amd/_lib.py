@@ -24,12 +24,16 @@ SIGNATURES = {
     "skg_abi_version": ("i", ""),
     "skg_last_error": ("s", ""),
     "skg_gemm_f16": ("i", "pipipiiiippifup"),
+    "skg_gemm_f16_gn": ("i", "pipipiiiippifupiip"),
+    "skg_gemm_gn_fused": ("i", "iiiiiii"),
     "skg_gemm_variant": ("i", "iiiii"),
     "skg_set_workspace": ("i", "pz"),
     "skg_conv3x3_f16": ("i", "pippiiiiiiippifup"),
+    "skg_conv3x3_f16_gn": ("i", "pippiiiiiiippifupip"),
     "skg_groupnorm_scratch_floats": ("z", "ii"),
     "skg_groupnorm_stats": ("i", "piiiiifppp"),
     "skg_groupnorm_fwd": ("i", "pipiiiiifppippp"),
+    "skg_groupnorm_from_partial": ("i", "pipiiiiifppippip"),
     "skg_groupnorm_apply": ("i", "pipiiiiipppip"),
     "skg_groupnorm_bwd": ("i", "pipipipiiiiipppipp"),
     "skg_layernorm_fwd": ("i", "pipiiippfpp"),

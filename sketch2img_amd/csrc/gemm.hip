@@ -179,7 +179,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 inline bool use_wide(int M, int N) { return (N % 128 == 0) && ((long)skg_cdiv(M, BM) * (N / 128) >= 256); }
 
 template <int MODE>
+int launch_plain(const GemmParams& p, hipStream_t st);
+
+// With p.gn_partial set the launch also leaves the GroupNorm partial sums of its output behind: from the kernel's own
+// epilogue when the instantiation that runs can (v8 256 x 320, v2 128 x 160), else from the stand-alone statistics pass.
+template <int MODE>
 int launch(const GemmParams& p, hipStream_t st) {
+  if (!p.gn_partial) return launch_plain<MODE>(p, st);
+  const bool fused = skg_gemm8_eligible(p, MODE) ? skg_gemm8_fuses_gn(p, MODE) : skg_gemm2_fuses_gn(p, MODE);
+  const int rc = launch_plain<MODE>(p, st);
+  if (rc != SKG_OK || fused) return rc;
+  skg_gn_partial_launch((const half_t*)p.C, p.ldc, p.M / p.gn_hw, p.gn_hw, p.N, p.gn_groups, p.gn_hw / 128, p.gn_partial, st);
+  SKG_CHECK_LAUNCH("skg_gemm (statistics pass)");
+  return SKG_OK;
+}
+
+template <int MODE>
+int launch_plain(const GemmParams& p, hipStream_t st) {
   if (skg_gemm8_try_launch(p, MODE, st)) {
     SKG_CHECK_LAUNCH("skg_gemm (v8)");
     return SKG_OK;
@@ -219,9 +235,33 @@ extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
   return v2 ? 2000 + v2 : 1000 + (use_wide(M, N) ? 128 : 64);
 }
 
+static int gemm_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     const void* bias, const void* residual, int ldr, float alpha, unsigned flags, float* gn_partial,
+                     int HW, int groups, void* stream);
+static int conv_impl(const void* X, int ldx, const void* Wp, void* Y, int ldy, int rows, int IH, int IW, int Cin,
+                     int Cout, int mode, const void* bias, const void* residual, int ldr, float alpha, unsigned flags,
+                     float* gn_partial, int groups, void* stream);
+
+// 1 when skg_gemm_f16_gn / skg_conv3x3_f16_gn of this shape (contiguous, 16-byte aligned output) gets its partial sums
+// from the kernel's own epilogue, 0 when the stand-alone statistics pass follows (bench.py spells kernel names from it)
+extern "C" int skg_gemm_gn_fused(int M, int N, int K, int Cin, int mode, int HW, int groups) {
+  if (HW <= 0 || groups <= 0 || M <= 0 || N <= 0) return 0;
+  static float dummy;
+  GemmParams q{};
+  q.M = M; q.N = N; q.K = K; q.Cin = Cin; q.lda = q.ldb = K; q.ldc = N; q.OH = q.OW = q.IH = q.IW = 1;
+  q.gn_partial = &dummy; q.gn_hw = HW; q.gn_groups = groups;
+  return (skg_gemm8_eligible(q, mode) ? skg_gemm8_fuses_gn(q, mode) : skg_gemm2_fuses_gn(q, mode)) ? 1 : 0;
+}
+
 extern "C" int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M,
                             int N, int K, const void* bias, const void* residual, int ldr,
                             float alpha, unsigned flags, void* stream) {
+  return gemm_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, alpha, flags, nullptr, 0, 0, stream);
+}
+
+static int gemm_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                     const void* bias, const void* residual, int ldr, float alpha, unsigned flags, float* gn_partial,
+                     int HW, int groups, void* stream) {
   SKG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
   SKG_REQUIRE(K % 32 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0);
   SKG_REQUIRE(skg_aligned(A, 16) && skg_aligned(B, 16) && skg_aligned(C, 8));
@@ -232,13 +272,44 @@ extern "C" int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void
   p.A = (const half_t*)A; p.lda = lda; p.B = (const half_t*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
   p.bias = (const half_t*)bias; p.res = (const half_t*)residual; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.flags = flags;
+  p.gn_partial = gn_partial; p.gn_hw = HW; p.gn_groups = groups;
   return launch<MODE_DIRECT>(p, (hipStream_t)stream);
+}
+
+static bool gn_args_ok(const float* partial, int M, int N, int HW, int groups, int ldc, unsigned flags) {
+  return partial && HW > 0 && HW % 128 == 0 && HW / 128 <= 128 && M % HW == 0 && groups > 0 && groups <= 64 &&
+         N % groups == 0 && N % 8 == 0 && (N / groups) % 2 == 0 && (N / groups) >= 4 && N <= 4096 && ldc % 8 == 0 &&
+         !(flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU));
+}
+
+extern "C" int skg_gemm_f16_gn(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                               const void* bias, const void* residual, int ldr, float alpha, unsigned flags,
+                               float* gn_partial, int HW, int groups, void* stream) {
+  SKG_REQUIRE(gn_args_ok(gn_partial, M, N, HW, groups, ldc, flags) && skg_aligned(C, 16));
+  return gemm_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, alpha, flags, gn_partial, HW, groups, stream);
+}
+
+extern "C" int skg_conv3x3_f16_gn(const void* X, int ldx, const void* Wp, void* Y, int ldy, int rows, int IH, int IW,
+                                  int Cin, int Cout, int mode, const void* bias, const void* residual, int ldr,
+                                  float alpha, unsigned flags, float* gn_partial, int groups, void* stream) {
+  const int up = (mode == SKG_CONV_UP2 || mode == SKG_CONV_S2T), dn = (mode == SKG_CONV_S2 || mode == SKG_CONV_S2A);
+  const int OH = up ? IH * 2 : dn ? IH / 2 : IH, OW = up ? IW * 2 : dn ? IW / 2 : IW;
+  SKG_REQUIRE(rows > 0 && OH > 0 && OW > 0);
+  SKG_REQUIRE(gn_args_ok(gn_partial, rows * OH * OW, Cout, OH * OW, groups, ldy, flags) && skg_aligned(Y, 16));
+  return conv_impl(X, ldx, Wp, Y, ldy, rows, IH, IW, Cin, Cout, mode, bias, residual, ldr, alpha, flags, gn_partial,
+                   groups, stream);
 }
 
 extern "C" int skg_conv3x3_f16(const void* X, int ldx, const void* Wp, void* Y, int ldy, int rows,
                                int IH, int IW, int Cin, int Cout, int mode, const void* bias,
                                const void* residual, int ldr, float alpha, unsigned flags,
                                void* stream) {
+  return conv_impl(X, ldx, Wp, Y, ldy, rows, IH, IW, Cin, Cout, mode, bias, residual, ldr, alpha, flags, nullptr, 0, stream);
+}
+
+static int conv_impl(const void* X, int ldx, const void* Wp, void* Y, int ldy, int rows, int IH, int IW, int Cin,
+                     int Cout, int mode, const void* bias, const void* residual, int ldr, float alpha, unsigned flags,
+                     float* gn_partial, int groups, void* stream) {
   SKG_REQUIRE(X && Wp && Y && rows > 0 && IH > 0 && IW > 0);
   SKG_REQUIRE(Cin % 32 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldx >= Cin && ldy % 4 == 0 && ldy >= Cout);
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Wp, 16) && skg_aligned(Y, 8));
@@ -249,24 +320,25 @@ extern "C" int skg_conv3x3_f16(const void* X, int ldx, const void* Wp, void* Y, 
   p.bias = (const half_t*)bias; p.res = (const half_t*)residual; p.ldr = ldr;
   p.N = Cout; p.K = 9 * Cin; p.alpha = alpha; p.flags = flags;
   p.IH = IH; p.IW = IW; p.Cin = Cin;
+  p.gn_partial = gn_partial; p.gn_groups = groups;
   hipStream_t st = (hipStream_t)stream;
   switch (mode) {
     case SKG_CONV_S1:
-      p.OH = IH; p.OW = IW; p.M = rows * p.OH * p.OW;
+      p.OH = IH; p.OW = IW; p.M = rows * p.OH * p.OW; p.gn_hw = p.OH * p.OW;
       return launch<MODE_S1>(p, st);
     case SKG_CONV_S2:
       SKG_REQUIRE(IH % 2 == 0 && IW % 2 == 0);
-      p.OH = IH / 2; p.OW = IW / 2; p.M = rows * p.OH * p.OW;
+      p.OH = IH / 2; p.OW = IW / 2; p.M = rows * p.OH * p.OW; p.gn_hw = p.OH * p.OW;
       return launch<MODE_S2>(p, st);
     case SKG_CONV_S2A:
       SKG_REQUIRE(IH % 2 == 0 && IW % 2 == 0);
-      p.OH = IH / 2; p.OW = IW / 2; p.M = rows * p.OH * p.OW;
+      p.OH = IH / 2; p.OW = IW / 2; p.M = rows * p.OH * p.OW; p.gn_hw = p.OH * p.OW;
       return launch<MODE_S2A>(p, st);
     case SKG_CONV_UP2:
-      p.OH = IH * 2; p.OW = IW * 2; p.M = rows * p.OH * p.OW;
+      p.OH = IH * 2; p.OW = IW * 2; p.M = rows * p.OH * p.OW; p.gn_hw = p.OH * p.OW;
       return launch<MODE_UP2>(p, st);
     case SKG_CONV_S2T:
-      p.OH = IH * 2; p.OW = IW * 2; p.M = rows * p.OH * p.OW;
+      p.OH = IH * 2; p.OW = IW * 2; p.M = rows * p.OH * p.OW; p.gn_hw = p.OH * p.OW;
       return launch<MODE_S2T>(p, st);
     default:
       return SKG_E_UNSUPPORTED;

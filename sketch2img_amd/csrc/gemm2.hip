@@ -127,7 +127,9 @@ __device__ unsigned long long g_phase[1 << 15][16];
 // NS = pipeline stages.  2: two workgroups per CU cover each other's DMA waits.  3: for launches with at most ONE
 // workgroup per CU (<= 256 tiles) nothing else is resident, so the lone workgroup keeps two K tiles in flight instead
 // (110 KB of LDS) and waits with a counted vmcnt.
-template <int BM, int BN, int WGM, int WGN, int MODE, int NS = 2>
+// GNS: the instantiation whose epilogue also writes the GroupNorm partial sums of the output (launched only when asked
+// for - its 25 extra epilogue registers and code cost the plain launches 0.3 % of a batch when they shared one kernel)
+template <int BM, int BN, int WGM, int WGN, int MODE, int NS = 2, bool GNS = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <= 80 * 1024) ? 2 : 1) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
                                                                   unsigned a_bytes, unsigned b_bytes,
                                                                   unsigned a_shift, int kt_per_split,
@@ -473,6 +475,57 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
   }
   const bool staged = !f32out && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                       (!p.res || ((p.ldr % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
+  // GroupNorm statistics of this tile's OUTPUT (launcher-checked: 128 x 160 tile, whole tiles, groups do not straddle the
+  // tile, staged epilogue): phase 2 of either staged path keeps, per 16-byte piece it stores, sum(y) and sum(y^2) of the
+  // four fp16 pairs (v_dot2: two values per instruction, no conversions; a pair never straddles a group because the
+  // group width is even); gn_fold() reduces them over the tile's rows in a fixed order (bitwise reproducible).
+  constexpr bool gn = GNS;
+  constexpr int GNP = (BN / 8) / (NTHR / 64);       // pieces per thread and row (5 for the 128 x 160 tile)
+  float gs[GNP][4][2];
+#pragma unroll
+  for (int k = 0; k < GNP; ++k)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gs[k][q][0] = gs[k][q][1] = 0.f;
+  auto gn_acc = [&](int k, const half8_t& y) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 one = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const h2 v = {y[2 * q], y[2 * q + 1]};
+      gs[k][q][0] = __builtin_amdgcn_fdot2(v, one, gs[k][q][0], false);
+      gs[k][q][1] = __builtin_amdgcn_fdot2(v, v, gs[k][q][1], false);
+    }
+  };
+  auto gn_fold = [&]() {
+    if constexpr (BM == 128 && NTHR == 256 && BN == 160) {
+      float* const red = reinterpret_cast<float*>(smem);                  // [256 threads][GNP * 8]: 40 KB of the dead stages
+      float* const csum = red + NTHR * GNP * 8;                           // [BN]: (column pair, quantity) totals
+      lds_barrier();                                                      // phase-2 reads of the staging slab are done
+#pragma unroll
+      for (int k = 0; k < GNP; ++k) {
+        *reinterpret_cast<float4_t*>(red + tid * (GNP * 8) + k * 8) = float4_t{gs[k][0][0], gs[k][0][1], gs[k][1][0], gs[k][1][1]};
+        *reinterpret_cast<float4_t*>(red + tid * (GNP * 8) + k * 8 + 4) = float4_t{gs[k][2][0], gs[k][2][1], gs[k][3][0], gs[k][3][1]};
+      }
+      lds_barrier();
+      if (tid < BN) {      // column pair cp = (8 tq + 32 k) / 2 + q: thread (er, tq) holds it for rows er (+ 64 / both slabs)
+        const int cp = tid >> 1, qq = tid & 1;
+        const int off = ((cp & 15) >> 2) * (GNP * 8) + (cp >> 4) * 8 + (cp & 3) * 2 + qq;
+        float t = 0.f;
+#pragma unroll 8
+        for (int er2 = 0; er2 < 64; ++er2) t += red[er2 * 4 * (GNP * 8) + off];
+        csum[tid] = t;
+      }
+      lds_barrier();
+      const int cpg = p.N / p.gn_groups, ngr = BN / cpg;
+      if (tid < 2 * ngr) {
+        const int gi = tid >> 1, qq = tid & 1;
+        float t = 0.f;
+        for (int c = 0; c < (cpg >> 1); ++c) t += csum[(gi * (cpg >> 1) + c) * 2 + qq];
+        const int nch = p.gn_hw >> 7, b = m0 / p.gn_hw, chunk = (m0 - b * p.gn_hw) >> 7;
+        p.gn_partial[(((size_t)b * nch + chunk) * p.gn_groups + n0 / cpg + gi) * 2 + qq] = t;
+      }
+    }
+  };
   if (staged && !p.res) {
     // No residual: bias, alpha and ReLU are applied in registers and the value is rounded to fp16 (its final rounding;
     // for the fused GEGLU the same rounding the unfused path and the reference apply to the FF1 output) BEFORE it
@@ -579,6 +632,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
         half8_t hv[IT2];
 #pragma unroll
         for (int k = 0; k < IT2; ++k) hv[k] = ld_half8(srow + k * TPR2 * 8);
+        if constexpr (IT2 == GNP) {
+          if (gn) {
+#pragma unroll
+            for (int k = 0; k < IT2; ++k) gn_acc(k, hv[k]);
+          }
+        }
 #pragma unroll
         for (int k = 0; k < IT2; ++k) {
           if (n0 + ec + k * TPR2 * 8 >= p.N) continue;
@@ -588,6 +647,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
         }
       }
     }
+    if (gn) gn_fold();
     SKG_PH(4);
     continue;
   }
@@ -670,6 +730,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+            if constexpr (ITER == GNP) {
+              if (gn) gn_acc(k, o);
+            }
             half8_t* dst8 = reinterpret_cast<half8_t*>(crow + k * TPR * 8);
 #ifdef SKG_PHASES
             if (p.flags & 0x4000u) { if (o[0] == (half_t)12345.f) *dst8 = o; continue; }   // probe: epilogue without stores
@@ -681,6 +744,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
         }
       }
     }
+    if (gn) gn_fold();
     SKG_PH(4);
     continue;
   }
@@ -821,6 +885,22 @@ inline int persistent_grid(int nwg, int nthr) {
 
 constexpr size_t STREAM_OUT_BYTES = (size_t)32 << 20;      // the aggregate L2 (8 x 4 MB)
 
+// GroupNorm statistics in the epilogue: the plain 128 x 160 instantiations (two or three stages, no split-K) with the
+// staged epilogue, whole tiles, 128-row chunks that stay inside one sample and groups that stay inside one tile
+inline bool gn_fusable(const GemmParams& p, int mode) {
+  if (!p.gn_partial || p.gn_groups <= 0 || p.gn_hw <= 0 || !eligible(p, mode)) return false;
+  if (p.flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) return false;
+  const TileCfg t = pick_tile(p.M, p.N, p.K);
+  if (t.bm != 128 || t.bn != 160 || getenv("SKG_GEMM4")) return false;
+  if (p.M % 128 != 0 || p.N % 160 != 0 || p.gn_hw % 128 != 0 || p.M % p.gn_hw != 0 || p.N % p.gn_groups != 0) return false;
+  const int cpg = p.N / p.gn_groups;
+  if ((cpg & 1) || 160 % cpg != 0) return false;
+  if (p.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0) return false;
+  if (p.res && (p.ldr % 8 != 0 || (reinterpret_cast<uintptr_t>(p.res) & 15) != 0)) return false;
+  const long ntiles = (long)(p.M / 128) * (p.N / 160);
+  return pick_splits(ntiles, p.K / BK, (size_t)p.M * p.N * 4) == 1;
+}
+
 template <int BM, int BN, int WGM, int WGN, int MODE>
 void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   GemmParams p = p_in;
@@ -837,6 +917,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
   int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
   constexpr int NTHR = WGM * WGN * 64;
+  if (BM == 128 && BN == 160 && splits == 1 && gn_fusable(p, MODE)) p.flags |= SKG_FLAG_GN_STATS;
   // XCDs per K slice: all 8 without split-K; 8 / ns when the slices line up with XCD boundaries
   const int ns_eff = splits > 1 ? skg_cdiv(KT, skg_cdiv(KT, splits)) : 1;
   const int G = (8 % ns_eff == 0) ? 8 / ns_eff : 0;
@@ -868,6 +949,13 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   if constexpr (BM == 128 && (BN == 160 || BN == 64) && (MODE == MODE_DIRECT || MODE == MODE_S1)) {
     static const bool off = getenv("SKG_NO_NS3") != nullptr;        // A/B switch (tools/gemm_bench.py)
     if (!off && KT >= 4 && (BN == 64 || ntiles <= 256)) {
+      if constexpr (BN == 160) {
+        if (p.flags & SKG_FLAG_GN_STATS) {
+          hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 3, true>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n,
+                             ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
+          return;
+        }
+      }
       hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 3>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles,
                          (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
       return;
@@ -881,6 +969,13 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
     return;
   }
 #endif
+  if constexpr (BM == 128 && BN == 160) {
+    if (p.flags & SKG_FLAG_GN_STATS) {
+      hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 2, true>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n,
+                         ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
+      return;
+    }
+  }
   hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles, NTHR)), dim3(NTHR), 0, st,
                      p, tiles_n, ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
 }
@@ -890,7 +985,7 @@ void launch_mode(const GemmParams& p, hipStream_t st) {
   const TileCfg t = pick_tile(p.M, p.N, p.K);
   if (t.bm == 256) launch_cfg<256, 320, 2, 4, MODE>(p, st);
   else if (t.bn == 160) {
-    if (!skg_gemm4_try_launch(p, MODE, st)) launch_cfg<128, 160, 2, 2, MODE>(p, st);
+    if (p.gn_partial || !skg_gemm4_try_launch(p, MODE, st)) launch_cfg<128, 160, 2, 2, MODE>(p, st);
   }
   else if (t.bn == 128) launch_cfg<128, 128, 2, 2, MODE>(p, st);
   else launch_cfg<128, 64, 2, 2, MODE>(p, st);
@@ -912,6 +1007,8 @@ int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode) {
                      pick_splits(ntiles, KT, (size_t)M * N * 4) == 1;
   return t.bn + (three ? 10000 : 0);
 }
+
+bool skg_gemm2_fuses_gn(const GemmParams& p, int mode) { return gn_fusable(p, mode); }
 
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
   if (!eligible(p, mode)) return false;

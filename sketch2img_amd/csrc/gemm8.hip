@@ -43,7 +43,7 @@ __device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); 
 
 // EXP: probe builds (SKG_G8_EXP; compute on stale / missing data, timing only): 1 = no DMA in the loop, 2 = no
 // fragment reads in the loop, 4 = no priority raise, 8 = no stagger between the two groups
-template <int BN, int MODE, int EXP = 0>
+template <int BN, int MODE, int EXP = 0, bool GNS = false>
 __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int tiles_n, int nwg, unsigned a_bytes,
                                                         unsigned b_bytes, unsigned a_shift) {
   constexpr int NS = BN == 160 ? 3 : 2;            // LDS stages
@@ -257,6 +257,15 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
     }
   }
   const int mrow = m0 + wm * WM + l16;
+  // GroupNorm statistics of the output (256 x 320 tile only; launcher-checked: whole tiles, WM = 128-row chunks inside
+  // one sample, groups inside one wave's 80 columns): sum(y), sum(y^2) of the fp16 pairs a lane stores (v_dot2), summed
+  // over the wave's 8 row blocks in registers, over the 16 row lanes by xor shuffles, folded into groups through a
+  // 640-byte per-wave LDS scratch - fixed order, no atomics.
+  constexpr bool gn = GNS && BN == 320;      // own instantiation: the plain launches keep the lean epilogue
+  __shared__ float gn_scr[gn ? NW * 80 : 1];
+  float gs[NT][2][2];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) gs[j][0][0] = gs[j][0][1] = gs[j][1][0] = gs[j][1][1] = 0.f;
 #pragma unroll
   for (int i0 = 0; i0 < MT; i0 += 4) {
     if (p.res) {
@@ -297,6 +306,39 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
         const float4_t v = acc[i0 + ii][j];
         const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
         st_half4(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n0 + wn * WN + j * 16 + g * 4, o);
+        if (gn) {
+          typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+          const h2 one = {(_Float16)1.f, (_Float16)1.f}, lo = {o[0], o[1]}, hi = {o[2], o[3]};
+          gs[j][0][0] = __builtin_amdgcn_fdot2(lo, one, gs[j][0][0], false);
+          gs[j][0][1] = __builtin_amdgcn_fdot2(lo, lo, gs[j][0][1], false);
+          gs[j][1][0] = __builtin_amdgcn_fdot2(hi, one, gs[j][1][0], false);
+          gs[j][1][1] = __builtin_amdgcn_fdot2(hi, hi, gs[j][1][1], false);
+        }
+      }
+    }
+  }
+  if constexpr (BN == 320) {
+    if (gn) {
+      float* const scr = gn_scr + wave * 80;       // [40 column pairs of the wave's 80 columns][sum, sum of squares]
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            float t = gs[j][h][q];
+            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+            if (l16 == 0) scr[(j * 8 + g * 2 + h) * 2 + q] = t;
+          }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave wrote it: in order, visible after the wait
+      const int cpg = p.N / p.gn_groups, ngr = WN / cpg;
+      if (lane < 2 * ngr) {
+        const int gi = lane >> 1, q = lane & 1;
+        float t = 0.f;
+        for (int c = 0; c < (cpg >> 1); ++c) t += scr[(gi * (cpg >> 1) + c) * 2 + q];
+        const int row0 = m0 + wm * WM;
+        const int nch = p.gn_hw >> 7, b = row0 / p.gn_hw, chunk = (row0 - b * p.gn_hw) >> 7;
+        p.gn_partial[(((size_t)b * nch + chunk) * p.gn_groups + (n0 + wn * WN) / cpg + gi) * 2 + q] = t;
       }
     }
   }
@@ -348,8 +390,19 @@ int gemm8_tile(const GemmParams& p, int mode) {
   return 0;
 }
 
+// the 256 x 320 instantiation writes the GroupNorm partials itself when every tile is whole, the 128-row halves stay
+// inside one sample and no group straddles a wave's 80 columns
+inline bool gn_fusable8(const GemmParams& p, int mode) {
+  if (!p.gn_partial || p.gn_groups <= 0 || p.gn_hw <= 0 || mode != MODE_S1 || gemm8_tile(p, mode) != 320) return false;
+  if (p.M % 256 != 0 || p.gn_hw % 128 != 0 || p.M % p.gn_hw != 0 || p.N % p.gn_groups != 0) return false;
+  const int cpg = p.N / p.gn_groups;
+  return !(cpg & 1) && 80 % cpg == 0;
+}
+
 template <int BN>
-void launch8(const GemmParams& p, int mode, hipStream_t st) {
+void launch8(const GemmParams& p_in, int mode, hipStream_t st) {
+  GemmParams p = p_in;
+  if (BN == 320 && gn_fusable8(p, mode)) p.flags |= SKG_FLAG_GN_STATS;
   unsigned long long a, b, s;
   operand_bytes(p, mode, a, b, s);
   const int tiles_n = p.N / BN;
@@ -366,7 +419,16 @@ void launch8(const GemmParams& p, int mode, hipStream_t st) {
       case 3: G8_LAUNCH(MODE_S1, 3); break;
       case 4: G8_LAUNCH(MODE_S1, 4); break;
       case 8: G8_LAUNCH(MODE_S1, 8); break;
-      default: G8_LAUNCH(MODE_S1, 0); break;
+      default:
+        if constexpr (BN == 320) {
+          if (p.flags & SKG_FLAG_GN_STATS) {
+            hipLaunchKernelGGL((gemm8_kernel<BN, MODE_S1, 0, true>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles,
+                               (unsigned)a, (unsigned)b, (unsigned)s);
+            break;
+          }
+        }
+        G8_LAUNCH(MODE_S1, 0);
+        break;
     }
   }
 #undef G8_LAUNCH
@@ -375,6 +437,7 @@ void launch8(const GemmParams& p, int mode, hipStream_t st) {
 }  // namespace
 
 bool skg_gemm8_eligible(const GemmParams& p, int mode) { return gemm8_tile(p, mode) != 0; }
+bool skg_gemm8_fuses_gn(const GemmParams& p, int mode) { return gn_fusable8(p, mode); }
 int skg_gemm8_tile_n(const GemmParams& p, int mode) { return gemm8_tile(p, mode); }
 
 bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st) {

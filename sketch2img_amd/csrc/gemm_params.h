@@ -13,7 +13,11 @@ struct GemmParams {
   int M, N, K;
   float alpha; unsigned flags;
   int IH, IW, OH, OW, Cin;   // conv only
+  // GroupNorm statistics of the OUTPUT from the producer's epilogue (skg_*_gn entry points): per (sample, 128-row chunk,
+  // group) sum(y) and sum(y^2) of the fp16-rounded outputs, gn_partial[((b * (gn_hw / 128) + chunk) * gn_groups + g) * 2]
+  float* gn_partial; int gn_hw, gn_groups;
 };
+constexpr unsigned SKG_FLAG_GN_STATS = 0x8000u;      // internal: set by the launcher when the chosen kernel fuses them
 
 // v2 (gemm2.hip): returns true and launches if the shape is eligible, false otherwise (nothing launched).
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st);
@@ -26,3 +30,9 @@ bool skg_gemm4_try_launch(const GemmParams& p, int mode, hipStream_t st);
 bool skg_gemm8_eligible(const GemmParams& p, int mode);
 int skg_gemm8_tile_n(const GemmParams& p, int mode);      // 160 / 320, or 0 when v8 does not take the launch
 bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st);
+// true when the kernel that skg_gemm8 / skg_gemm2 would run for this launch writes p.gn_partial itself
+bool skg_gemm8_fuses_gn(const GemmParams& p, int mode);
+bool skg_gemm2_fuses_gn(const GemmParams& p, int mode);
+// norms.hip: the stand-alone statistics pass in the same partial format (nch chunks per sample)
+void skg_gn_partial_launch(const half_t* X, int ldx, int rows, int HW, int C, int groups, int nch, float* partial,
+                           hipStream_t st);

@@ -3,6 +3,7 @@
 // statistics, wave-shuffle + LDS reductions, deterministic two-stage partial sums (no atomics
 // on global memory, so results do not depend on workgroup scheduling).
 #include "common.h"
+#include "gemm_params.h"
 
 namespace {
 
@@ -608,6 +609,32 @@ extern "C" int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int r
                      (const half_t*)gamma, (const half_t*)beta, silu, (const float*)partial, nch,
                      1.f / ((float)HW * (C / groups)), eps, stats);
   SKG_CHECK_LAUNCH("skg_groupnorm_fwd");
+  return SKG_OK;
+}
+
+// the statistics pass alone, nch chunks per sample (the fallback behind skg_gemm_f16_gn / skg_conv3x3_f16_gn when the
+// producer's tile cannot write the partial sums itself)
+void skg_gn_partial_launch(const half_t* X, int ldx, int rows, int HW, int C, int groups, int nch, float* partial,
+                           hipStream_t st) {
+  hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(nch, rows), dim3(256), 0, st, X, ldx, (const half_t*)nullptr, 0, HW,
+                     C, groups, (const float*)nullptr, (const half_t*)nullptr, (const half_t*)nullptr, 0, partial);
+}
+
+// GroupNorm forward from partial sums somebody else produced (a producer epilogue: skg_gemm_f16_gn, skg_conv3x3_f16_gn):
+// one launch - the apply kernel folds the nch chunk partials per (row, group) itself and publishes (mean, rstd).
+extern "C" int skg_groupnorm_from_partial(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
+                                          float eps, const void* gamma, const void* beta, int silu, float* stats,
+                                          const float* partial, int nch, void* stream) {
+  SKG_REQUIRE(X && Y && stats && partial && gamma && beta && rows > 0 && HW > 0 && groups > 0 && groups <= 64);
+  SKG_REQUIRE(nch > 0 && nch <= GN_MAX_CHUNKS);
+  SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && (C / groups) % 2 == 0 && (C / groups) >= 4 && C <= GN_MAX_C);
+  SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
+  hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, groups, (const float*)nullptr,
+                     (const half_t*)gamma, (const half_t*)beta, silu, partial, nch,
+                     1.f / ((float)HW * (C / groups)), eps, stats);
+  SKG_CHECK_LAUNCH("skg_groupnorm_from_partial");
   return SKG_OK;
 }
 

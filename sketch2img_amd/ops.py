@@ -58,11 +58,28 @@ def _f16(*ts):
         assert t is None or (t.is_cuda and t.dtype == torch.float16), "fp16 CUDA tensor expected"
 
 
+class GNPartial:
+    """Per (sample, 128-row chunk, group) sum / sum of squares of a producer's output - what `groupnorm(partial=)` folds
+    instead of reading the tensor a second time (skg_gemm_f16_gn / skg_conv3x3_f16_gn)."""
+    __slots__ = ("buf", "nch", "rows", "groups")
+
+    def __init__(self, rows: int, HW: int, groups: int, dev):
+        self.rows, self.nch, self.groups = rows, HW // 128, groups
+        self.buf = torch.empty(rows * self.nch * groups * 2, device=dev, dtype=torch.float32)
+
+
+def gn_fusable(M: int, N: int, HW: int, groups: int) -> bool:
+    """Shapes the `gn_stats=` form of gemm / conv3x3 accepts (whole 128-row chunks per sample, even group width)."""
+    return (HW % 128 == 0 and HW // 128 <= 128 and M % HW == 0 and N % groups == 0 and N % 8 == 0 and
+            (N // groups) % 2 == 0 and N // groups >= 4 and N <= 4096)
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-         alpha: float = 1.0, relu: bool = False, out_f32: bool = False, geglu: bool = False) -> torch.Tensor:
+         alpha: float = 1.0, relu: bool = False, out_f32: bool = False, geglu: bool = False, gn_stats=None):
     """out[m][n] = epi(alpha*(A[m,:] . B[n,:] + bias[n]) + residual[m][n]);  A [M,K], B [N,K].
-    geglu=True: B / bias are the interleaved FF1 pack and out is [M, N/2] = a * gelu(g)."""
+    geglu=True: B / bias are the interleaved FF1 pack and out is [M, N/2] = a * gelu(g).
+    gn_stats=(HW, groups): also returns the GroupNorm partial sums of the output -> (out, GNPartial)."""
     _f16(A, B, bias, residual)
     M, K = A.shape
     N = B.shape[0]
@@ -71,6 +88,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *
         out = torch.empty(M, N // 2 if geglu else N, device=A.device,
                           dtype=torch.float32 if out_f32 else torch.float16)
     flags = (EPI_RELU if relu else 0) | (EPI_OUT_F32 if out_f32 else 0) | (EPI_GEGLU if geglu else 0)
+    if gn_stats is not None:
+        HW, groups = gn_stats
+        part = GNPartial(M // HW, HW, groups, A.device)
+        check(lib.skg_gemm_f16_gn(_p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out), M, N, K, _p(bias),
+                                  _p(residual), _ld(residual) if residual is not None else 0, alpha, flags,
+                                  _p(part.buf), HW, groups, _stream()), "skg_gemm_f16_gn")
+        return out, part
     check(lib.skg_gemm_f16(_p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out), M, N, K, _p(bias),
                            _p(residual), _ld(residual) if residual is not None else 0, alpha, flags,
                            _stream()), "skg_gemm_f16")
@@ -79,8 +103,9 @@ def gemm(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *
 
 def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode: int = CONV_S1,
             out: Optional[torch.Tensor] = None, *, bias=None, residual=None, alpha: float = 1.0,
-            relu: bool = False) -> torch.Tensor:
-    """X [rows*IH*IW, Cin] (view), Wp [Cout, 9*Cin] tap-major.  Returns [rows*OH*OW, Cout]."""
+            relu: bool = False, gn_groups: Optional[int] = None):
+    """X [rows*IH*IW, Cin] (view), Wp [Cout, 9*Cin] tap-major.  Returns [rows*OH*OW, Cout];
+    gn_groups=G: (out, GNPartial) - the GroupNorm partial sums of the output come with it."""
     _f16(X, Wp, bias, residual)
     Cin = X.shape[1]
     Cout = Wp.shape[0]
@@ -93,6 +118,13 @@ def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode
         OH, OW = IH * 2, IW * 2
     if out is None:
         out = torch.empty(rows * OH * OW, Cout, device=X.device, dtype=torch.float16)
+    if gn_groups is not None:
+        part = GNPartial(rows, OH * OW, gn_groups, X.device)
+        check(lib.skg_conv3x3_f16_gn(_p(X), _ld(X), _p(Wp), _p(out), _ld(out), rows, IH, IW, Cin, Cout, mode,
+                                     _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
+                                     alpha, EPI_RELU if relu else 0, _p(part.buf), gn_groups, _stream()),
+              "skg_conv3x3_f16_gn")
+        return out, part
     check(lib.skg_conv3x3_f16(_p(X), _ld(X), _p(Wp), _p(out), _ld(out), rows, IH, IW, Cin, Cout, mode,
                               _p(bias), _p(residual), _ld(residual) if residual is not None else 0,
                               alpha, EPI_RELU if relu else 0, _stream()), "skg_conv3x3_f16")
@@ -130,10 +162,23 @@ def groupnorm_apply(X, rows, HW, groups, stats, gamma, beta, silu: bool, out=Non
     return out
 
 
-def groupnorm(X, rows, HW, groups, eps, gamma, beta, silu: bool, out=None):
-    """Forward GroupNorm.  Up to 32x32 maps: two launches (chunk partial sums; apply, which folds the partials itself
+def groupnorm(X, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, partial: Optional[GNPartial] = None):
+    """Forward GroupNorm.  partial=: the producer of X already left the chunk sums behind (gemm / conv3x3 with
+    gn_stats= / gn_groups=): ONE launch that folds them and applies, X is read once.
+    Otherwise:  Up to 32x32 maps: two launches (chunk partial sums; apply, which folds the partials itself
     and publishes the statistics) - at 64x64 the 86 chunk partials per group make the in-kernel fold dearer than the
     4.7 us finalize launch it replaces, so the three-launch path stays (measured: tools/ew_bench.py)."""
+    if partial is not None:
+        assert partial.rows == rows and partial.groups == groups and partial.nch == HW // 128
+        _f16(X, gamma, beta)
+        C = X.shape[1]
+        if out is None:
+            out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
+        st = torch.empty(rows, groups, 2, device=X.device, dtype=torch.float32)
+        check(lib.skg_groupnorm_from_partial(_p(X), _ld(X), _p(out), _ld(out), rows, HW, C, groups, eps, _p(gamma),
+                                             _p(beta), int(silu), _p(st), _p(partial.buf), partial.nch, _stream()),
+              "skg_groupnorm_from_partial")
+        return out, st
     if HW >= 4096:
         st = groupnorm_stats(X, rows, HW, groups, eps)
         return groupnorm_apply(X, rows, HW, groups, st, gamma, beta, silu, out), st

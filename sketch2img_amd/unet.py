@@ -20,6 +20,7 @@ Work hoisted out of the per-step loop because it does not depend on the latent:
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -27,6 +28,8 @@ import torch
 
 from . import ops
 from .config import UNetConfig, up_block_plan
+
+_GN_FROM_PRODUCER = os.environ.get("SKG_GN_PRODUCER", "1") != "0"      # A/B switch (bench.py on one box)
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -189,22 +192,40 @@ class HipUNet:
         self.ctx = ctx
 
     # ------------------------------------------------------------------ modules, forward
-    def _res_fwd(self, p, x, rows, H, tb, stash: Optional[Stash], out=None):
+    def _gn_from_producer(self, rows: int, HW: int, C: int) -> bool:
+        """GroupNorm inputs of the 64 x 64 / 32 x 32 levels get their statistics from the epilogue of the kernel that
+        writes them (ops.gemm / ops.conv3x3 with gn_stats= / gn_groups=): the separate statistics pass - a second read of
+        a 10-40 MB tensor - disappears.  Smaller maps keep the one-launch GroupNorm that holds a slice in registers."""
+        return _GN_FROM_PRODUCER and HW >= 1024 and ops.gn_fusable(rows * HW, C, HW, self.cfg.norm_groups)
+
+    def _res_fwd(self, p, x, rows, H, tb, stash: Optional[Stash], out=None, xpart=None, want_part=False):
+        """xpart: GroupNorm partial sums of x from its producer (or None).  Returns (out, partial sums of out or None):
+        they are produced when want_part is set and the level takes its statistics from the producers."""
         cfg, W = self.cfg, self.W
         G, HW = cfg.norm_groups, H * H
-        n1, st1 = ops.groupnorm(x, rows, HW, G, 1e-5, W[p + ".norm1.weight"], W[p + ".norm1.bias"], True)
-        h1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, bias=tb[p])
-        n2, st2 = ops.groupnorm(h1, rows, HW, G, 1e-5, W[p + ".norm2.weight"], W[p + ".norm2.bias"], True)
+        n1, st1 = ops.groupnorm(x, rows, HW, G, 1e-5, W[p + ".norm1.weight"], W[p + ".norm1.bias"], True, partial=xpart)
+        Cout = W[p + ".conv1.weight"].shape[0]
+        fuse = self._gn_from_producer(rows, HW, Cout)
+        if fuse:
+            h1, part1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, bias=tb[p], gn_groups=G)
+        else:
+            h1, part1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, bias=tb[p]), None
+        n2, st2 = ops.groupnorm(h1, rows, HW, G, 1e-5, W[p + ".norm2.weight"], W[p + ".norm2.bias"], True, partial=part1)
         if (p + ".conv_shortcut.weight") in W:
             sc = ops.gemm(x, W[p + ".conv_shortcut.weight"], bias=W[p + ".conv_shortcut.bias"])
         else:
             sc = x
-        out = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out, bias=W[p + ".conv2.bias"], residual=sc)
+        opart = None
+        if want_part and fuse:
+            out, opart = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out, bias=W[p + ".conv2.bias"],
+                                     residual=sc, gn_groups=G)
+        else:
+            out = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out, bias=W[p + ".conv2.bias"], residual=sc)
         if stash is not None:
             stash.res[p] = dict(x=x, st1=st1, h1=h1, st2=st2, H=H)
-        return out
+        return out, opart
 
-    def _tr_fwd(self, p, x, rows, H, heads, stash: Optional[Stash], out=None):
+    def _tr_fwd(self, p, x, rows, H, heads, stash: Optional[Stash], out=None, xpart=None, want_part=False):
         cfg, W = self.cfg, self.W
         HW = H * H
         C = x.shape[1]
@@ -212,7 +233,8 @@ class HipUNet:
         scale = dh ** -0.5
         t = p + ".transformer_blocks.0"
         keep = stash is not None
-        g, gst = ops.groupnorm(x, rows, HW, cfg.norm_groups, 1e-6, W[p + ".norm.weight"], W[p + ".norm.bias"], False)
+        g, gst = ops.groupnorm(x, rows, HW, cfg.norm_groups, 1e-6, W[p + ".norm.weight"], W[p + ".norm.bias"], False,
+                               partial=xpart)
         pin = ops.gemm(g, W[p + ".proj_in.weight"], bias=W[p + ".proj_in.bias"])
         a1, st1 = ops.layernorm(pin, W[t + ".norm1.weight"], W[t + ".norm1.bias"], want_stats=True)
         qkv = ops.gemm(a1, W[t + ".attn1.qkv"])
@@ -245,11 +267,16 @@ class HipUNet:
             gg = ops.geglu(f, interleaved=True)
             f = f[(rows // 2) * HW:]
         p3 = ops.gemm(gg, W[t + ".ff.net.2.weight"], bias=W[t + ".ff.net.2.bias"], residual=p2)
-        out = ops.gemm(p3, W[p + ".proj_out.weight"], out, bias=W[p + ".proj_out.bias"], residual=x)
+        opart = None
+        if want_part and self._gn_from_producer(rows, HW, C):
+            out, opart = ops.gemm(p3, W[p + ".proj_out.weight"], out, bias=W[p + ".proj_out.bias"], residual=x,
+                                  gn_stats=(HW, cfg.norm_groups))
+        else:
+            out = ops.gemm(p3, W[p + ".proj_out.weight"], out, bias=W[p + ".proj_out.bias"], residual=x)
         if keep:
             stash.tr[p] = dict(x=x, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1, st2=st2, q2=q2,
                                o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads)
-        return out
+        return out, opart
 
     # ------------------------------------------------------------------ forward
     def forward(self, x32: torch.Tensor, t: int, rows: int, H: int, stash: Optional[Stash] = None,
@@ -280,23 +307,37 @@ class HipUNet:
             return cats[u][:, ch_h[u]:]
 
         skips: List[torch.Tensor] = []
-        h = ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, out=skip_slot(boc[0], H), bias=W["conv_in.bias"])
+        G = cfg.norm_groups
+        # hp: GroupNorm partial sums of h left behind by the kernel that produced it, whenever the next consumer of h is a
+        # GroupNorm of the 64 x 64 / 32 x 32 levels (None otherwise: concatenated inputs, small maps)
+        if self._gn_from_producer(rows, H * H, boc[0]):
+            h, hp = ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, out=skip_slot(boc[0], H), bias=W["conv_in.bias"],
+                                gn_groups=G)
+        else:
+            h, hp = ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, out=skip_slot(boc[0], H), bias=W["conv_in.bias"]), None
         skips.append(h)
         taps_down = []
         cur = H
         for i in range(nb):
             for j in range(cfg.layers_per_block):
                 if i < nb - 1:
-                    h = self._res_fwd(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, stash)
-                    h = self._tr_fwd(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i], stash,
-                                     out=skip_slot(boc[i], cur))
+                    h, hp = self._res_fwd(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, stash, xpart=hp, want_part=True)
+                    # the block's last transformer feeds the downsampling conv, the others the next resnet's norm1
+                    h, hp = self._tr_fwd(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i], stash,
+                                         out=skip_slot(boc[i], cur), xpart=hp, want_part=j < cfg.layers_per_block - 1)
                 else:
-                    h = self._res_fwd(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, stash, out=skip_slot(boc[i], cur))
+                    h, hp = self._res_fwd(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, stash,
+                                          out=skip_slot(boc[i], cur), xpart=hp, want_part=True)
                 skips.append(h)
             if i < nb - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
-                h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_S2, out=skip_slot(boc[i], cur // 2),
-                                bias=W[p + ".bias"])
+                half = cur // 2
+                if self._gn_from_producer(rows, half * half, boc[i]):
+                    h, hp = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_S2, out=skip_slot(boc[i], half),
+                                        bias=W[p + ".bias"], gn_groups=G)
+                else:
+                    h, hp = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_S2, out=skip_slot(boc[i], half),
+                                        bias=W[p + ".bias"]), None
                 cur //= 2
                 skips.append(h)
             if i < 3:
@@ -311,12 +352,13 @@ class HipUNet:
                 out.append(tuple((skips[k + j], sizes[j]) for j in range(n)))
                 k += n
             return out
-        h = self._res_fwd("mid_block.resnets.0", h, rows, cur, tb, stash)
+        h, hp = self._res_fwd("mid_block.resnets.0", h, rows, cur, tb, stash, xpart=hp, want_part=True)
         tap_r0 = (h, cur)
-        h = self._tr_fwd("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash)
+        h, hp = self._tr_fwd("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash, xpart=hp, want_part=True)
         tap_at = (h, cur)
-        h = self._res_fwd("mid_block.resnets.1", h, rows, cur, tb, stash, out=cats[0][:, :ch_h[0]])
+        h, _ = self._res_fwd("mid_block.resnets.1", h, rows, cur, tb, stash, out=cats[0][:, :ch_h[0]], xpart=hp)
         tap_r1 = (h, cur)
+        hp = None
         taps_up = []
         rev_heads = tuple(reversed(cfg.num_heads))
         last_needed = 2 if not want_eps else nb - 1
@@ -330,10 +372,14 @@ class HipUNet:
                 # where this layer's output goes: the next concat buffer of the same block, else a fresh tensor
                 nxt = cats[u + 1][:, :ch_h[u + 1]] if j < lpb1 - 1 else None
                 if i > 0:
-                    h = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash)
-                    h = self._tr_fwd(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], stash, out=nxt)
+                    # (the resnet reads a concatenation: its norm1 keeps the stand-alone statistics pass)
+                    h, hp = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash, want_part=True)
+                    # only the very last transformer output goes to a GroupNorm (conv_norm_out); the others are concatenated
+                    last = want_eps and i == nb - 1 and j == lpb1 - 1
+                    h, hp = self._tr_fwd(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], stash, out=nxt,
+                                         xpart=hp, want_part=last)
                 else:
-                    h = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash, out=nxt)
+                    h, _ = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash, out=nxt)
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 u = (i + 1) * lpb1
@@ -345,7 +391,7 @@ class HipUNet:
         eps = None
         if want_eps:
             n, _ = ops.groupnorm(h, rows, cur * cur, cfg.norm_groups, 1e-5, W["conv_norm_out.weight"],
-                                 W["conv_norm_out.bias"], True)
+                                 W["conv_norm_out.bias"], True, partial=hp)
             eps = ops.conv3x3(n, W["conv_out.weight"], rows, cur, cur, bias=W["conv_out.bias"])
         taps = taps_down + [tap_at, tap_r0, tap_r1] + taps_up
         if stash is not None:

@@ -253,6 +253,55 @@ def test_groupnorm_fwd_bwd(ops, B, C, H, G, silu):
     assert report(f"gn bwd C{C}", from_nhwc(dx.float().cpu(), B, H, H), xr.grad + res.float())[0] < 2 * FP16_RND
 
 
+# (kind, rows, H, Cin, Cout, residual): which kernel's epilogue writes the partial sums is the launcher's choice - the
+# cases walk through the v8 256 x 320 tile (64 x 64 level, K >= 1024), the v2 128 x 160 tile with two and with three
+# stages, with and without residual (fp16 / fp32 staging slabs), group widths 10 / 20 / 40, and the fall-back pass
+# (128 x 64 tile / split-K at the 16 x 16 level)
+@pytest.mark.parametrize("kind,rows,H,Cin,Cout,res", [
+    ("conv", 16, 64, 320, 320, False), ("conv", 16, 64, 320, 320, True), ("conv", 8, 64, 320, 320, False),
+    ("conv", 4, 64, 320, 320, True), ("conv", 16, 32, 640, 640, False), ("conv", 16, 32, 640, 640, True),
+    ("conv", 2, 32, 320, 640, True), ("conv", 16, 16, 1280, 1280, True), ("conv", 16, 32, 320, 1280, False),
+    ("gemm", 16, 64, 320, 320, True), ("gemm", 16, 32, 640, 640, True), ("gemm", 8, 64, 320, 320, False),
+    ("gemm", 2, 32, 640, 640, True), ("up2", 4, 16, 640, 640, False), ("down", 8, 64, 320, 320, False)])
+def test_groupnorm_statistics_from_the_producer_epilogue(ops, kind, rows, H, Cin, Cout, res):
+    d = dev()
+    G = 32
+    mode = {"conv": ops.CONV_S1, "up2": ops.CONV_UP2, "down": ops.CONV_S2}.get(kind)
+    OH = H * 2 if kind == "up2" else H // 2 if kind == "down" else H
+    M, HW = rows * OH * OH, OH * OH
+    x = (rnd(rows * H * H, Cin, seed=1).float() * 0.5).half().to(d)
+    r = rnd(M, Cout, seed=4).to(d) if res else None
+    b = rnd(Cout, seed=3).to(d)
+    if kind == "gemm":
+        w = (rnd(Cout, Cin, seed=2).float() * Cin ** -0.5).half().to(d)
+        y0 = ops.gemm(x, w, bias=b, residual=r)
+        y, part = ops.gemm(x, w, bias=b, residual=r, gn_stats=(HW, G))
+    else:
+        w = (rnd(Cout, 9 * Cin, seed=2).float() * (9 * Cin) ** -0.5).half().to(d)
+        y0 = ops.conv3x3(x, w, rows, H, H, mode, bias=b, residual=r)
+        y, part = ops.conv3x3(x, w, rows, H, H, mode, bias=b, residual=r, gn_groups=G)
+    assert torch.equal(y, y0)                                   # the output itself does not change
+    cpg = Cout // G
+    yf = y.float().view(rows, HW // 128, 128, G, cpg)
+    ref = torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1)       # [rows, nch, G, 2]
+    got = part.buf.view(rows, HW // 128, G, 2)
+    scale = ref.abs().amax(dim=(1, 2), keepdim=True) + 1e-6
+    err = ((got - ref).abs() / scale).max().item()
+    print(f"gn partial {kind} rows{rows} H{H} {Cin}->{Cout} res={res}: max err / max |sum| {err:.2e}")
+    assert err < 2e-5
+    ga, be = (1 + 0.2 * rnd(Cout, seed=5).float()).half().to(d), (0.2 * rnd(Cout, seed=6).float()).half().to(d)
+    n1, st1 = ops.groupnorm(y, rows, HW, G, 1e-5, ga, be, True, partial=part)
+    n0, st0 = ops.groupnorm(y, rows, HW, G, 1e-5, ga, be, True)
+    assert (st1 - st0).abs().max().item() < 1e-4 * (1 + st0.abs().max().item())
+    assert (n1.float() - n0.float()).abs().max().item() <= 2e-3 * (1 + n0.float().abs().max().item())
+    # fixed summation order: a second launch reproduces the partial sums bit for bit
+    if kind == "gemm":
+        _, part2 = ops.gemm(x, w, bias=b, residual=r, gn_stats=(HW, G))
+    else:
+        _, part2 = ops.conv3x3(x, w, rows, H, H, mode, bias=b, residual=r, gn_groups=G)
+    assert torch.equal(part.buf, part2.buf)
+
+
 @pytest.mark.parametrize("M,C", [(77, 320), (1024, 1280), (5, 32), (4096, 640)])
 def test_layernorm_fwd_bwd(ops, M, C):
     x = rnd(M, C, seed=1) * 2 + 0.5
