@@ -91,3 +91,11 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
+
+// x + (x of the lane DPP control CTRL points at), inside a 16-lane row: one VALU instruction, no LDS (quad_perm
+// 0xB1 = lane ^ 1, 0x4E = lane ^ 2; row_ror:4 = 0x124, row_ror:8 = 0x128 - rotations: fine for an all-reduce)
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+  const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false);
+  return x + __builtin_bit_cast(float, y);
+}

@@ -498,21 +498,32 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
   };
   auto gn_fold = [&]() {
     if constexpr (BM == 128 && NTHR == 256 && BN == 160) {
-      float* const red = reinterpret_cast<float*>(smem);                  // [256 threads][GNP * 8]: 40 KB of the dead stages
-      float* const csum = red + NTHR * GNP * 8;                           // [BN]: (column pair, quantity) totals
-      lds_barrier();                                                      // phase-2 reads of the staging slab are done
+      // thread (er = tid / 4, tq = tid % 4): the four row lanes of a 16-lane DPP row that share tq are summed in registers
+      // (rotations by 4 and 8), so 64 threads write and the LDS fold walks 16 slots instead of 64
+      float* const red = reinterpret_cast<float*>(smem);                  // [16 slots][4 tq][GNP * 8]: 10 KB of the dead stages
+      float* const csum = red + 64 * GNP * 8;                             // [BN]: (column pair, quantity) totals
 #pragma unroll
-      for (int k = 0; k < GNP; ++k) {
-        *reinterpret_cast<float4_t*>(red + tid * (GNP * 8) + k * 8) = float4_t{gs[k][0][0], gs[k][0][1], gs[k][1][0], gs[k][1][1]};
-        *reinterpret_cast<float4_t*>(red + tid * (GNP * 8) + k * 8 + 4) = float4_t{gs[k][2][0], gs[k][2][1], gs[k][3][0], gs[k][3][1]};
+      for (int k = 0; k < GNP; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int z = 0; z < 2; ++z) gs[k][q][z] = dpp_add<0x124>(dpp_add<0x128>(gs[k][q][z]));
+      lds_barrier();                                                      // phase-2 reads of the staging slab are done
+      if ((tid & 15) < 4) {
+        float* const dst = red + ((tid >> 4) * 4 + (tid & 3)) * (GNP * 8);
+#pragma unroll
+        for (int k = 0; k < GNP; ++k) {
+          *reinterpret_cast<float4_t*>(dst + k * 8) = float4_t{gs[k][0][0], gs[k][0][1], gs[k][1][0], gs[k][1][1]};
+          *reinterpret_cast<float4_t*>(dst + k * 8 + 4) = float4_t{gs[k][2][0], gs[k][2][1], gs[k][3][0], gs[k][3][1]};
+        }
       }
       lds_barrier();
-      if (tid < BN) {      // column pair cp = (8 tq + 32 k) / 2 + q: thread (er, tq) holds it for rows er (+ 64 / both slabs)
+      if (tid < BN) {      // column pair cp = (8 tq + 32 k) / 2 + q
         const int cp = tid >> 1, qq = tid & 1;
         const int off = ((cp & 15) >> 2) * (GNP * 8) + (cp >> 4) * 8 + (cp & 3) * 2 + qq;
         float t = 0.f;
-#pragma unroll 8
-        for (int er2 = 0; er2 < 64; ++er2) t += red[er2 * 4 * (GNP * 8) + off];
+#pragma unroll
+        for (int sl2 = 0; sl2 < 16; ++sl2) t += red[sl2 * 4 * (GNP * 8) + off];
         csum[tid] = t;
       }
       lds_barrier();

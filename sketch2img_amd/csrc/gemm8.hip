@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
   const int mrow = m0 + wm * WM + l16;
   // GroupNorm statistics of the output (256 x 320 tile only; launcher-checked: whole tiles, WM = 128-row chunks inside
   // one sample, groups inside one wave's 80 columns): sum(y), sum(y^2) of the fp16 pairs a lane stores (v_dot2), summed
-  // over the wave's 8 row blocks in registers, over the 16 row lanes by xor shuffles, folded into groups through a
+  // over the wave's 8 row blocks in registers, over the 16 row lanes by DPP adds, folded into groups through a
   // 640-byte per-wave LDS scratch - fixed order, no atomics.
   constexpr bool gn = GNS && BN == 320;      // own instantiation: the plain launches keep the lean epilogue
   __shared__ float gn_scr[gn ? NW * 80 : 1];
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             float t = gs[j][h][q];
-            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+            t = dpp_add<0x128>(t); t = dpp_add<0x124>(t); t = dpp_add<0x4E>(t); t = dpp_add<0xB1>(t);     // over the 16 row lanes
             if (l16 == 0) scr[(j * 8 + g * 2 + h) * 2 + q] = t;
           }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // same wave wrote it: in order, visible after the wait
