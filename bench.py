@@ -96,7 +96,7 @@ class LaunchTimer:
 
     def __init__(self, ops):
         self.ops, self.rec = ops, []
-        self._gemm, self._conv, self._attn = ops.gemm, ops.conv3x3, ops.attn_fwd
+        self._gemm, self._conv, self._attn, self._keep = ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep
 
     def __enter__(self):
         from sketch2img_amd._lib import lib
@@ -162,11 +162,22 @@ class LaunchTimer:
                              f"attn B{batch} H{heads} Nq{Nq} Nkv{Nkv} d{dh}"))
             return out
 
-        ops.gemm, ops.conv3x3, ops.attn_fwd = gemm, conv, attn
+        def gemm_keep(A, B, *a, **k):        # FF1 with the fused gate that also stores the pre-activation
+            M, K = A.shape
+            N = B.shape[0]
+            e0, e1 = ev()
+            e0.record()
+            out = self._keep(A, B, *a, **k)
+            e1.record()
+            self.rec.append((kname(lib.skg_gemm_variant(M, N, K, 0, 0), "DIRECT"), 2.0 * M * N * K, e0, e1,
+                             2.0 * (M * K + N * K + M * N + M * N // 2), f"gemm M{M} N{N} K{K}+geglu+keep"))
+            return out
+
+        ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep = gemm, conv, attn, gemm_keep
         return self
 
     def __exit__(self, *exc):
-        self.ops.gemm, self.ops.conv3x3, self.ops.attn_fwd = self._gemm, self._conv, self._attn
+        self.ops.gemm, self.ops.conv3x3, self.ops.attn_fwd, self.ops.gemm_geglu_keep = self._gemm, self._conv, self._attn, self._keep
 
     def summary(self):
         """per kernel: [launches, flops, seconds, algorithmic bytes, roofline seconds, seconds of HBM-bound launches];

@@ -139,6 +139,12 @@ int skg_layernorm_bwd(const void* X, int ldx, const void* dY, int lddy, void* dX
                       const void* residual, int ldr, int M, int C, const void* gamma,
                       const float* stats, void* stream);
 
+/* skg_gemm_f16 with SKG_EPI_GEGLU that ALSO stores the pre-activation: Y [M][N/2] = a * gelu(g) and H [M][N] = A B^T + bias
+ * in the interleaved pack order (what skg_geglu_bwd takes as its saved H).  One launch instead of GEMM + skg_geglu_fwd
+ * for the rows whose gate will be differentiated (the cond rows of a guided step).  K % 64 == 0, N % 16 == 0. */
+int skg_gemm_f16_geglu_keep(const void* A, int lda, const void* B, int ldb, void* Y, int ldy, void* H, int ldh,
+                            int M, int N, int K, const void* bias, void* stream);
+
 /* ---- GEGLU: Y[m][j] = a_j * gelu(g_j),  H fp16 [M][2F] -----------------------------------------------
  * interleaved == 0: H = [a (F columns) | g (F columns)] (diffusers' chunk(2));  interleaved == 1: groups of four
  * columns [a_2t a_2t+1 g_2t g_2t+1] (the pack SKG_EPI_GEGLU uses).  bwd writes dH [M][2F] in the same layout from

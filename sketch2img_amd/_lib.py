@@ -26,6 +26,7 @@ SIGNATURES = {
     "skg_gemm_f16": ("i", "pipipiiiippifup"),
     "skg_gemm_f16_gn": ("i", "pipipiiiippifupiip"),
     "skg_gemm_gn_fused": ("i", "iiiiiii"),
+    "skg_gemm_f16_geglu_keep": ("i", "pipipipiiiipp"),
     "skg_gemm_variant": ("i", "iiiii"),
     "skg_set_workspace": ("i", "pz"),
     "skg_conv3x3_f16": ("i", "pippiiiiiiippifup"),

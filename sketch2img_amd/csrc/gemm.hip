@@ -242,6 +242,19 @@ static int conv_impl(const void* X, int ldx, const void* Wp, void* Y, int ldy, i
                      int Cout, int mode, const void* bias, const void* residual, int ldr, float alpha, unsigned flags,
                      float* gn_partial, int groups, void* stream);
 
+extern "C" int skg_gemm_f16_geglu_keep(const void* A, int lda, const void* B, int ldb, void* Y, int ldy, void* H,
+                                       int ldh, int M, int N, int K, const void* bias, void* stream) {
+  SKG_REQUIRE(A && B && Y && H && M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 16 == 0);
+  SKG_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldy % 8 == 0 && ldh % 8 == 0 && lda >= K && ldb >= K && ldy >= N / 2 && ldh >= N);
+  SKG_REQUIRE(skg_aligned(A, 16) && skg_aligned(B, 16) && skg_aligned(Y, 16) && skg_aligned(H, 16));
+  SKG_REQUIRE(!bias || skg_aligned(bias, 8));
+  GemmParams p{};
+  p.A = (const half_t*)A; p.lda = lda; p.B = (const half_t*)B; p.ldb = ldb; p.C = Y; p.ldc = ldy;
+  p.bias = (const half_t*)bias; p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.flags = SKG_EPI_GEGLU;
+  p.aux = (half_t*)H; p.ldaux = ldh;
+  return launch<MODE_DIRECT>(p, (hipStream_t)stream);
+}
+
 // 1 when skg_gemm_f16_gn / skg_conv3x3_f16_gn of this shape (contiguous, 16-byte aligned output) gets its partial sums
 // from the kernel's own epilogue, 0 when the stand-alone statistics pass follows (bench.py spells kernel names from it)
 extern "C" int skg_gemm_gn_fused(int M, int N, int K, int Cin, int mode, int HW, int groups) {

@@ -606,8 +606,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
             half4_t y = {(half_t)((float)a[0] * gelu_fast_f((float)a[2])), (half_t)((float)a[1] * gelu_fast_f((float)a[3])),
                          (half_t)((float)a[4] * gelu_fast_f((float)a[6])), (half_t)((float)a[5] * gelu_fast_f((float)a[7]))};
             half4_t* dst4 = reinterpret_cast<half4_t*>(crow + k * TPR2 * 4);
-            if (stream_out) asm volatile("global_store_dwordx2 %0, %1, off nt" ::"v"(dst4), "v"(y) : "memory");
+            if (stream_out) asm volatile("global_store_dwordx2 %0, %1, off nt\n\ts_nop 1" ::"v"(dst4), "v"(y) : "memory");
             else *dst4 = y;
+            if (p.aux) {      // the pre-activation too (what the backward of the gate needs)
+              half8_t* h8 = reinterpret_cast<half8_t*>(p.aux + (size_t)(m0 + sl * HROWS + hr * 64 + er) * p.ldaux + n0 + ec + k * TPR2 * 8);
+              asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(h8), "v"(a) : "memory");
+            }
           }
         }
         continue;
@@ -630,8 +634,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
                        (half_t)((float)b[4] * gelu_fast_f((float)b[6])), (half_t)((float)b[5] * gelu_fast_f((float)b[7]))};
           half8_t* dst8 = reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(p.C) + (size_t)(m0 + sl * HROWS + row) * p.ldc +
                                                      (n0 >> 1) + pp * 8);
-          if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst8), "v"(y) : "memory");
+          if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst8), "v"(y) : "memory");
           else *dst8 = y;
+          if (p.aux) {        // the pre-activation too (what the backward of the gate needs): 32 contiguous bytes
+            half_t* const hrow = p.aux + (size_t)(m0 + sl * HROWS + row) * p.ldaux + n0 + pp * 16;
+            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(hrow), "v"(a) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(hrow + 8), "v"(b) : "memory");
+          }
         }
         continue;
       }
@@ -653,7 +662,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
         for (int k = 0; k < IT2; ++k) {
           if (n0 + ec + k * TPR2 * 8 >= p.N) continue;
           half8_t* dst8 = reinterpret_cast<half8_t*>(crow + k * TPR2 * 8);
-          if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst8), "v"(hv[k]) : "memory");
+          if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst8), "v"(hv[k]) : "memory");
           else *dst8 = hv[k];
         }
       }
@@ -748,8 +757,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
 #ifdef SKG_PHASES
             if (p.flags & 0x4000u) { if (o[0] == (half_t)12345.f) *dst8 = o; continue; }   // probe: epilogue without stores
 #endif
-            // (inline asm: hipcc merges an if/else pair of builtin stores into ONE plain store and drops the hint)
-            if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst8), "v"(o) : "memory");
+            // (inline asm: hipcc merges an if/else pair of builtin stores into ONE plain store and drops the hint.
+            //  The s_nop behind every asm store is the gfx9 "VMEM store of more than 8 bytes, then a VALU write of its
+            //  data registers" wait states (two on gfx940+): hipcc's hazard recognizer does not look inside an asm block, and it is free
+            //  to reuse the registers in the very next instruction - seen with the GEGLU pre-activation store, whose
+            //  first 8 bytes came out as the next store's address.)
+            if (stream_out) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst8), "v"(o) : "memory");
             else *dst8 = o;
           }
         }

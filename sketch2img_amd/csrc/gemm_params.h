@@ -16,6 +16,8 @@ struct GemmParams {
   // GroupNorm statistics of the OUTPUT from the producer's epilogue (skg_*_gn entry points): per (sample, 128-row chunk,
   // group) sum(y) and sum(y^2) of the fp16-rounded outputs, gn_partial[((b * (gn_hw / 128) + chunk) * gn_groups + g) * 2]
   float* gn_partial; int gn_hw, gn_groups;
+  // fused GEGLU that also keeps the pre-activation (skg_gemm_f16_geglu_keep): H [M][N] in the interleaved pack order
+  half_t* aux; int ldaux;
 };
 constexpr unsigned SKG_FLAG_GN_STATS = 0x8000u;      // internal: set by the launcher when the chosen kernel fuses them
 

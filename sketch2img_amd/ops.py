@@ -101,6 +101,20 @@ def gemm(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *
     return out
 
 
+def gemm_geglu_keep(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor] = None, out=None, pre=None):
+    """FF1 with the gate fused AND the pre-activation kept: returns (a * gelu(g) [M, N/2], H [M, N] interleaved pack)."""
+    _f16(A, B, bias)
+    M, K = A.shape
+    N = B.shape[0]
+    if out is None:
+        out = torch.empty(M, N // 2, device=A.device, dtype=torch.float16)
+    if pre is None:
+        pre = torch.empty(M, N, device=A.device, dtype=torch.float16)
+    check(lib.skg_gemm_f16_geglu_keep(_p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out), _p(pre), _ld(pre), M, N, K,
+                                      _p(bias), _stream()), "skg_gemm_f16_geglu_keep")
+    return out, pre
+
+
 def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode: int = CONV_S1,
             out: Optional[torch.Tensor] = None, *, bias=None, residual=None, alpha: float = 1.0,
             relu: bool = False, gn_groups: Optional[int] = None):

@@ -29,7 +29,8 @@ import torch
 from . import ops
 from .config import UNetConfig, up_block_plan
 
-_GN_FROM_PRODUCER = os.environ.get("SKG_GN_PRODUCER", "1") != "0"      # A/B switch (bench.py on one box)
+_GN_FROM_PRODUCER = os.environ.get("SKG_GN_PRODUCER", "1") != "0"      # A/B switches (bench.py on one box)
+_GEGLU_KEEP = os.environ.get("SKG_GEGLU_KEEP", "1") != "0"
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -260,8 +261,12 @@ class HipUNet:
             M0 = (rows // 2) * HW
             gg = torch.empty(rows * HW, 4 * C, device=x.device, dtype=torch.float16)
             ops.gemm(a3[:M0], W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"], geglu=True, out=gg[:M0])
-            f = ops.gemm(a3[M0:], W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"])     # cond rows only
-            ops.geglu(f, out=gg[M0:], interleaved=True)
+            # cond rows: the same fused epilogue also stores the pre-activation the gate's backward needs
+            if _GEGLU_KEEP:
+                _, f = ops.gemm_geglu_keep(a3[M0:], W[t + ".ff.net.0.proj.weight"], W[t + ".ff.net.0.proj.bias"], out=gg[M0:])
+            else:
+                f = ops.gemm(a3[M0:], W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"])
+                ops.geglu(f, out=gg[M0:], interleaved=True)
         else:
             f = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"])
             gg = ops.geglu(f, interleaved=True)

@@ -366,6 +366,13 @@ def test_geglu_interleaved_and_fused_gemm(ops):
     from sketch2img_amd._lib import SkgError
     with pytest.raises(SkgError):                            # K % 64 != 0 -> generic kernel -> no fused GEGLU
         ops.gemm(rnd(64, 32).to(d), rnd(16, 32).to(d), geglu=True)
+    # the fused gate that also keeps the pre-activation (cond rows of a guided step): both outputs are bit for bit what
+    # the two separate launches of the fused epilogue / the plain GEMM give; 128 x 160 and 256 x 320 tile paths
+    for Mk, Ck in ((700, 128), (4096, 1280), (8192, 320)):
+        xk = rnd(Mk, Ck, seed=8).to(d)
+        wk, bk = rnd(8 * Ck, Ck, seed=9, scale=Ck ** -0.5).to(d), rnd(8 * Ck, seed=10).to(d)
+        yk, hk = ops.gemm_geglu_keep(xk, wk, bk)
+        assert torch.equal(yk, ops.gemm(xk, wk, bias=bk, geglu=True)) and torch.equal(hk, ops.gemm(xk, wk, bias=bk))
 
 
 def test_data_movement(ops):
