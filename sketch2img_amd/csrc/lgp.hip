@@ -379,42 +379,86 @@ __global__ void bn_from_running_kernel(const float* __restrict__ rm, const float
 }
 
 // MODE 0: y = (x-mean)*rstd*gamma+beta.   MODE 1: dx = [x>0] * gamma*rstd*(dy - m1 - xhat*m2)
+// Workgroup = (row chunk, sample), thread = fixed 8-channel piece x strided rows (the decomposition of bn_partial_kernel):
+// the per-channel coefficients are loop-invariant registers -  y = x*a + sh,  dx = [x>0] * (dy*a - b - x*c)  - and four
+// rows are in flight per thread.  (The first version re-read 128 bytes of statistics per 16 bytes of x through the
+// vector-memory path, which capped it at 1.3 TB/s.)
+// row chunks per sample: >= 8 rows per thread and chunk, <= 512 chunks
+inline int bn_apply_chunks(int n, int C) {
+  const int C8 = C >> 3, RL = C8 >= 256 ? 1 : 256 / C8;
+  int c = n / (8 * RL);
+  return c < 1 ? 1 : (c > 512 ? 512 : c);
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const half_t* __restrict__ X, int ldx,
                                                        const half_t* __restrict__ dY, int lddy,
-                                                       half_t* __restrict__ Y, int ldy, int S, int seg_rows,
-                                                       size_t nrows, int C, const float* __restrict__ stats,
+                                                       half_t* __restrict__ Y, int ldy, int S, int segs, int seg_rows,
+                                                       int C, const float* __restrict__ stats,
                                                        const float* __restrict__ sums,
                                                        const half_t* __restrict__ gamma,
                                                        const half_t* __restrict__ beta, int train) {
+  const int g = blockIdx.y, chunk = blockIdx.x;
+  const int n = segs * seg_rows;
+  const int per = (n + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int i0 = chunk * per, i1 = min(n, i0 + per);
   const int C8 = C >> 3;
-  const size_t total = nrows * C8;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const size_t row = i / C8;
-    const int c0 = (int)(i - row * C8) * 8;
-    const int g = (int)((row / seg_rows) % S);
-    const half8_t xv = ld_half8(X + row * ldx + c0);
-    const half8_t gv = ld_half8(gamma + c0);
-    const float* st = stats + ((size_t)g * C + c0) * 2;
-    half8_t o;
-    if (MODE == 0) {
-      const half8_t bv = ld_half8(beta + c0);
+  auto rowof = [&](int i) {
+    const int jseg = i / seg_rows, ii = i - jseg * seg_rows;
+    return ((size_t)jseg * S + g) * seg_rows + ii;
+  };
+  for (int pb = 0; pb < C8; pb += 256) {
+    const int npc = min(256, C8 - pb);
+    const int RL = 256 / npc;
+    const int piece = threadIdx.x % npc, rl = threadIdx.x / npc;
+    if (rl >= RL) continue;
+    const int c0 = (pb + piece) * 8;
+    float ca[8], cb[8], cc[8];
+    {
+      const half8_t gv = ld_half8(gamma + c0);
+      const half8_t bv = MODE == 0 ? ld_half8(beta + c0) : zero_half8();
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        o[j] = (half_t)(((float)xv[j] - st[2 * j]) * st[2 * j + 1] * (float)gv[j] + (float)bv[j]);
-    } else {
-      const half8_t dv = ld_half8(dY + row * lddy + c0);
-      const float* sm = sums + ((size_t)g * C + c0) * 2;
+      for (int j = 0; j < 8; ++j) {
+        const float mean = stats[((size_t)g * C + c0 + j) * 2], rstd = stats[((size_t)g * C + c0 + j) * 2 + 1];
+        const float a = (float)gv[j] * rstd;
+        ca[j] = a;
+        if (MODE == 0) {
+          cb[j] = (float)bv[j] - mean * a;
+          cc[j] = 0.f;
+        } else {
+          const float m1 = train ? sums[((size_t)g * C + c0 + j) * 2] : 0.f;
+          const float m2 = train ? sums[((size_t)g * C + c0 + j) * 2 + 1] : 0.f;
+          cc[j] = a * rstd * m2;                       // dx = [x>0] * (a*dy - a*m1 - a*rstd*m2*(x - mean))
+          cb[j] = a * m1 - cc[j] * mean;
+        }
+      }
+    }
+    auto apply = [&](const half8_t& xv, const half8_t& dv) {
+      half8_t o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float x = (float)xv[j];
-        const float rstd = st[2 * j + 1];
-        float d = (float)dv[j];
-        if (train) d = d - sm[2 * j] - (x - st[2 * j]) * rstd * sm[2 * j + 1];
-        o[j] = x > 0.f ? (half_t)((float)gv[j] * rstd * d) : (half_t)0.f;
+        if (MODE == 0) o[j] = (half_t)(x * ca[j] + cb[j]);
+        else o[j] = x > 0.f ? (half_t)((float)dv[j] * ca[j] - cb[j] - x * cc[j]) : (half_t)0.f;
       }
+      return o;
+    };
+    int i = i0 + rl;
+    for (; i + 3 * RL < i1; i += 4 * RL) {
+      size_t r[4];
+      half8_t xv[4], dv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        r[u] = rowof(i + u * RL);
+        xv[u] = ld_half8(X + r[u] * ldx + c0);
+        dv[u] = MODE == 1 ? ld_half8(dY + r[u] * lddy + c0) : zero_half8();
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) st_half8(Y + r[u] * ldy + c0, apply(xv[u], dv[u]));
     }
-    st_half8(Y + row * ldy + c0, o);
+    for (; i < i1; i += RL) {
+      const size_t r = rowof(i);
+      st_half8(Y + r * ldy + c0, apply(ld_half8(X + r * ldx + c0), MODE == 1 ? ld_half8(dY + r * lddy + c0) : zero_half8()));
+    }
   }
 }
 
@@ -640,9 +684,9 @@ extern "C" int skg_bn_apply(const void* X, int ldx, void* Y, int ldy, int sample
                             const float* stats, const void* gamma, const void* beta, void* stream) {
   SKG_REQUIRE(X && Y && stats && gamma && beta && samples > 0 && C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0);
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
-  const size_t nrows = (size_t)samples * segs * seg_rows;
-  hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(ew_grid(nrows * C / 8)), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)X, ldx, (const half_t*)nullptr, 0, (half_t*)Y, ldy, samples, seg_rows, nrows, C,
+  SKG_REQUIRE(segs > 0 && seg_rows > 0);
+  hipLaunchKernelGGL((bn_apply_kernel<0>), dim3(bn_apply_chunks(segs * seg_rows, C), samples), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)X, ldx, (const half_t*)nullptr, 0, (half_t*)Y, ldy, samples, segs, seg_rows, C,
                      stats, (const float*)nullptr, (const half_t*)gamma, (const half_t*)beta, 1);
   SKG_CHECK_LAUNCH("skg_bn_apply");
   return SKG_OK;
@@ -662,9 +706,8 @@ extern "C" int skg_bn_relu_bwd(const void* X, int ldx, const void* dY, int lddy,
     hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(skg_cdiv(C, 128), samples), dim3(128), 0, st, scratch, samples, C,
                        segs * seg_rows, 0.f, sums, (float*)nullptr);
   }
-  const size_t nrows = (size_t)samples * segs * seg_rows;
-  hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(ew_grid(nrows * C / 8)), dim3(256), 0, st, (const half_t*)X, ldx,
-                     (const half_t*)dY, lddy, (half_t*)dX, lddx, samples, seg_rows, nrows, C, stats, sums,
+  hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(bn_apply_chunks(segs * seg_rows, C), samples), dim3(256), 0, st, (const half_t*)X, ldx,
+                     (const half_t*)dY, lddy, (half_t*)dX, lddx, samples, segs, seg_rows, C, stats, sums,
                      (const half_t*)gamma, (const half_t*)nullptr, train_mode);
   SKG_CHECK_LAUNCH("skg_bn_relu_bwd");
   return SKG_OK;

@@ -536,11 +536,12 @@ def test_lgp_layer0_gather_and_scatter(ops):
         assert report(f"lgp scatter s{s}", dP.float().cpu().reshape(S, s, s, H0).permute(0, 3, 1, 2), pr.grad)[0] < FP16_RND
 
 
+@pytest.mark.parametrize("S,hw,C", [(3, 64, 256), (2, 1024, 512), (2, 200, 64), (1, 333, 128)])
 @pytest.mark.parametrize("train", [True, False])
-def test_batchnorm_per_sample_fwd_bwd(ops, train):
+def test_batchnorm_per_sample_fwd_bwd(ops, train, S, hw, C):
     """BatchNorm1d with one sample's two CFG segments as the batch + backward through the preceding ReLU,
-    checked on the SAME post-ReLU activations (so no gate can flip between the two sides)."""
-    S, hw, C = 3, 64, 256
+    checked on the SAME post-ReLU activations (so no gate can flip between the two sides).  Shapes: several row
+    chunks per sample, the four-rows-in-flight loop and its ragged tail, 8 / 16 / 32 / 64 channel pieces."""
     d = dev()
     x = torch.relu(rnd(2 * S * hw, C, seed=1).float() + 0.2).half()                 # post-ReLU activations
     ga, be = (1 + 0.2 * rnd(C, seed=2).float()).half(), (0.2 * rnd(C, seed=3).float()).half()
