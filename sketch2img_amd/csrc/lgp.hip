@@ -201,10 +201,14 @@ __global__ __launch_bounds__(256) void lgp_gather_tiled_kernel(const TapArgs tap
 }
 
 // adjoint of the bilinear resize for one tap: one block per native pixel; thread = (8-channel piece, window lane):
-// 16-byte loads, the (2f)^2 window pixels are dealt round-robin to the 256 / (H0/8) window lanes and folded in LDS
+// 16-byte loads, the window ROWS are dealt round-robin to the 256 / (H0/8) window lanes and folded in LDS.  The
+// bilinear weight is separable: the row / column factors of the (<= 3f)^2 window are computed once per block into LDS,
+// so the inner loop is a multiply, a test and a load + 8 FMAs (the first version redid both coordinate computations and
+// an integer division for every window pixel: ~40 VALU per 16-byte load, and two thirds of the window has zero weight).
 __global__ __launch_bounds__(256) void lgp_scatter_kernel(const half_t* __restrict__ dZ, int lddz,
                                                           half_t* __restrict__ dP, int rows, int h, int s, int H0) {
   __shared__ float red[256][9];
+  __shared__ float cys[256], cxs[256];
   const int ss = s * s;
   const int row = blockIdx.x / ss;
   const int np = blockIdx.x - row * ss;
@@ -213,6 +217,18 @@ __global__ __launch_bounds__(256) void lgp_scatter_kernel(const half_t* __restri
   const int ylo = max(0, f * py - f), yhi = min(h - 1, f * py + 2 * f - 1);
   const int xlo = max(0, f * px - f), xhi = min(h - 1, f * px + 2 * f - 1);
   const int wy_n = yhi - ylo + 1, wx_n = xhi - xlo + 1;
+  const bool tab = wy_n <= 256 && wx_n <= 256;            // (always, for the resolutions of the pipeline)
+  auto coef = [&](int v, int p) {
+    int v0, v1;
+    float w;
+    bil_coord(v, s, h, v0, v1, w);
+    return (v0 == p ? 1.f - w : 0.f) + (v1 == p ? w : 0.f);
+  };
+  if (tab) {
+    for (int i = threadIdx.x; i < wy_n; i += 256) cys[i] = coef(ylo + i, py);
+    for (int i = threadIdx.x; i < wx_n; i += 256) cxs[i] = coef(xlo + i, px);
+    __syncthreads();
+  }
   const int C8 = H0 >> 3;
   for (int pb = 0; pb < C8; pb += 256) {
     const int npc = min(256, C8 - pb);
@@ -221,19 +237,17 @@ __global__ __launch_bounds__(256) void lgp_scatter_kernel(const half_t* __restri
     const int c0 = (pb + piece) * 8;
     float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (wl < WL) {
-      for (int wi = wl; wi < wy_n * wx_n; wi += WL) {
-        const int y = ylo + wi / wx_n, x = xlo + wi % wx_n;
-        int y0, y1, x0, x1;
-        float wy, wx;
-        bil_coord(y, s, h, y0, y1, wy);
-        bil_coord(x, s, h, x0, x1, wx);
-        const float cy = (y0 == py ? 1.f - wy : 0.f) + (y1 == py ? wy : 0.f);
-        const float cx = (x0 == px ? 1.f - wx : 0.f) + (x1 == px ? wx : 0.f);
-        const float w = cy * cx;
-        if (w == 0.f) continue;
-        const half8_t v = ld_half8(dZ + ((size_t)row * h * h + y * h + x) * lddz + c0);
+      for (int yy = wl; yy < wy_n; yy += WL) {
+        const float cy = tab ? cys[yy] : coef(ylo + yy, py);
+        if (cy == 0.f) continue;
+        const half_t* src = dZ + ((size_t)row * h * h + (size_t)(ylo + yy) * h + xlo) * lddz + c0;
+        for (int xx = 0; xx < wx_n; ++xx) {
+          const float w = cy * (tab ? cxs[xx] : coef(xlo + xx, px));
+          if (w == 0.f) continue;
+          const half8_t v = ld_half8(src + (size_t)xx * lddz);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] += w * (float)v[j];
+          for (int j = 0; j < 8; ++j) a[j] += w * (float)v[j];
+        }
       }
     }
     __syncthreads();
