@@ -121,6 +121,16 @@ int skg_gemm_gn_fused(int M, int N, int K, int Cin, int mode, int HW, int groups
 int skg_groupnorm_from_partial(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
                                float eps, const void* gamma, const void* beta, int silu, float* stats,
                                const float* partial, int nch, void* stream);
+/* The same for a CONCATENATION X = [A (CA channels) | B (C - CA channels)] whose halves were written by two producers
+ * (the skip connection of the UNet's up path and the layer in front of it): partialA / partialB hold groupsA / groupsB
+ * groups per chunk over each half's own channels; the concatenation's group width must be a multiple of both source
+ * widths and CA a multiple of it (320 + 320, 640 + 640 channels: two source groups per output group), otherwise
+ * SKG_E_UNSUPPORTED (nothing launched: run skg_groupnorm_fwd).  Replaces: the GroupNorm on torch.cat([h, skip]) in
+ * diffusers' CrossAttnUpBlock2D / UpBlock2D resnets (modules/pipeline.py:96). */
+int skg_groupnorm_from_partial2(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int CA,
+                                int groups, float eps, const void* gamma, const void* beta, int silu,
+                                float* stats, const float* partialA, int groupsA, const float* partialB,
+                                int groupsB, int nch, void* stream);
 int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C,
                         int groups, const float* stats, const void* gamma, const void* beta,
                         int silu, void* stream);

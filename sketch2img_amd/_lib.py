@@ -35,6 +35,7 @@ SIGNATURES = {
     "skg_groupnorm_stats": ("i", "piiiiifppp"),
     "skg_groupnorm_fwd": ("i", "pipiiiiifppippp"),
     "skg_groupnorm_from_partial": ("i", "pipiiiiifppippip"),
+    "skg_groupnorm_from_partial2": ("i", "pipiiiiiifppippipiip"),
     "skg_groupnorm_apply": ("i", "pipiiiiipppip"),
     "skg_groupnorm_bwd": ("i", "pipipipiiiiipppipp"),
     "skg_layernorm_fwd": ("i", "pipiiippfpp"),

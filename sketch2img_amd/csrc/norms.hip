@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // FOLD: the statistics are folded here from the stage-1 chunk partials (every workgroup of a row repeats the same
 // fixed-order fold into LDS; chunk 0 also publishes (mean, rstd) for the backward pass) - this removes the separate
 // finalize launch (4.7 us of an otherwise ~15-40 us GroupNorm).
+struct GnSrc { const float* partialB; int split, unused, ratioA, ratioB; };
 template <bool FOLD>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ X, int ldx,
                                                        half_t* __restrict__ Y, int ldy, int HW, int C, int groups,
@@ -172,19 +173,28 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
                                                        const half_t* __restrict__ gamma,
                                                        const half_t* __restrict__ beta, int silu,
                                                        const float* __restrict__ partial, int pch, float inv_n,
-                                                       float eps, float* __restrict__ stats_out) {
+                                                       float eps, float* __restrict__ stats_out,
+                                                       GnSrc src = GnSrc{nullptr, 0, 0, 1, 1}) {
   const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
   __shared__ float st_s[64][2];
   if (FOLD) {
-    // 8 lanes per group, lanes stride over the pch chunk partials, xor-shuffle fold (fixed order)
+    // 8 lanes per group, lanes stride over the pch chunk partials, xor-shuffle fold (fixed order).  `src` (GroupNorm of a
+    // CONCATENATION whose halves were written by two producers): groups below src.split come from `partial`, the others
+    // from src.partialB, and every output group adds ratioA / ratioB adjacent (narrower) source groups.
+    const int split = src.partialB ? src.split : groups;
+    const int sgA = split * src.ratioA, sgB = (groups - split) * src.ratioB;
     for (int g0 = 0; g0 < groups; g0 += 32) {
       const int grp = g0 + (threadIdx.x >> 3), sub = threadIdx.x & 7;
       float s1 = 0.f, s2 = 0.f;
-      if (grp < groups)
+      if (grp < groups) {
+        const bool inA = grp < split;
+        const float* base = inA ? partial : src.partialB;
+        const int sg = inA ? sgA : sgB, r = inA ? src.ratioA : src.ratioB, gs = (inA ? grp : grp - split) * r;
         for (int c = sub; c < pch; c += 8) {
-          const float* q = partial + (((size_t)b * pch + c) * groups + grp) * 2;
-          s1 += q[0]; s2 += q[1];
+          const float* q = base + (((size_t)b * pch + c) * sg + gs) * 2;
+          for (int k = 0; k < r; ++k) { s1 += q[2 * k]; s2 += q[2 * k + 1]; }
         }
+      }
 #pragma unroll
       for (int o = 4; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
       if (grp < groups && sub == 0) {
@@ -635,6 +645,32 @@ extern "C" int skg_groupnorm_from_partial(const void* X, int ldx, void* Y, int l
                      (const half_t*)gamma, (const half_t*)beta, silu, partial, nch,
                      1.f / ((float)HW * (C / groups)), eps, stats);
   SKG_CHECK_LAUNCH("skg_groupnorm_from_partial");
+  return SKG_OK;
+}
+
+// GroupNorm of a concatenation [A (CA channels) | B (C - CA channels)] whose halves were written by two producers that
+// each left partial sums behind (groupsA / groupsB groups per chunk over their own channels).  The concatenation's group
+// width must be a multiple of both source group widths and CA a multiple of it (e.g. 320 + 320 or 640 + 640 channels with
+// 32 groups each way: two source groups per output group); otherwise SKG_E_UNSUPPORTED - run the stand-alone pass.
+extern "C" int skg_groupnorm_from_partial2(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int CA,
+                                           int groups, float eps, const void* gamma, const void* beta, int silu,
+                                           float* stats, const float* partialA, int groupsA, const float* partialB,
+                                           int groupsB, int nch, void* stream) {
+  SKG_REQUIRE(X && Y && stats && partialA && partialB && gamma && beta && rows > 0 && HW > 0 && groups > 0 && groups <= 64);
+  SKG_REQUIRE(nch > 0 && nch <= GN_MAX_CHUNKS && CA > 0 && CA < C && groupsA > 0 && groupsB > 0);
+  SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && (C / groups) % 2 == 0 && (C / groups) >= 4 && C <= GN_MAX_C);
+  SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
+  const int cpg = C / groups, CB = C - CA;
+  if (CA % cpg != 0 || CA % groupsA != 0 || CB % groupsB != 0) return SKG_E_UNSUPPORTED;
+  const int cpgA = CA / groupsA, cpgB = CB / groupsB;
+  if (cpg % cpgA != 0 || cpg % cpgB != 0) return SKG_E_UNSUPPORTED;
+  const GnSrc src{partialB, CA / cpg, 0, cpg / cpgA, cpg / cpgB};
+  hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, groups, (const float*)nullptr,
+                     (const half_t*)gamma, (const half_t*)beta, silu, partialA, nch,
+                     1.f / ((float)HW * cpg), eps, stats, src);
+  SKG_CHECK_LAUNCH("skg_groupnorm_from_partial2");
   return SKG_OK;
 }
 

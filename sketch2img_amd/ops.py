@@ -74,6 +74,15 @@ def gn_fusable(M: int, N: int, HW: int, groups: int) -> bool:
             (N // groups) % 2 == 0 and N // groups >= 4 and N <= 4096)
 
 
+def gn_concat_ok(CA: int, CB: int, groups: int, ga: int, gb: int) -> bool:
+    """Can groupnorm(partial=(pa, CA, pb)) regroup the two producers' sums for a [CA | CB]-channel concatenation?"""
+    C = CA + CB
+    if C % groups or CA % ga or CB % gb:
+        return False
+    cpg = C // groups
+    return CA % cpg == 0 and cpg % (CA // ga) == 0 and cpg % (CB // gb) == 0
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          alpha: float = 1.0, relu: bool = False, out_f32: bool = False, geglu: bool = False, gn_stats=None):
@@ -182,6 +191,19 @@ def groupnorm(X, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, parti
     Otherwise:  Up to 32x32 maps: two launches (chunk partial sums; apply, which folds the partials itself
     and publishes the statistics) - at 64x64 the 86 chunk partials per group make the in-kernel fold dearer than the
     4.7 us finalize launch it replaces, so the three-launch path stays (measured: tools/ew_bench.py)."""
+    if isinstance(partial, tuple):
+        # X = [A | B], each half written by its own producer: (GNPartial of A, channels of A, GNPartial of B)
+        pa, CA, pb = partial
+        assert pa.rows == rows and pb.rows == rows and pa.nch == pb.nch == HW // 128
+        _f16(X, gamma, beta)
+        C = X.shape[1]
+        if out is None:
+            out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
+        st = torch.empty(rows, groups, 2, device=X.device, dtype=torch.float32)
+        check(lib.skg_groupnorm_from_partial2(_p(X), _ld(X), _p(out), _ld(out), rows, HW, C, CA, groups, eps, _p(gamma),
+                                              _p(beta), int(silu), _p(st), _p(pa.buf), pa.groups, _p(pb.buf),
+                                              pb.groups, pa.nch, _stream()), "skg_groupnorm_from_partial2")
+        return out, st
     if partial is not None:
         assert partial.rows == rows and partial.groups == groups and partial.nch == HW // 128
         _f16(X, gamma, beta)

@@ -312,6 +312,7 @@ class HipUNet:
             return cats[u][:, ch_h[u]:]
 
         skips: List[torch.Tensor] = []
+        skip_parts: List[Optional[ops.GNPartial]] = []       # partial sums of each skip, when its producer left them
         G = cfg.norm_groups
         # hp: GroupNorm partial sums of h left behind by the kernel that produced it, whenever the next consumer of h is a
         # GroupNorm of the 64 x 64 / 32 x 32 levels (None otherwise: concatenated inputs, small maps)
@@ -321,6 +322,7 @@ class HipUNet:
         else:
             h, hp = ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, out=skip_slot(boc[0], H), bias=W["conv_in.bias"]), None
         skips.append(h)
+        skip_parts.append(hp)
         taps_down = []
         cur = H
         for i in range(nb):
@@ -334,6 +336,7 @@ class HipUNet:
                     h, hp = self._res_fwd(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, stash,
                                           out=skip_slot(boc[i], cur), xpart=hp, want_part=True)
                 skips.append(h)
+                skip_parts.append(hp)
             if i < nb - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
                 half = cur // 2
@@ -345,6 +348,7 @@ class HipUNet:
                                         bias=W[p + ".bias"]), None
                 cur //= 2
                 skips.append(h)
+                skip_parts.append(hp)
             if i < 3:
                 taps_down.append((h, cur))
         if down_only:
@@ -373,23 +377,31 @@ class HipUNet:
             for j in range(lpb1):
                 u = i * lpb1 + j
                 skips.pop()                                   # already sits in cats[u][:, ch_h[u]:]
+                sp = skip_parts.pop() if skip_parts else None
                 cat = cats[u]
+                # norm1 of a resnet that reads [h | skip]: both halves' producers may have left their sums behind
+                cpart = None
+                if hp is not None and sp is not None and ops.gn_concat_ok(ch_h[u], cat.shape[1] - ch_h[u], G, hp.groups, sp.groups):
+                    cpart = (hp, ch_h[u], sp)
                 # where this layer's output goes: the next concat buffer of the same block, else a fresh tensor
                 nxt = cats[u + 1][:, :ch_h[u + 1]] if j < lpb1 - 1 else None
                 if i > 0:
-                    # (the resnet reads a concatenation: its norm1 keeps the stand-alone statistics pass)
-                    h, hp = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash, want_part=True)
-                    # only the very last transformer output goes to a GroupNorm (conv_norm_out); the others are concatenated
-                    last = want_eps and i == nb - 1 and j == lpb1 - 1
+                    # (norm1 reads the concatenation: regrouped producer sums where the widths allow, else its own pass)
+                    h, hp = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash, xpart=cpart, want_part=True)
+                    # the transformer's output goes to conv_norm_out (the very last one) or into the next concatenation,
+                    # whose GroupNorm regroups its sums with the skip's; the block's last output feeds the upsampling conv
+                    keep = (want_eps and i == nb - 1 and j == lpb1 - 1) or j < lpb1 - 1
                     h, hp = self._tr_fwd(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], stash, out=nxt,
-                                         xpart=hp, want_part=last)
+                                         xpart=hp, want_part=keep)
                 else:
-                    h, _ = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash, out=nxt)
+                    h, hp = self._res_fwd(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash, out=nxt, xpart=cpart,
+                                          want_part=j < lpb1 - 1)
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 u = (i + 1) * lpb1
                 h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=cats[u][:, :ch_h[u]],
                                 bias=W[p + ".bias"])
+                hp = None              # (the next concatenation's widths do not line up with 32 groups per half)
                 cur *= 2
             if i < 3:
                 taps_up.append((h, cur))

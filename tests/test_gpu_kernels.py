@@ -302,6 +302,32 @@ def test_groupnorm_statistics_from_the_producer_epilogue(ops, kind, rows, H, Cin
     assert torch.equal(part.buf, part2.buf)
 
 
+@pytest.mark.parametrize("rows,H,CA,CB", [(4, 64, 320, 320), (4, 32, 640, 640), (2, 32, 320, 320)])
+def test_groupnorm_of_a_concatenation_from_two_producers(ops, rows, H, CA, CB):
+    """The up path's norm1 reads torch.cat([h, skip]): h and skip are written into one buffer by two producers that each
+    leave 32-group partial sums of their own channels; the GroupNorm over the concatenation (32 groups of twice the
+    width) regroups them - same result as the stand-alone statistics pass."""
+    d = dev()
+    G, HW, M = 32, H * H, rows * H * H
+    cat = torch.empty(M, CA + CB, device=d, dtype=torch.float16)
+    xa, xb = rnd(M, 320, seed=1).to(d), rnd(M, 320, seed=2).to(d)
+    wa = (rnd(CA, 320, seed=3).float() * 320 ** -0.5).half().to(d)
+    wb = (rnd(CB, 320, seed=4).float() * 320 ** -0.5).half().to(d)
+    _, pa = ops.gemm(xa, wa, cat[:, :CA], bias=rnd(CA, seed=5).to(d), gn_stats=(HW, G))
+    _, pb = ops.gemm(xb, wb, cat[:, CA:], bias=rnd(CB, seed=6).to(d), residual=rnd(M, CB, seed=7).to(d), gn_stats=(HW, G))
+    assert ops.gn_concat_ok(CA, CB, G, pa.groups, pb.groups)
+    ga, be = (1 + 0.2 * rnd(CA + CB, seed=8).float()).half().to(d), (0.2 * rnd(CA + CB, seed=9).float()).half().to(d)
+    n1, st1 = ops.groupnorm(cat, rows, HW, G, 1e-5, ga, be, True, partial=(pa, CA, pb))
+    n0, st0 = ops.groupnorm(cat, rows, HW, G, 1e-5, ga, be, True)
+    assert (st1 - st0).abs().max().item() < 1e-4 * (1 + st0.abs().max().item())
+    assert (n1.float() - n0.float()).abs().max().item() <= 2e-3 * (1 + n0.float().abs().max().item())
+    assert not ops.gn_concat_ok(640, 320, G, 32, 32)              # 960 channels: 30-wide groups straddle the halves
+    from sketch2img_amd._lib import SkgError
+    with pytest.raises(SkgError):
+        bad = torch.empty(M, 960, device=d, dtype=torch.float16)
+        ops.groupnorm(bad, rows, HW, G, 1e-5, ga[:960].contiguous(), be[:960].contiguous(), True, partial=(pa, 640, pb))
+
+
 @pytest.mark.parametrize("M,C", [(77, 320), (1024, 1280), (5, 32), (4096, 640)])
 def test_layernorm_fwd_bwd(ops, M, C):
     x = rnd(M, C, seed=1) * 2 + 0.5
