@@ -31,6 +31,7 @@ from .config import UNetConfig, up_block_plan
 
 _GN_FROM_PRODUCER = os.environ.get("SKG_GN_PRODUCER", "1") != "0"      # A/B switches (bench.py on one box)
 _GEGLU_KEEP = os.environ.get("SKG_GEGLU_KEEP", "1") != "0"
+_GN_CONCAT = os.environ.get("SKG_GN_CONCAT", "1") != "0"
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -381,7 +382,7 @@ class HipUNet:
                 cat = cats[u]
                 # norm1 of a resnet that reads [h | skip]: both halves' producers may have left their sums behind
                 cpart = None
-                if hp is not None and sp is not None and ops.gn_concat_ok(ch_h[u], cat.shape[1] - ch_h[u], G, hp.groups, sp.groups):
+                if _GN_CONCAT and hp is not None and sp is not None and ops.gn_concat_ok(ch_h[u], cat.shape[1] - ch_h[u], G, hp.groups, sp.groups):
                     cpart = (hp, ch_h[u], sp)
                 # where this layer's output goes: the next concat buffer of the same block, else a fresh tensor
                 nxt = cats[u + 1][:, :ch_h[u + 1]] if j < lpb1 - 1 else None
