@@ -66,6 +66,18 @@ def test_host_side_argument_checks_do_not_need_a_gpu():
     assert lib.skg_conv3x3_f16(16, 32, 16, 16, 8, 1, 4, 4, 32, 8, 9, None, None, 0, 1.0, 0, None) == -2  # mode 9
     assert lib.skg_gemm_variant(65536, 320, 2880, 320, 2) == 2160
     assert lib.skg_gemm_variant(4096, 64, 96, 32, 2) == 1064
+    # GroupNorm statistics in the producer's epilogue: which launches fuse them (the rest run the stand-alone pass)
+    assert lib.skg_gemm_gn_fused(65536, 320, 2880, 320, 1, 4096, 32) == 1      # 64 x 64 conv: the 256 x 320 ping-pong tile
+    assert lib.skg_gemm_gn_fused(65536, 320, 320, 0, 0, 4096, 32) == 1         # proj_out GEMM: 128 x 160 tile
+    assert lib.skg_gemm_gn_fused(16384, 640, 5760, 640, 1, 1024, 32) == 1      # 32 x 32 conv
+    assert lib.skg_gemm_gn_fused(65536, 320, 288, 32, 1, 4096, 32) == 0         # conv_in: Cin = 32 -> generic kernel
+    assert lib.skg_gemm_gn_fused(65536, 960, 2880, 320, 1, 4096, 32) == 0       # 30-wide groups straddle the 160-column tile
+    assert lib.skg_gemm_gn_fused(65536, 320, 2880, 320, 1, 4000, 32) == 0       # chunks must be whole 128-row blocks
+    assert lib.skg_gemm_f16_gn(16, 32, 16, 32, 16, 320, 256, 320, 32, None, None, 0, 1.0, 0, None, 128, 32, None) == -1  # no buffer
+    from sketch2img_amd import ops
+    assert ops.gn_fusable(65536, 320, 4096, 32) and not ops.gn_fusable(65536, 320, 4000, 32)
+    assert ops.gn_concat_ok(320, 320, 32, 32, 32) and ops.gn_concat_ok(640, 640, 32, 32, 32)
+    assert not ops.gn_concat_ok(640, 320, 32, 32, 32) and not ops.gn_concat_ok(1280, 640, 32, 32, 32)
 
 
 def test_ddim_tables_bit_exact_vs_oracle():
