@@ -30,7 +30,7 @@ extern "C" {
 #define SKG_E_UNSUPPORTED (-2)
 #define SKG_E_LAUNCH (-3)    /* hipGetLastError() != hipSuccess after the launch */
 
-#define SKG_ABI_VERSION 1
+#define SKG_ABI_VERSION 2
 int skg_abi_version(void);
 /* Human-readable text of the last SKG_E_LAUNCH on this thread ("" if none). */
 const char* skg_last_error(void);
@@ -54,11 +54,13 @@ int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void* C, int ld
                  int M, int N, int K, const void* bias, const void* residual, int ldr,
                  float alpha, unsigned flags, void* stream);
 
-/* Optional split-K workspace for skg_gemm_f16 / skg_conv3x3_f16: a caller-owned device buffer (>= 1 MiB, 16-byte
- * aligned, fp32 partial slabs) that must stay valid until replaced.  With it, launches that would put fewer
- * than one workgroup on every CU (the 8x8 / 16x16-resolution layers) split their K loop over up to 8
- * workgroups per tile and a second tiny kernel sums the slabs and applies the epilogue.  NULL disables it. */
-int skg_set_workspace(void* ws, size_t bytes);
+/* Optional split-K workspace for skg_gemm_f16 / skg_conv3x3_f16 launches on `stream` of the CURRENT device: a caller-owned
+ * device buffer (>= 1 MiB, 16-byte aligned, fp32 partial slabs) that must stay valid until replaced.  With it, launches that
+ * would put fewer than one workgroup on every CU (the 8x8 / 16x16-resolution layers) split their K loop over several
+ * workgroups per tile and a second tiny kernel sums the slabs and applies the epilogue.  One slab per stream: launches on
+ * one stream are ordered and share theirs, launches on different streams never do (the registry is mutex-protected and
+ * the pointer reaches the kernel as an argument).  ws = NULL removes the stream's entry. */
+int skg_set_workspace(void* ws, size_t bytes, void* stream);
 
 /* Which kernel instantiation skg_gemm_f16 (mode 0, Cin ignored) / skg_conv3x3_f16 (mode = 1 + SKG_CONV_*)
  * run for this shape: 2000 + BN for the LDS-DMA kernel (gemm2_kernel<BN,MODE>), 1000 + BN for the generic one;

@@ -19,6 +19,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SKG_LIB: another build of the same ABI (same-box A/B measurements of kernel variants); default = the in-tree library
 LIB_PATH = os.environ.get("SKG_LIB") or os.path.join(_HERE, "libskg.so")
 
+# include/skg.h SKG_ABI_VERSION: bumped whenever an entry point changes its signature (2: skg_attn_bwd_dq / _dkv lost
+# their transposed-operand pointers, skg_set_workspace became per stream), so that a stale build selected through
+# SKG_LIB fails at load instead of receiving shifted arguments
+ABI_VERSION = 2
+
 # spec letters: p = device/host pointer, i = int, f = float, u = unsigned, z = size_t (return only)
 SIGNATURES = {
     "skg_abi_version": ("i", ""),
@@ -28,7 +33,7 @@ SIGNATURES = {
     "skg_gemm_gn_fused": ("i", "iiiiiii"),
     "skg_gemm_f16_geglu_keep": ("i", "pipipipiiiipp"),
     "skg_gemm_variant": ("i", "iiiii"),
-    "skg_set_workspace": ("i", "pz"),
+    "skg_set_workspace": ("i", "pzp"),
     "skg_conv3x3_f16": ("i", "pippiiiiiiippifup"),
     "skg_conv3x3_f16_gn": ("i", "pippiiiiiiippifupip"),
     "skg_groupnorm_scratch_floats": ("z", "ii"),
@@ -105,8 +110,9 @@ def _load():
             raise ImportError(f"libskg.so does not export {name}") from e
         fn.restype = _CT[ret]
         fn.argtypes = [_CT[a] for a in args]
-    if lib.skg_abi_version() != 1:
-        raise ImportError("libskg.so ABI version mismatch")
+    if lib.skg_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {lib.skg_abi_version()}, this package binds version {ABI_VERSION} "
+                          "(include/skg.h SKG_ABI_VERSION) - rebuild with `make -C sketch2img_amd/csrc`")
     return lib
 
 

@@ -13,6 +13,8 @@
 // four accumulator registers are four CONSECUTIVE output channels of one pixel: the epilogue
 // then does 8-byte bias/residual loads and 8-byte stores instead of 2-byte ones.
 #include "gemm_params.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -219,9 +221,39 @@ int launch_plain(const GemmParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int skg_set_workspace(void* ws, size_t bytes) {
+// ---- split-K workspaces: one caller-owned slab per (device, stream) ---------------------------------------------------
+// Launches on ONE stream are ordered and may share a slab; launches on different streams (several pipelines in one process, a
+// capture stream beside the eager stream) may run concurrently and must not.  The registry is read under a mutex by every
+// gemm / conv entry point and the slab pointer travels to the kernel as an argument, so two host threads on two streams
+// never see each other's slab (round 2 kept ONE process-global pointer that the Python side re-pointed: ADVICE r2).
+namespace {
+struct WsEntry { int dev; hipStream_t st; float* ws; size_t bytes; };
+std::mutex g_ws_mu;
+std::vector<WsEntry> g_ws_tab;
+size_t g_ws_last_bytes = 0;        // what the shape queries (skg_gemm_variant, skg_gemm_gn_fused) assume
+
+void ws_attach(GemmParams& p, hipStream_t st) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (const WsEntry& e : g_ws_tab)
+    if (e.dev == dev && e.st == st) { p.ws = e.ws; p.ws_bytes = e.bytes; return; }
+  p.ws = nullptr; p.ws_bytes = 0;
+}
+}  // namespace
+
+extern "C" int skg_set_workspace(void* ws, size_t bytes, void* stream) {
   SKG_REQUIRE(ws == nullptr || (skg_aligned(ws, 16) && bytes >= (1u << 20)));
-  skg_gemm2_set_workspace((float*)ws, ws ? bytes : 0);
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (size_t i = 0; i < g_ws_tab.size(); ++i)
+    if (g_ws_tab[i].dev == dev && g_ws_tab[i].st == (hipStream_t)stream) {
+      if (ws) { g_ws_tab[i].ws = (float*)ws; g_ws_tab[i].bytes = bytes; g_ws_last_bytes = bytes; }
+      else g_ws_tab.erase(g_ws_tab.begin() + i);
+      return SKG_OK;
+    }
+  if (ws) { g_ws_tab.push_back({dev, (hipStream_t)stream, (float*)ws, bytes}); g_ws_last_bytes = bytes; }
   return SKG_OK;
 }
 
@@ -231,7 +263,7 @@ extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
     q.M = M; q.N = N; q.K = K; q.Cin = Cin; q.lda = q.ldb = K; q.ldc = N; q.OH = q.OW = q.IH = q.IW = 1;
     if (const int bn8 = skg_gemm8_tile_n(q, mode)) return 8000 + bn8;
   }
-  const int v2 = skg_gemm2_tile_n(M, N, K, Cin, mode);
+  const int v2 = skg_gemm2_tile_n(M, N, K, Cin, mode, g_ws_last_bytes);
   return v2 ? 2000 + v2 : 1000 + (use_wide(M, N) ? 128 : 64);
 }
 
@@ -252,6 +284,7 @@ extern "C" int skg_gemm_f16_geglu_keep(const void* A, int lda, const void* B, in
   p.A = (const half_t*)A; p.lda = lda; p.B = (const half_t*)B; p.ldb = ldb; p.C = Y; p.ldc = ldy;
   p.bias = (const half_t*)bias; p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.flags = SKG_EPI_GEGLU;
   p.aux = (half_t*)H; p.ldaux = ldh;
+  ws_attach(p, (hipStream_t)stream);
   return launch<MODE_DIRECT>(p, (hipStream_t)stream);
 }
 
@@ -263,6 +296,7 @@ extern "C" int skg_gemm_gn_fused(int M, int N, int K, int Cin, int mode, int HW,
   GemmParams q{};
   q.M = M; q.N = N; q.K = K; q.Cin = Cin; q.lda = q.ldb = K; q.ldc = N; q.OH = q.OW = q.IH = q.IW = 1;
   q.gn_partial = &dummy; q.gn_hw = HW; q.gn_groups = groups;
+  q.ws = g_ws_last_bytes ? (float*)&dummy : nullptr; q.ws_bytes = g_ws_last_bytes;
   return (skg_gemm8_eligible(q, mode) ? skg_gemm8_fuses_gn(q, mode) : skg_gemm2_fuses_gn(q, mode)) ? 1 : 0;
 }
 
@@ -286,6 +320,7 @@ static int gemm_impl(const void* A, int lda, const void* B, int ldb, void* C, in
   p.bias = (const half_t*)bias; p.res = (const half_t*)residual; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.flags = flags;
   p.gn_partial = gn_partial; p.gn_hw = HW; p.gn_groups = groups;
+  ws_attach(p, (hipStream_t)stream);
   return launch<MODE_DIRECT>(p, (hipStream_t)stream);
 }
 
@@ -335,6 +370,7 @@ static int conv_impl(const void* X, int ldx, const void* Wp, void* Y, int ldy, i
   p.IH = IH; p.IW = IW; p.Cin = Cin;
   p.gn_partial = gn_partial; p.gn_groups = groups;
   hipStream_t st = (hipStream_t)stream;
+  ws_attach(p, st);
   switch (mode) {
     case SKG_CONV_S1:
       p.OH = IH; p.OW = IW; p.M = rows * p.OH * p.OW; p.gn_hw = p.OH * p.OW;

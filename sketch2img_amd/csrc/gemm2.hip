@@ -33,9 +33,6 @@
 
 namespace {
 
-float* g_ws = nullptr;          // caller-owned split-K workspace (skg_set_workspace)
-size_t g_ws_bytes = 0;
-
 constexpr int BK = 64;
 constexpr unsigned OOB = 0x80000000u;     // voffset that fails the descriptor's range check -> zeros
 
@@ -838,15 +835,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 
 
 // number of K splits for a launch of `nwg` 128-row tiles over KT K-tiles (1 = no split)
-inline int pick_splits(long nwg, int KT, size_t slab_bytes) {
+inline int pick_splits(long nwg, int KT, size_t slab_bytes, const float* ws, size_t ws_bytes) {
   // nwg == 256 is ONE workgroup per CU: nothing overlaps its DMA waits.  Two K halves per CU (16x16-level convs,
   // K >= 8192: 720 -> 990 TFLOP/s) beat the three-stage single workgroup (870) there; below that the fp32 slabs +
   // reduce pass cost more than they hide and the launch takes the three-stage kernel instead
-  if (!g_ws || nwg > 256 || KT < (nwg == 256 ? 128 : 16)) return 1;
+  if (!ws || nwg > 256 || KT < (nwg == 256 ? 128 : 16)) return 1;
   int s = (int)((512 + nwg - 1) / nwg);
   if (s > 8) s = 8;
   while (s > 1 && KT / s < 8) --s;
-  while (s > 1 && (size_t)s * slab_bytes > g_ws_bytes) --s;
+  while (s > 1 && (size_t)s * slab_bytes > ws_bytes) --s;
   return s;
 }
 
@@ -915,14 +912,14 @@ inline bool gn_fusable(const GemmParams& p, int mode) {
   if (!p.gn_partial || p.gn_groups <= 0 || p.gn_hw <= 0 || !eligible(p, mode)) return false;
   if (p.flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) return false;
   const TileCfg t = pick_tile(p.M, p.N, p.K);
-  if (t.bm != 128 || t.bn != 160 || getenv("SKG_GEMM4")) return false;
+  if (t.bm != 128 || t.bn != 160) return false;
   if (p.M % 128 != 0 || p.N % 160 != 0 || p.gn_hw % 128 != 0 || p.M % p.gn_hw != 0 || p.N % p.gn_groups != 0) return false;
   const int cpg = p.N / p.gn_groups;
   if ((cpg & 1) || 160 % cpg != 0) return false;
   if (p.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0) return false;
   if (p.res && (p.ldr % 8 != 0 || (reinterpret_cast<uintptr_t>(p.res) & 15) != 0)) return false;
   const long ntiles = (long)(p.M / 128) * (p.N / 160);
-  return pick_splits(ntiles, p.K / BK, (size_t)p.M * p.N * 4) == 1;
+  return pick_splits(ntiles, p.K / BK, (size_t)p.M * p.N * 4, p.ws, p.ws_bytes) == 1;
 }
 
 template <int BM, int BN, int WGM, int WGN, int MODE>
@@ -939,7 +936,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   operand_bytes(p, MODE, a, b, s);
   const int KT = p.K / BK;
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
-  int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4) : 1;
+  int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4, p.ws, p.ws_bytes) : 1;
   constexpr int NTHR = WGM * WGN * 64;
   if (BM == 128 && BN == 160 && splits == 1 && gn_fusable(p, MODE)) p.flags |= SKG_FLAG_GN_STATS;
   // XCDs per K slice: all 8 without split-K; 8 / ns when the slices line up with XCD boundaries
@@ -962,10 +959,10 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
     const int per = skg_cdiv(KT, splits);
     const int ns = skg_cdiv(KT, per);            // every split non-empty
     hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles * ns, NTHR)), dim3(NTHR),
-                       0, st, p, tiles_n, ntiles * ns, (unsigned)a, (unsigned)b, (unsigned)s, per, g_ws);
+                       0, st, p, tiles_n, ntiles * ns, (unsigned)a, (unsigned)b, (unsigned)s, per, p.ws);
     size_t blocks = ((size_t)p.M * (p.N / 4) + 255) / 256;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p,
-                       (const float*)g_ws, ns);
+                       (const float*)p.ws, ns);
     return;
   }
   // three stages: the 128 x 160 tile when the launch has at most one workgroup per CU anyway (110 KB of LDS), the
@@ -1009,7 +1006,7 @@ void launch_mode(const GemmParams& p, hipStream_t st) {
   const TileCfg t = pick_tile(p.M, p.N, p.K);
   if (t.bm == 256) launch_cfg<256, 320, 2, 4, MODE>(p, st);
   else if (t.bn == 160) {
-    if (p.gn_partial || !skg_gemm4_try_launch(p, MODE, st)) launch_cfg<128, 160, 2, 2, MODE>(p, st);
+    launch_cfg<128, 160, 2, 2, MODE>(p, st);
   }
   else if (t.bn == 128) launch_cfg<128, 128, 2, 2, MODE>(p, st);
   else launch_cfg<128, 64, 2, 2, MODE>(p, st);
@@ -1017,18 +1014,16 @@ void launch_mode(const GemmParams& p, hipStream_t st) {
 
 }  // namespace
 
-void skg_gemm2_set_workspace(float* ws, size_t bytes) { g_ws = ws; g_ws_bytes = bytes; }
-
 // tile width of the instantiation a plain (no fused GEGLU) launch of this shape runs, + 10000 when it is the
 // three-stage one (bench.py / tools spell the rocprofv3 kernel name from this)
-int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode) {
+int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode, size_t ws_bytes) {
   if (K % BK != 0 || M < 1 || (mode != MODE_DIRECT && Cin % BK != 0)) return 0;
   const TileCfg t = pick_tile(M, N, K);
   const int KT = K / BK;
   const long ntiles = (long)skg_cdiv(M, t.bm) * skg_cdiv(N, t.bn);
   const bool three = t.bm == 128 && (t.bn == 160 || t.bn == 64) && (mode == MODE_DIRECT || mode == MODE_S1) &&
                      !getenv("SKG_NO_NS3") && KT >= 4 && (t.bn == 64 || ntiles <= 256) &&
-                     pick_splits(ntiles, KT, (size_t)M * N * 4) == 1;
+                     pick_splits(ntiles, KT, (size_t)M * N * 4, ws_bytes ? (const float*)1 : nullptr, ws_bytes) == 1;
   return t.bn + (three ? 10000 : 0);
 }
 

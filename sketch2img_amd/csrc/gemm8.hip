@@ -358,13 +358,17 @@ inline bool operand_bytes(const GemmParams& p, int mode, unsigned long long& a, 
   return a < 0x7fffffffull && b < 0x7fffffffull;
 }
 
-// SKG_GEMM8 (read once): 0 = off; 1 = both tiles for every eligible shape (experiments); 2 = the 256 x 320 tile for
+// SKG_GEMM8 (read once): 0 = off; 1 = both tiles for every eligible shape (lab build only: `make lab`; the 256 x 160 form
+// and the probe instantiations are not part of libskg.so); 2 = the 256 x 320 tile for
 // long-K launches (K >= 1024) of both modes; unset = what ships: the 256 x 320 tile for 3x3 convolutions only - same
 // box, interleaved (tools/gemm8_bench.py, profiles/r02_gemm8_320.txt): conv 640->320 @ 64x64 213-221 -> 199 us, 960->320
 // 306-327 -> 275-292 us (1.24-1.32 PFLOP/s), 320->320 124-127 -> 121 us; the FF2 GEMM (K = 1280) is 5 % SLOWER with the
 // direct-store epilogue and stays on gemm2.hip, like every shape the 256 x 160 tile would take.
 int gemm8_mode() {
   static const int v = getenv("SKG_GEMM8") ? atoi(getenv("SKG_GEMM8")) : 3;
+#ifndef SKG_LAB
+  if (v == 1) return 3;
+#endif
   return v;
 }
 
@@ -393,6 +397,11 @@ int gemm8_tile(const GemmParams& p, int mode) {
 // the 256 x 320 instantiation writes the GroupNorm partials itself when every tile is whole, the 128-row halves stay
 // inside one sample and no group straddles a wave's 80 columns
 inline bool gn_fusable8(const GemmParams& p, int mode) {
+#ifdef SKG_LAB
+  // probe instantiations (SKG_G8_EXP) have no statistics epilogue: the caller must run the stand-alone pass
+  static const bool probe = getenv("SKG_G8_EXP") && atoi(getenv("SKG_G8_EXP")) != 0;
+  if (probe) return false;
+#endif
   if (!p.gn_partial || p.gn_groups <= 0 || p.gn_hw <= 0 || mode != MODE_S1 || gemm8_tile(p, mode) != 320) return false;
   if (p.M % 256 != 0 || p.gn_hw % 128 != 0 || p.M % p.gn_hw != 0 || p.N % p.gn_groups != 0) return false;
   const int cpg = p.N / p.gn_groups;
@@ -407,18 +416,24 @@ void launch8(const GemmParams& p_in, int mode, hipStream_t st) {
   operand_bytes(p, mode, a, b, s);
   const int tiles_n = p.N / BN;
   const int ntiles = skg_cdiv(p.M, BM) * tiles_n;
+#ifdef SKG_LAB
   static const int exp = getenv("SKG_G8_EXP") ? atoi(getenv("SKG_G8_EXP")) : 0;
+#else
+  constexpr int exp = 0;
+#endif
 #define G8_LAUNCH(M_, E_) hipLaunchKernelGGL((gemm8_kernel<BN, M_, E_>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles, \
                                              (unsigned)a, (unsigned)b, (unsigned)s)
   if (mode == MODE_DIRECT) {
     G8_LAUNCH(MODE_DIRECT, 0);
   } else {
     switch (exp) {
+#ifdef SKG_LAB
       case 1: G8_LAUNCH(MODE_S1, 1); break;
       case 2: G8_LAUNCH(MODE_S1, 2); break;
       case 3: G8_LAUNCH(MODE_S1, 3); break;
       case 4: G8_LAUNCH(MODE_S1, 4); break;
       case 8: G8_LAUNCH(MODE_S1, 8); break;
+#endif
       default:
         if constexpr (BN == 320) {
           if (p.flags & SKG_FLAG_GN_STATS) {
@@ -444,6 +459,10 @@ bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st) {
   const int bn = gemm8_tile(p, mode);
   if (!bn) return false;
   if (bn == 320) launch8<320>(p, mode, st);
+#ifdef SKG_LAB
   else launch8<160>(p, mode, st);
+#else
+  else return false;
+#endif
   return true;
 }

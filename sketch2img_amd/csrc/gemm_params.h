@@ -18,17 +18,17 @@ struct GemmParams {
   float* gn_partial; int gn_hw, gn_groups;
   // fused GEGLU that also keeps the pre-activation (skg_gemm_f16_geglu_keep): H [M][N] in the interleaved pack order
   half_t* aux; int ldaux;
+  // split-K workspace of the launch stream (host side: filled by the entry points from the per-stream registry of
+  // skg_set_workspace; the kernels get the slab pointer as an argument)
+  float* ws; size_t ws_bytes;
 };
 constexpr unsigned SKG_FLAG_GN_STATS = 0x8000u;      // internal: set by the launcher when the chosen kernel fuses them
 
 // v2 (gemm2.hip): returns true and launches if the shape is eligible, false otherwise (nothing launched).
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st);
 // column width of the tile v2 would use for an M x N output, or 0 if v2 does not take this shape
-int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode);
-void skg_gemm2_set_workspace(float* ws, size_t bytes);
-// v4 (gemm4.hip): persistent wave-specialised 128 x 160 kernel (DIRECT mode, plain epilogue); false = out of scope.
-bool skg_gemm4_try_launch(const GemmParams& p, int mode, hipStream_t st);
-// v8 (gemm8.hip): 256 x 160 tiles, one 8-wave workgroup per CU, ping-pong schedule (DIRECT / S1, plain epilogue).
+int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode, size_t ws_bytes);
+// v8 (gemm8.hip): 256 x 320 tiles, one 8-wave workgroup per CU, ping-pong schedule (S1 convolutions of the 64 x 64 level).
 bool skg_gemm8_eligible(const GemmParams& p, int mode);
 int skg_gemm8_tile_n(const GemmParams& p, int mode);      // 160 / 320, or 0 when v8 does not take the launch
 bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st);

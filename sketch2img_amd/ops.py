@@ -18,30 +18,70 @@ CONV_S1, CONV_S2, CONV_UP2, CONV_S2T, CONV_S2A = 0, 1, 2, 3, 4
 
 
 _workspace = {}
-_workspace_key = None
 WORKSPACE_BYTES = 128 << 20
+_capture_owner = None      # set by private_buffers(): scratch / workspace owned by one hipGraph set
 
 
 def _stream() -> int:
-    """Current HIP stream; also hands libskg.so the split-K workspace of the CURRENT (device, stream): one slab per
-    stream, because launches on different streams may run concurrently (several pipelines in one process, a graph
-    capture stream next to the eager stream); the library holds one pointer that it reads at
-    launch time, so it is re-pointed whenever the (device, stream) of the caller changes.  Launches on ONE stream are
-    ordered, so they can share their stream's slab and scratch buffers."""
-    global _workspace_key
+    """Current HIP stream.  The first launch on a (device, stream) registers that stream's split-K workspace with
+    libskg.so (skg_set_workspace keeps one slab per stream: launches on different streams may run concurrently -
+    several pipelines in one process, a graph capture stream next to the eager stream - and never share a slab;
+    launches on ONE stream are ordered, so they share their stream's slab and scratch buffers)."""
     st = torch.cuda.current_stream()
     key = (st.device.index, st.cuda_stream)
-    if key != _workspace_key:
-        if key not in _workspace:
+    if key not in _workspace:
+        with torch.cuda.device(st.device):
             _workspace[key] = torch.empty(WORKSPACE_BYTES // 4, device=st.device, dtype=torch.float32)
-        check(lib.skg_set_workspace(_workspace[key].data_ptr(), WORKSPACE_BYTES), "skg_set_workspace")
-        _workspace_key = key
+            check(lib.skg_set_workspace(_workspace[key].data_ptr(), WORKSPACE_BYTES, st.cuda_stream), "skg_set_workspace")
     return st.cuda_stream
+
+
+class private_buffers:
+    """``with private_buffers(owner):`` inside a ``torch.cuda.graph`` capture - the launches captured in the block use a
+    split-K workspace and scratch buffers that belong to `owner` (a dict that keeps them alive) instead of the capture
+    stream's shared ones, so two graph sets captured on torch's one capture stream can be replayed concurrently on
+    different streams.  The workspace must be allocated BEFORE the capture starts: ``prepare(owner, dev)``."""
+
+    @staticmethod
+    def prepare(owner: dict, dev):
+        owner["ws"] = torch.empty(WORKSPACE_BYTES // 4, device=dev, dtype=torch.float32)
+        owner["scratch"] = {}
+
+    def __init__(self, owner: dict):
+        self.owner = owner
+
+    def __enter__(self):
+        global _capture_owner
+        st = torch.cuda.current_stream()
+        self.key = (st.device.index, st.cuda_stream)
+        self.prev_owner, _capture_owner = _capture_owner, self.owner
+        self.prev_ws = _workspace.get(self.key)
+        _workspace[self.key] = self.owner["ws"]
+        check(lib.skg_set_workspace(self.owner["ws"].data_ptr(), WORKSPACE_BYTES, st.cuda_stream), "skg_set_workspace")
+        return self
+
+    def __exit__(self, *exc):
+        global _capture_owner
+        _capture_owner = self.prev_owner
+        if self.prev_ws is None:
+            del _workspace[self.key]
+            check(lib.skg_set_workspace(None, 0, self.key[1]), "skg_set_workspace")
+        else:
+            _workspace[self.key] = self.prev_ws
+            check(lib.skg_set_workspace(self.prev_ws.data_ptr(), WORKSPACE_BYTES, self.key[1]), "skg_set_workspace")
 
 
 def _skey(dev):
     """Scratch-buffer key part: device + current stream (see _stream)."""
     return (str(dev), torch.cuda.current_stream().cuda_stream)
+
+
+def _scratch_buf(key, n: int, dev) -> torch.Tensor:
+    """fp32 scratch of n floats for `key`: the current stream's, or - inside private_buffers() - the graph set's own."""
+    store = _scratch if _capture_owner is None else _capture_owner["scratch"]
+    if key not in store:
+        store[key] = torch.empty(n, device=dev, dtype=torch.float32)
+    return store[key]
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -159,10 +199,7 @@ _scratch = {}
 
 def _gn_scratch(rows: int, groups: int, dev) -> torch.Tensor:
     n = lib.skg_groupnorm_scratch_floats(rows, groups)
-    key = ("gn", _skey(dev), n)
-    if key not in _scratch:
-        _scratch[key] = torch.empty(n, device=dev, dtype=torch.float32)
-    return _scratch[key]
+    return _scratch_buf(("gn", _skey(dev), n), n, dev)
 
 
 def groupnorm_stats(X, rows, HW, groups, eps, stats=None):
@@ -448,10 +485,7 @@ def lgp_layer0_scatter(dZ, rows, h, s, H0):
 
 def _bn_scratch(samples, C, dev):
     n = lib.skg_bn_scratch_floats(samples, C)
-    key = ("bn", _skey(dev), n)
-    if key not in _scratch:
-        _scratch[key] = torch.empty(n, device=dev, dtype=torch.float32)
-    return _scratch[key]
+    return _scratch_buf(("bn", _skey(dev), n), n, dev)
 
 
 def bn_stats(X, samples, segs, seg_rows, eps=1e-5, running_mean=None, running_var=None):
@@ -507,10 +541,8 @@ def colsum(X, scale: float = 1.0):
     _f16(X)
     M, C = X.shape
     out = torch.empty(C, device=X.device, dtype=torch.float32)
-    key = ("colsum", _skey(X.device), C)
-    if key not in _scratch:
-        _scratch[key] = torch.empty(lib.skg_colsum_scratch_floats(C), device=X.device, dtype=torch.float32)
-    check(lib.skg_colsum_f16(_p(X), _ld(X), M, C, scale, _p(out), _p(_scratch[key]), _stream()), "skg_colsum_f16")
+    scr = _scratch_buf(("colsum", _skey(X.device), C), lib.skg_colsum_scratch_floats(C), X.device)
+    check(lib.skg_colsum_f16(_p(X), _ld(X), M, C, scale, _p(out), _p(scr), _stream()), "skg_colsum_f16")
     return out
 
 

@@ -118,7 +118,8 @@ class HipSampler:
         self.last_latents: Optional[torch.Tensor] = None
         self._x0_before: Optional[torch.Tensor] = None      # DPM-Solver++ history (one x0 prediction)
         self._seen = 0
-        self._graphs: dict = {}
+        self._graphs: dict = {}                   # insertion-ordered: least recently used first
+        self.max_graph_sets = 4
 
     def reset_history(self):
         self._x0_before, self._seen = None, 0
@@ -185,15 +186,31 @@ class HipSampler:
         step goes to torch's current stream, which is the capturing stream inside ``torch.cuda.graph``; nothing on the
         step path allocates outside torch's (graph-private) pool or synchronises with the host."""
         T = len(tab.timesteps)
+        inj = self.unet.inject
         key = (type(tab).__name__, tuple(int(t) for t in tab.timesteps), tuple(x.shape), tgt is None,
-               float(guidance_scale), float(beta), id(self.unet.inject), self.unet.ctx is not None and id(self.unet.ctx))
+               float(guidance_scale), float(beta))
+        # What a captured step points at besides the static latents: the text context's K / V (prepare_context builds a
+        # NEW dict per prompt) and the injector's per-image K / V (set_state / set_res_samples build a new dict per sketch)
+        # and scale.  The entry keeps STRONG references to those objects and is valid only while the pipeline still holds
+        # the very same ones - ids alone could be recycled after the old objects were freed (ADVICE r2).
         ent = self._graphs.get(key)
+        if ent is not None and not (ent["ctx"] is self.unet.ctx and ent["inject"] is inj and
+                                    (inj is None or (ent["per_image"] is inj.per_image and ent["scale"] == inj.scale))):
+            del self._graphs[key]          # stale: prompt, sketch or scale changed since the capture
+            ent = None
+        if ent is not None:
+            self._graphs[key] = self._graphs.pop(key)       # most recently used last
         if ent is None:
+            while len(self._graphs) >= self.max_graph_sets:   # LRU bound: every set owns T graphs + a private pool
+                self._graphs.pop(next(iter(self._graphs)))
+            owner: dict = {}
+            ops.private_buffers.prepare(owner, x.device)
             xs, ns = torch.empty_like(x), torch.empty_like(x)
             ts = None if tgt is None else torch.empty_like(tgt)
             x0b = torch.zeros_like(x)
-            # one eager pass first: lazily created scratch / workspace buffers and the per-timestep bias vectors must
-            # exist before a capture (allocations inside a capture belong to the graph's pool)
+            # one eager pass first: the per-timestep bias vectors and every lazily built per-image buffer must exist before
+            # a capture.  The split-K workspace of the captured launches is the set's own (allocated above, outside the
+            # capture); scratch buffers first touched inside the capture come from the set's private pool.
             xs.copy_(x); ns.copy_(x)
             if ts is not None:
                 ts.copy_(tgt)
@@ -213,14 +230,16 @@ class HipSampler:
             self._x0_before, self._seen = x0b, 0
             for i in range(T):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                with torch.cuda.graph(g, pool=pool), ops.private_buffers(owner):
                     xn, _, aux = self.step(xs, ns, ts, tab, i, guidance_scale, beta)
                     xs.copy_(xn)
                 graphs.append(g)
                 auxs.append(aux)
             if saved is not None:       # captures do not execute, but keep the Python-side counters where they were
                 self.lgp.num_batches_tracked = list(saved[2])
-            ent = self._graphs[key] = dict(graphs=graphs, auxs=auxs, xs=xs, ns=ns, ts=ts, x0b=x0b)
+            ent = self._graphs[key] = dict(graphs=graphs, auxs=auxs, xs=xs, ns=ns, ts=ts, x0b=x0b, owner=owner,
+                                           ctx=self.unet.ctx, inject=inj, per_image=None if inj is None else inj.per_image,
+                                           scale=None if inj is None else inj.scale)
         ent["xs"].copy_(x); ent["ns"].copy_(x)
         if tgt is not None:
             ent["ts"].copy_(tgt)

@@ -282,6 +282,42 @@ def test_graph_replay_with_injected_attention_is_bit_identical(variant):
     assert not torch.equal(plain, a)
 
 
+def test_graph_cache_follows_prompt_sketch_and_scale_changes():
+    """a captured step points at the prompt's K / V and the injector's per-image K / V.  A second image with
+    another prompt, another sketch or another scale must not replay the old graphs: every graphed call equals the eager
+    call made in the same state, the cache stays bounded, and going back to an earlier state re-captures (no stale hit)."""
+    from oracle import unet as ounet
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import TINY
+    from sketch2img_amd.inject import HipInjector
+    from sketch2img_amd.sampler import DDIMTables, HipSampler
+    from sketch2img_amd.unet import HipUNet
+    W = ounet.init_weights(ounet.TINY)
+    g = torch.Generator().manual_seed(5)
+    h, T, S = 32, 3, 1
+    x0 = torch.randn(S, 4, h, h, generator=g)
+    prompts = [torch.randn(2 * S, 77, TINY.cross_attention_dim, generator=g).half().float() for _ in range(2)]
+    net = HipUNet(TINY, W, DEV, need_backward=False)
+    inj = HipInjector(TINY, synthetic.satmixin_state_dict(TINY, "sketch"), "sketch", DEV)
+    net.inject = inj
+    tab = DDIMTables.make(T)
+    gs = HipSampler(net, None, use_graphs=True)
+    gs.max_graph_sets = 2
+    seen = []
+    for prompt, sketch, scale in [(0, 0, 1.0), (1, 0, 1.0), (1, 3, 1.0), (1, 3, 0.5), (0, 0, 1.0)]:
+        net.prepare_context(prompts[prompt])
+        inj.set_res_samples(synthetic.res_samples(TINY, sketch, S, h))
+        inj.set_scale(scale)
+        e = HipSampler(net, None).sample(x0, None, T, tables=tab).clone()
+        a = gs.sample(x0, None, T, tables=tab).clone()
+        b = gs.sample(x0, None, T, tables=tab).clone()          # replay of the graphs captured for THIS state
+        assert torch.equal(e, a) and torch.equal(e, b), (prompt, sketch, scale)
+        seen.append(e)
+        assert len(gs._graphs) <= 2
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2]) and not torch.equal(seen[2], seen[3])
+    assert torch.equal(seen[0], seen[4])
+
+
 # ------------------------------------------------------------------------------------- N > 1 on real hardware
 def _bench(args, env=None, nproc=1, port=29611):
     cmd = [sys.executable]
