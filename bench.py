@@ -294,6 +294,12 @@ def cpu_baseline(extrapolate_c2: bool = True):
         out = og.sample_one(cfg, W, dict(sd), ehs, x0, tgt, T)
         runs.append(time.time() - t0)
     assert torch.isfinite(out).all()
+    # end-to-end parity number carried by every bench line: the same architecture / shape / seed,
+    # UNGUIDED (a free-running guided trajectory separates chaotically), oracle here, HIP in main()
+    t0 = time.time()
+    with torch.no_grad():
+        ref_unguided = og.sample_one(cfg, W, None, ehs, x0, None, T)
+    t_unguided = time.time() - t0
     timed = runs[1:]
     mean = sum(timed) / len(timed)
     res = dict(value=1.0 / mean, unit="images/s", cores=cores, kind="port",
@@ -301,7 +307,8 @@ def cpu_baseline(extrapolate_c2: bool = True):
                       f"LGP guidance on steps 0..5, as-written formulation (autograd through both CFG rows), SD1.5 fp32 "
                       f"eager PyTorch on {cores} host threads; 1 warm-up ({runs[0]:.1f} s) + 3 timed runs "
                       f"({', '.join(f'{t:.1f}' for t in timed)} s), value = 1 / mean",
-               runs_s=timed, warmup_s=runs[0], tflop_per_image=6.11)
+               runs_s=timed, warmup_s=runs[0], tflop_per_image=6.11,
+               _parity=dict(x0=x0, ehs=ehs, ref=ref_unguided, T=T, seconds=t_unguided))
     if extrapolate_c2:
         h = 64
         x, tgt = synthetic.initial_latents(0, 1, h), synthetic.sketch_targets(0, 1, h)
@@ -348,7 +355,7 @@ def build_workload(args, rank, world, dev, dist):
 
     def weights(make, shapes=None):
         sd = make() if rank == 0 else None
-        return broadcast_state_dict(sd, shapes, dev, src=0) if world > 1 else sd
+        return broadcast_state_dict(sd, shapes, dev, src=0) if dist is not None else sd
 
     sd_unet = weights(lambda: synthetic.unet_state_dict(cfg), synthetic.unet_param_shapes(cfg))
     net = HipUNet(cfg, sd_unet, dev, need_backward=(C == 2))
@@ -388,7 +395,7 @@ def build_workload(args, rank, world, dev, dist):
             x = vae.decode_to_u8(x)                      # [S, 8h, 8h, 3] uint8: what the final gather carries
             e1.record()
             decode_events.append((e0, e1))
-        if world > 1:
+        if dist is not None:
             got = (gather_images if vae is not None else gather_latents)(x, world, dst=0)
             return x if got is None else torch.cat(got)
         return x
@@ -409,9 +416,14 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # SKG_BENCH_FORCE_DIST=1: initialise the process group even at world size 1, so that the weight broadcast and the
+    # image gather issue real RCCL calls on device tensors on the one GPU a test box has (tests/test_gpu_configs.py)
+    if world > 1 or os.environ.get("SKG_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29655")
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)    # RCCL over xGMI
         else:
@@ -426,7 +438,7 @@ def main():
     t_setup = time.time() - t_setup
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
 
     out = None
@@ -439,13 +451,13 @@ def main():
         out = one_batch()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     lat_final = wl["sampler"].last_latents
     finite = bool(torch.isfinite(lat_final).all())
-    if world > 1:
+    if dist is not None:
         ft = torch.tensor([int(finite)], device=dev)
         dist.all_reduce(ft, op=dist.ReduceOp.MIN)
         finite = bool(int(ft))
@@ -494,6 +506,21 @@ def main():
                                    source=f"committed {f} (rocprofv3 --kernel-trace --stats of this command)")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
+        par = cpu.pop("_parity")
+        if C == 2:
+            # the HIP path on the oracle's inputs: full SD1.5, 1 sample, 32 x 32 latents, 10 unguided DDIM steps, free running
+            from sketch2img_amd.sampler import HipSampler
+            net = wl["net"]
+            saved_ctx = net.ctx
+            net.prepare_context(par["ehs"])
+            got = HipSampler(net, None).sample(par["x0"], None, par["T"]).cpu()
+            net.ctx = saved_ctx
+            d = got - par["ref"]
+            cpu["hip_vs_oracle_rel"] = float(d.norm() / par["ref"].norm())
+            cpu["hip_vs_oracle_max_abs"] = float(d.abs().max())
+            cpu["hip_vs_oracle"] = ("end latents of the HIP path vs the fp32 CPU oracle on identical inputs: full SD1.5, 1 sample, "
+                                    f"256x256, {par['T']} UNGUIDED DDIM steps, CFG 7.5, free running (oracle run: {par['seconds']:.1f} s); "
+                                    "relative Frobenius / max abs")
 
     if rank == 0:
         sched = "DPM-Solver++ 2M" if args.scheduler == "dpm" else "DDIM"
@@ -511,8 +538,11 @@ def main():
                        "output": ("decoded uint8 images [S, H, W, 3] (VAE decode on-rank, inside the timed region"
                                   + (", gathered on rank 0)" if world > 1 else ")")) if args.gather == "images"
                        else "fp32 latents (no decode)",
-                       "parallelism": f"replicas x{world} (samples sharded, weights broadcast, "
-                                      f"{'decoded images' if args.gather == 'images' else 'latents'} gathered)"},
+                       "parallelism": (f"replicas x{world} (samples sharded, weights broadcast, "
+                                       f"{'decoded images' if args.gather == 'images' else 'latents'} gathered"
+                                       + (f"; torch.distributed backend {dist.get_backend()}"
+                                          + (" = RCCL" if dist.get_backend() == "nccl" else "") + ")" if dist is not None
+                                          else "; single process, no process group)"))},
             "ms_per_image": dt / args.steps / S * 1e3,
             "decode_ms_per_step": decode_s / args.steps * 1e3 if wl["decode_events"] else None,
             "value_excluding_decode": world * S * args.steps / (dt - decode_s) if wl["decode_events"] and world == 1 else None,
@@ -521,7 +551,7 @@ def main():
             "setup_s": t_setup, "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(res))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
     if not finite:
         sys.exit("bench.py: non-finite latents - the throughput above is INVALID")

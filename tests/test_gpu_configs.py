@@ -216,6 +216,68 @@ def test_tiny_50_step_trajectories_unguided_bounded_guided_reported():
     assert abs(l_hip - l_ref) < 0.25 * l_ref
 
 
+# ------------------------------------------------------------------ full architecture, config[0]'s trajectory shape
+def test_sd15_config0_trajectories_vs_oracle():
+    """VERDICT r2 missing #4: trajectory-level parity on the REAL architecture.  BASELINE configs[0]'s shape - full SD1.5
+    (860 M parameters), one sketch, 256x256 (32x32 latents), 10 DDIM steps, guidance on steps 0..5 - against
+    oracle.guidance.sample_one (the loop of modules/pipeline.py:83-115):
+      (a) UNGUIDED, free running: end latents of the HIP loop vs the oracle's, tight bound (per-step errors do not amplify);
+      (b) GUIDED, teacher-forced per step from the oracle's trace (so that the chaotic separation of guided trajectories,
+          DESIGN.md 5, does not enter): CFG eps, the norm of the update (alpha = sqrt(2) ||dx|| / ||g|| * beta), its
+          direction, the loss - at every one of the 10 steps, 6 of them guided."""
+    from oracle import guidance as og, unet as ounet
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import SD15, tap_channels
+    from sketch2img_amd.lgp import HipLGP
+    from sketch2img_amd.sampler import DDIMTables, HipSampler
+    from sketch2img_amd.unet import HipUNet
+    _threads()
+    cfg = ounet.SD15
+    W = synthetic.unet_state_dict(SD15)
+    sd = synthetic.lgp_state_dict(synthetic.lgp_input_dim(SD15))
+    ehs = synthetic.text_embeddings(1)
+    h, T = 32, 10
+    x0, tgt = synthetic.initial_latents(0, 1, h), synthetic.sketch_targets(0, 1, h)
+    net = HipUNet(SD15, W, DEV)
+    net.prepare_context(ehs)
+    tab = DDIMTables.make(T)
+    # (a) unguided, free running
+    with torch.no_grad():
+        ref_u = og.sample_one(cfg, W, None, ehs, x0, None, T)
+    out_u = HipSampler(net, None).sample(x0, None, T, tables=tab).cpu()
+    ru, mu = report("sd15 config[0] unguided 10-step end latents, free running", out_u, ref_u)
+    assert torch.isfinite(out_u).all() and ru < 5e-3
+    # (b) guided, teacher-forced
+    tr = []
+    og.sample_one(cfg, W, dict(sd), ehs, x0, tgt, T, trace=tr)
+    assert [t["aux"] is not None for t in tr] == [i <= 5 for i in range(T)]              # Q6: i <= 0.5 T
+    sampler = HipSampler(net, HipLGP(sd, tap_channels(SD15), DEV))
+    net.prepare_timesteps(tab.timesteps.tolist())
+    noise = x0.to(DEV)
+    worst = dict(eps=0.0, nr=0.0, cos=1.0, loss=0.0)
+    for i in range(T):
+        x_i = x0 if i == 0 else tr[i - 1]["latents"]
+        xp, eps, aux = sampler.step(x_i.to(DEV).contiguous(), noise, tgt.to(DEV), tab, i, 7.5, 1.6, want_eps=True)
+        e, _ = report(f"sd15 config[0] step{i} CFG eps (teacher-forced)", eps.cpu(), tr[i]["eps"])
+        worst["eps"] = max(worst["eps"], e)
+        assert e < 1.4e-2                                # CFG-combined eps: 8.4 x the single-row error (DESIGN.md 5)
+        if tr[i]["aux"] is None:
+            assert aux is None
+            assert report(f"sd15 config[0] step{i} x_prev", xp.cpu(), tr[i]["latents"])[0] < 2e-3
+            continue
+        upd_ref = float(tr[i]["aux"]["alpha"]) * tr[i]["aux"]["cond_grad"]
+        upd = xp.cpu() - (tr[i]["latents"] - upd_ref)
+        nr = float(upd.norm() / upd_ref.norm())
+        cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm()))
+        dl = abs(float(aux[0, 3]) - float(tr[i]["aux"]["loss"])) / float(tr[i]["aux"]["loss"])
+        print(f"[parity] sd15 config[0] step{i} update: |hip|/|oracle|={nr:.4f} cos={cos:.5f} "
+              f"loss hip={float(aux[0, 3]):.4e} oracle={float(tr[i]['aux']['loss']):.4e}")
+        worst["nr"], worst["cos"], worst["loss"] = max(worst["nr"], abs(nr - 1)), min(worst["cos"], cos), max(worst["loss"], dl)
+        assert abs(nr - 1) < 2e-2 and cos > 0.997 and dl < 2e-2
+    print(f"[parity] sd15 config[0] guided, worst over 10 steps: eps rel {worst['eps']:.2e}, | |upd| ratio - 1 | {worst['nr']:.2e}, "
+          f"cos {worst['cos']:.5f}, loss rel {worst['loss']:.2e}")
+
+
 # ----------------------------------------------------------------------------------------------- hipGraph replay
 @pytest.mark.parametrize("sched", ["ddim", "dpm"])
 def test_graph_replay_is_bit_identical_to_eager(sched):
@@ -319,9 +381,9 @@ def test_graph_cache_follows_prompt_sketch_and_scale_changes():
 
 
 # ------------------------------------------------------------------------------------- N > 1 on real hardware
-def _bench(args, env=None, nproc=1, port=29611):
+def _bench(args, env=None, nproc=1, port=29611, launcher=False):
     cmd = [sys.executable]
-    if nproc > 1:
+    if nproc > 1 or launcher:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                 "--master-port", str(port)]
     cmd += [os.path.join(ROOT, "bench.py")] + args
@@ -354,6 +416,22 @@ def test_two_ranks_on_one_device_equal_one_rank_bitwise(tmp_path):
         ref = torch.load(one)["images"]
         assert torch.equal(got[i:i + 1], ref), f"global sample {i}: 2-rank gather differs from the 1-rank result"
     assert not torch.equal(got[0], got[1])
+
+
+def test_rccl_path_executes_on_one_gpu(tmp_path):
+    """VERDICT r2 missing #2: the `nccl` backend (= RCCL) had never executed.  bench.py under torch.distributed.run with ONE
+    rank and SKG_BENCH_FORCE_DIST=1 initialises the process group on the device and sends the weight broadcast
+    (broadcast_state_dict: UNet / LGP / VAE buckets, int64 buffers included) and the final gather of the decoded uint8 images
+    through real RCCL calls on device tensors; the gathered images must equal the plain single-process run bit for bit."""
+    common = ["--steps", "1", "--warmup", "0", "--ddim-steps", "3", "--samples-per-gpu", "2", "--no-cpu-baseline",
+              "--no-roofline", "--gpus", "1"]
+    a, b = tmp_path / "rccl.pt", tmp_path / "plain.pt"
+    d = _bench(common + ["--dump-images", str(a)], env={"SKG_BENCH_FORCE_DIST": "1"}, launcher=True, port=29633)
+    assert "backend nccl = RCCL" in d["config"]["parallelism"] and d["outputs_finite"] and d["out_shape"] == [2, 512, 512, 3]
+    p = _bench(common + ["--dump-images", str(b)])
+    assert "no process group" in p["config"]["parallelism"]
+    ia, ib = torch.load(a), torch.load(b)
+    assert ia["images"].dtype == torch.uint8 and torch.equal(ia["images"], ib["images"]) and torch.equal(ia["latents"], ib["latents"])
 
 
 @pytest.mark.parametrize("config", [4, 5])

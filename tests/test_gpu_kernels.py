@@ -132,11 +132,10 @@ def test_forced_tiles(force, env):
     assert r.returncode == 0 and "ALL OK" in r.stdout
 
 
-def test_gemm8_pingpong_320_tile_convolutions():
+def test_gemm8_pingpong_320_tile_convolutions(ops):
     """The 256 x 320 ping-pong tile (gemm8.hip) is what the 64 x 64-level 3x3 convolutions run by default: check that
     the dispatcher really takes it for those shapes and that it agrees with F.conv2d (bias, residual, ragged last tile).
     (The withdrawn 256 x 160 form and the persistent gemm4 kernel live in tools/lab/, outside libskg.so.)"""
-    import torch.nn.functional as F
     from sketch2img_amd._lib import lib
     g = torch.Generator().manual_seed(17)
     for rows, hw, cin, cout, res in [(16, 64, 64, 320, True), (15, 64, 128, 320, False), (16, 64, 320, 320, True)]:
@@ -144,10 +143,10 @@ def test_gemm8_pingpong_320_tile_convolutions():
         x = torch.randn(rows, cin, hw, hw, generator=g).half()
         w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
         b = torch.randn(cout, generator=g).half()
-        r = torch.randn(rows * hw * hw, cout, generator=g).half().to(DEV) if res else None
-        out = ops.conv3x3(x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(DEV),
-                          w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(DEV), rows, hw, hw, 0, bias=b.to(DEV), residual=r)
-        ref = F.conv2d(x.float().to(DEV), w.float().to(DEV), b.float().to(DEV), padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+        r = torch.randn(rows * hw * hw, cout, generator=g).half().to(dev()) if res else None
+        out = ops.conv3x3(x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(dev()),
+                          w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(dev()), rows, hw, hw, 0, bias=b.to(dev()), residual=r)
+        ref = F.conv2d(x.float().to(dev()), w.float().to(dev()), b.float().to(dev()), padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
         if res:
             ref = ref + r.float()
         e = float((out.float() - ref).norm() / ref.norm())

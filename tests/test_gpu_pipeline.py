@@ -87,9 +87,13 @@ def test_guidance_step_matches_reference_golden(h):
     r, _ = report(f"guidance update vs reference h{h}", upd, upd_ref)
     expect = math.sqrt(2.0) * float((x - lat).norm()) * 1.6
     assert abs(float(upd.norm()) - expect) / expect < 2e-3
-    # same bound as the oracle-vs-reference test: ReLU-gate sensitivity to 1-ulp forward differences
-    assert r < 0.06
-    assert float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm())) > 0.998
+    # Measured 2.81e-2 (h = 8) / 2.07e-2 (h = 16); bound = measured x 1.5.  tools/lgp_rounding_floor.py (8 seeds, CPU, the
+    # reference imported) separates what this is made of: ANY two fp16 realisations of this ReLU -> BatchNorm x 4 MLP differ
+    # in ~0.006 % of their ReLU gates and by 2-4 % in direction (oracle-as-written vs reference 3.1 %, re-associated layer 0
+    # vs reference 3.7 %, fp64 truth vs reference 3.7 %), while the moved rounding point of the re-associated layer 0 with
+    # the gates held fixed is 0.11 % - the floor is the gates, not the re-association.
+    assert r < 4.2e-2
+    assert float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm())) > 0.9991
 
 
 def test_lgp_forward_backward_vs_oracle_two_samples():
