@@ -223,7 +223,11 @@ class fp16_storage:
 
 
 def _r(x: torch.Tensor, kind: str = "lin") -> torch.Tensor:
-    return x.half().to(x.dtype) if (_FP16_STORAGE and kind not in _FP16_SKIP) else x
+    """kind "lin_n" / "lin_a": a conv / Linear output consumed by a norm or a sum (lin_n: conv1 -> norm2, conv_shortcut ->
+    residual sum) or by an activation / matmul (lin_a: FF1 -> GEGLU -> FF2); skip=("lin",) covers both."""
+    if not _FP16_STORAGE or kind in _FP16_SKIP or kind.split("_")[0] in _FP16_SKIP:
+        return x
+    return x.half().to(x.dtype)
 
 
 def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -242,11 +246,11 @@ def resnet_forward(cfg, W, p, x, temb_act):
     h = _r(F.silu(_gn(x, W, p + ".norm1", cfg.norm_groups, 1e-5)), "norm")
     tproj = _r(F.linear(temb_act, W[p + ".time_emb_proj.weight"], W[p + ".time_emb_proj.bias"]), "temb")
     tb = _r(tproj + W[p + ".conv1.bias"], "temb")
-    h = _r(F.conv2d(h, W[p + ".conv1.weight"], None, padding=1) + tb[:, :, None, None])
+    h = _r(F.conv2d(h, W[p + ".conv1.weight"], None, padding=1) + tb[:, :, None, None], "lin_n")
     h = _r(F.silu(_gn(h, W, p + ".norm2", cfg.norm_groups, 1e-5)), "norm")
     h = F.conv2d(h, W[p + ".conv2.weight"], W[p + ".conv2.bias"], padding=1)
     if (p + ".conv_shortcut.weight") in W:
-        x = _r(F.conv2d(x, W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"]))
+        x = _r(F.conv2d(x, W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"]), "lin_n")
     return _r(x + h, "res")
 
 
@@ -292,9 +296,9 @@ def transformer_block_forward(W, p, x, ehs, heads, inject: Optional[InjectFn] = 
     n = _r(F.layer_norm(x, (c,), W[p + ".norm2.weight"], W[p + ".norm2.bias"], 1e-5), "norm")
     x = _r(cross_attention_module(W, p + ".attn2", n, ehs, heads) + x, "res")
     n = _r(F.layer_norm(x, (c,), W[p + ".norm3.weight"], W[p + ".norm3.bias"], 1e-5), "norm")
-    hcat = _r(F.linear(n, W[p + ".ff.net.0.proj.weight"], W[p + ".ff.net.0.proj.bias"]))
+    hcat = _r(F.linear(n, W[p + ".ff.net.0.proj.weight"], W[p + ".ff.net.0.proj.bias"]), "lin_a")
     hid, gate = hcat.chunk(2, dim=-1)
-    ff = F.linear(_r(hid * F.gelu(gate)), W[p + ".ff.net.2.weight"], W[p + ".ff.net.2.bias"])
+    ff = F.linear(_r(hid * F.gelu(gate), "lin_a"), W[p + ".ff.net.2.weight"], W[p + ".ff.net.2.bias"])
     return _r(ff + x, "res")
 
 

@@ -188,7 +188,7 @@ int launch_plain(const GemmParams& p, hipStream_t st);
 template <int MODE>
 int launch(const GemmParams& p, hipStream_t st) {
   if (!p.gn_partial) return launch_plain<MODE>(p, st);
-  const bool fused = skg_gemm8_eligible(p, MODE) ? skg_gemm8_fuses_gn(p, MODE) : skg_gemm2_fuses_gn(p, MODE);
+  const bool fused = skg_gemm8_eligible(p, MODE) ? skg_gemm8_fuses_gn(p, MODE) : skg_gemm2_fuses_gn(p, MODE);      // (the k-pair kernel declines launches that ask for statistics)
   const int rc = launch_plain<MODE>(p, st);
   if (rc != SKG_OK || fused) return rc;
   skg_gn_partial_launch((const half_t*)p.C, p.ldc, p.M / p.gn_hw, p.gn_hw, p.N, p.gn_groups, p.gn_hw / 128, p.gn_partial, st);
@@ -202,6 +202,12 @@ int launch_plain(const GemmParams& p, hipStream_t st) {
     SKG_CHECK_LAUNCH("skg_gemm (v8)");
     return SKG_OK;
   }
+#ifdef SKG_LAB      // withdrawn round-3 experiment (tools/lab/gemmk.hip, EXPERIMENTS.md): lab build only, SKG_GEMMK=1
+  if (skg_gemmk_try_launch(p, MODE, st)) {
+    SKG_CHECK_LAUNCH("skg_gemm (k-pair)");
+    return SKG_OK;
+  }
+#endif
   if (skg_gemm2_try_launch(p, MODE, st)) {
     SKG_CHECK_LAUNCH("skg_gemm (v2)");
     return SKG_OK;
@@ -262,6 +268,10 @@ extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
     GemmParams q{};
     q.M = M; q.N = N; q.K = K; q.Cin = Cin; q.lda = q.ldb = K; q.ldc = N; q.OH = q.OW = q.IH = q.IW = 1;
     if (const int bn8 = skg_gemm8_tile_n(q, mode)) return 8000 + bn8;
+#ifdef SKG_LAB
+    q.C = (void*)16;      // (alignment checks only)
+    if (skg_gemmk_eligible(q, mode)) return 9160;
+#endif
   }
   const int v2 = skg_gemm2_tile_n(M, N, K, Cin, mode, g_ws_last_bytes);
   return v2 ? 2000 + v2 : 1000 + (use_wide(M, N) ? 128 : 64);

@@ -1029,6 +1029,11 @@ int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode, size_t ws_bytes) {
 
 bool skg_gemm2_fuses_gn(const GemmParams& p, int mode) { return gn_fusable(p, mode); }
 
+void skg_splitk_reduce_launch(const GemmParams& p, const float* ws, int splits, hipStream_t st) {
+  size_t blocks = ((size_t)p.M * (p.N / 4) + 255) / 256;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p, ws, splits);
+}
+
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
   if (!eligible(p, mode)) return false;
   if ((p.flags & SKG_EPI_GEGLU) && ((p.flags & SKG_EPI_OUT_F32) || p.res || p.ldc % 8 != 0 ||

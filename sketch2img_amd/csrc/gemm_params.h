@@ -32,6 +32,12 @@ int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode, size_t ws_bytes);
 bool skg_gemm8_eligible(const GemmParams& p, int mode);
 int skg_gemm8_tile_n(const GemmParams& p, int mode);      // 160 / 320, or 0 when v8 does not take the launch
 bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st);
+// k-pair kernel (gemmk.hip): 128 x 160 tiles, one 8-wave workgroup per CU whose two wave groups take alternate K tiles -
+// the launches with at most one tile per CU (DIRECT / S1, plain epilogue, optional split-K across workgroups on top).
+bool skg_gemmk_eligible(const GemmParams& p, int mode);
+bool skg_gemmk_try_launch(const GemmParams& p, int mode, hipStream_t st);
+// out = epi(sum of `splits` fp32 slabs) (gemm2.hip)
+void skg_splitk_reduce_launch(const GemmParams& p, const float* ws, int splits, hipStream_t st);
 // true when the kernel that skg_gemm8 / skg_gemm2 would run for this launch writes p.gn_partial itself
 bool skg_gemm8_fuses_gn(const GemmParams& p, int mode);
 bool skg_gemm2_fuses_gn(const GemmParams& p, int mode);

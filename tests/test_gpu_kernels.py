@@ -138,7 +138,7 @@ def test_gemm8_pingpong_320_tile_convolutions(ops):
     (The withdrawn 256 x 160 form and the persistent gemm4 kernel live in tools/lab/, outside libskg.so.)"""
     from sketch2img_amd._lib import lib
     g = torch.Generator().manual_seed(17)
-    for rows, hw, cin, cout, res in [(16, 64, 64, 320, True), (15, 64, 128, 320, False), (16, 64, 320, 320, True)]:
+    for rows, hw, cin, cout, res in [(16, 64, 128, 320, True), (15, 64, 128, 320, False), (16, 64, 320, 320, True)]:
         assert lib.skg_gemm_variant(rows * hw * hw, cout, 9 * cin, cin, 1) == 8320
         x = torch.randn(rows, cin, hw, hw, generator=g).half()
         w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
