@@ -79,6 +79,10 @@ def parse():
     ap.add_argument("--gather", default="images", choices=("images", "latents"),
                     help="images (default): VAE decode on-rank + gather of uint8 images inside the timed region, as "
                          "north_star states; latents: gather the fp32 latents, no decode (round-1 behaviour)")
+    ap.add_argument("--no-guidance", action="store_true", help="informational: config 2 without the LGP guidance (no backward)")
+    ap.add_argument("--residual-fp32", action="store_true",
+                    help="informational: HipUNet's opt-in accuracy mode (hi / lo residual stream, forward only: needs --no-guidance "
+                         "or config 4 / 5 without injection) - prices the mode that meets north_star's 1e-3 eps bound")
     ap.add_argument("--graph", action="store_true", help="replay the two step variants from captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -358,9 +362,13 @@ def build_workload(args, rank, world, dev, dist):
         return broadcast_state_dict(sd, shapes, dev, src=0) if dist is not None else sd
 
     sd_unet = weights(lambda: synthetic.unet_state_dict(cfg), synthetic.unet_param_shapes(cfg))
-    net = HipUNet(cfg, sd_unet, dev, need_backward=(C == 2))
+    guided = C == 2 and not args.no_guidance
+    assert not args.residual_fp32 or (C == 2 and args.no_guidance), "--residual-fp32 is forward only: use it with --config 2 --no-guidance"
+    net = HipUNet(cfg, sd_unet, dev, need_backward=guided, residual_fp32=args.residual_fp32)
     lgp, target, sd_lgp = None, None, None
-    if C == 2:
+    if C == 2 and not guided:
+        pass
+    elif C == 2:
         sd_lgp = weights(lambda: synthetic.lgp_state_dict(synthetic.lgp_input_dim(cfg)))
         lgp = HipLGP(sd_lgp, tap_channels(cfg), dev)
         target = synthetic.sketch_targets(first, S, h).to(dev)
@@ -532,7 +540,9 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": WORKLOADS[C].format(S=S, T=T, G=int(0.5 * T), sched=sched),
+            "config": {"workload": WORKLOADS[C].format(S=S, T=T, G=int(0.5 * T), sched=sched)
+                       + (" - INFORMATIONAL VARIANT: guidance off" if args.no_guidance else "")
+                       + (", accuracy mode (hi / lo residual stream)" if args.residual_fp32 else ""),
                        "baseline_config": C, "samples_per_gpu": S, "global_batch": world * S, "ddim_steps": T,
                        "scheduler": args.scheduler, "hip_graphs": bool(args.graph),
                        "output": ("decoded uint8 images [S, H, W, 3] (VAE decode on-rank, inside the timed region"
@@ -546,7 +556,7 @@ def main():
             "ms_per_image": dt / args.steps / S * 1e3,
             "decode_ms_per_step": decode_s / args.steps * 1e3 if wl["decode_events"] else None,
             "value_excluding_decode": world * S * args.steps / (dt - decode_s) if wl["decode_events"] and world == 1 else None,
-            "achieved_tflops_per_gpu": value / world * f_img_tflop(C, T) if args.scheduler == "ddim" else None,
+            "achieved_tflops_per_gpu": value / world * f_img_tflop(C, T) if args.scheduler == "ddim" and not args.no_guidance else None,
             "tflop_per_image": f_img_tflop(C, T), "outputs_finite": finite, "out_shape": list(out.shape),
             "setup_s": t_setup, "roofline": roof, "cpu_baseline": cpu,
         }

@@ -133,6 +133,27 @@ int skg_groupnorm_from_partial2(const void* X, int ldx, void* Y, int ldy, int ro
                                 int groups, float eps, const void* gamma, const void* beta, int silu,
                                 float* stats, const float* partialA, int groupsA, const float* partialB,
                                 int groupsB, int nch, void* stream);
+/* ---- accuracy mode ("residual_fp32"): tensors as (hi, lo) PAIRS of fp16, value = hi + lo (~22 mantissa bits) -------
+ * north_star asks for <= 1e-3 max latent-eps deviation from the fp32 reference (modules/pipeline.py:96 in fp32 on CPU);
+ * with every stored tensor in fp16 - what the reference's own GPU path does (app.py:34) - an evaluation is 1.5e-3 away,
+ * 1.0e-3 of it from the fp16 residual stream.  HipUNet(residual_fp32=True) keeps the residual stream and the conv outputs
+ * that feed a norm or the residual sum as pairs: the producer's epilogue writes hi = fp16(v) and lo = fp16(v - hi), adds a
+ * residual pair in fp32; norms read hi + lo; where the stream itself is a matmul operand the pair is the operand
+ * ([hi | lo] along K against [W | W]).  skg_gemm_f16 / skg_conv3x3_f16 with a second output / residual pointer (same leading
+ * dimensions); C_lo / residual_lo may be NULL individually, not both.  fp16 output only, K % 64 == 0, 16-byte aligned. */
+int skg_gemm_f16_hilo(const void* A, int lda, const void* B, int ldb, void* C, void* C_lo, int ldc, int M, int N, int K,
+                      const void* bias, const void* residual, const void* residual_lo, int ldr, float alpha,
+                      unsigned flags, void* stream);
+int skg_conv3x3_f16_hilo(const void* X, int ldx, const void* Wp, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW,
+                         int Cin, int Cout, int mode, const void* bias, const void* residual, const void* residual_lo,
+                         int ldr, float alpha, unsigned flags, void* stream);
+/* GroupNorm(+SiLU) apply and LayerNorm of a pair (statistics [rows][groups][2] from skg_groupnorm_stats on the hi part). */
+int skg_groupnorm_apply_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int rows, int HW, int C,
+                             int groups, const float* stats, const void* gamma, const void* beta, int silu,
+                             void* stream);
+int skg_layernorm_fwd_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int M, int C,
+                           const void* gamma, const void* beta, float eps, void* stream);
+
 int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C,
                         int groups, const float* stats, const void* gamma, const void* beta,
                         int silu, void* stream);

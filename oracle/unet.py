@@ -202,7 +202,8 @@ def init_weights(cfg: UNetConfig, seed: int = 20260929, dtype=torch.float32,
 # Every rounding point carries a kind so that tools/eps_decompose.py can switch classes of tensors off one at a
 # time ("which stored tensors cost the accuracy"): "res" = the residual stream (ResnetBlock / attention / FF sums,
 # conv_in / resampling outputs), "norm" = GroupNorm(+SiLU) / LayerNorm outputs, "lin" = conv / Linear outputs that
-# feed a norm or an activation, "attn" = q / k / v and attention outputs, "temb" = the time-embedding path.
+# feed a norm or an activation, "attn" = q / k / v and attention outputs, "temb" = the time-embedding path, "rop" = the residual stream where it is
+# itself a matmul OPERAND (conv_shortcut, the resampling convolutions; idempotent when "res" is rounded anyway).
 _FP16_STORAGE = False
 _FP16_SKIP: frozenset = frozenset()
 
@@ -250,7 +251,7 @@ def resnet_forward(cfg, W, p, x, temb_act):
     h = _r(F.silu(_gn(h, W, p + ".norm2", cfg.norm_groups, 1e-5)), "norm")
     h = F.conv2d(h, W[p + ".conv2.weight"], W[p + ".conv2.bias"], padding=1)
     if (p + ".conv_shortcut.weight") in W:
-        x = _r(F.conv2d(x, W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"]), "lin_n")
+        x = _r(F.conv2d(_r(x, "rop"), W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"]), "lin_n")
     return _r(x + h, "res")
 
 
@@ -368,7 +369,7 @@ def unet_forward(cfg: UNetConfig, W: Dict[str, torch.Tensor], x: torch.Tensor, t
             blk_res.append(h)
         if i < nb - 1:
             p = f"down_blocks.{i}.downsamplers.0.conv"
-            h = _r(F.conv2d(h, W[p + ".weight"], W[p + ".bias"], stride=2, padding=1), "res")
+            h = _r(F.conv2d(_r(h, "rop"), W[p + ".weight"], W[p + ".bias"], stride=2, padding=1), "res")
             skips.append(h)
             blk_res.append(h)
         per_block.append(tuple(blk_res))
@@ -396,7 +397,7 @@ def unet_forward(cfg: UNetConfig, W: Dict[str, torch.Tensor], x: torch.Tensor, t
         if i < nb - 1:
             p = f"up_blocks.{i}.upsamplers.0.conv"
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
-            h = _r(F.conv2d(h, W[p + ".weight"], W[p + ".bias"], padding=1), "res")
+            h = _r(F.conv2d(_r(h, "rop"), W[p + ".weight"], W[p + ".bias"], padding=1), "res")
         if i < 3:
             taps_up.append(h)
     h = _r(F.silu(_gn(h, W, "conv_norm_out", cfg.norm_groups, 1e-5)), "norm")

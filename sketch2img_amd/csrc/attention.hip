@@ -531,6 +531,136 @@ __global__ __launch_bounds__(256, ((VAR >> 2) ? (VAR >> 2) : KS >= 5 ? 1 : (KS =
   }
 }
 
+// ---- forward for SHORT key sequences (cross-attention over the 77 text tokens: modules/pipeline.py:96 -> diffusers
+// CrossAttention with encoder_hidden_states) -------------------------------------------------------------------------------
+// Round 2 ran these through the flash kernel above: two 64-key tiles of which the second holds 13 keys, a prologue / epilogue
+// per 128 queries that never amortises, 45 us at 64x64 for 14 us of HBM time (128-142 TFLOP/s).
+// With <= 80 keys there is nothing to stream and nothing "online": K [80][d] and V [96][d] of one (row, head) are staged in
+// LDS ONCE per workgroup (25 KB at d = 40: four workgroups per CU), every wave then walks 16-query tiles: Q fragments
+// straight from global memory (the next tile's loads in flight while this one computes), S^T = K Q^T in 5 x KS MFMAs, one
+// plain softmax over the wave's 20 scores per lane (the maximum is exact: no running reference), O^T = V^T P^T with the
+// probabilities as the B operand out of the accumulator registers, normalise, store.  What is left is one read of Q and one
+// write of O: the kernel is HBM-bound.
+template <int KS, int ND>
+__global__ __launch_bounds__(256, (KS >= 5 ? 2 : (KS >= 3 ? 3 : 4))) void attn_fwd_short_kernel(const AttnParams p, int qchunk) {
+  constexpr int NT = 5;                 // 16-key score tiles: kv_stride <= 80
+  constexpr int NSV = 3;                // 32-key k-steps of the PV product (the last half step is zero rows)
+  constexpr int KP = KS * 32 + 16;
+  constexpr int VP = vrow_pitch(ND);
+  __shared__ __attribute__((aligned(16))) half_t Ks[16 * NT * KP];
+  __shared__ __attribute__((aligned(16))) half_t Vs[32 * NSV * VP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l16 = lane & 15, g = lane >> 4;
+  const BlkMap bm = attn_block_map(p);
+  const int b = bm.b, h = bm.h, dh = p.dh;
+  const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
+  const half_t* Vb = p.Vt + (size_t)b * p.kv_stride * p.ldvt + h * dh;
+  // ---- stage K [80][KP] and V [96][VP]: rows behind the last key and head-dim columns behind dh are zero
+  for (int pi = threadIdx.x; pi < 16 * NT * (KS * 4); pi += 256) {
+    const int row = pi / (KS * 4), pc = (pi - row * (KS * 4)) * 8;
+    st_half8(Ks + row * KP + pc, (row < p.Nkv && pc < dh) ? ld_half8(Kb + (size_t)row * p.ldk + pc) : zero_half8());
+  }
+  for (int pi = threadIdx.x; pi < 32 * NSV * (2 * ND); pi += 256) {
+    const int row = pi / (2 * ND), pc = (pi - row * (2 * ND)) * 8;
+    st_half8(Vs + row * VP + pc, (row < p.Nkv && pc < dh) ? ld_half8(Vb + (size_t)row * p.ldvt + pc) : zero_half8());
+  }
+  __syncthreads();
+  const int vlane = (4 * g + (l16 >> 2)) * VP + 4 * (l16 & 3);
+  const float sc = p.scale * LOG2E;
+  // keys this lane holds in score tile t, register r: 16 t + 4 g + r.  77 text tokens: only the last tile is ragged
+  // (three registers of the g = 3 lanes); fewer than 65 keys (tests, other callers) take the general mask
+  bool dead[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dead[r] = 16 * (NT - 1) + 4 * g + r >= p.Nkv;
+  const bool short_rows = p.Nkv <= 16 * (NT - 1);        // wave-uniform
+  const int klim = p.Nkv - 4 * g;
+  const int q_begin = bm.bx * qchunk, q_end = min(p.Nq, q_begin + qchunk);
+  const size_t rowbase = (size_t)b * p.Nq;
+  auto load_q = [&](half8_t (&dst)[KS], int q0) {          // rows behind q_end read row q_end - 1 (not stored)
+    const int q = min(q0 + l16, q_end - 1);
+    const half_t* src = p.Q + (rowbase + q) * p.ldq + h * dh + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) dst[ks] = (32 * ks + 8 * g < dh) ? ld_half8(src + 32 * ks) : zero_half8();
+  };
+  half8_t qn[KS];
+  int q0 = q_begin + wave * 16;
+  if (q0 < q_end) load_q(qn, q0);
+  for (; q0 < q_end; q0 += 64) {
+    half8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)qn[ks][j] * sc);
+    if (q0 + 64 < q_end) load_q(qn, q0 + 64);               // in flight under this tile's work
+    float4_t s[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const half8_t kf = ld_half8(Ks + (16 * t + l16) * KP + 32 * ks + 8 * g);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], ks == 0 ? float4_t{0.f, 0.f, 0.f, 0.f} : s[t], 0, 0, 0);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (dead[r]) s[NT - 1][r] = NEG_BIG;
+    if (short_rows) {
+#pragma unroll
+      for (int t = 0; t < NT - 1; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * t + r >= klim) s[t][r] = NEG_BIG;
+    }
+    float mx = max3f(s[0][0], s[0][1], s[0][2]);
+    mx = max3f(mx, s[0][3], s[1][0]); mx = max3f(mx, s[1][1], s[1][2]); mx = max3f(mx, s[1][3], s[2][0]);
+    mx = max3f(mx, s[2][1], s[2][2]); mx = max3f(mx, s[2][3], s[3][0]); mx = max3f(mx, s[3][1], s[3][2]);
+    mx = max3f(mx, s[3][3], s[4][0]); mx = max3f(mx, s[4][1], s[4][2]); mx = max3f(mx, s[4][3], mx);
+    mx = max3f(mx, __shfl_xor(mx, 16, 64), mx);
+    mx = max3f(mx, __shfl_xor(mx, 32, 64), mx);
+    float li = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[t][r] - mx);
+        s[t][r] = e;
+        li += e;
+      }
+    li += __shfl_xor(li, 16, 64);
+    li += __shfl_xor(li, 32, 64);
+    // B-operand fragments of P^T: element i of k-step sv <-> key 32 sv + 16 (i >> 2) + 4 g + (i & 3)
+    half8_t pb[NSV];
+#pragma unroll
+    for (int sv = 0; sv < NSV; ++sv)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int t = 2 * sv + (i >> 2);
+        pb[sv][i] = t < NT ? (half_t)s[t][i & 3] : (half_t)0.f;
+      }
+    float4_t o[ND];
+#pragma unroll
+    for (int u = 0; u < ND; ++u) {
+      o[u] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sv = 0; sv < NSV; ++sv)
+        o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag_rows<VP>(Vs + vlane, u, sv), pb[sv], o[u], 0, 0, 0);
+    }
+    const int q = q0 + l16;
+    if (q < q_end) {
+      const float inv = 1.f / li;
+      half_t* orow = p.O + (rowbase + q) * p.ldo + h * dh;
+#pragma unroll
+      for (int u = 0; u < ND; ++u) {
+        const int d = 16 * u + 4 * g;
+        if (d < dh) {
+          half4_t v = {(half_t)(o[u][0] * inv), (half_t)(o[u][1] * inv), (half_t)(o[u][2] * inv), (half_t)(o[u][3] * inv)};
+          st_half4(orow + d, v);
+        }
+      }
+      if (p.lse && g == 0) p.lse[((size_t)b * p.heads + h) * p.Nq + q] = (log2f(li) + mx) * LN2;
+    }
+  }
+}
+
 // dQ: per 64-query block, loop over key tiles.  dS^T = P^T o (dP^T - delta);  dQ^T += K^T dS^T.
 template <int KS, int ND, int QT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
@@ -867,6 +997,23 @@ static int attn_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const v
   p.O = (half_t*)O; p.ldo = ldo; p.lse = lse;
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
+  // short key sequences (the 77 text tokens of every cross-attention): the LDS-resident kernel, HBM-bound
+  static const bool no_short = getenv("SKG_NO_ATTN_SHORT") != nullptr;        // A/B switch
+  if (vrow && !causal && kv_stride <= 80 && !no_short && (dh == 40 || dh == 64 || dh == 80 || dh == 160)) {
+    // queries per workgroup: ~1024+ workgroups where the launch has them, at least 64, a multiple of 64
+    long qch = ((long)heads * batch * Nq / 1024 + 63) / 64 * 64;
+    qch = qch < 64 ? 64 : (qch > 512 ? 512 : qch);
+    p.nx = skg_cdiv(Nq, (int)qch);
+    dim3 gs((unsigned)p.nx * heads * batch);
+    switch (dh) {
+      case 40: hipLaunchKernelGGL((attn_fwd_short_kernel<2, 3>), gs, dim3(256), 0, st, p, (int)qch); break;
+      case 64: hipLaunchKernelGGL((attn_fwd_short_kernel<2, 4>), gs, dim3(256), 0, st, p, (int)qch); break;
+      case 80: hipLaunchKernelGGL((attn_fwd_short_kernel<3, 5>), gs, dim3(256), 0, st, p, (int)qch); break;
+      default: hipLaunchKernelGGL((attn_fwd_short_kernel<5, 10>), gs, dim3(256), 0, st, p, (int)qch); break;
+    }
+    SKG_CHECK_LAUNCH("skg_attn_fwd (short keys)");
+    return SKG_OK;
+  }
   p.nx = skg_cdiv(Nq, dh == 160 ? 64 : 128);       // query tiles per workgroup: see SKG_ATTN_FWD_DISPATCH
   dim3 grid((unsigned)p.nx * heads * batch);
   if (causal) {

@@ -213,6 +213,7 @@ int launch_plain(const GemmParams& p, hipStream_t st) {
     return SKG_OK;
   }
   if (p.flags & SKG_EPI_GEGLU) return SKG_E_UNSUPPORTED;     // fused GEGLU exists in the LDS-DMA kernel only
+  if (p.c_lo || p.res_lo) return SKG_E_UNSUPPORTED;          // so does the hi / lo epilogue
   const int tm = skg_cdiv(p.M, BM);
   if (use_wide(p.M, p.N)) {
     dim3 grid(p.N / 128, tm);
@@ -279,10 +280,10 @@ extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
 
 static int gemm_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const void* bias, const void* residual, int ldr, float alpha, unsigned flags, float* gn_partial,
-                     int HW, int groups, void* stream);
+                     int HW, int groups, void* stream, void* c_lo = nullptr, const void* res_lo = nullptr);
 static int conv_impl(const void* X, int ldx, const void* Wp, void* Y, int ldy, int rows, int IH, int IW, int Cin,
                      int Cout, int mode, const void* bias, const void* residual, int ldr, float alpha, unsigned flags,
-                     float* gn_partial, int groups, void* stream);
+                     float* gn_partial, int groups, void* stream, void* c_lo = nullptr, const void* res_lo = nullptr);
 
 extern "C" int skg_gemm_f16_geglu_keep(const void* A, int lda, const void* B, int ldb, void* Y, int ldy, void* H,
                                        int ldh, int M, int N, int K, const void* bias, void* stream) {
@@ -318,7 +319,7 @@ extern "C" int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void
 
 static int gemm_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                      const void* bias, const void* residual, int ldr, float alpha, unsigned flags, float* gn_partial,
-                     int HW, int groups, void* stream) {
+                     int HW, int groups, void* stream, void* c_lo, const void* res_lo) {
   SKG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
   SKG_REQUIRE(K % 32 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0);
   SKG_REQUIRE(skg_aligned(A, 16) && skg_aligned(B, 16) && skg_aligned(C, 8));
@@ -330,6 +331,7 @@ static int gemm_impl(const void* A, int lda, const void* B, int ldb, void* C, in
   p.bias = (const half_t*)bias; p.res = (const half_t*)residual; p.ldr = ldr;
   p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.flags = flags;
   p.gn_partial = gn_partial; p.gn_hw = HW; p.gn_groups = groups;
+  p.c_lo = (half_t*)c_lo; p.res_lo = (const half_t*)res_lo;
   ws_attach(p, (hipStream_t)stream);
   return launch<MODE_DIRECT>(p, (hipStream_t)stream);
 }
@@ -358,6 +360,26 @@ extern "C" int skg_conv3x3_f16_gn(const void* X, int ldx, const void* Wp, void* 
                    groups, stream);
 }
 
+// ---- accuracy mode: outputs / residuals as (hi, lo) pairs of fp16 tensors (include/skg.h) ------------------------------
+extern "C" int skg_gemm_f16_hilo(const void* A, int lda, const void* B, int ldb, void* C, void* C_lo, int ldc, int M, int N,
+                                 int K, const void* bias, const void* residual, const void* residual_lo, int ldr,
+                                 float alpha, unsigned flags, void* stream) {
+  SKG_REQUIRE((C_lo || residual_lo) && !(flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) && K % 64 == 0 && ldc % 8 == 0);
+  SKG_REQUIRE(skg_aligned(C, 16) && (!C_lo || skg_aligned(C_lo, 16)) && (!residual_lo || skg_aligned(residual_lo, 16)) &&
+              (!residual || skg_aligned(residual, 16)) && ((!residual && !residual_lo) || ldr % 8 == 0));
+  return gemm_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, alpha, flags, nullptr, 0, 0, stream, C_lo, residual_lo);
+}
+
+extern "C" int skg_conv3x3_f16_hilo(const void* X, int ldx, const void* Wp, void* Y, void* Y_lo, int ldy, int rows, int IH,
+                                    int IW, int Cin, int Cout, int mode, const void* bias, const void* residual,
+                                    const void* residual_lo, int ldr, float alpha, unsigned flags, void* stream) {
+  SKG_REQUIRE((Y_lo || residual_lo) && !(flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) && Cin % 64 == 0 && ldy % 8 == 0);
+  SKG_REQUIRE(skg_aligned(Y, 16) && (!Y_lo || skg_aligned(Y_lo, 16)) && (!residual_lo || skg_aligned(residual_lo, 16)) &&
+              (!residual || skg_aligned(residual, 16)) && ((!residual && !residual_lo) || ldr % 8 == 0));
+  return conv_impl(X, ldx, Wp, Y, ldy, rows, IH, IW, Cin, Cout, mode, bias, residual, ldr, alpha, flags, nullptr, 0, stream,
+                   Y_lo, residual_lo);
+}
+
 extern "C" int skg_conv3x3_f16(const void* X, int ldx, const void* Wp, void* Y, int ldy, int rows,
                                int IH, int IW, int Cin, int Cout, int mode, const void* bias,
                                const void* residual, int ldr, float alpha, unsigned flags,
@@ -367,7 +389,7 @@ extern "C" int skg_conv3x3_f16(const void* X, int ldx, const void* Wp, void* Y, 
 
 static int conv_impl(const void* X, int ldx, const void* Wp, void* Y, int ldy, int rows, int IH, int IW, int Cin,
                      int Cout, int mode, const void* bias, const void* residual, int ldr, float alpha, unsigned flags,
-                     float* gn_partial, int groups, void* stream) {
+                     float* gn_partial, int groups, void* stream, void* c_lo, const void* res_lo) {
   SKG_REQUIRE(X && Wp && Y && rows > 0 && IH > 0 && IW > 0);
   SKG_REQUIRE(Cin % 32 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldx >= Cin && ldy % 4 == 0 && ldy >= Cout);
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Wp, 16) && skg_aligned(Y, 8));
@@ -379,6 +401,7 @@ static int conv_impl(const void* X, int ldx, const void* Wp, void* Y, int ldy, i
   p.N = Cout; p.K = 9 * Cin; p.alpha = alpha; p.flags = flags;
   p.IH = IH; p.IW = IW; p.Cin = Cin;
   p.gn_partial = gn_partial; p.gn_groups = groups;
+  p.c_lo = (half_t*)c_lo; p.res_lo = (const half_t*)res_lo;
   hipStream_t st = (hipStream_t)stream;
   ws_attach(p, st);
   switch (mode) {

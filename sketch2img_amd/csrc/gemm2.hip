@@ -126,7 +126,9 @@ __device__ unsigned long long g_phase[1 << 15][16];
 // (110 KB of LDS) and waits with a counted vmcnt.
 // GNS: the instantiation whose epilogue also writes the GroupNorm partial sums of the output (launched only when asked
 // for - its 25 extra epilogue registers and code cost the plain launches 0.3 % of a batch when they shared one kernel)
-template <int BM, int BN, int WGM, int WGN, int MODE, int NS = 2, bool GNS = false>
+// HILO: the accuracy-mode instantiation (skg_*_hilo): the fp32-staged epilogue also adds p.res_lo and stores
+// lo = fp16(v - fp16(v)) to p.c_lo, whatever the launch (an own instantiation: the plain kernels stay as tuned)
+template <int BM, int BN, int WGM, int WGN, int MODE, int NS = 2, bool GNS = false, bool HILO = false>
 __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <= 80 * 1024) ? 2 : 1) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
                                                                   unsigned a_bytes, unsigned b_bytes,
                                                                   unsigned a_shift, int kt_per_split,
@@ -470,8 +472,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
     }
     continue;
   }
-  const bool staged = !f32out && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
-                      (!p.res || ((p.ldr % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0));
+  const bool staged = HILO ||      // (launcher-checked alignment)
+                      (!f32out && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                       (!p.res || ((p.ldr % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
   // GroupNorm statistics of this tile's OUTPUT (launcher-checked: 128 x 160 tile, whole tiles, groups do not straddle the
   // tile, staged epilogue): phase 2 of either staged path keeps, per 16-byte piece it stores, sum(y) and sum(y^2) of the
   // four fp16 pairs (v_dot2: two values per instruction, no conversions; a pair never straddles a group because the
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
       }
     }
   };
-  if (staged && !p.res) {
+  if (staged && !p.res && !HILO) {
     // No residual: bias, alpha and ReLU are applied in registers and the value is rounded to fp16 (its final rounding;
     // for the fused GEGLU the same rounding the unfused path and the reference apply to the FF1 output) BEFORE it
     // goes through LDS - half the staging bytes, all 128 rows in one slab, every wave writes at once, two barriers
@@ -740,6 +743,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
             half8_t o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + (float)rv[sl][k][e];
+            if constexpr (HILO) {
+              if (p.res_lo) {
+                const half8_t rl = ld_half8(p.res_lo + (size_t)(m0 + er + sl * SROWS) * p.ldr + n0 + ec + k * TPR * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rl[e];
+              }
+            }
             if (relu) {
               asm volatile("" ::: "memory");       // a real (wave-uniform) branch instead of 8 selects per piece
 #pragma unroll
@@ -749,6 +759,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
             for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
             if constexpr (ITER == GNP) {
               if (gn) gn_acc(k, o);
+            }
+            if constexpr (HILO) {
+              if (p.c_lo) {
+                half8_t lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) lo[e] = (half_t)(v[e] - (float)o[e]);
+                st_half8(p.c_lo + (size_t)(m0 + er + sl * SROWS) * p.ldc + n0 + ec + k * TPR * 8, lo);
+              }
             }
             half8_t* dst8 = reinterpret_cast<half8_t*>(crow + k * TPR * 8);
 #ifdef SKG_PHASES
@@ -938,6 +956,13 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
   int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4, p.ws, p.ws_bytes) : 1;
   constexpr int NTHR = WGM * WGN * 64;
+  if constexpr (BM == 128) {
+    if (p.c_lo || p.res_lo) {      // accuracy mode: one instantiation per tile, two stages, no split-K, no statistics
+      hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 2, false, true>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n,
+                         ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
+      return;
+    }
+  }
   if (BM == 128 && BN == 160 && splits == 1 && gn_fusable(p, MODE)) p.flags |= SKG_FLAG_GN_STATS;
   // XCDs per K slice: all 8 without split-K; 8 / ns when the slices line up with XCD boundaries
   const int ns_eff = splits > 1 ? skg_cdiv(KT, skg_cdiv(KT, splits)) : 1;
@@ -1003,7 +1028,8 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
 
 template <int MODE>
 void launch_mode(const GemmParams& p, hipStream_t st) {
-  const TileCfg t = pick_tile(p.M, p.N, p.K);
+  TileCfg t = pick_tile(p.M, p.N, p.K);
+  if (t.bm == 256 && (p.c_lo || p.res_lo)) t = TileCfg{128, 160};      // (the hi / lo epilogue exists for the 128-row tiles)
   if (t.bm == 256) launch_cfg<256, 320, 2, 4, MODE>(p, st);
   else if (t.bn == 160) {
     launch_cfg<128, 160, 2, 2, MODE>(p, st);
@@ -1036,6 +1062,12 @@ void skg_splitk_reduce_launch(const GemmParams& p, const float* ws, int splits, 
 
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
   if (!eligible(p, mode)) return false;
+  if ((p.c_lo || p.res_lo) &&
+      ((p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) || p.gn_partial || p.aux || p.ldc % 8 != 0 ||
+       (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 || (p.c_lo && (reinterpret_cast<uintptr_t>(p.c_lo) & 15) != 0) ||
+       ((p.res || p.res_lo) && p.ldr % 8 != 0) || (p.res && (reinterpret_cast<uintptr_t>(p.res) & 15) != 0) ||
+       (p.res_lo && (reinterpret_cast<uintptr_t>(p.res_lo) & 15) != 0)))
+    return false;
   if ((p.flags & SKG_EPI_GEGLU) && ((p.flags & SKG_EPI_OUT_F32) || p.res || p.ldc % 8 != 0 ||
                                      (reinterpret_cast<uintptr_t>(p.C) & 15) != 0))
     return false;

@@ -18,6 +18,9 @@ struct GemmParams {
   float* gn_partial; int gn_hw, gn_groups;
   // fused GEGLU that also keeps the pre-activation (skg_gemm_f16_geglu_keep): H [M][N] in the interleaved pack order
   half_t* aux; int ldaux;
+  // accuracy mode (skg_*_hilo entry points): the residual and / or the output are PAIRS of fp16 tensors whose sum carries
+  // ~22 mantissa bits - lo = fp16(v - fp16(v)); same leading dimension as the hi part (ldr / ldc)
+  const half_t* res_lo; half_t* c_lo;
   // split-K workspace of the launch stream (host side: filled by the entry points from the per-stream registry of
   // skg_set_workspace; the kernels get the slab pointer as an argument)
   float* ws; size_t ws_bytes;

@@ -125,14 +125,25 @@ def gn_concat_ok(CA: int, CB: int, groups: int, ga: int, gb: int) -> bool:
 
 def gemm(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *,
          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-         alpha: float = 1.0, relu: bool = False, out_f32: bool = False, geglu: bool = False, gn_stats=None):
+         alpha: float = 1.0, relu: bool = False, out_f32: bool = False, geglu: bool = False, gn_stats=None,
+         out_lo: Optional[torch.Tensor] = None, residual_lo: Optional[torch.Tensor] = None):
     """out[m][n] = epi(alpha*(A[m,:] . B[n,:] + bias[n]) + residual[m][n]);  A [M,K], B [N,K].
     geglu=True: B / bias are the interleaved FF1 pack and out is [M, N/2] = a * gelu(g).
-    gn_stats=(HW, groups): also returns the GroupNorm partial sums of the output -> (out, GNPartial)."""
-    _f16(A, B, bias, residual)
+    gn_stats=(HW, groups): also returns the GroupNorm partial sums of the output -> (out, GNPartial).
+    out_lo / residual_lo (accuracy mode): the output / residual as (hi, lo) pairs of fp16 views with equal pitch."""
+    _f16(A, B, bias, residual, out_lo, residual_lo)
     M, K = A.shape
     N = B.shape[0]
     assert B.shape[1] == K
+    if out_lo is not None or residual_lo is not None:
+        assert out is not None and not (out_f32 or geglu) and gn_stats is None
+        assert out_lo is None or _ld(out_lo) == _ld(out)
+        assert residual_lo is None or residual is None or _ld(residual_lo) == _ld(residual)
+        r_any = residual if residual is not None else residual_lo
+        check(lib.skg_gemm_f16_hilo(_p(A), _ld(A), _p(B), _ld(B), _p(out), _p(out_lo), _ld(out), M, N, K, _p(bias),
+                                    _p(residual), _p(residual_lo), _ld(r_any) if r_any is not None else 0, alpha,
+                                    EPI_RELU if relu else 0, _stream()), "skg_gemm_f16_hilo")
+        return out
     if out is None:
         out = torch.empty(M, N // 2 if geglu else N, device=A.device,
                           dtype=torch.float32 if out_f32 else torch.float16)
@@ -166,10 +177,11 @@ def gemm_geglu_keep(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tenso
 
 def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode: int = CONV_S1,
             out: Optional[torch.Tensor] = None, *, bias=None, residual=None, alpha: float = 1.0,
-            relu: bool = False, gn_groups: Optional[int] = None):
+            relu: bool = False, gn_groups: Optional[int] = None, out_lo=None, residual_lo=None):
     """X [rows*IH*IW, Cin] (view), Wp [Cout, 9*Cin] tap-major.  Returns [rows*OH*OW, Cout];
-    gn_groups=G: (out, GNPartial) - the GroupNorm partial sums of the output come with it."""
-    _f16(X, Wp, bias, residual)
+    gn_groups=G: (out, GNPartial) - the GroupNorm partial sums of the output come with it.
+    out_lo / residual_lo (accuracy mode): see gemm."""
+    _f16(X, Wp, bias, residual, out_lo, residual_lo)
     Cin = X.shape[1]
     Cout = Wp.shape[0]
     assert Wp.shape[1] == 9 * Cin and Wp.is_contiguous() and X.shape[0] == rows * IH * IW
@@ -181,6 +193,14 @@ def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode
         OH, OW = IH * 2, IW * 2
     if out is None:
         out = torch.empty(rows * OH * OW, Cout, device=X.device, dtype=torch.float16)
+    if out_lo is not None or residual_lo is not None:
+        assert gn_groups is None and (out_lo is None or _ld(out_lo) == _ld(out))
+        assert residual_lo is None or residual is None or _ld(residual_lo) == _ld(residual)
+        r_any = residual if residual is not None else residual_lo
+        check(lib.skg_conv3x3_f16_hilo(_p(X), _ld(X), _p(Wp), _p(out), _p(out_lo), _ld(out), rows, IH, IW, Cin, Cout, mode,
+                                       _p(bias), _p(residual), _p(residual_lo), _ld(r_any) if r_any is not None else 0,
+                                       alpha, EPI_RELU if relu else 0, _stream()), "skg_conv3x3_f16_hilo")
+        return out
     if gn_groups is not None:
         part = GNPartial(rows, OH * OW, gn_groups, X.device)
         check(lib.skg_conv3x3_f16_gn(_p(X), _ld(X), _p(Wp), _p(out), _ld(out), rows, IH, IW, Cin, Cout, mode,
@@ -264,6 +284,30 @@ def groupnorm(X, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, parti
                                 int(silu), _p(st), _p(_gn_scratch(rows, groups, X.device)), _stream()),
           "skg_groupnorm_fwd")
     return out, st
+
+
+def groupnorm_hilo(X, X_lo, rows, HW, groups, eps, gamma, beta, silu: bool, out=None):
+    """GroupNorm(+SiLU) of the pair X + X_lo (accuracy mode): statistics from the hi part, apply on the sum."""
+    _f16(X, X_lo, gamma, beta)
+    assert _ld(X) == _ld(X_lo)
+    C = X.shape[1]
+    st = groupnorm_stats(X, rows, HW, groups, eps)
+    if out is None:
+        out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
+    check(lib.skg_groupnorm_apply_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _ld(out), rows, HW, C, groups, _p(st), _p(gamma),
+                                       _p(beta), int(silu), _stream()), "skg_groupnorm_apply_hilo")
+    return out
+
+
+def layernorm_hilo(X, X_lo, gamma, beta, eps=1e-5, out=None):
+    _f16(X, X_lo, gamma, beta)
+    assert _ld(X) == _ld(X_lo)
+    M, C = X.shape
+    if out is None:
+        out = torch.empty(M, C, device=X.device, dtype=torch.float16)
+    check(lib.skg_layernorm_fwd_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _ld(out), M, C, _p(gamma), _p(beta), eps, _stream()),
+          "skg_layernorm_fwd_hilo")
+    return out
 
 
 def groupnorm_bwd(X, dY, rows, HW, groups, stats, gamma, beta, silu: bool, residual=None, out=None):

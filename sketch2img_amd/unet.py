@@ -79,12 +79,18 @@ class Stash:
 
 class HipUNet:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda",
-                 need_backward: bool = True):
+                 need_backward: bool = True, residual_fp32: bool = False):
+        """residual_fp32: opt-in ACCURACY mode (forward only) that meets north_star's <= 1e-3 max eps deviation from the
+        fp32 reference: the residual stream and every conv output that feeds a norm or the residual sum are kept as
+        (hi, lo) pairs of fp16 tensors (~22 mantissa bits), see forward() / _forward_hp()."""
         self.cfg = cfg
         self.dev = torch.device(device)
         self.need_backward = need_backward
+        self.residual_fp32 = residual_fp32
         self.W: Dict[str, torch.Tensor] = {}
         self._pack(state_dict)
+        if residual_fp32:
+            self._pack_hp(state_dict)
         self._sd_time = {k: v for k, v in state_dict.items()
                          if k.startswith("time_embedding.") or ".time_emb_proj." in k or k.endswith("conv1.bias")}
         self.tbias: Dict[int, Dict[str, torch.Tensor]] = {}
@@ -139,6 +145,17 @@ class HipUNet:
                 W[p + ".qkv"] = _h(qkv, dev)
                 if bw:
                     W[p + ".qkv:T"] = _h(qkv.t(), dev)
+
+    def _pack_hp(self, sd):
+        """Accuracy mode: where the residual stream itself is a matmul operand (conv_shortcut, the resampling
+        convolutions, proj_out) the operand is the PAIR [hi | lo] along K and the weight pack is [W | W]."""
+        W, dev = self.W, self.dev
+        for k, v in sd.items():
+            if k.endswith(".conv_shortcut.weight") or k.endswith(".proj_out.weight"):
+                w = v.reshape(v.shape[0], v.shape[1])
+                W[k + ":2"] = _h(torch.cat([w, w], 1), dev)
+            elif ".downsamplers." in k and k.endswith(".weight") or ".upsamplers." in k and k.endswith(".weight"):
+                W[k + ":2"] = pack_conv(torch.cat([v, v], 1), dev)
 
     # ------------------------------------------------------------------ hoisted precompute
     def prepare_timesteps(self, timesteps: Sequence[int]):
@@ -292,6 +309,9 @@ class HipUNet:
         cfg, W = self.cfg, self.W
         assert self.ctx is not None and self.ctx["rows"] == rows, "call prepare_context first"
         self.prepare_timesteps([t])
+        if self.residual_fp32:
+            assert stash is None and not down_only and self.inject is None, "accuracy mode: plain forward only"
+            return self._forward_hp(x32, t, rows, H, want_taps, want_eps)
         tb = self.tbias[int(t)]
         boc = cfg.block_out_channels
         nb = len(boc)
@@ -414,6 +434,173 @@ class HipUNet:
         taps = taps_down + [tap_at, tap_r0, tap_r1] + taps_up
         if stash is not None:
             stash.misc.update(rows=rows, H=H)
+        return eps, (taps if want_taps else None)
+
+
+    # ------------------------------------------------------------------ accuracy mode (residual_fp32)
+    class _Pair:
+        """(hi, lo) views with one pitch; `full` = the [M, 2C] tensor [hi | lo] when the two are its halves."""
+        __slots__ = ("hi", "lo", "full")
+
+        def __init__(self, hi, lo, full=None):
+            self.hi, self.lo, self.full = hi, lo, full
+
+    def _pair(self, M: int, C: int) -> "HipUNet._Pair":
+        buf = torch.empty(M, 2 * C, device=self.dev, dtype=torch.float16)
+        return HipUNet._Pair(buf[:, :C], buf[:, C:], buf)
+
+    def _gn_hp(self, x, rows, HW, eps, name, silu):
+        return ops.groupnorm_hilo(x.hi, x.lo, rows, HW, self.cfg.norm_groups, eps, self.W[name + ".weight"],
+                                  self.W[name + ".bias"], silu)
+
+    def _res_fwd_hp(self, p, x, rows, H, tb, out=None, full_of=None):
+        W = self.W
+        HW, M = H * H, rows * H * H
+        Cout = W[p + ".conv1.weight"].shape[0]
+        n1 = self._gn_hp(x, rows, HW, 1e-5, p + ".norm1", True)
+        h1 = self._pair(M, Cout)                                    # conv1 output feeds norm2: kept as a pair ("lin_n")
+        ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p])
+        n2 = self._gn_hp(h1, rows, HW, 1e-5, p + ".norm2", True)
+        if (p + ".conv_shortcut.weight") in W:
+            sc = self._pair(M, Cout)                                 # the stream as a matmul operand: [hi | lo] . [W | W]
+            xf = x.full if x.full is not None else full_of(x, x.hi.shape[1])
+            ops.gemm(xf, W[p + ".conv_shortcut.weight:2"], out=sc.hi, out_lo=sc.lo, bias=W[p + ".conv_shortcut.bias"])
+        else:
+            sc = x
+        out = out or self._pair(M, Cout)
+        ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
+                    residual=sc.hi, residual_lo=sc.lo)
+        return out
+
+    def _tr_fwd_hp(self, p, x, rows, H, heads, out=None):
+        W = self.W
+        HW, M = H * H, rows * H * H
+        C = x.hi.shape[1]
+        dh = C // heads
+        scale = dh ** -0.5
+        t = p + ".transformer_blocks.0"
+        g = self._gn_hp(x, rows, HW, 1e-6, p + ".norm", False)
+        pin = self._pair(M, C)
+        ops.gemm(g, W[p + ".proj_in.weight"], out=pin.hi, out_lo=pin.lo, bias=W[p + ".proj_in.bias"])
+        a1 = ops.layernorm_hilo(pin.hi, pin.lo, W[t + ".norm1.weight"], W[t + ".norm1.bias"])
+        qkv = ops.gemm(a1, W[t + ".attn1.qkv"])
+        o1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], rows, heads, HW, HW, HW, dh, scale, v_rows=True)
+        p1 = self._pair(M, C)
+        ops.gemm(o1, W[t + ".attn1.to_out.0.weight"], out=p1.hi, out_lo=p1.lo, bias=W[t + ".attn1.to_out.0.bias"],
+                 residual=pin.hi, residual_lo=pin.lo)
+        a2 = ops.layernorm_hilo(p1.hi, p1.lo, W[t + ".norm2.weight"], W[t + ".norm2.bias"])
+        q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"])
+        cb = self.ctx["blocks"][t + ".attn2"]
+        o2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale, v_rows=True)
+        p2 = self._pair(M, C)
+        ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], out=p2.hi, out_lo=p2.lo, bias=W[t + ".attn2.to_out.0.bias"],
+                 residual=p1.hi, residual_lo=p1.lo)
+        a3 = ops.layernorm_hilo(p2.hi, p2.lo, W[t + ".norm3.weight"], W[t + ".norm3.bias"])
+        if C % 64 == 0:
+            gg = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"], geglu=True)
+        else:
+            gg = ops.geglu(ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"]), interleaved=True)
+        p3 = self._pair(M, C)
+        ops.gemm(gg, W[t + ".ff.net.2.weight"], out=p3.hi, out_lo=p3.lo, bias=W[t + ".ff.net.2.bias"],
+                 residual=p2.hi, residual_lo=p2.lo)
+        out = out or self._pair(M, C)
+        ops.gemm(p3.full, W[p + ".proj_out.weight:2"], out=out.hi, out_lo=out.lo, bias=W[p + ".proj_out.bias"],
+                 residual=x.hi, residual_lo=x.lo)
+        return out
+
+    def _forward_hp(self, x32, t, rows, H, want_taps, want_eps):
+        """The forward of forward() with the residual stream as (hi, lo) pairs; the same graph, the same kernels for every
+        contraction, pair-aware epilogues / norms (skg_*_hilo).  Concatenations [h | skip] are pair buffers
+        [h_hi | skip_hi | h_lo | skip_lo], filled in place by their producers."""
+        cfg, W = self.cfg, self.W
+        tb = self.tbias[int(t)]
+        boc = cfg.block_out_channels
+        nb = len(boc)
+        lpb1 = cfg.layers_per_block + 1
+        rev = list(reversed(boc))
+        n_skips = 1 + sum(cfg.layers_per_block + (1 if i < nb - 1 else 0) for i in range(nb))
+        ch_h = [rev[0] if u == 0 else (rev[u // lpb1 - 1] if u % lpb1 == 0 else rev[u // lpb1]) for u in range(nb * lpb1)]
+        cats: List[Optional[torch.Tensor]] = [None] * (nb * lpb1)
+        P = HipUNet._Pair
+        n_made = [0]
+
+        def skip_slot(ch_s: int, size: int):
+            """The pair view inside the concat buffer that will consume the skip produced next."""
+            u = n_skips - 1 - n_made[0]
+            n_made[0] += 1
+            ct = ch_h[u] + ch_s
+            cats[u] = torch.empty(rows * size * size, 2 * ct, device=self.dev, dtype=torch.float16)
+            return P(cats[u][:, ch_h[u]:ct], cats[u][:, ct + ch_h[u]:], None)
+
+        def full_of(pv, C):
+            """[hi | lo] as ONE operand: the pair's own buffer, or a packed copy when it lives inside a concat buffer."""
+            if pv.full is not None:
+                return pv.full
+            buf = torch.empty(pv.hi.shape[0], 2 * C, device=self.dev, dtype=torch.float16)
+            ops.axpby(pv.hi, None, out=buf[:, :C])
+            ops.axpby(pv.lo, None, out=buf[:, C:])
+            return buf
+
+        h = skip_slot(boc[0], H)
+        ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, out=h.hi, out_lo=h.lo, bias=W["conv_in.bias"])
+        taps_down = []
+        cur = H
+        for i in range(nb):
+            for j in range(cfg.layers_per_block):
+                if i < nb - 1:
+                    h = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, full_of=full_of)
+                    h = self._tr_fwd_hp(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i], out=skip_slot(boc[i], cur))
+                else:
+                    h = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, out=skip_slot(boc[i], cur),
+                                         full_of=full_of)
+            if i < nb - 1:
+                p = f"down_blocks.{i}.downsamplers.0.conv"
+                half = cur // 2
+                o = skip_slot(boc[i], half)
+                ops.conv3x3(full_of(h, boc[i]), W[p + ".weight:2"], rows, cur, cur, ops.CONV_S2, out=o.hi, out_lo=o.lo, bias=W[p + ".bias"])
+                h = o
+                cur //= 2
+            if i < 3:
+                taps_down.append((h.hi, cur))
+        h = self._res_fwd_hp("mid_block.resnets.0", h, rows, cur, tb, full_of=full_of)
+        tap_r0 = (h.hi, cur)
+        h = self._tr_fwd_hp("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1])
+        tap_at = (h.hi, cur)
+        ct0 = cats[0].shape[1] // 2
+        h = self._res_fwd_hp("mid_block.resnets.1", h, rows, cur, tb, out=P(cats[0][:, :ch_h[0]], cats[0][:, ct0:ct0 + ch_h[0]]))
+        tap_r1 = (h.hi, cur)
+        taps_up = []
+        rev_heads = tuple(reversed(cfg.num_heads))
+        for i in range(nb):
+            for j in range(lpb1):
+                u = i * lpb1 + j
+                ct = cats[u].shape[1] // 2
+                cat = P(cats[u][:, :ct], cats[u][:, ct:], cats[u])
+                nxt = None
+                if j < lpb1 - 1:
+                    ctn = cats[u + 1].shape[1] // 2
+                    nxt = P(cats[u + 1][:, :ch_h[u + 1]], cats[u + 1][:, ctn:ctn + ch_h[u + 1]])
+                if i > 0:
+                    h = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb)
+                    h = self._tr_fwd_hp(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], out=nxt)
+                else:
+                    h = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, out=nxt)
+            if i < nb - 1:
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                u = (i + 1) * lpb1
+                ctn = cats[u].shape[1] // 2
+                o = P(cats[u][:, :ch_h[u]], cats[u][:, ctn:ctn + ch_h[u]])
+                ops.conv3x3(full_of(h, h.hi.shape[1]), W[p + ".weight:2"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo,
+                            bias=W[p + ".bias"])
+                h = o
+                cur *= 2
+            if i < 3:
+                taps_up.append((h.hi, cur))
+        eps = None
+        if want_eps:
+            n = self._gn_hp(h, rows, cur * cur, 1e-5, "conv_norm_out", True)
+            eps = ops.conv3x3(n, W["conv_out.weight"], rows, cur, cur, bias=W["conv_out.bias"])
+        taps = taps_down + [tap_at, tap_r0, tap_r1] + taps_up
         return eps, (taps if want_taps else None)
 
     # ------------------------------------------------------------------ modules, backward (cond rows)

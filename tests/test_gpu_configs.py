@@ -86,6 +86,37 @@ def test_sd15_eps_error_decomposition_hip_vs_fp16_storage_vs_fp32():
     assert rAB < 2e-3 and mAB < 3e-3
 
 
+def test_sd15_accuracy_mode_meets_north_star_eps_bound():
+    """north_star: <= 1e-3 max latent-eps deviation vs the (fp32 CPU) reference.  With every stored tensor in fp16 - the
+    reference's own GPU configuration - no implementation gets there (previous test: 1.5-1.8e-3, 1.0e-3 of it from the
+    fp16 residual stream alone, tools/eps_decompose.py).  HipUNet(residual_fp32=True) keeps the residual stream and the conv
+    outputs that feed a norm / the residual sum as (hi, lo) fp16 pairs (~22 mantissa bits; the pair is the K-doubled operand
+    where the stream itself enters a matmul) - predicted by the oracle emulation fp16_storage(skip=("res", "lin_n", "rop")):
+    rel 5.2e-4, max 7.2e-4.  Same full-size SD1.5 evaluation as above; asserts the north-star number itself."""
+    from oracle import unet as ounet
+    from sketch2img_amd.config import SD15
+    from sketch2img_amd.unet import HipUNet
+    _threads()
+    cfg = ounet.SD15
+    W = ounet.init_weights(cfg)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 4, 64, 64, generator=g).half().float()
+    xx = torch.cat([x, x])
+    ehs = torch.randn(2, 77, 768, generator=g).half().float()
+    net = HipUNet(SD15, W, DEV, need_backward=False, residual_fp32=True)
+    net.prepare_context(ehs)
+    A, _ = _hip_eps(net, xx, 981, 2, 64)
+    with torch.no_grad():
+        C, _ = ounet.unet_forward(cfg, W, xx, 981, ehs)
+        with ounet.fp16_storage(skip=("res", "lin_n", "rop")):
+            B, _ = ounet.unet_forward(cfg, W, xx, 981, ehs)
+    rAC, mAC = report("sd15 eps  HIP accuracy mode vs fp32 oracle", A, C)
+    rBC, mBC = report("sd15 eps  oracle emulation of the accuracy mode vs fp32 oracle", B, C)
+    report("sd15 eps  HIP accuracy mode vs its oracle emulation", A, B)
+    assert mAC <= 1e-3 and rAC <= 7e-4
+    assert mAC < 1.35 * mBC and rAC < 1.25 * rBC + 5e-5
+
+
 # ------------------------------------------------------------------------------------------------------ config 4
 def test_config4_sd15_full_size_sketch_guided_attn_vs_oracle():
     """BASELINE configs[3] at its real size: one CFG-doubled evaluation of the full SD1.5 UNet at 64x64 latents with

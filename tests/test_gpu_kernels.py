@@ -154,6 +154,72 @@ def test_gemm8_pingpong_320_tile_convolutions(ops):
         assert e < 5e-4
 
 
+def test_hilo_pair_epilogue_and_norms(ops):
+    """Accuracy mode primitives (skg_*_hilo): a GEMM / conv whose output and residual are (hi, lo) fp16 pairs carries
+    ~22 mantissa bits (hi + lo vs an fp64 reference of the same fp16 operands: fp32-accumulation error only), hi alone is
+    the plain fp16 result; GroupNorm / LayerNorm of a pair equal torch on hi + lo."""
+    g = torch.Generator().manual_seed(31)
+    for M, N, K, res in [(1024, 320, 640, True), (300, 1280, 320, False), (4096, 640, 1280, True)]:
+        a = torch.randn(M, K, generator=g).half().to(dev())
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev())
+        b = torch.randn(N, generator=g).half().to(dev())
+        r32 = torch.randn(M, N, generator=g).to(dev()) if res else None
+        rbuf = None
+        if res:
+            rbuf = torch.empty(M, 2 * N, device=dev(), dtype=torch.float16)
+            rbuf[:, :N] = r32.half()
+            rbuf[:, N:] = (r32 - rbuf[:, :N].float()).half()
+            r32 = rbuf[:, :N].float() + rbuf[:, N:].float()
+        out = torch.zeros(M, 2 * N + 8, device=dev(), dtype=torch.float16)
+        ops.gemm(a, w, out=out[:, :N], out_lo=out[:, N:2 * N], bias=b, alpha=0.75,
+                 residual=rbuf[:, :N] if res else None, residual_lo=rbuf[:, N:] if res else None)
+        ref = 0.75 * (a.double() @ w.double().t() + b.double()) + (r32.double() if res else 0)
+        got = out[:, :N].double() + out[:, N:2 * N].double()
+        e = float((got - ref).norm() / ref.norm())
+        e_hi = float((out[:, :N].double() - ref).norm() / ref.norm())
+        plain = ops.gemm(a, w, bias=b, alpha=0.75, residual=rbuf[:, :N].contiguous() if res else None)
+        print(f"hilo gemm M{M} N{N} K{K} res{int(res)}: pair rel {e:.2e}, hi alone {e_hi:.2e}")
+        assert e < 2e-6 and 1e-4 < e_hi < 6e-4 and float(out[:, 2 * N:].abs().max()) == 0
+        # hi is the plain fp16 result up to the last bit (the two epilogues apply bias and alpha in a different fp32 order)
+        assert float((out[:, :N].float() - plain.float()).abs().max()) <= 2.0 ** -9 * float(plain.float().abs().max())
+    # 3x3 conv with a pair as the K-doubled operand ([hi | lo] x [W | W]) and a pair output
+    rows, hw, cin, cout = 2, 16, 64, 320
+    x32 = torch.randn(rows, cin, hw, hw, generator=g)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
+    xp = torch.empty(rows * hw * hw, 2 * cin, device=dev(), dtype=torch.float16)
+    xn = nhwc(x32).to(dev())
+    xp[:, :cin] = xn.half()
+    xp[:, cin:] = (xn - xp[:, :cin].float()).half()
+    w2 = torch.cat([w, w], 1).permute(0, 2, 3, 1).reshape(cout, -1).contiguous().to(dev())
+    o = torch.empty(rows * hw * hw, 2 * cout, device=dev(), dtype=torch.float16)
+    ops.conv3x3(xp, w2, rows, hw, hw, 0, out=o[:, :cout], out_lo=o[:, cout:])
+    xs = (xp[:, :cin].double() + xp[:, cin:].double()).reshape(rows, hw, hw, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xs, w.double().to(dev()), padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    e = float(((o[:, :cout].double() + o[:, cout:].double()) - ref).norm() / ref.norm())
+    print(f"hilo conv pair operand + pair output: rel {e:.2e}")
+    assert e < 2e-6
+    # norms of a pair
+    rows, HW, C, G = 2, 256, 320, 32
+    v = 3 * torch.randn(rows * HW, C, generator=g).to(dev()) + 1.5
+    pr = torch.empty(rows * HW, 2 * C, device=dev(), dtype=torch.float16)
+    pr[:, :C] = v.half()
+    pr[:, C:] = (v - pr[:, :C].float()).half()
+    vs = pr[:, :C].float() + pr[:, C:].float()
+    ga, be = (1 + 0.1 * torch.randn(C, generator=g)).half().to(dev()), (0.1 * torch.randn(C, generator=g)).half().to(dev())
+    y = ops.groupnorm_hilo(pr[:, :C], pr[:, C:], rows, HW, G, 1e-5, ga, be, True)
+    ref = F.silu(F.group_norm(vs.reshape(rows, HW, C).permute(0, 2, 1), G, ga.float(), be.float(), 1e-5)).permute(0, 2, 1).reshape(-1, C)
+    e = float((y.float() - ref).norm() / ref.norm())
+    y16 = ops.groupnorm(pr[:, :C].contiguous(), rows, HW, G, 1e-5, ga, be, True)[0]
+    e16 = float((y16.float() - ref).norm() / ref.norm())
+    print(f"hilo groupnorm: rel {e:.2e} (fp16-input kernel on hi alone: {e16:.2e})")
+    assert e < 4e-4 and e <= e16 * 1.05
+    z = ops.layernorm_hilo(pr[:, :C], pr[:, C:], ga, be)
+    refl = F.layer_norm(vs, (C,), ga.float(), be.float(), 1e-5)
+    e = float((z.float() - refl).norm() / refl.norm())
+    print(f"hilo layernorm: rel {e:.2e}")
+    assert e < 4e-4
+
+
 # ---------------------------------------------------------------------------------------------- conv
 def nhwc(x):   # [B,C,H,W] -> [B*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
@@ -443,7 +509,8 @@ def ref_attention(q, k, v, heads, scale):
 
 @pytest.mark.parametrize("dh,heads,Nq,Nkv", [(40, 8, 256, 256), (80, 8, 128, 128), (160, 8, 64, 64), (64, 5, 200, 200),
                                             (16, 2, 72, 72), (32, 2, 1024, 1024), (40, 8, 4096, 4096),
-                                            (40, 8, 256, 77), (160, 8, 64, 77), (64, 5, 144, 401)])
+                                            (40, 8, 256, 77), (160, 8, 64, 77), (64, 5, 144, 401), (80, 8, 1000, 77),
+                                            (64, 5, 300, 77), (40, 8, 200, 50), (40, 8, 4096, 77)])
 def test_attention_forward(ops, dh, heads, Nq, Nkv):
     B, C = 2, heads * dh
     kvs = (Nkv + 7) // 8 * 8
@@ -462,7 +529,15 @@ def test_attention_forward(ops, dh, heads, Nq, Nkv):
     # V handed over row-major (skg_attn_fwd_rowv: fragments through ds_read_b64_tr_b16): the same products in the same
     # order, so the result is the transposed-copy path's bit for bit
     o2, lse2 = ops.attn_fwd(Q, K, V, B, heads, Nq, Nkv, kvs, dh, scale, want_lse=True, v_rows=True)
-    assert torch.equal(o2, o) and torch.equal(lse2, lse)
+    if kvs <= 80 and dh in (40, 64, 80, 160):
+        # short key sequences (the 77 text tokens) with row-major V take the LDS-resident kernel (attn_fwd_short_kernel):
+        # another kernel, so not bit-equal to the flash kernel - checked against the reference like it, and deterministic
+        assert report(f"attn fwd short-key kernel dh{dh} {Nq}x{Nkv}", o2.float().cpu().view(B, Nq, C), ro)[0] < 2e-3
+        assert report("attn lse short-key kernel", lse2.cpu(), rl)[1] < 2e-3
+        o3, lse3 = ops.attn_fwd(Q, K, V, B, heads, Nq, Nkv, kvs, dh, scale, want_lse=True, v_rows=True)
+        assert torch.equal(o2, o3) and torch.equal(lse2, lse3)
+    else:
+        assert torch.equal(o2, o) and torch.equal(lse2, lse)
 
 
 @pytest.mark.parametrize("dh,heads,N,Nkv", [(64, 12, 80, 77), (16, 4, 80, 77), (32, 3, 320, 320), (64, 2, 200, 197)])

@@ -1,16 +1,13 @@
 set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/t1
+mkdir -p gpurun_out/t2
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "gemm or conv or forced or three" > gpurun_out/t1/kernels.log 2>&1; echo "kernels rc=$?"
-tail -5 gpurun_out/t1/kernels.log
-timeout 600 python tools/smallm_bench.py --rounds 3 --iters 20 --out gpurun_out/t1/smallm.txt > gpurun_out/t1/smallm.log 2>&1; echo "smallm rc=$?"
-tail -4 gpurun_out/t1/smallm.log
-SKG_LIB=$PWD/sketch2img_amd/libskg_lab.so timeout 600 python tools/smallm_bench.py --rounds 2 --iters 20 --probes --out gpurun_out/t1/smallm_probes.txt > gpurun_out/t1/smallm_probes.log 2>&1; echo "probes rc=$?"
-timeout 900 python -m pytest tests/test_gpu_configs.py -x -q -m gpu -k "rccl or config0 or graph_cache or graph_replay" -s > gpurun_out/t1/configs.log 2>&1; echo "configs rc=$?"
-tail -5 gpurun_out/t1/configs.log
-SKG_GEMMK=0 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/t1/bench_gk0.json 2> gpurun_out/t1/bench_gk0.err; echo "b0 rc=$?"
-SKG_GEMMK=1 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/t1/bench_gk1.json 2> gpurun_out/t1/bench_gk1.err; echo "b1 rc=$?"
-SKG_GEMMK=0 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/t1/bench_gk0b.json 2> gpurun_out/t1/bench_gk0b.err; echo "b0b rc=$?"
-SKG_GEMMK=1 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --shape-report gpurun_out/t1/shapes_gk1.txt > gpurun_out/t1/bench_gk1b.json 2> gpurun_out/t1/bench_gk1b.err; echo "b1b rc=$?"
-grep -o '"value": [0-9.]*' gpurun_out/t1/bench_gk*.json
+timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "hilo or gemm8 or gemm_plain or forced" -s > gpurun_out/t2/kernels.log 2>&1; echo "kernels rc=$?"
+grep "hilo\|passed\|failed\|Error" gpurun_out/t2/kernels.log | tail -12
+timeout 1200 python -m pytest tests/test_gpu_configs.py -x -q -m gpu -k "accuracy_mode or decomposition" -s > gpurun_out/t2/acc.log 2>&1; echo "acc rc=$?"
+grep "parity\|passed\|failed\|Error" gpurun_out/t2/acc.log | tail -30
+timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-guidance > gpurun_out/t2/bench_ng.json 2> gpurun_out/t2/bench_ng.err; echo "ng rc=$?"
+timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-guidance --residual-fp32 > gpurun_out/t2/bench_ng_hp.json 2> gpurun_out/t2/bench_ng_hp.err; echo "hp rc=$?"
+grep -o '"value": [0-9.]*' gpurun_out/t2/bench_ng*.json
+tail -3 gpurun_out/t2/bench_ng_hp.err
+for S in 1 2 4 8 16 32; do timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --samples-per-gpu $S > gpurun_out/t2/sweep_s$S.json 2> gpurun_out/t2/sweep_s$S.err; echo "S=$S rc=$? $(grep -o '"value": [0-9.]*' gpurun_out/t2/sweep_s$S.json)"; done
