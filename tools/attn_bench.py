@@ -58,4 +58,7 @@ if __name__ == "__main__":
     case(16, 8, 1024, 80, bwd=False)
     case(8, 8, 1024, 80)
     case(16, 8, 256, 160, bwd=False)
+    case(16, 8, 1024, 80, Nkv=77, bwd=False)
+    case(16, 8, 256, 160, Nkv=77, bwd=False)
+    case(16, 8, 64, 160, Nkv=77, bwd=False)
     case(8, 8, 256, 160)
