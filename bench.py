@@ -117,7 +117,8 @@ class LaunchTimer:
                 return f"gemm8_kernel<{variant - 8000}, {MODES[mode]}, 0, {g}>"
             if variant >= 2000:
                 stages = 3 if variant >= 10000 else 2
-                return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}, {stages}, {g}>"
+                # (..., GNS, HILO): the accuracy-mode instantiation is never part of a bench batch
+                return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}, {stages}, {g}, false>"
             return f"gemm_kernel<{bn}, {MODES[mode]}>"
 
         def ev():

@@ -12,6 +12,7 @@ SURVEY Q1): alpha, the BatchNorm statistics and the loss are per sample.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, List, Optional
 
@@ -118,6 +119,7 @@ class HipSampler:
         self.last_latents: Optional[torch.Tensor] = None
         self._x0_before: Optional[torch.Tensor] = None      # DPM-Solver++ history (one x0 prediction)
         self._seen = 0
+        self.share_cfg_prefix = os.environ.get("SKG_SHARE_CFG", "1") != "0"      # A/B switch (bench.py on one box)
         self._graphs: dict = {}                   # insertion-ordered: least recently used first
         self.max_graph_sets = 4
 
@@ -135,7 +137,8 @@ class HipSampler:
         guided = guided_step(i, T) and target is not None and self.lgp is not None
         x32 = ops.nchw_to_nhwc(torch.cat([x, x]).contiguous(), CIN_PAD)
         stash = Stash() if guided else None
-        eps, taps = self.unet.forward(x32, t, 2 * S, h, stash, want_taps=guided)
+        # (the two CFG halves of x32 are the same latents: the text-independent front of the UNet runs once)
+        eps, taps = self.unet.forward(x32, t, 2 * S, h, stash, want_taps=guided, shared_input=self.share_cfg_prefix)
         if isinstance(tab, DPMTables):
             if self._x0_before is None or self._x0_before.shape != x.shape:
                 self._x0_before, self._seen = torch.zeros_like(x), 0

@@ -217,9 +217,10 @@ class HipUNet:
         a 10-40 MB tensor - disappears.  Smaller maps keep the one-launch GroupNorm that holds a slice in registers."""
         return _GN_FROM_PRODUCER and HW >= 1024 and ops.gn_fusable(rows * HW, C, HW, self.cfg.norm_groups)
 
-    def _res_fwd(self, p, x, rows, H, tb, stash: Optional[Stash], out=None, xpart=None, want_part=False):
+    def _res_fwd(self, p, x, rows, H, tb, stash: Optional[Stash], out=None, xpart=None, want_part=False, half=False):
         """xpart: GroupNorm partial sums of x from its producer (or None).  Returns (out, partial sums of out or None):
-        they are produced when want_part is set and the level takes its statistics from the producers."""
+        they are produced when want_part is set and the level takes its statistics from the producers.
+        half: `rows` are the COND rows only (the shared CFG prefix, see forward): the stash says so."""
         cfg, W = self.cfg, self.W
         G, HW = cfg.norm_groups, H * H
         n1, st1 = ops.groupnorm(x, rows, HW, G, 1e-5, W[p + ".norm1.weight"], W[p + ".norm1.bias"], True, partial=xpart)
@@ -241,10 +242,15 @@ class HipUNet:
         else:
             out = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out, bias=W[p + ".conv2.bias"], residual=sc)
         if stash is not None:
-            stash.res[p] = dict(x=x, st1=st1, h1=h1, st2=st2, H=H)
+            stash.res[p] = dict(x=x, st1=st1, h1=h1, st2=st2, H=H, half=half)
         return out, opart
 
-    def _tr_fwd(self, p, x, rows, H, heads, stash: Optional[Stash], out=None, xpart=None, want_part=False):
+    def _tr_fwd(self, p, x, rows, H, heads, stash: Optional[Stash], out=None, xpart=None, want_part=False, shared=False,
+                x_full=None):
+        """shared: x holds the COND rows only (rows // 2 of them) of a CFG-doubled batch whose two halves are identical up
+        to here (see forward): everything in front of the first text-dependent operation - GroupNorm, proj_in, the whole
+        self-attention, LayerNorm 2, to_q - runs once; p1 and q2 are written into the cond half of full-size buffers and
+        copied to the uncond half (x_full: the same for x, filled by the caller)."""
         cfg, W = self.cfg, self.W
         HW = H * H
         C = x.shape[1]
@@ -252,19 +258,34 @@ class HipUNet:
         scale = dh ** -0.5
         t = p + ".transformer_blocks.0"
         keep = stash is not None
-        g, gst = ops.groupnorm(x, rows, HW, cfg.norm_groups, 1e-6, W[p + ".norm.weight"], W[p + ".norm.bias"], False,
+        r1 = rows // 2 if shared else rows                    # rows of the text-independent part
+        g, gst = ops.groupnorm(x, r1, HW, cfg.norm_groups, 1e-6, W[p + ".norm.weight"], W[p + ".norm.bias"], False,
                                partial=xpart)
         pin = ops.gemm(g, W[p + ".proj_in.weight"], bias=W[p + ".proj_in.bias"])
         a1, st1 = ops.layernorm(pin, W[t + ".norm1.weight"], W[t + ".norm1.bias"], want_stats=True)
         qkv = ops.gemm(a1, W[t + ".attn1.qkv"])
         # V straight out of the fused projection (row-major; the kernel's LDS transpose read replaces the V^T copy)
-        o1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], rows, heads, HW, HW, HW, dh, scale,
+        o1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], r1, heads, HW, HW, HW, dh, scale,
                                 want_lse=True, v_rows=True)
-        p1 = ops.gemm(o1, W[t + ".attn1.to_out.0.weight"], bias=W[t + ".attn1.to_out.0.bias"], residual=pin)
+        M1 = r1 * HW
+        p1_full = torch.empty(rows * HW, C, device=x.device, dtype=torch.float16) if shared else None
+        p1 = ops.gemm(o1, W[t + ".attn1.to_out.0.weight"], p1_full[M1:] if shared else None,
+                      bias=W[t + ".attn1.to_out.0.bias"], residual=pin)
+        x_c, p1_c = x, p1                                     # what the backward of the cond rows reads
         if self.inject is not None:
+            if shared:                                        # the injected K / V differ between the halves: diverge here
+                ops.batch_copy(p1, M1, p1_full, M1, 1, M1)
+                x, p1, shared = x_full, p1_full, False
             p1 = self.inject(t, p1, rows, HW, heads)
+            p1_c = p1
         a2, st2 = ops.layernorm(p1, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
-        q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"])
+        q2_full = torch.empty(rows * HW, C, device=x.device, dtype=torch.float16) if shared else None
+        q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"], q2_full[M1:] if shared else None)
+        q2_c = q2
+        if shared:      # the text-dependent part needs both halves: one copy each into the uncond half
+            ops.batch_copy(p1, M1, p1_full, M1, 1, M1)
+            ops.batch_copy(q2, M1, q2_full, M1, 1, M1)
+            x, p1, q2 = x_full, p1_full, q2_full
         cb = self.ctx["blocks"][t + ".attn2"]
         o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
                                 want_lse=True, v_rows=True)
@@ -297,15 +318,39 @@ class HipUNet:
         else:
             out = ops.gemm(p3, W[p + ".proj_out.weight"], out, bias=W[p + ".proj_out.bias"], residual=x)
         if keep:
-            stash.tr[p] = dict(x=x, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1, st2=st2, q2=q2,
-                               o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads)
+            # half: the tensors of the text-independent part hold the cond rows only (r1 == rows // 2)
+            half = ("x", "gst", "pin", "st1", "qkv", "o1", "lse1", "p1", "st2", "q2") if r1 != rows else ()
+            if r1 != rows and self.inject is None:
+                stash.tr[p] = dict(x=x_c, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1_c, st2=st2, q2=q2_c,
+                                   o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=half)
+            else:
+                stash.tr[p] = dict(x=x, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1, st2=st2, q2=q2,
+                                   o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=())
         return out, opart
+
+    @staticmethod
+    def _dup_partial(part):
+        """GroupNorm partial sums of the cond rows -> of [uncond rows ; cond rows] (the halves are identical)."""
+        if part is None:
+            return None
+        both = ops.GNPartial.__new__(ops.GNPartial)
+        both.rows, both.nch, both.groups = 2 * part.rows, part.nch, part.groups
+        both.buf = torch.cat([part.buf, part.buf])
+        return both
 
     # ------------------------------------------------------------------ forward
     def forward(self, x32: torch.Tensor, t: int, rows: int, H: int, stash: Optional[Stash] = None,
-                want_taps: bool = True, want_eps: bool = True, down_only: bool = False):
+                want_taps: bool = True, want_eps: bool = True, down_only: bool = False, shared_input: bool = False):
         """x32: fp16 [rows*H*H, 32] (latent channels zero-padded).  Returns (eps [rows*H*H, 8] or None,
-        taps: list of 9 (tensor [rows*s*s, C], s))."""
+        taps: list of 9 (tensor [rows*s*s, C], s)).
+
+        shared_input: the caller guarantees that the two halves of x32 are IDENTICAL - the CFG-doubled batch of
+        modules/pipeline.py:85, `torch.cat([latents] * 2)`.  The two halves of the evaluation then only differ from the
+        first text-dependent operation on (the first cross-attention), so everything in front of it - conv_in, the first
+        ResnetBlock, and GroupNorm / proj_in / self-attention / LayerNorm 2 / to_q of the first transformer block, all at
+        the full 64 x 64 resolution - is evaluated ONCE on the cond rows and copied to the uncond rows.  Exact: every
+        kernel's result for a row depends on that row only, so the outputs are bit-identical to the doubled evaluation
+        (tests/test_gpu_pipeline.py::test_shared_cfg_prefix_is_bit_identical)."""
         cfg, W = self.cfg, self.W
         assert self.ctx is not None and self.ctx["rows"] == rows, "call prepare_context first"
         self.prepare_timesteps([t])
@@ -337,17 +382,40 @@ class HipUNet:
         G = cfg.norm_groups
         # hp: GroupNorm partial sums of h left behind by the kernel that produced it, whenever the next consumer of h is a
         # GroupNorm of the 64 x 64 / 32 x 32 levels (None otherwise: concatenated inputs, small maps)
-        if self._gn_from_producer(rows, H * H, boc[0]):
+        shared = shared_input and rows % 2 == 0 and rows >= 2 and not down_only and nb > 1 and cfg.layers_per_block >= 1
+        cur = H
+        if shared:
+            S1, M1 = rows // 2, (rows // 2) * H * H
+            slot = skip_slot(boc[0], H)                           # the skip of conv_in, all rows
+            if self._gn_from_producer(S1, H * H, boc[0]):
+                h1, hp1 = ops.conv3x3(x32[M1:], W["conv_in.weight"], S1, H, H, out=slot[M1:], bias=W["conv_in.bias"], gn_groups=G)
+            else:
+                h1, hp1 = ops.conv3x3(x32[M1:], W["conv_in.weight"], S1, H, H, out=slot[M1:], bias=W["conv_in.bias"]), None
+            ops.batch_copy(h1, M1, slot, M1, 1, M1)
+            skips.append(slot)
+            skip_parts.append(self._dup_partial(hp1))
+            x_full = torch.empty(rows * H * H, boc[0], device=self.dev, dtype=torch.float16)
+            h1, hp1 = self._res_fwd("down_blocks.0.resnets.0", h1, S1, cur, tb, stash, out=x_full[M1:], xpart=hp1,
+                                    want_part=True, half=True)
+            ops.batch_copy(h1, M1, x_full, M1, 1, M1)
+            h, hp = self._tr_fwd("down_blocks.0.attentions.0", h1, rows, cur, cfg.num_heads[0], stash,
+                                 out=skip_slot(boc[0], cur), xpart=hp1, want_part=0 < cfg.layers_per_block - 1,
+                                 shared=True, x_full=x_full)
+            skips.append(h)
+            skip_parts.append(hp)
+        elif self._gn_from_producer(rows, H * H, boc[0]):
             h, hp = ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, out=skip_slot(boc[0], H), bias=W["conv_in.bias"],
                                 gn_groups=G)
         else:
             h, hp = ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, out=skip_slot(boc[0], H), bias=W["conv_in.bias"]), None
-        skips.append(h)
-        skip_parts.append(hp)
+        if not shared:
+            skips.append(h)
+            skip_parts.append(hp)
         taps_down = []
-        cur = H
         for i in range(nb):
             for j in range(cfg.layers_per_block):
+                if shared and i == 0 and j == 0:
+                    continue                                      # done above, once for both halves
                 if i < nb - 1:
                     h, hp = self._res_fwd(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, stash, xpart=hp, want_part=True)
                     # the block's last transformer feeds the downsampling conv, the others the next resnet's norm1
@@ -608,8 +676,11 @@ class HipUNet:
         cfg, W = self.cfg, self.W
         H = st["H"]
         HW, G = H * H, cfg.norm_groups
-        x, h1 = st["x"][S * HW:], st["h1"][S * HW:]
-        st1, st2 = st["st1"][S:], st["st2"][S:]
+        if st.get("half"):        # the shared CFG prefix was evaluated on the cond rows only
+            x, h1, st1, st2 = st["x"], st["h1"], st["st1"], st["st2"]
+        else:
+            x, h1 = st["x"][S * HW:], st["h1"][S * HW:]
+            st1, st2 = st["st1"][S:], st["st2"][S:]
         dn2 = ops.conv3x3(dout, W[p + ".conv2.weight:T"], S, H, H)
         dh1 = ops.groupnorm_bwd(h1, dn2, S, HW, G, st2, W[p + ".norm2.weight"], W[p + ".norm2.bias"], True)
         dn1 = ops.conv3x3(dh1, W[p + ".conv1.weight:T"], S, H, H)
@@ -629,7 +700,10 @@ class HipUNet:
         dh = C // heads
         scale = dh ** -0.5
         t = p + ".transformer_blocks.0"
+        half = st.get("half", ())
         c = lambda a: a[M0:]
+        cc = lambda k: st[k] if k in half else st[k][M0:]        # activations [rows*HW, .] of the cond rows
+        cs = lambda k: st[k] if k in half else st[k][S:]         # per-row statistics / lse of the cond rows
         dp3 = ops.gemm(dout, W[p + ".proj_out.weight:T"])
         dgg = ops.gemm(dp3, W[t + ".ff.net.2.weight:T"])
         df = ops.geglu_bwd(st["f"], dgg, interleaved=True)            # f is stashed for the cond rows only
@@ -640,23 +714,23 @@ class HipUNet:
         cb = self.ctx["blocks"][t + ".attn2"]
         L, Lp = self.ctx["L"], self.ctx["Lp"]
         delta2 = ops.attn_bwd_delta(c(st["o2"]), do2, S, heads, HW, dh)
-        dq2 = ops.attn_bwd_dq(c(st["q2"]), cb["K"][S * Lp:], cb["V"][S * Lp:], do2, st["lse2"][S:],
+        dq2 = ops.attn_bwd_dq(cc("q2"), cb["K"][S * Lp:], cb["V"][S * Lp:], do2, st["lse2"][S:],
                               delta2, S, heads, HW, L, Lp, dh, scale)
         da2 = ops.gemm(dq2, W[t + ".attn2.to_q.weight:T"])
-        dp1 = ops.layernorm_bwd(c(st["p1"]), da2, W[t + ".norm2.weight"], c(st["st2"]), residual=dp2)
+        dp1 = ops.layernorm_bwd(cc("p1"), da2, W[t + ".norm2.weight"], cc("st2"), residual=dp2)
         # self-attention
         do1 = ops.gemm(dp1, W[t + ".attn1.to_out.0.weight:T"])
-        qkv = c(st["qkv"])
+        qkv = cc("qkv")
         Q, K, V = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-        delta1 = ops.attn_bwd_delta(c(st["o1"]), do1, S, heads, HW, dh)
-        lse1 = st["lse1"][S:]
+        delta1 = ops.attn_bwd_delta(cc("o1"), do1, S, heads, HW, dh)
+        lse1 = cs("lse1")
         dqkv = torch.empty(M0, 3 * C, device=self.dev, dtype=torch.float16)
         ops.attn_bwd_dq(Q, K, V, do1, lse1, delta1, S, heads, HW, HW, HW, dh, scale, out=dqkv[:, :C])
         ops.attn_bwd_dkv(Q, K, V, do1, lse1, delta1, S, heads, HW, HW, dh, scale, dK=dqkv[:, C:2 * C], dV=dqkv[:, 2 * C:])
         da1 = ops.gemm(dqkv, W[t + ".attn1.qkv:T"])
-        dpin = ops.layernorm_bwd(c(st["pin"]), da1, W[t + ".norm1.weight"], c(st["st1"]), residual=dp1)
+        dpin = ops.layernorm_bwd(cc("pin"), da1, W[t + ".norm1.weight"], cc("st1"), residual=dp1)
         dg = ops.gemm(dpin, W[p + ".proj_in.weight:T"])
-        return ops.groupnorm_bwd(c(st["x"]), dg, S, HW, cfg.norm_groups, st["gst"][S:], W[p + ".norm.weight"],
+        return ops.groupnorm_bwd(cc("x"), dg, S, HW, cfg.norm_groups, cs("gst"), W[p + ".norm.weight"],
                                  W[p + ".norm.bias"], False, residual=dout)
 
     # ------------------------------------------------------------------ backward

@@ -267,6 +267,51 @@ def test_sampler_tiny_vs_oracle(tiny):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_shared_cfg_prefix_is_bit_identical(tiny):
+    """HipUNet.forward(shared_input=True): the text-independent front of the UNet (conv_in, the first ResnetBlock,
+    GroupNorm / proj_in / self-attention / LayerNorm 2 / to_q of the first transformer block) is evaluated once for the two
+    identical CFG halves (modules/pipeline.py:85 `torch.cat([latents] * 2)`).  Exact: eps and all nine taps equal the
+    doubled evaluation bit for bit - TINY and the full SD1.5 architecture - and so do a guided step's update, its auxiliaries
+    and the backward-to-input that reads the half-size stash."""
+    from oracle import lgp as olgp, unet as ounet
+    from sketch2img_amd import ops, synthetic
+    from sketch2img_amd.config import SD15
+    from sketch2img_amd.lgp import HipLGP
+    from sketch2img_amd.sampler import DDIMTables, HipSampler
+    from sketch2img_amd.unet import CIN_PAD, HipUNet
+    S, h, net = tiny["S"], tiny["h"], tiny["net"]
+    xx = torch.cat([tiny["x"], tiny["x"]])
+    x32 = ops.nchw_to_nhwc(xx.to(DEV), CIN_PAD)
+    e0, t0 = net.forward(x32, 501, 2 * S, h)
+    e1, t1 = net.forward(x32, 501, 2 * S, h, shared_input=True)
+    assert torch.equal(e0, e1) and all(torch.equal(a[0], b[0]) for a, b in zip(t0, t1))
+    # a guided step: forward with stash, LGP, backward through the half-size stash of the shared front
+    sd = olgp.init_state_dict(sum(ounet.tap_channels(tiny["cfg"])) + 40, seed=12)
+    g = torch.Generator().manual_seed(5)
+    target = 0.18215 * torch.randn(S, 4, h, h, generator=g)
+    tab = DDIMTables.make(4)
+    outs = []
+    for share in (False, True):
+        smp = HipSampler(net, HipLGP(sd, ounet.tap_channels(tiny["cfg"]), DEV))
+        smp.share_cfg_prefix = share
+        xp, eps, aux = smp.step(tiny["x"].to(DEV), tiny["x"].to(DEV), target.to(DEV), tab, 0, 7.5, 1.6, want_eps=True)
+        outs.append((xp.clone(), eps.clone(), aux.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+    # the real architecture at its real top-level resolution (other kernel instantiations than TINY: 256 x 320 tiles ...)
+    W = synthetic.unet_state_dict(SD15)
+    big = HipUNet(SD15, W, DEV, need_backward=False)
+    rows = 4
+    big.prepare_context(synthetic.text_embeddings(rows // 2))
+    xb = synthetic.initial_latents(0, rows // 2, 64)
+    x32 = ops.nchw_to_nhwc(torch.cat([xb, xb]).to(DEV), CIN_PAD)
+    e0, t0 = big.forward(x32, 981, rows, 64)
+    e1, t1 = big.forward(x32, 981, rows, 64, shared_input=True)
+    same = torch.equal(e0, e1) and all(torch.equal(a[0], b[0]) for a, b in zip(t0, t1))
+    print(f"[parity] sd15 shared CFG prefix vs doubled evaluation: bit-identical {same}, "
+          f"max |d eps| {float((e0.float() - e1.float()).abs().max()):.3e}")
+    assert same
+
+
 def test_unet_sd15_forward_vs_oracle_full_size():
     """One full-size SD1.5 evaluation (2 rows, 64x64 latent, 860 M parameters) vs the fp32 CPU oracle."""
     from oracle import unet as ounet
