@@ -297,19 +297,25 @@ def test_shared_cfg_prefix_is_bit_identical(tiny):
         xp, eps, aux = smp.step(tiny["x"].to(DEV), tiny["x"].to(DEV), target.to(DEV), tab, 0, 7.5, 1.6, want_eps=True)
         outs.append((xp.clone(), eps.clone(), aux.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
-    # the real architecture at its real top-level resolution (other kernel instantiations than TINY: 256 x 320 tiles ...)
+    # the real architecture at its real top-level resolution.  Bit-identity needs both evaluations to run the same kernel
+    # instantiations for the shared layers: true at the bench's size (8 samples: 16 vs 8 rows, no split-K either way); with 4
+    # vs 2 rows the 2-row convolutions take split-K (another summation order) and the two results are two fp16 evaluations
+    # of the same thing - as far apart as either is from the oracle
     W = synthetic.unet_state_dict(SD15)
     big = HipUNet(SD15, W, DEV, need_backward=False)
-    rows = 4
-    big.prepare_context(synthetic.text_embeddings(rows // 2))
-    xb = synthetic.initial_latents(0, rows // 2, 64)
-    x32 = ops.nchw_to_nhwc(torch.cat([xb, xb]).to(DEV), CIN_PAD)
-    e0, t0 = big.forward(x32, 981, rows, 64)
-    e1, t1 = big.forward(x32, 981, rows, 64, shared_input=True)
-    same = torch.equal(e0, e1) and all(torch.equal(a[0], b[0]) for a, b in zip(t0, t1))
-    print(f"[parity] sd15 shared CFG prefix vs doubled evaluation: bit-identical {same}, "
-          f"max |d eps| {float((e0.float() - e1.float()).abs().max()):.3e}")
-    assert same
+    for rows, want_equal in ((4, False), (16, True)):
+        big.prepare_context(synthetic.text_embeddings(rows // 2))
+        xb = synthetic.initial_latents(0, rows // 2, 64)
+        x32 = ops.nchw_to_nhwc(torch.cat([xb, xb]).to(DEV), CIN_PAD)
+        e0, t0 = big.forward(x32, 981, rows, 64)
+        e1, t1 = big.forward(x32, 981, rows, 64, shared_input=True)
+        same = torch.equal(e0, e1) and all(torch.equal(a[0], b[0]) for a, b in zip(t0, t1))
+        rel = float((e0.float() - e1.float()).norm() / e0.float().norm())
+        print(f"[parity] sd15 shared CFG prefix vs doubled evaluation, {rows} rows: bit-identical {same}, eps rel {rel:.3e}, "
+              f"max |d eps| {float((e0.float() - e1.float()).abs().max()):.3e}")
+        assert rel < 2e-3
+        if want_equal:
+            assert same
 
 
 def test_unet_sd15_forward_vs_oracle_full_size():

@@ -5,9 +5,9 @@
 #   3. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -> profiles/<tag>_cfg<C>_mfma_counters.{json,txt}
 # (counter passes carry --pmc only: no trace domains).  The counter passes run a 6-step schedule of the same workload
 # (per-launch figures do not depend on the step count).  Run on the GPU box from the repo root:
-#   bash tools/collect_profiles.sh r02 2
+#   bash tools/collect_profiles.sh r03 2
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 CFG=${2:-2}
 EXTRA=${3:-}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
