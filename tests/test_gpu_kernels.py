@@ -220,6 +220,30 @@ def test_hilo_pair_epilogue_and_norms(ops):
     assert e < 4e-4
 
 
+def test_split_k_workspace_is_per_stream(ops):
+    """the split-K slab used to be ONE process-global pointer.  Since ABI 2 libskg.so keeps one slab per (device,
+    stream) and hands it to the kernel as an argument: split-K launches issued alternately on two streams - free to overlap on
+    the device - each reproduce the single-stream result bit for bit, and the two streams' slabs are different buffers."""
+    g = torch.Generator().manual_seed(41)
+    M, N, K = 1024, 1280, 5120                    # 64 tiles -> split-K (fp32 slabs + reduce)
+    a = [torch.randn(M, K, generator=g).half().to(dev()) for _ in range(2)]
+    w = [(torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev()) for _ in range(2)]
+    ref = [ops.gemm(a[i], w[i]).clone() for i in range(2)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for rep in range(40):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[i].append(ops.gemm(a[i], w[i]))
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert all(torch.equal(o, ref[i]) for o in outs[i]), f"stream {i}: a split-K result changed under concurrency"
+    keys = [(s.device.index, s.cuda_stream) for s in streams]
+    assert all(k in ops._workspace for k in keys)
+    assert ops._workspace[keys[0]].data_ptr() != ops._workspace[keys[1]].data_ptr()
+
+
 # ---------------------------------------------------------------------------------------------- conv
 def nhwc(x):   # [B,C,H,W] -> [B*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
