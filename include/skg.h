@@ -152,7 +152,7 @@ int skg_groupnorm_apply_hilo(const void* X, const void* X_lo, int ldx, void* Y, 
                              int groups, const float* stats, const void* gamma, const void* beta, int silu,
                              void* stream);
 int skg_layernorm_fwd_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int M, int C,
-                           const void* gamma, const void* beta, float eps, void* stream);
+                           const void* gamma, const void* beta, float eps, float* stats /* [M][2] or NULL */, void* stream);
 
 int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C,
                         int groups, const float* stats, const void* gamma, const void* beta,

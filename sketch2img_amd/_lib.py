@@ -32,7 +32,7 @@ SIGNATURES = {
     "skg_gemm_f16_hilo": ("i", "pipippiiiipppifup".replace(" ", "")),
     "skg_conv3x3_f16_hilo": ("i", "pipppiiiiiiipppifup"),
     "skg_groupnorm_apply_hilo": ("i", "ppipiiiiippp ip".replace(" ", "")),
-    "skg_layernorm_fwd_hilo": ("i", "ppipiiippfp"),
+    "skg_layernorm_fwd_hilo": ("i", "ppipiiippfpp"),
     "skg_gemm_f16_gn": ("i", "pipipiiiippifupiip"),
     "skg_gemm_gn_fused": ("i", "iiiiiii"),
     "skg_gemm_f16_geglu_keep": ("i", "pipipipiiiipp"),

@@ -50,7 +50,8 @@ template <int NQ>
 __global__ __launch_bounds__(256) void ln_fwd_hilo_kernel(const half_t* __restrict__ Xh, const half_t* __restrict__ Xl,
                                                           int ldx, half_t* __restrict__ Y, int ldy, int M, int C,
                                                           const half_t* __restrict__ gamma,
-                                                          const half_t* __restrict__ beta, float eps) {
+                                                          const half_t* __restrict__ beta, float eps,
+                                                          float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void ln_fwd_hilo_kernel(const half_t* __restri
       st_half8(Y + (size_t)row * ldy + pc * 8, o);
     }
   }
+  if (stats && lane == 0) { stats[(size_t)row * 2] = mean; stats[(size_t)row * 2 + 1] = rstd; }      // for skg_layernorm_bwd
 }
 
 }  // namespace
@@ -104,18 +106,18 @@ extern "C" int skg_groupnorm_apply_hilo(const void* X, const void* X_lo, int ldx
 }
 
 extern "C" int skg_layernorm_fwd_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int M, int C,
-                                      const void* gamma, const void* beta, float eps, void* stream) {
+                                      const void* gamma, const void* beta, float eps, float* stats, void* stream) {
   SKG_REQUIRE(X && X_lo && Y && gamma && beta && M > 0 && C % 8 == 0 && C <= 2048);
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && skg_aligned(X, 16) && skg_aligned(X_lo, 16) && skg_aligned(Y, 16) &&
               skg_aligned(gamma, 16) && skg_aligned(beta, 16));
   hipStream_t st = (hipStream_t)stream;
   const half_t *xh = (const half_t*)X, *xl = (const half_t*)X_lo, *g = (const half_t*)gamma, *b = (const half_t*)beta;
   if (C <= 512)
-    hipLaunchKernelGGL((ln_fwd_hilo_kernel<1>), dim3(skg_cdiv(M, 4)), dim3(256), 0, st, xh, xl, ldx, (half_t*)Y, ldy, M, C, g, b, eps);
+    hipLaunchKernelGGL((ln_fwd_hilo_kernel<1>), dim3(skg_cdiv(M, 4)), dim3(256), 0, st, xh, xl, ldx, (half_t*)Y, ldy, M, C, g, b, eps, stats);
   else if (C <= 1024)
-    hipLaunchKernelGGL((ln_fwd_hilo_kernel<2>), dim3(skg_cdiv(M, 4)), dim3(256), 0, st, xh, xl, ldx, (half_t*)Y, ldy, M, C, g, b, eps);
+    hipLaunchKernelGGL((ln_fwd_hilo_kernel<2>), dim3(skg_cdiv(M, 4)), dim3(256), 0, st, xh, xl, ldx, (half_t*)Y, ldy, M, C, g, b, eps, stats);
   else
-    hipLaunchKernelGGL((ln_fwd_hilo_kernel<4>), dim3(skg_cdiv(M, 4)), dim3(256), 0, st, xh, xl, ldx, (half_t*)Y, ldy, M, C, g, b, eps);
+    hipLaunchKernelGGL((ln_fwd_hilo_kernel<4>), dim3(skg_cdiv(M, 4)), dim3(256), 0, st, xh, xl, ldx, (half_t*)Y, ldy, M, C, g, b, eps, stats);
   SKG_CHECK_LAUNCH("skg_layernorm_fwd_hilo");
   return SKG_OK;
 }

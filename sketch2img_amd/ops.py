@@ -286,7 +286,7 @@ def groupnorm(X, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, parti
     return out, st
 
 
-def groupnorm_hilo(X, X_lo, rows, HW, groups, eps, gamma, beta, silu: bool, out=None):
+def groupnorm_hilo(X, X_lo, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, want_stats=False):
     """GroupNorm(+SiLU) of the pair X + X_lo (accuracy mode): statistics from the hi part, apply on the sum."""
     _f16(X, X_lo, gamma, beta)
     assert _ld(X) == _ld(X_lo)
@@ -296,18 +296,19 @@ def groupnorm_hilo(X, X_lo, rows, HW, groups, eps, gamma, beta, silu: bool, out=
         out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
     check(lib.skg_groupnorm_apply_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _ld(out), rows, HW, C, groups, _p(st), _p(gamma),
                                        _p(beta), int(silu), _stream()), "skg_groupnorm_apply_hilo")
-    return out
+    return (out, st) if want_stats else out
 
 
-def layernorm_hilo(X, X_lo, gamma, beta, eps=1e-5, out=None):
+def layernorm_hilo(X, X_lo, gamma, beta, eps=1e-5, out=None, want_stats=False):
     _f16(X, X_lo, gamma, beta)
     assert _ld(X) == _ld(X_lo)
     M, C = X.shape
     if out is None:
         out = torch.empty(M, C, device=X.device, dtype=torch.float16)
-    check(lib.skg_layernorm_fwd_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _ld(out), M, C, _p(gamma), _p(beta), eps, _stream()),
-          "skg_layernorm_fwd_hilo")
-    return out
+    stats = torch.empty(M, 2, device=X.device, dtype=torch.float32) if want_stats else None
+    check(lib.skg_layernorm_fwd_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _ld(out), M, C, _p(gamma), _p(beta), eps, _p(stats),
+                                     _stream()), "skg_layernorm_fwd_hilo")
+    return (out, stats) if want_stats else out
 
 
 def groupnorm_bwd(X, dY, rows, HW, groups, stats, gamma, beta, silu: bool, residual=None, out=None):

@@ -355,8 +355,8 @@ class HipUNet:
         assert self.ctx is not None and self.ctx["rows"] == rows, "call prepare_context first"
         self.prepare_timesteps([t])
         if self.residual_fp32:
-            assert stash is None and not down_only and self.inject is None, "accuracy mode: plain forward only"
-            return self._forward_hp(x32, t, rows, H, want_taps, want_eps)
+            assert not down_only and self.inject is None, "accuracy mode: the plain UNet (with or without a stash)"
+            return self._forward_hp(x32, t, rows, H, want_taps, want_eps, stash)
         tb = self.tbias[int(t)]
         boc = cfg.block_out_channels
         nb = len(boc)
@@ -518,17 +518,20 @@ class HipUNet:
         return HipUNet._Pair(buf[:, :C], buf[:, C:], buf)
 
     def _gn_hp(self, x, rows, HW, eps, name, silu):
+        """-> (normalised fp16 tensor, statistics [rows, groups, 2])"""
         return ops.groupnorm_hilo(x.hi, x.lo, rows, HW, self.cfg.norm_groups, eps, self.W[name + ".weight"],
-                                  self.W[name + ".bias"], silu)
+                                  self.W[name + ".bias"], silu, want_stats=True)
 
-    def _res_fwd_hp(self, p, x, rows, H, tb, out=None, full_of=None):
+    def _res_fwd_hp(self, p, x, rows, H, tb, out=None, full_of=None, stash=None):
         W = self.W
         HW, M = H * H, rows * H * H
         Cout = W[p + ".conv1.weight"].shape[0]
-        n1 = self._gn_hp(x, rows, HW, 1e-5, p + ".norm1", True)
+        n1, st1 = self._gn_hp(x, rows, HW, 1e-5, p + ".norm1", True)
         h1 = self._pair(M, Cout)                                    # conv1 output feeds norm2: kept as a pair ("lin_n")
         ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p])
-        n2 = self._gn_hp(h1, rows, HW, 1e-5, p + ".norm2", True)
+        n2, st2 = self._gn_hp(h1, rows, HW, 1e-5, p + ".norm2", True)
+        if stash is not None:      # the backward differentiates the fp16 (hi) values, as in the default mode
+            stash.res[p] = dict(x=x.hi, st1=st1, h1=h1.hi, st2=st2, H=H, half=False)
         if (p + ".conv_shortcut.weight") in W:
             sc = self._pair(M, Cout)                                 # the stream as a matmul operand: [hi | lo] . [W | W]
             xf = x.full if x.full is not None else full_of(x, x.hi.shape[1])
@@ -540,34 +543,48 @@ class HipUNet:
                     residual=sc.hi, residual_lo=sc.lo)
         return out
 
-    def _tr_fwd_hp(self, p, x, rows, H, heads, out=None):
+    def _tr_fwd_hp(self, p, x, rows, H, heads, out=None, stash=None):
         W = self.W
         HW, M = H * H, rows * H * H
         C = x.hi.shape[1]
         dh = C // heads
         scale = dh ** -0.5
         t = p + ".transformer_blocks.0"
-        g = self._gn_hp(x, rows, HW, 1e-6, p + ".norm", False)
+        keep = stash is not None
+        g, gst = self._gn_hp(x, rows, HW, 1e-6, p + ".norm", False)
         pin = self._pair(M, C)
         ops.gemm(g, W[p + ".proj_in.weight"], out=pin.hi, out_lo=pin.lo, bias=W[p + ".proj_in.bias"])
-        a1 = ops.layernorm_hilo(pin.hi, pin.lo, W[t + ".norm1.weight"], W[t + ".norm1.bias"])
+        a1, st1 = ops.layernorm_hilo(pin.hi, pin.lo, W[t + ".norm1.weight"], W[t + ".norm1.bias"], want_stats=True)
         qkv = ops.gemm(a1, W[t + ".attn1.qkv"])
-        o1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], rows, heads, HW, HW, HW, dh, scale, v_rows=True)
+        o1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], rows, heads, HW, HW, HW, dh, scale,
+                                want_lse=True, v_rows=True)
         p1 = self._pair(M, C)
         ops.gemm(o1, W[t + ".attn1.to_out.0.weight"], out=p1.hi, out_lo=p1.lo, bias=W[t + ".attn1.to_out.0.bias"],
                  residual=pin.hi, residual_lo=pin.lo)
-        a2 = ops.layernorm_hilo(p1.hi, p1.lo, W[t + ".norm2.weight"], W[t + ".norm2.bias"])
+        a2, st2 = ops.layernorm_hilo(p1.hi, p1.lo, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
         q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"])
         cb = self.ctx["blocks"][t + ".attn2"]
-        o2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale, v_rows=True)
+        o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
+                                want_lse=True, v_rows=True)
         p2 = self._pair(M, C)
         ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], out=p2.hi, out_lo=p2.lo, bias=W[t + ".attn2.to_out.0.bias"],
                  residual=p1.hi, residual_lo=p1.lo)
-        a3 = ops.layernorm_hilo(p2.hi, p2.lo, W[t + ".norm3.weight"], W[t + ".norm3.bias"])
-        if C % 64 == 0:
+        a3, st3 = ops.layernorm_hilo(p2.hi, p2.lo, W[t + ".norm3.weight"], W[t + ".norm3.bias"], want_stats=True)
+        f = None
+        if keep and C % 64 == 0 and rows % 2 == 0:     # guided step: the cond half's gate also keeps its pre-activation
+            M0 = (rows // 2) * HW
+            gg = torch.empty(M, 4 * C, device=self.dev, dtype=torch.float16)
+            ops.gemm(a3[:M0], W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"], geglu=True, out=gg[:M0])
+            _, f = ops.gemm_geglu_keep(a3[M0:], W[t + ".ff.net.0.proj.weight"], W[t + ".ff.net.0.proj.bias"], out=gg[M0:])
+        elif C % 64 == 0:
             gg = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"], geglu=True)
         else:
-            gg = ops.geglu(ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"]), interleaved=True)
+            ff = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"])
+            gg = ops.geglu(ff, interleaved=True)
+            f = ff[(rows // 2) * HW:]
+        if keep:
+            stash.tr[p] = dict(x=x.hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1.hi, st2=st2, q2=q2,
+                               o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=())
         p3 = self._pair(M, C)
         ops.gemm(gg, W[t + ".ff.net.2.weight"], out=p3.hi, out_lo=p3.lo, bias=W[t + ".ff.net.2.bias"],
                  residual=p2.hi, residual_lo=p2.lo)
@@ -576,7 +593,7 @@ class HipUNet:
                  residual=x.hi, residual_lo=x.lo)
         return out
 
-    def _forward_hp(self, x32, t, rows, H, want_taps, want_eps):
+    def _forward_hp(self, x32, t, rows, H, want_taps, want_eps, stash=None):
         """The forward of forward() with the residual stream as (hi, lo) pairs; the same graph, the same kernels for every
         contraction, pair-aware epilogues / norms (skg_*_hilo).  Concatenations [h | skip] are pair buffers
         [h_hi | skip_hi | h_lo | skip_lo], filled in place by their producers."""
@@ -616,11 +633,11 @@ class HipUNet:
         for i in range(nb):
             for j in range(cfg.layers_per_block):
                 if i < nb - 1:
-                    h = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, full_of=full_of)
-                    h = self._tr_fwd_hp(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i], out=skip_slot(boc[i], cur))
+                    h = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, full_of=full_of, stash=stash)
+                    h = self._tr_fwd_hp(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i], out=skip_slot(boc[i], cur), stash=stash)
                 else:
                     h = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, out=skip_slot(boc[i], cur),
-                                         full_of=full_of)
+                                         full_of=full_of, stash=stash)
             if i < nb - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
                 half = cur // 2
@@ -630,12 +647,13 @@ class HipUNet:
                 cur //= 2
             if i < 3:
                 taps_down.append((h.hi, cur))
-        h = self._res_fwd_hp("mid_block.resnets.0", h, rows, cur, tb, full_of=full_of)
+        h = self._res_fwd_hp("mid_block.resnets.0", h, rows, cur, tb, full_of=full_of, stash=stash)
         tap_r0 = (h.hi, cur)
-        h = self._tr_fwd_hp("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1])
+        h = self._tr_fwd_hp("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash=stash)
         tap_at = (h.hi, cur)
         ct0 = cats[0].shape[1] // 2
-        h = self._res_fwd_hp("mid_block.resnets.1", h, rows, cur, tb, out=P(cats[0][:, :ch_h[0]], cats[0][:, ct0:ct0 + ch_h[0]]))
+        h = self._res_fwd_hp("mid_block.resnets.1", h, rows, cur, tb, out=P(cats[0][:, :ch_h[0]], cats[0][:, ct0:ct0 + ch_h[0]]),
+                             stash=stash)
         tap_r1 = (h.hi, cur)
         taps_up = []
         rev_heads = tuple(reversed(cfg.num_heads))
@@ -649,10 +667,10 @@ class HipUNet:
                     ctn = cats[u + 1].shape[1] // 2
                     nxt = P(cats[u + 1][:, :ch_h[u + 1]], cats[u + 1][:, ctn:ctn + ch_h[u + 1]])
                 if i > 0:
-                    h = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb)
-                    h = self._tr_fwd_hp(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], out=nxt)
+                    h = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash=stash)
+                    h = self._tr_fwd_hp(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], out=nxt, stash=stash)
                 else:
-                    h = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, out=nxt)
+                    h = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, out=nxt, stash=stash)
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 u = (i + 1) * lpb1
@@ -669,6 +687,8 @@ class HipUNet:
             n = self._gn_hp(h, rows, cur * cur, 1e-5, "conv_norm_out", True)
             eps = ops.conv3x3(n, W["conv_out.weight"], rows, cur, cur, bias=W["conv_out.bias"])
         taps = taps_down + [tap_at, tap_r0, tap_r1] + taps_up
+        if stash is not None:
+            stash.misc.update(rows=rows, H=H)
         return eps, (taps if want_taps else None)
 
     # ------------------------------------------------------------------ modules, backward (cond rows)

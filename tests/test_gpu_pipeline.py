@@ -318,6 +318,47 @@ def test_shared_cfg_prefix_is_bit_identical(tiny):
             assert same
 
 
+def test_accuracy_mode_runs_guided_steps(tiny):
+    """HipUNet(residual_fp32=True) is not forward-only: the pair forward stashes the fp16 (hi) activations and the ordinary
+    backward-to-input runs on them.  One guided step per sample vs the oracle's trace: the CFG eps is closer to the fp32
+    oracle than the default mode's, the guidance update keeps its norm and direction."""
+    from oracle import guidance as og, lgp as olgp, unet as ounet
+    from sketch2img_amd.config import TINY
+    from sketch2img_amd.lgp import HipLGP
+    from sketch2img_amd.sampler import DDIMTables, HipSampler
+    from sketch2img_amd.unet import HipUNet
+    cfg, S, h = tiny["cfg"], tiny["S"], tiny["h"]
+    sd = olgp.init_state_dict(sum(ounet.tap_channels(cfg)) + 40, seed=12)
+    g = torch.Generator().manual_seed(44)
+    target = 0.18215 * torch.randn(S, 4, h, h, generator=g)
+    x0 = tiny["x"]
+    T = 4
+    tab = DDIMTables.make(T)
+    refs = []
+    for smp in range(S):
+        tr = []
+        og.sample_one(cfg, tiny["W"], sd, tiny["ehs"][[smp, S + smp]], x0[smp:smp + 1], target[smp:smp + 1], T, trace=tr)
+        refs.append(tr[0])
+    errs = {}
+    for mode in (False, True):
+        net = HipUNet(TINY, tiny["W"], DEV, residual_fp32=mode)
+        net.prepare_context(tiny["ehs"])
+        sampler = HipSampler(net, HipLGP(sd, ounet.tap_channels(cfg), DEV))
+        xp, eps, aux = sampler.step(x0.to(DEV), x0.to(DEV), target.to(DEV), tab, 0, 7.5, 1.6, want_eps=True)
+        e = 0.0
+        for smp in range(S):
+            ref = refs[smp]
+            e = max(e, report(f"guided step, residual_fp32={mode}, s{smp} CFG eps", eps[smp:smp + 1].cpu(), ref["eps"])[0])
+            upd_ref = float(ref["aux"]["alpha"]) * ref["aux"]["cond_grad"]
+            upd = xp[smp:smp + 1].cpu() - (ref["latents"] - upd_ref)
+            nr = float(upd.norm() / upd_ref.norm())
+            cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm()))
+            print(f"[parity] guided step, residual_fp32={mode}, s{smp}: |hip|/|oracle|={nr:.4f} cos={cos:.5f}")
+            assert abs(nr - 1) < 2e-2 and cos > 0.998
+        errs[mode] = e
+    assert errs[True] < 1.4e-2 and errs[True] < 0.9 * errs[False]
+
+
 def test_unet_sd15_forward_vs_oracle_full_size():
     """One full-size SD1.5 evaluation (2 rows, 64x64 latent, 860 M parameters) vs the fp32 CPU oracle."""
     from oracle import unet as ounet
