@@ -93,6 +93,7 @@ def parse():
 
 
 ATTN_NAMES = {16: "1, 1, 2", 32: "1, 2, 2", 40: "2, 3, 2", 64: "2, 4, 2", 80: "3, 5, 2", 160: "5, 10, 1"}
+ATTN_SHORT_NAMES = {40: "2, 3", 64: "2, 4", 80: "3, 5", 160: "5, 10"}      # attn_fwd_short_kernel<KS, ND>: kv_stride <= 80
 
 
 class LaunchTimer:
@@ -163,8 +164,11 @@ class LaunchTimer:
             fl = 4.0 * batch * heads * Nq * Nkv * dh                      # QK^T + PV
             nbytes = 2.0 * batch * heads * dh * (2 * Nq + 2 * Nkv)
             vrow = "true" if k.get("v_rows") else "false"         # row-major V through the LDS transpose read
-            self.rec.append((f"attn_fwd_kernel<{ATTN_NAMES.get(dh, '?')}, false, {14 if dh == 64 else 0}, {vrow}>", fl, e0, e1, nbytes,
-                             f"attn B{batch} H{heads} Nq{Nq} Nkv{Nkv} d{dh}"))
+            if k.get("v_rows") and kv_stride <= 80 and dh in ATTN_SHORT_NAMES and not os.environ.get("SKG_NO_ATTN_SHORT"):
+                name = f"attn_fwd_short_kernel<{ATTN_SHORT_NAMES[dh]}>"      # the 77 text tokens: the LDS-resident kernel
+            else:
+                name = f"attn_fwd_kernel<{ATTN_NAMES.get(dh, '?')}, false, {14 if dh == 64 else 0}, {vrow}>"
+            self.rec.append((name, fl, e0, e1, nbytes, f"attn B{batch} H{heads} Nq{Nq} Nkv{Nkv} d{dh}"))
             return out
 
         def gemm_keep(A, B, *a, **k):        # FF1 with the fused gate that also stores the pre-activation

@@ -270,9 +270,10 @@ def test_sampler_tiny_vs_oracle(tiny):
 def test_shared_cfg_prefix_is_bit_identical(tiny):
     """HipUNet.forward(shared_input=True): the text-independent front of the UNet (conv_in, the first ResnetBlock,
     GroupNorm / proj_in / self-attention / LayerNorm 2 / to_q of the first transformer block) is evaluated once for the two
-    identical CFG halves (modules/pipeline.py:85 `torch.cat([latents] * 2)`).  Exact: eps and all nine taps equal the
-    doubled evaluation bit for bit - TINY and the full SD1.5 architecture - and so do a guided step's update, its auxiliaries
-    and the backward-to-input that reads the half-size stash."""
+    identical CFG halves (modules/pipeline.py:85 `torch.cat([latents] * 2)`).  Exact in exact arithmetic.  Where the shared
+    layers run the same kernel instantiations at half size (TINY) eps, all nine taps, a guided step's update, its auxiliaries
+    and the backward-to-input through the half-size stash equal the doubled evaluation bit for bit; on the full SD1.5
+    architecture the half-size launches take other instantiations and the results agree to fp16 rounding noise (below)."""
     from oracle import lgp as olgp, unet as ounet
     from sketch2img_amd import ops, synthetic
     from sketch2img_amd.config import SD15
@@ -297,25 +298,25 @@ def test_shared_cfg_prefix_is_bit_identical(tiny):
         xp, eps, aux = smp.step(tiny["x"].to(DEV), tiny["x"].to(DEV), target.to(DEV), tab, 0, 7.5, 1.6, want_eps=True)
         outs.append((xp.clone(), eps.clone(), aux.clone()))
     assert all(torch.equal(a, b) for a, b in zip(*outs))
-    # the real architecture at its real top-level resolution.  Bit-identity needs both evaluations to run the same kernel
-    # instantiations for the shared layers: true at the bench's size (8 samples: 16 vs 8 rows, no split-K either way); with 4
-    # vs 2 rows the 2-row convolutions take split-K (another summation order) and the two results are two fp16 evaluations
-    # of the same thing - as far apart as either is from the oracle
+    # the real architecture at its real top-level resolution: the half-size launches of the shared front take other kernel
+    # instantiations than the full-size ones (128 x 160 tiles instead of the 256 x 320 ping-pong tile, split-K at 2 rows), whose
+    # GroupNorm partial sums / K slices are summed in another order - the two evaluations then are two fp16 evaluations of
+    # the same function, as far apart (measured: eps rel 1.25e-3, max 2.2e-3) as either is from the fp32 oracle, and each
+    # deterministic
     W = synthetic.unet_state_dict(SD15)
     big = HipUNet(SD15, W, DEV, need_backward=False)
-    for rows, want_equal in ((4, False), (16, True)):
+    for rows in (4, 16):
         big.prepare_context(synthetic.text_embeddings(rows // 2))
         xb = synthetic.initial_latents(0, rows // 2, 64)
         x32 = ops.nchw_to_nhwc(torch.cat([xb, xb]).to(DEV), CIN_PAD)
         e0, t0 = big.forward(x32, 981, rows, 64)
         e1, t1 = big.forward(x32, 981, rows, 64, shared_input=True)
+        e2, _ = big.forward(x32, 981, rows, 64, shared_input=True)
         same = torch.equal(e0, e1) and all(torch.equal(a[0], b[0]) for a, b in zip(t0, t1))
         rel = float((e0.float() - e1.float()).norm() / e0.float().norm())
         print(f"[parity] sd15 shared CFG prefix vs doubled evaluation, {rows} rows: bit-identical {same}, eps rel {rel:.3e}, "
               f"max |d eps| {float((e0.float() - e1.float()).abs().max()):.3e}")
-        assert rel < 2e-3
-        if want_equal:
-            assert same
+        assert rel < 2e-3 and torch.equal(e1, e2)
 
 
 def test_accuracy_mode_runs_guided_steps(tiny):
