@@ -90,6 +90,8 @@ class HipUNet:
         self.W: Dict[str, torch.Tensor] = {}
         self._pack(state_dict)
         if residual_fp32:
+            assert all(c % 64 == 0 for c in cfg.block_out_channels), \
+                "accuracy mode: the pair epilogue lives in the LDS-DMA kernels (channel counts must be multiples of 64)"
             self._pack_hp(state_dict)
         self._sd_time = {k: v for k, v in state_dict.items()
                          if k.startswith("time_embedding.") or ".time_emb_proj." in k or k.endswith("conv1.bias")}
@@ -685,7 +687,7 @@ class HipUNet:
                 taps_up.append((h.hi, cur))
         eps = None
         if want_eps:
-            n = self._gn_hp(h, rows, cur * cur, 1e-5, "conv_norm_out", True)
+            n, _ = self._gn_hp(h, rows, cur * cur, 1e-5, "conv_norm_out", True)
             eps = ops.conv3x3(n, W["conv_out.weight"], rows, cur, cur, bias=W["conv_out.bias"])
         taps = taps_down + [tap_at, tap_r0, tap_r1] + taps_up
         if stash is not None:
