@@ -191,7 +191,7 @@ class HipSampler:
         T = len(tab.timesteps)
         inj = self.unet.inject
         key = (type(tab).__name__, tuple(int(t) for t in tab.timesteps), tuple(x.shape), tgt is None,
-               float(guidance_scale), float(beta))
+               float(guidance_scale), float(beta), bool(self.share_cfg_prefix))
         # What a captured step points at besides the static latents: the text context's K / V (prepare_context builds a
         # NEW dict per prompt) and the injector's per-image K / V (set_state / set_res_samples build a new dict per sketch)
         # and scale.  The entry keeps STRONG references to those objects and is valid only while the pipeline still holds
