@@ -310,6 +310,56 @@ def test_sd15_config0_trajectories_vs_oracle():
           f"cos {worst['cos']:.5f}, loss rel {worst['loss']:.2e}")
 
 
+@pytest.mark.parametrize("case", ["dpm", "sketch", "clip"])
+def test_full_architecture_free_running_trajectories_other_configs(case):
+    """Free-running multi-step parity on the REAL architectures for the paths the previous test does not walk:
+      dpm    - SD1.5, DPM-Solver++ 2M (the scheduler app.py:13-25 actually builds), 6 unguided steps, 32x32 latents;
+      sketch - SD1.5 with sketch_guided_attn injection (BASELINE configs[3]), 4 DDIM steps, 32x32 latents;
+      clip   - the SD2.1 architecture with clip_guided_attn on [zeros; h] (configs[4]), 3 DDIM steps, 32x32 latents
+               (1024 + 257 tokens in the injected attention).
+    End latents of the HIP loop vs oracle.guidance.sample_one on identical inputs (loop: modules/pipeline.py:83-115;
+    injection: modules/sketch_guided_attn.py:120-132, modules/clip_guided_attn.py:111-125)."""
+    from oracle import attn_inject, guidance as og, unet as ounet
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import SD15, SD21
+    from sketch2img_amd.inject import HipInjector
+    from sketch2img_amd.sampler import DDIMTables, DPMTables, HipSampler
+    from sketch2img_amd.unet import HipUNet
+    _threads()
+    h = 32
+    hcfg, ocfg = (SD21, ounet.SD21) if case == "clip" else (SD15, ounet.SD15)
+    W = synthetic.unet_state_dict(hcfg)
+    ehs = synthetic.text_embeddings(1, dim=hcfg.cross_attention_dim)
+    x0 = synthetic.initial_latents(0, 1, h)
+    net = HipUNet(hcfg, W, DEV, need_backward=False)
+    net.prepare_context(ehs)
+    inject, T, tab, sched = None, 4, None, "ddim"
+    if case == "dpm":
+        T, sched = 6, "dpm++2m"
+        tab = DPMTables.make(T)
+    elif case == "sketch":
+        sd = synthetic.satmixin_state_dict(SD15, "sketch")
+        res = synthetic.res_samples(SD15, 0, 1, h)
+        inj = HipInjector(SD15, sd, "sketch", DEV)
+        inj.set_res_samples(res)
+        net.inject = inj
+        inject = attn_inject.make_sketch_inject(ocfg, sd, res, 1.0)
+    else:
+        T = 3
+        sd = synthetic.satmixin_state_dict(SD21, "clip")
+        state = synthetic.sketch_state(0, 1)
+        inj = HipInjector(SD21, sd, "clip", DEV)
+        inj.set_state(state)
+        net.inject = inj
+        inject = attn_inject.make_clip_inject(sd, state, 1.0)
+    tab = tab or DDIMTables.make(T)
+    with torch.no_grad():
+        ref = og.sample_one(ocfg, W, None, ehs, x0, None, T, inject=inject, scheduler=sched)
+    out = HipSampler(net, None).sample(x0, None, T, tables=tab).cpu()
+    r, _ = report(f"{case}: {T}-step free-running end latents on the full architecture", out, ref)
+    assert torch.isfinite(out).all() and r < 3e-3
+
+
 # ----------------------------------------------------------------------------------------------- hipGraph replay
 @pytest.mark.parametrize("sched", ["ddim", "dpm"])
 def test_graph_replay_is_bit_identical_to_eager(sched):

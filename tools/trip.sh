@@ -1,7 +1,5 @@
 set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/t10
-export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 3000 python -m pytest tests -q -m gpu > gpurun_out/t10/gpu_suite.log 2>&1; echo "suite rc=$?"
-tail -6 gpurun_out/t10/gpu_suite.log
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/t10/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 gpurun_out/t10/smoke.log
+mkdir -p gpurun_out/t11
+timeout 1500 python -m pytest tests/test_gpu_configs.py -q -m gpu -k "other_configs" -s > gpurun_out/t11/traj.log 2>&1; echo "rc=$?"
+grep "parity\]\|passed\|failed\|Error" gpurun_out/t11/traj.log | tail -12
