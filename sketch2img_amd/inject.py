@@ -81,6 +81,7 @@ class HipInjector:
         self.scale = 1.0
         self.W: Dict[str, Dict[str, torch.Tensor]] = {}
         self.per_image: Dict[str, dict] = {}
+        self.halves_equal = False      # set_res_samples: both CFG halves carry the same sketch features (checked, not assumed)
         h16 = lambda t: t.detach().to(self.dev, torch.float16).contiguous()
         for path, c, heads in block_dims(cfg):
             n = module_name(path)
@@ -117,9 +118,14 @@ class HipInjector:
     def set_res_samples(self, res_samples: Optional[Sequence[Sequence[torch.Tensor]]]):
         """Feature variant.  res_samples: per down block a tuple of NCHW tensors [rows, C, h, w]."""
         self.per_image = {}
+        self.halves_equal = False
         if res_samples is None:
             return
         routed = route_res_samples(res_samples)
+        # the SketchEncoder usually sees the same sketch for the uncond and the cond row of a sample: when the two halves of
+        # EVERY routed tensor are equal (checked here, once per image) the injected attention is text-independent too and
+        # HipUNet's shared CFG front extends through it
+        self.halves_equal = all(r.shape[0] % 2 == 0 and torch.equal(r[: r.shape[0] // 2], r[r.shape[0] // 2:]) for r in routed)
         for (path, w), r in zip(self.W.items(), routed):
             rows, C, hh, ww = r.shape
             assert C == w["C"]
@@ -128,9 +134,14 @@ class HipInjector:
             self.per_image[path] = dict(K=kv[:, :C], V=kv[:, C:], rows=rows, N=hh * ww)
 
     # ---- per UNet evaluation ------------------------------------------------------------------------------
-    def __call__(self, path: str, h: torch.Tensor, rows: int, N: int, heads: int) -> torch.Tensor:
+    def __call__(self, path: str, h: torch.Tensor, rows: int, N: int, heads: int, cond_only: bool = False,
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """cond_only (sketch variant, halves_equal): h holds the cond rows only (rows // 2 of them); K / V of the cond half."""
         pi = self.per_image.get(path)
         if pi is None:
+            if out is not None:
+                ops.batch_copy(h, h.shape[0], out, h.shape[0], 1, h.shape[0])
+                return out
             return h
         w = self.W[path]
         C = w["C"]
@@ -138,11 +149,16 @@ class HipInjector:
         scale = dh ** -0.5
         if self.variant == "sketch":
             assert pi["rows"] == rows and pi["N"] == N
+            K, V, r = pi["K"], pi["V"], rows
+            if cond_only:
+                assert self.halves_equal
+                r = rows // 2
+                K, V = K[r * N:], V[r * N:]
             z = ops.layernorm(h, w["ng"], w["nb"])
             q = ops.gemm(z, w["wq"])
-            a = ops.attn_fwd(q, pi["K"], pi["V"], rows, heads, N, N, N, dh, scale, v_rows=True)
+            a = ops.attn_fwd(q, K, V, r, heads, N, N, N, dh, scale, v_rows=True)
             o = ops.gemm(a, w["wo"], bias=w["bo"])
-            return ops.gemm(o, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)
+            return ops.gemm(o, w["wc"], out, bias=w["bc"], residual=h, alpha=self.scale)
         # CLIP variant: self-attention of the N image-token queries over [N image tokens ; T sketch tokens]
         assert pi["rows"] == rows
         T = pi["T"]

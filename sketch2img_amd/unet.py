@@ -275,10 +275,16 @@ class HipUNet:
                       bias=W[t + ".attn1.to_out.0.bias"], residual=pin)
         x_c, p1_c = x, p1                                     # what the backward of the cond rows reads
         if self.inject is not None:
-            if shared:                                        # the injected K / V differ between the halves: diverge here
-                ops.batch_copy(p1, M1, p1_full, M1, 1, M1)
-                x, p1, shared = x_full, p1_full, False
-            p1 = self.inject(t, p1, rows, HW, heads)
+            if shared and getattr(self.inject, "halves_equal", False):
+                # the injected K / V are the same for both halves too (checked by the injector): stay shared through it
+                p1_full2 = torch.empty(rows * HW, C, device=x.device, dtype=torch.float16)
+                p1 = self.inject(t, p1, rows, HW, heads, cond_only=True, out=p1_full2[M1:])
+                p1_full = p1_full2
+            else:
+                if shared:                                    # the injected K / V differ between the halves: diverge here
+                    ops.batch_copy(p1, M1, p1_full, M1, 1, M1)
+                    x, p1, shared = x_full, p1_full, False
+                p1 = self.inject(t, p1, rows, HW, heads)
             p1_c = p1
         a2, st2 = ops.layernorm(p1, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
         q2_full = torch.empty(rows * HW, C, device=x.device, dtype=torch.float16) if shared else None

@@ -421,6 +421,13 @@ def test_graph_replay_with_injected_attention_is_bit_identical(variant):
     b = gs.sample(x0, None, T, tables=tab).clone()
     c = gs.sample(x0, None, T, tables=tab).clone()
     assert torch.equal(a, b) and torch.equal(a, c)
+    # the shared CFG front (HipUNet.forward(shared_input=True), on by default in the sampler) vs the doubled evaluation:
+    # for the sketch variant with equal halves of the res samples it runs THROUGH the injection, for the clip variant
+    # ([zeros; h]) it ends in front of it; TINY runs the same kernel instantiations at half size -> bit-identical
+    assert inj.halves_equal == (variant == "sketch")
+    off = HipSampler(net, None)
+    off.share_cfg_prefix = False
+    assert torch.equal(off.sample(x0, None, T, tables=tab), a)
     net.inject = None
     plain = HipSampler(net, None).sample(x0, None, T, tables=tab)
     assert not torch.equal(plain, a)
