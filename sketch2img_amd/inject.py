@@ -18,6 +18,7 @@ last padding keys are masked by Nkv < kv_stride.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -72,6 +73,9 @@ def route_res_samples(res_samples: Sequence[Sequence[torch.Tensor]]) -> List[tor
     return list(down + up[::-1] + mid)
 
 
+_BATCH_KV = os.environ.get("SKG_INJ_BATCH", "1") != "0"      # A/B switch (bench.py on one box)
+
+
 class HipInjector:
     """Callable installed as ``HipUNet.inject``; ``variant`` is 'clip' or 'sketch'."""
 
@@ -95,6 +99,7 @@ class HipInjector:
                      wc=h16(state_dict[f"{n}.sketch_conv.weight"].reshape(c, c)),
                      bc=h16(state_dict[f"{n}.sketch_conv.bias"]))
             if variant == "clip":
+                w["wqkv"] = torch.cat([w["wq"], w["wkv"]], 0).contiguous()
                 w["wp"] = h16(state_dict[f"{n}.sketch_proj.weight"])
                 w["bp"] = h16(state_dict[f"{n}.sketch_proj.bias"])
             self.W[path] = w
@@ -169,9 +174,19 @@ class HipInjector:
             ops.batch_copy(pi["kvs"], T, kvbuf[N:], L, rows, T)     # K / V of the normalised sketch tokens, once per image
             pi["bufs"][N] = kvbuf
         zh = ops.layernorm(h, w["ng"], w["nb"])
-        q = ops.gemm(zh, w["wq"])
-        for b in range(rows):
-            ops.gemm(zh[b * N:(b + 1) * N], w["wkv"], out=kvbuf[b * L:b * L + N])
+        # K / V of the image tokens go to rows [b L, b L + N) of the [rows * L, 2C] buffer (the sketch tokens sit behind them).
+        # Large maps: one GEMM per batch row straight into place (each launch fills the chip).  Small maps - a batch row is
+        # under 256 tiles of 128 x 160 - : ONE GEMM over all rows for q, k and v into a dense buffer + one strided copy of the
+        # k | v columns, 2 launches instead of 1 + `rows` launches of ~10-25 us each (round 3: ~12 800 of config 5's 16 000
+        # GEMM launches per batch were these; same-box A/B 2.218 -> 2.266 images/s)
+        if _BATCH_KV and rows > 2 and ((N + 127) // 128) * ((2 * C + 159) // 160) < 256:
+            dense = ops.gemm(zh, w["wqkv"])
+            q = dense[:, :C]
+            ops.batch_copy(dense[:, C:], N, kvbuf, L, rows, N)
+        else:
+            q = ops.gemm(zh, w["wq"])
+            for b in range(rows):
+                ops.gemm(zh[b * N:(b + 1) * N], w["wkv"], out=kvbuf[b * L:b * L + N])
         a = ops.attn_fwd(q, kvbuf[:, :C], kvbuf[:, C:], rows, heads, N, N + T, L, dh, scale, v_rows=True)
         o = ops.gemm(a, w["wo"], bias=w["bo"])
         return ops.gemm(o, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)
