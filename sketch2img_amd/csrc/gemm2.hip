@@ -859,7 +859,9 @@ inline int pick_splits(long nwg, int KT, size_t slab_bytes, const float* ws, siz
   // reduce pass cost more than they hide and the launch takes the three-stage kernel instead
   if (!ws || nwg > 256 || KT < (nwg == 256 ? 128 : 16)) return 1;
   int s = (int)((512 + nwg - 1) / nwg);
-  if (s > 8) s = 8;
+  const char* cap = getenv("SKG_MAX_SPLITS");          // tuning (tools/smallm_bench.py --splits): read per launch
+  const int smax = cap ? atoi(cap) : 8;
+  if (s > smax) s = smax < 1 ? 1 : smax;
   while (s > 1 && KT / s < 8) --s;
   while (s > 1 && (size_t)s * slab_bytes > ws_bytes) --s;
   return s;
