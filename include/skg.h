@@ -133,6 +133,15 @@ int skg_groupnorm_from_partial2(const void* X, int ldx, void* Y, int ldy, int ro
                                 int groups, float eps, const void* gamma, const void* beta, int silu,
                                 float* stats, const float* partialA, int groupsA, const float* partialB,
                                 int groupsB, int nch, void* stream);
+/* Nearest-neighbour 2x upsample followed by a 3x3 convolution (diffusers Upsample2D: the up path of the UNet at
+ * modules/pipeline.py:96, the VAE decoder at :118), POLYPHASE: out (2i+a, 2j+b) = sum over the 2 x 2 low-resolution pixels the
+ * nine taps land on, with the taps that land on one pixel pre-summed - four 4-tap stride-1 convolutions over the low-res
+ * input, 16 tap-products per input pixel instead of 36 (skg_conv3x3_f16 with SKG_CONV_UP2 is the 9-tap form, same result up
+ * to the fp16 rounding of the summed weights).  X [rows*IH*IW, Cin] (ldx), Y [rows*2IH*2IW, Cout] (ldy), Wpp: packed
+ * [4 phases 2a+b][Cout][4 taps][Cin] (sketch2img_amd.unet.pack_conv_up2).  Cin % 64 == 0. */
+int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void* Y, int ldy, int rows, int IH, int IW, int Cin,
+                        int Cout, const void* bias, void* stream);
+
 /* ---- accuracy mode ("residual_fp32"): tensors as (hi, lo) PAIRS of fp16, value = hi + lo (~22 mantissa bits) -------
  * north_star asks for <= 1e-3 max latent-eps deviation from the fp32 reference (modules/pipeline.py:96 in fp32 on CPU);
  * with every stored tensor in fp16 - what the reference's own GPU path does (app.py:34) - an evaluation is 1.5e-3 away,

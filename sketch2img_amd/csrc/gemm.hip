@@ -214,6 +214,7 @@ int launch_plain(const GemmParams& p, hipStream_t st) {
   }
   if (p.flags & SKG_EPI_GEGLU) return SKG_E_UNSUPPORTED;     // fused GEGLU exists in the LDS-DMA kernel only
   if (p.c_lo || p.res_lo) return SKG_E_UNSUPPORTED;          // so does the hi / lo epilogue
+  if (p.ntaps || p.up2) return SKG_E_UNSUPPORTED;            // and the polyphase tap walk
   const int tm = skg_cdiv(p.M, BM);
   if (use_wide(p.M, p.N)) {
     dim3 grid(p.N / 128, tm);
@@ -358,6 +359,37 @@ extern "C" int skg_conv3x3_f16_gn(const void* X, int ldx, const void* Wp, void* 
   SKG_REQUIRE(gn_args_ok(gn_partial, rows * OH * OW, Cout, OH * OW, groups, ldy, flags) && skg_aligned(Y, 16));
   return conv_impl(X, ldx, Wp, Y, ldy, rows, IH, IW, Cin, Cout, mode, bias, residual, ldr, alpha, flags, gn_partial,
                    groups, stream);
+}
+
+// ---- nearest-2x upsample + 3x3 conv, polyphase (include/skg.h) -----------------------------------------------------------
+// Output pixel (2 i + a, 2 j + b) only ever reads the 2 x 2 low-resolution neighbourhood rows {i - 1, i} (a = 0) or {i, i + 1}
+// (a = 1) x the same for columns, with the three taps of the 3 x 3 filter that land on one low-res row / column pre-summed:
+// four stride-1 convolutions with FOUR taps each over the low-res input (16 tap-products per low-res pixel) instead of nine
+// taps at every high-res pixel (36).  Wpp: [4 phases (2 a + b)][Cout][4 taps (row-major over the phase's 2 x 2)][Cin].
+extern "C" int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void* Y, int ldy, int rows, int IH, int IW,
+                                   int Cin, int Cout, const void* bias, void* stream) {
+  SKG_REQUIRE(X && Wpp && Y && rows > 0 && IH > 0 && IW > 0 && Cin % 64 == 0 && Cout % 8 == 0);
+  SKG_REQUIRE(ldx % 8 == 0 && ldx >= Cin && ldy % 8 == 0 && ldy >= Cout && skg_aligned(X, 16) && skg_aligned(Wpp, 16) &&
+              skg_aligned(Y, 16) && (!bias || skg_aligned(bias, 8)));
+  hipStream_t st = (hipStream_t)stream;
+  for (int ph = 0; ph < 4; ++ph) {
+    const int a = ph >> 1, b = ph & 1;
+    GemmParams p{};
+    p.A = (const half_t*)X; p.lda = ldx;
+    p.B = (const half_t*)Wpp + (size_t)ph * Cout * 4 * Cin; p.ldb = 4 * Cin;
+    p.C = Y; p.ldc = ldy; p.bias = (const half_t*)bias;
+    p.N = Cout; p.K = 4 * Cin; p.alpha = 1.f; p.flags = 0;
+    p.IH = IH; p.IW = IW; p.OH = IH; p.OW = IW; p.Cin = Cin; p.M = rows * IH * IW;
+    p.ntaps = 4; p.up2 = 1 + ph;
+    // low-res rows (ky) / columns (kx) this phase reads, as stride-1 tap ids ky * 3 + kx with ky, kx in {0: -1, 1: 0, 2: +1}
+    const int ky0 = a ? 1 : 0, kx0 = b ? 1 : 0;
+    p.tapmap = (unsigned)(ky0 * 3 + kx0) | (unsigned)(ky0 * 3 + kx0 + 1) << 4 | (unsigned)((ky0 + 1) * 3 + kx0) << 8 |
+               (unsigned)((ky0 + 1) * 3 + kx0 + 1) << 12;
+    ws_attach(p, st);
+    if (!skg_gemm2_try_launch(p, MODE_S1, st)) return SKG_E_UNSUPPORTED;
+    SKG_CHECK_LAUNCH("skg_conv3x3_up2_f16");
+  }
+  return SKG_OK;
 }
 
 // ---- accuracy mode: outputs / residuals as (hi, lo) pairs of fp16 tensors (include/skg.h) ------------------------------

@@ -270,15 +270,18 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
       // for nine consecutive K steps - 32 KB per workgroup instead of the whole 3-row halo of all channels - so the
       // slices of all workgroups of an XCD fit its 4 MB L2 (tap-major order: 2.5 x the algorithmic bytes fetched
       // from beyond L2, rocprofv3 FETCH_SIZE).
+      int ti;                              // position in the tap walk = position in the weight pack
       if (tap_minor) {
-        const int cb = kt / 9;
-        tap = kt - cb * 9;
+        const int nt = p.ntaps ? p.ntaps : 9;
+        const int cb = kt / nt;
+        ti = kt - cb * nt;
         c0 = cb * BK;
       } else {
-        tap = k0 / p.Cin;
-        c0 = k0 - tap * p.Cin;
+        ti = k0 / p.Cin;
+        c0 = k0 - ti * p.Cin;
       }
-      kb = (unsigned)(tap * p.Cin + c0);
+      tap = p.ntaps ? (int)((p.tapmap >> (4 * ti)) & 0xfu) : ti;      // polyphase launches walk a subset of the taps
+      kb = (unsigned)(ti * p.Cin + c0);
       ky = tap / 3;
       kx = tap - ky * 3;
       soff = (unsigned)((ky * p.IW + kx) * p.lda + c0) * 2u;
@@ -648,7 +651,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
       for (int hr = 0; hr < RPT; ++hr) {
         if (m0 + sl * HROWS + hr * 64 + er >= p.M) continue;
         const half_t* const srow = hst + (hr * 64 + er) * OPH + ec;
-        half_t* const crow = crow0 + (size_t)(sl * HROWS + hr * 64) * p.ldc;
+        half_t* crow = crow0 + (size_t)(sl * HROWS + hr * 64) * p.ldc;
+        if (p.up2) {      // polyphase upsample: low-res pixel (i, j) of image b -> high-res pixel (2 i + a, 2 j + b)
+          const int m = m0 + sl * HROWS + hr * 64 + er, hw = p.OH * p.OW;
+          const int img = m / hw, rr = m - img * hw, i = rr / p.OW, j = rr - i * p.OW;
+          const size_t r = (size_t)img * 4 * hw + (size_t)(2 * i + ((p.up2 - 1) >> 1)) * (2 * p.OW) + 2 * j + ((p.up2 - 1) & 1);
+          crow = reinterpret_cast<half_t*>(p.C) + r * p.ldc + n0 + ec;
+        }
         half8_t hv[IT2];
 #pragma unroll
         for (int k = 0; k < IT2; ++k) hv[k] = ld_half8(srow + k * TPR2 * 8);
@@ -956,7 +965,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   operand_bytes(p, MODE, a, b, s);
   const int KT = p.K / BK;
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
-  int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU)) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4, p.ws, p.ws_bytes) : 1;
+  int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU) && !p.up2) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4, p.ws, p.ws_bytes) : 1;
   constexpr int NTHR = WGM * WGN * 64;
   if constexpr (BM == 128) {
     if (p.c_lo || p.res_lo) {      // accuracy mode: one instantiation per tile, two stages, no split-K, no statistics
@@ -1031,7 +1040,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
 template <int MODE>
 void launch_mode(const GemmParams& p, hipStream_t st) {
   TileCfg t = pick_tile(p.M, p.N, p.K);
-  if (t.bm == 256 && (p.c_lo || p.res_lo)) t = TileCfg{128, 160};      // (the hi / lo epilogue exists for the 128-row tiles)
+  if (t.bm == 256 && (p.c_lo || p.res_lo || p.up2)) t = TileCfg{128, 160};      // (hi / lo epilogue, polyphase row map: 128-row tiles)
   if (t.bm == 256) launch_cfg<256, 320, 2, 4, MODE>(p, st);
   else if (t.bn == 160) {
     launch_cfg<128, 160, 2, 2, MODE>(p, st);
@@ -1064,6 +1073,10 @@ void skg_splitk_reduce_launch(const GemmParams& p, const float* ws, int splits, 
 
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
   if (!eligible(p, mode)) return false;
+  if ((p.ntaps || p.up2) &&      // polyphase: stride-1 walk, the plain fp16-staged epilogue (no residual / statistics)
+      (mode != MODE_S1 || p.res || p.gn_partial || p.c_lo || p.res_lo || (p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) ||
+       p.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 || p.M % (p.OH * p.OW) != 0))
+    return false;
   if ((p.c_lo || p.res_lo) &&
       ((p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) || p.gn_partial || p.aux || p.ldc % 8 != 0 ||
        (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 || (p.c_lo && (reinterpret_cast<uintptr_t>(p.c_lo) & 15) != 0) ||

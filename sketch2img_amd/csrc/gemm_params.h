@@ -21,6 +21,10 @@ struct GemmParams {
   // accuracy mode (skg_*_hilo entry points): the residual and / or the output are PAIRS of fp16 tensors whose sum carries
   // ~22 mantissa bits - lo = fp16(v - fp16(v)); same leading dimension as the hi part (ldr / ldc)
   const half_t* res_lo; half_t* c_lo;
+  // polyphase nearest-2x-upsample + 3x3 conv (skg_conv3x3_up2_f16): a stride-1 conv over the LOW-resolution input that walks
+  // only `ntaps` of the nine taps (tap id of walk position i = (tapmap >> 4 i) & 15; weight pack [Cout][ntaps][Cin]) and stores
+  // low-res pixel (i, j) to high-res pixel (2 i + a, 2 j + b) of the output, up2 = 1 + 2 a + b (0 = ordinary conv)
+  int ntaps; unsigned tapmap; int up2;
   // split-K workspace of the launch stream (host side: filled by the entry points from the per-stream registry of
   // skg_set_workspace; the kernels get the slab pointer as an argument)
   float* ws; size_t ws_bytes;

@@ -214,6 +214,19 @@ def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode
     return out
 
 
+def conv_up2(X: torch.Tensor, Wpp: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None):
+    """Nearest-2x upsample + 3x3 conv, polyphase (four 4-tap convs over the low-res input).  X [rows*IH*IW, Cin] (view),
+    Wpp [4, Cout, 4*Cin] (unet.pack_conv_up2).  Returns [rows*2IH*2IW, Cout]."""
+    _f16(X, Wpp, bias)
+    Cin, Cout = X.shape[1], Wpp.shape[1]
+    assert Wpp.shape == (4, Cout, 4 * Cin) and Wpp.is_contiguous() and X.shape[0] == rows * IH * IW
+    if out is None:
+        out = torch.empty(rows * 4 * IH * IW, Cout, device=X.device, dtype=torch.float16)
+    check(lib.skg_conv3x3_up2_f16(_p(X), _ld(X), _p(Wpp), _p(out), _ld(out), rows, IH, IW, Cin, Cout, _p(bias), _stream()),
+          "skg_conv3x3_up2_f16")
+    return out
+
+
 _scratch = {}
 
 

@@ -65,6 +65,26 @@ def pack_conv_dgrad(w: torch.Tensor, dev, cin_pad: int = 0, cout_pad: int = 0) -
     return _h(p.reshape(p.shape[0], -1), dev)
 
 
+def pack_conv_up2(w: torch.Tensor, dev) -> torch.Tensor:
+    """Polyphase pack of a 3x3 filter applied after a nearest 2x upsample (ops.conv_up2): [4 phases 2a+b][Cout][4 taps][Cin].
+    Output pixel (2i+a, 2j+b) reads low-res rows {i-1, i} (a = 0) or {i, i+1} (a = 1): the filter rows that land on one
+    low-res row are summed (fp32, one fp16 rounding), the same for columns."""
+    w = w.detach().float()
+    co, ci = w.shape[:2]
+    phases = []
+    for a in (0, 1):
+        rws = (w[:, :, 0], w[:, :, 1] + w[:, :, 2]) if a == 0 else (w[:, :, 0] + w[:, :, 1], w[:, :, 2])      # [co, ci, kx]
+        for b in (0, 1):
+            taps = []
+            for r in rws:
+                taps += [r[:, :, 0], r[:, :, 1] + r[:, :, 2]] if b == 0 else [r[:, :, 0] + r[:, :, 1], r[:, :, 2]]
+            phases.append(torch.stack(taps, 1).reshape(co, 4 * ci))                                            # [co][tap][ci]
+    return _h(torch.stack(phases, 0), dev)
+
+
+UP2_POLYPHASE = os.environ.get("SKG_UP2_POLY", "1") != "0"      # A/B switch (bench.py on one box)
+
+
 def _pad_vec(v: torch.Tensor, n: int) -> torch.Tensor:
     return torch.nn.functional.pad(v, (0, n - v.shape[0])) if n > v.shape[0] else v
 
@@ -114,6 +134,8 @@ class HipUNet:
                     W[k] = pack_conv(v, dev)
                     if bw:
                         W[k + ":T"] = pack_conv_dgrad(v, dev)
+                    if ".upsamplers." in k and UP2_POLYPHASE and v.shape[1] % 64 == 0:
+                        W[k + ":pp"] = pack_conv_up2(v, dev)
             elif v.dim() == 4:                                  # 1x1 conv
                 W[k] = _h(v.reshape(v.shape[0], v.shape[1]), dev)
                 if bw:
@@ -497,8 +519,12 @@ class HipUNet:
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 u = (i + 1) * lpb1
-                h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=cats[u][:, :ch_h[u]],
-                                bias=W[p + ".bias"])
+                # polyphase (16 instead of 36 tap-products per low-res pixel) where its four launches still fill the chip
+                if (p + ".weight:pp") in W and (rows * cur * cur // 128) * (h.shape[1] // 160) >= 200:
+                    h = ops.conv_up2(h, W[p + ".weight:pp"], rows, cur, cur, out=cats[u][:, :ch_h[u]], bias=W[p + ".bias"])
+                else:
+                    h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=cats[u][:, :ch_h[u]],
+                                    bias=W[p + ".bias"])
                 hp = None              # (the next concatenation's widths do not line up with 32 groups per half)
                 cur *= 2
             if i < 3:

@@ -25,7 +25,7 @@ import torch
 
 from . import ops
 from .config import VAEConfig, SD_VAE, vae_up_plan
-from .unet import CIN_PAD, COUT_PAD, _h, _pad_vec, pack_conv
+from .unet import CIN_PAD, COUT_PAD, UP2_POLYPHASE, _h, _pad_vec, pack_conv, pack_conv_up2
 
 
 class _HipVAEBlocks:
@@ -120,6 +120,8 @@ class HipVAEDecoder(_HipVAEBlocks):
                 W[k] = _h(_pad_vec(v, COUT_PAD), dev)
             elif v.ndim == 4 and v.shape[2] == 3:
                 W[k] = pack_conv(v, dev)
+                if ".upsamplers." in k and UP2_POLYPHASE and v.shape[1] % 64 == 0:
+                    W[k + ":pp"] = pack_conv_up2(v, dev)
             elif v.ndim == 4:                              # 1x1 conv_shortcut
                 W[k] = _h(v.reshape(v.shape[0], v.shape[1]), dev)
             else:
@@ -145,7 +147,10 @@ class HipVAEDecoder(_HipVAEBlocks):
                 x = self._res(f"decoder.up_blocks.{i}.resnets.{j}", x, S, H)
             if up:
                 u = f"decoder.up_blocks.{i}.upsamplers.0.conv"
-                x = ops.conv3x3(x, W[u + ".weight"], S, H, H, ops.CONV_UP2, bias=W[u + ".bias"])
+                if (u + ".weight:pp") in W:      # polyphase: 16 instead of 36 tap-products per low-res pixel
+                    x = ops.conv_up2(x, W[u + ".weight:pp"], S, H, H, bias=W[u + ".bias"])
+                else:
+                    x = ops.conv3x3(x, W[u + ".weight"], S, H, H, ops.CONV_UP2, bias=W[u + ".bias"])
                 H *= 2
         n, _ = ops.groupnorm(x, S, H * H, cfg.norm_groups, 1e-6, W["decoder.conv_norm_out.weight"],
                              W["decoder.conv_norm_out.bias"], True)

@@ -154,6 +154,29 @@ def test_gemm8_pingpong_320_tile_convolutions(ops):
         assert e < 5e-4
 
 
+def test_conv_up2_polyphase(ops):
+    """skg_conv3x3_up2_f16: nearest-2x upsample + 3x3 conv as four 4-tap convolutions over the low-res input (pre-summed taps)
+    vs F.interpolate + F.conv2d, and vs the 9-tap UP2 gather form of skg_conv3x3_f16; output into a strided view."""
+    from sketch2img_amd.unet import pack_conv, pack_conv_up2
+    g = torch.Generator().manual_seed(53)
+    for rows, hw, cin, cout in [(2, 16, 64, 160), (3, 8, 128, 320), (16, 32, 640, 640),
+                                (1, 64, 512, 512), (1, 128, 512, 512), (1, 64, 256, 256)]:      # last three: VAE decoder (128 x 64 / 128 x 128 tiles)
+        x = torch.randn(rows, cin, hw, hw, generator=g).half()
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
+        b = torch.randn(cout, generator=g).half()
+        xs = nhwc(x).to(dev())
+        buf = torch.zeros(rows * 4 * hw * hw, cout + 16, device=dev(), dtype=torch.float16)
+        ops.conv_up2(xs, pack_conv_up2(w, dev()), rows, hw, hw, out=buf[:, 8:8 + cout], bias=b.to(dev()))
+        ref = F.conv2d(F.interpolate(x.float().to(dev()), scale_factor=2.0, mode="nearest"), w.float().to(dev()), b.float().to(dev()),
+                       padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+        nine = ops.conv3x3(xs, pack_conv(w, dev()), rows, hw, hw, ops.CONV_UP2, bias=b.to(dev()))
+        e = float((buf[:, 8:8 + cout].float() - ref).norm() / ref.norm())
+        e9 = float((nine.float() - ref).norm() / ref.norm())
+        stray = float(buf[:, :8].abs().max() + buf[:, 8 + cout:].abs().max())
+        print(f"conv_up2 polyphase rows{rows} {cin}->{cout} @{hw}->{2 * hw}: rel {e:.2e} (9-tap form {e9:.2e}) stray {stray}")
+        assert e < 5e-4 and stray == 0
+
+
 def test_hilo_pair_epilogue_and_norms(ops):
     """Accuracy mode primitives (skg_*_hilo): a GEMM / conv whose output and residual are (hi, lo) fp16 pairs carries
     ~22 mantissa bits (hi + lo vs an fp64 reference of the same fp16 operands: fp32-accumulation error only), hi alone is
