@@ -81,8 +81,8 @@ def parse():
                          "north_star states; latents: gather the fp32 latents, no decode (round-1 behaviour)")
     ap.add_argument("--no-guidance", action="store_true", help="informational: config 2 without the LGP guidance (no backward)")
     ap.add_argument("--residual-fp32", action="store_true",
-                    help="informational: HipUNet's opt-in accuracy mode (hi / lo residual stream, forward only: needs --no-guidance "
-                         "or config 4 / 5 without injection) - prices the mode that meets north_star's 1e-3 eps bound")
+                    help="informational: HipUNet's opt-in accuracy mode (hi / lo residual stream; config 2, with or without guidance) - "
+                         "prices the mode that meets north_star's 1e-3 eps bound")
     ap.add_argument("--graph", action="store_true", help="replay the two step variants from captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -368,7 +368,7 @@ def build_workload(args, rank, world, dev, dist):
 
     sd_unet = weights(lambda: synthetic.unet_state_dict(cfg), synthetic.unet_param_shapes(cfg))
     guided = C == 2 and not args.no_guidance
-    assert not args.residual_fp32 or (C == 2 and args.no_guidance), "--residual-fp32 is forward only: use it with --config 2 --no-guidance"
+    assert not args.residual_fp32 or C == 2, "--residual-fp32: config 2 (the plain UNet; the injected attentions have no pair path)"
     net = HipUNet(cfg, sd_unet, dev, need_backward=guided, residual_fp32=args.residual_fp32)
     lgp, target, sd_lgp = None, None, None
     if C == 2 and not guided:

@@ -141,6 +141,13 @@ int skg_groupnorm_from_partial2(const void* X, int ldx, void* Y, int ldy, int ro
  * [4 phases 2a+b][Cout][4 taps][Cin] (sketch2img_amd.unet.pack_conv_up2).  Cin % 64 == 0. */
 int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void* Y, int ldy, int rows, int IH, int IW, int Cin,
                         int Cout, const void* bias, void* stream);
+/* Data gradient of the polyphase upsample + convolution above (the autograd backward of diffusers Upsample2D inside
+ * torch.autograd.grad at modules/pipeline.py:159): ONE 4 x 4 stride-2 convolution, padding 1, over the gradient at the upsampled
+ * size.  X [rows*IH*IW, Cin] (ldx; IH, IW even), Y [rows*(IH/2)*(IW/2), Cout] (ldy), W16 [Cout][16 taps ky*4+kx][Cin]
+ * (sketch2img_amd.unet.pack_conv_up2_dgrad: the transposed pre-summed polyphase weights).  16 tap-products per output pixel
+ * where the 9-tap dgrad at the upsampled size + 2 x 2 sum-pool spends 36.  Cin % 64 == 0. */
+int skg_conv4x4s2_f16(const void* X, int ldx, const void* W16, void* Y, int ldy, int rows, int IH, int IW, int Cin,
+                      int Cout, const void* bias, void* stream);
 
 /* ---- accuracy mode ("residual_fp32"): tensors as (hi, lo) PAIRS of fp16, value = hi + lo (~22 mantissa bits) -------
  * north_star asks for <= 1e-3 max latent-eps deviation from the fp32 reference (modules/pipeline.py:96 in fp32 on CPU);

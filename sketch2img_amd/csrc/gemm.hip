@@ -372,7 +372,9 @@ extern "C" int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void
   SKG_REQUIRE(ldx % 8 == 0 && ldx >= Cin && ldy % 8 == 0 && ldy >= Cout && skg_aligned(X, 16) && skg_aligned(Wpp, 16) &&
               skg_aligned(Y, 16) && (!bias || skg_aligned(bias, 8)));
   hipStream_t st = (hipStream_t)stream;
-  for (int ph = 0; ph < 4; ++ph) {
+  // a phase that does not fill the chip by itself (the 8 -> 16 / 12 -> 24 maps): the four phases as ONE grid
+  const bool one_grid = (long)skg_cdiv(rows * IH * IW, 128) * skg_cdiv(Cout, 160) < 200;
+  for (int ph = 0; ph < (one_grid ? 1 : 4); ++ph) {
     const int a = ph >> 1, b = ph & 1;
     GemmParams p{};
     p.A = (const half_t*)X; p.lda = ldx;
@@ -380,7 +382,7 @@ extern "C" int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void
     p.C = Y; p.ldc = ldy; p.bias = (const half_t*)bias;
     p.N = Cout; p.K = 4 * Cin; p.alpha = 1.f; p.flags = 0;
     p.IH = IH; p.IW = IW; p.OH = IH; p.OW = IW; p.Cin = Cin; p.M = rows * IH * IW;
-    p.ntaps = 4; p.up2 = 1 + ph;
+    p.ntaps = 4; p.up2 = one_grid ? 5 : 1 + ph;
     // low-res rows (ky) / columns (kx) this phase reads, as stride-1 tap ids ky * 3 + kx with ky, kx in {0: -1, 1: 0, 2: +1}
     const int ky0 = a ? 1 : 0, kx0 = b ? 1 : 0;
     p.tapmap = (unsigned)(ky0 * 3 + kx0) | (unsigned)(ky0 * 3 + kx0 + 1) << 4 | (unsigned)((ky0 + 1) * 3 + kx0) << 8 |
@@ -389,6 +391,28 @@ extern "C" int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void
     if (!skg_gemm2_try_launch(p, MODE_S1, st)) return SKG_E_UNSUPPORTED;
     SKG_CHECK_LAUNCH("skg_conv3x3_up2_f16");
   }
+  return SKG_OK;
+}
+
+// dX of the polyphase upsample + conv above = ONE 4 x 4 stride-2 convolution (padding 1) over dY at the upsampled size with
+// the transposed pre-summed weights: dX[i, j] = sum_{ky, kx < 4} W16[ky, kx]^T dY[2 i - 1 + ky, 2 j - 1 + kx] - 16 tap-products
+// per low-res pixel where the 9-tap dgrad at the upsampled size + 2 x 2 sum-pool spends 36.
+extern "C" int skg_conv4x4s2_f16(const void* X, int ldx, const void* W16, void* Y, int ldy, int rows, int IH, int IW,
+                                 int Cin, int Cout, const void* bias, void* stream) {
+  SKG_REQUIRE(X && W16 && Y && rows > 0 && IH > 0 && IW > 0 && IH % 2 == 0 && IW % 2 == 0 && Cin % 64 == 0 && Cout % 8 == 0);
+  SKG_REQUIRE(ldx % 8 == 0 && ldx >= Cin && ldy % 8 == 0 && ldy >= Cout && skg_aligned(X, 16) && skg_aligned(W16, 16) &&
+              skg_aligned(Y, 16) && (!bias || skg_aligned(bias, 8)));
+  hipStream_t st = (hipStream_t)stream;
+  GemmParams p{};
+  p.A = (const half_t*)X; p.lda = ldx;
+  p.B = (const half_t*)W16; p.ldb = 16 * Cin;
+  p.C = Y; p.ldc = ldy; p.bias = (const half_t*)bias;
+  p.N = Cout; p.K = 16 * Cin; p.alpha = 1.f; p.flags = 0;
+  p.IH = IH; p.IW = IW; p.OH = IH / 2; p.OW = IW / 2; p.Cin = Cin; p.M = rows * p.OH * p.OW;
+  p.ntaps = 16;
+  ws_attach(p, st);
+  if (!skg_gemm2_try_launch(p, MODE_S2, st)) return SKG_E_UNSUPPORTED;
+  SKG_CHECK_LAUNCH("skg_conv4x4s2_f16");
   return SKG_OK;
 }
 

@@ -183,6 +183,14 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
   const int ntiles = ws ? nwg / ((p.K / BK + kt_per_split - 1) / kt_per_split) : nwg;
   const int split = lid / ntiles;
   lid -= split * ntiles;
+  // polyphase upsample: phase 2a + b of this tile (p.up2 = 1 + phase: one launch per phase; 5: all four phases in this
+  // launch, tiles [ph * ntiles / 4, (ph + 1) * ntiles / 4) - the small maps, where one phase does not fill the chip)
+  int ph = p.up2 ? p.up2 - 1 : 0;
+  if (p.up2 == 5) {
+    const int per = ntiles >> 2;
+    ph = lid / per;
+    lid -= ph * per;
+  }
   int tile_m = lid / tiles_n;
   int tile_n = lid - tile_m * tiles_n;
   // Weight-heavy launches (16x16 / 8x8 levels: W = 30-60 MB, A = 10-20 MB): with the plain order every XCD walks all
@@ -231,10 +239,18 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
         // with the shifted base, tap (ky,kx) of this row is at voff + ((ky*IW + kx)*lda + c0)*2
         a_voff[j] = ok ? ((img + (unsigned)(cy * p.IW + cx)) * (unsigned)p.lda) * 2u + pk : OOB;
         unsigned mk = 0;
+        if (MODE == MODE_S2 && p.ntaps == 16) {      // 4 x 4 stride-2 window, rows 2 oy - 1 .. 2 oy + 2 (skg_conv4x4s2_f16)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
-          if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mk |= 1u << t;
+          for (int t = 0; t < 16; ++t) {
+            const int iy = cy + (t >> 2) - 1, ix = cx + (t & 3) - 1;
+            if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mk |= 1u << t;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+            if (ok && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) mk |= 1u << t;
+          }
         }
         a_mask[j] = mk;
       } else {
@@ -250,7 +266,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
     const int r = (j * NW + wave) * 8 + lr;
     const unsigned pk = (unsigned)(lq ^ ((r >> 1) & 7)) * 16u;
     const int n = n0 + r;
-    b_voff[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb * 2u + pk : OOB;
+    b_voff[j] = n < p.N ? ((unsigned)n + (p.up2 == 5 ? (unsigned)(ph * p.N) : 0u)) * (unsigned)p.ldb * 2u + pk : OOB;
   }
 
   // LDS-DMA of K tile kt into stage `buf`, split into the per-step address part (`dma_prepare`: SALU + a few VALU
@@ -280,10 +296,18 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
         ti = k0 / p.Cin;
         c0 = k0 - ti * p.Cin;
       }
-      tap = p.ntaps ? (int)((p.tapmap >> (4 * ti)) & 0xfu) : ti;      // polyphase launches walk a subset of the taps
       kb = (unsigned)(ti * p.Cin + c0);
-      ky = tap / 3;
-      kx = tap - ky * 3;
+      if (MODE == MODE_S2 && p.ntaps == 16) {      // 4 x 4 window
+        tap = ti;
+        ky = ti >> 2;
+        kx = ti & 3;
+      } else {
+        // polyphase launches walk a 2 x 2 subset of the stride-1 taps: rows {a, a + 1}, columns {b, b + 1} of the 3 x 3 ids
+        const unsigned tapmap = p.up2 == 5 ? (unsigned)((ph >> 1) * 3 + (ph & 1)) * 0x1111u + 0x4310u : p.tapmap;
+        tap = p.ntaps ? (int)((tapmap >> (4 * ti)) & 0xfu) : ti;
+        ky = tap / 3;
+        kx = tap - ky * 3;
+      }
       soff = (unsigned)((ky * p.IW + kx) * p.lda + c0) * 2u;
     }
 #pragma unroll
@@ -655,7 +679,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
         if (p.up2) {      // polyphase upsample: low-res pixel (i, j) of image b -> high-res pixel (2 i + a, 2 j + b)
           const int m = m0 + sl * HROWS + hr * 64 + er, hw = p.OH * p.OW;
           const int img = m / hw, rr = m - img * hw, i = rr / p.OW, j = rr - i * p.OW;
-          const size_t r = (size_t)img * 4 * hw + (size_t)(2 * i + ((p.up2 - 1) >> 1)) * (2 * p.OW) + 2 * j + ((p.up2 - 1) & 1);
+          const size_t r = (size_t)img * 4 * hw + (size_t)(2 * i + (ph >> 1)) * (2 * p.OW) + 2 * j + (ph & 1);
           crow = reinterpret_cast<half_t*>(p.C) + r * p.ldc + n0 + ec;
         }
         half8_t hv[IT2];
@@ -879,7 +903,7 @@ inline int pick_splits(long nwg, int KT, size_t slab_bytes, const float* ws, siz
 // bytes of the A / B operands reachable through their descriptors (must stay below 2^31 for the OOB trick)
 inline bool operand_bytes(const GemmParams& p, int mode, unsigned long long& a, unsigned long long& b,
                           unsigned long long& shift) {
-  b = ((unsigned long long)(p.N - 1) * p.ldb + p.K) * 2ull;
+  b = ((unsigned long long)((p.up2 == 5 ? 4 : 1) * p.N - 1) * p.ldb + p.K) * 2ull;
   if (mode == MODE_DIRECT) {
     shift = 0;
     a = ((unsigned long long)(p.M - 1) * p.lda + p.K) * 2ull;
@@ -960,7 +984,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   static const char* smb = getenv("SKG_STREAM_MB");          // tuning only
   if (out_bytes >= (smb ? (size_t)atoi(smb) << 20 : STREAM_OUT_BYTES)) p.flags |= 0x800u;
   const int tiles_n = skg_cdiv(p.N, BN);
-  const int ntiles = skg_cdiv(p.M, BM) * tiles_n;
+  const int ntiles = skg_cdiv(p.M, BM) * tiles_n * (p.up2 == 5 ? 4 : 1);      // (5: the four polyphase launches in one grid)
   unsigned long long a, b, s;
   operand_bytes(p, MODE, a, b, s);
   const int KT = p.K / BK;
@@ -978,7 +1002,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   // XCDs per K slice: all 8 without split-K; 8 / ns when the slices line up with XCD boundaries
   const int ns_eff = splits > 1 ? skg_cdiv(KT, skg_cdiv(KT, splits)) : 1;
   const int G = (8 % ns_eff == 0) ? 8 / ns_eff : 0;
-  if (G >= 2 && ntiles % G == 0) {
+  if (G >= 2 && ntiles % G == 0 && p.up2 != 5) {
     static const bool off = getenv("SKG_NO_XGRID") != nullptr;        // A/B switch (tools/gemm_bench.py)
     const int tiles_m = ntiles / tiles_n;
     const double a_mb = (double)p.M * (MODE == MODE_DIRECT ? p.K : p.Cin) * 2.0, w_mb = (double)p.N * p.K * 2.0;
@@ -1073,8 +1097,8 @@ void skg_splitk_reduce_launch(const GemmParams& p, const float* ws, int splits, 
 
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
   if (!eligible(p, mode)) return false;
-  if ((p.ntaps || p.up2) &&      // polyphase: stride-1 walk, the plain fp16-staged epilogue (no residual / statistics)
-      (mode != MODE_S1 || p.res || p.gn_partial || p.c_lo || p.res_lo || (p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) ||
+  if ((p.ntaps || p.up2) &&      // polyphase: stride-1 walk (4 x 4 window: stride 2), the plain fp16-staged epilogue (no residual / statistics)
+      ((p.ntaps == 16 ? (mode != MODE_S2 || p.up2) : mode != MODE_S1) || p.res || p.gn_partial || p.c_lo || p.res_lo || (p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) ||
        p.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 || p.M % (p.OH * p.OW) != 0))
     return false;
   if ((p.c_lo || p.res_lo) &&

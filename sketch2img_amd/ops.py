@@ -227,6 +227,19 @@ def conv_up2(X: torch.Tensor, Wpp: torch.Tensor, rows: int, IH: int, IW: int, ou
     return out
 
 
+def conv4x4s2(X: torch.Tensor, W16: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None):
+    """4 x 4 stride-2 convolution, padding 1 (the data gradient of conv_up2).  X [rows*IH*IW, Cin] (view), W16 [Cout, 16*Cin]
+    (unet.pack_conv_up2_dgrad).  Returns [rows*(IH/2)*(IW/2), Cout]."""
+    _f16(X, W16, bias)
+    Cin, Cout = X.shape[1], W16.shape[0]
+    assert W16.shape == (Cout, 16 * Cin) and W16.is_contiguous() and X.shape[0] == rows * IH * IW
+    if out is None:
+        out = torch.empty(rows * (IH // 2) * (IW // 2), Cout, device=X.device, dtype=torch.float16)
+    check(lib.skg_conv4x4s2_f16(_p(X), _ld(X), _p(W16), _p(out), _ld(out), rows, IH, IW, Cin, Cout, _p(bias), _stream()),
+          "skg_conv4x4s2_f16")
+    return out
+
+
 _scratch = {}
 
 

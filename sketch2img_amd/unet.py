@@ -82,7 +82,26 @@ def pack_conv_up2(w: torch.Tensor, dev) -> torch.Tensor:
     return _h(torch.stack(phases, 0), dev)
 
 
+def pack_conv_up2_dgrad(w: torch.Tensor, dev) -> torch.Tensor:
+    """Data gradient of the polyphase upsample + conv (ops.conv4x4s2): [Cin][16 taps ky*4+kx][Cout], the transposed pre-summed
+    weights of pack_conv_up2.  dX[p] = sum over phases a and taps ty of Wpp[a][ty]^T dY[2 (p - oy(a, ty)) + a] with
+    oy(0, .) = (-1, 0), oy(1, .) = (0, +1): rows 2p - 1 .. 2p + 2 of dY, window row ky = 0..3 <-> (a, ty) = (1,1), (0,1), (1,0), (0,0)."""
+    w = w.detach().float()
+    co, ci = w.shape[:2]
+
+    def split(t, axis):          # 3 filter taps along `axis` -> the four window positions along that axis
+        t0, t1, t2 = t.unbind(axis)
+        return [t2, t1 + t2, t0 + t1, t0]      # ky = 0: (a=1, ty=1) = w2;  1: (0,1) = w1 + w2;  2: (1,0) = w0 + w1;  3: (0,0) = w0
+    taps = []
+    for r in split(w, 2):                                        # 4 x [co, ci, kx]
+        taps += split(r, 2)                                      # 16 x [co, ci], order ky * 4 + kx
+    p = torch.stack(taps, 0)                                     # [16, co, ci]
+    return _h(p.permute(2, 0, 1).reshape(ci, 16 * co), dev)
+
+
 UP2_POLYPHASE = os.environ.get("SKG_UP2_POLY", "1") != "0"      # A/B switch (bench.py on one box)
+UP2_SMALL_MAPS = os.environ.get("SKG_UP2_SMALL", "1") != "0"    # A/B: polyphase also where one phase does not fill the chip
+UP2_DGRAD = os.environ.get("SKG_UP2_DGRAD", "1") != "0"         # A/B: the upsampler's backward as one 4 x 4 stride-2 convolution
 
 
 def _pad_vec(v: torch.Tensor, n: int) -> torch.Tensor:
@@ -136,6 +155,8 @@ class HipUNet:
                         W[k + ":T"] = pack_conv_dgrad(v, dev)
                     if ".upsamplers." in k and UP2_POLYPHASE and v.shape[1] % 64 == 0:
                         W[k + ":pp"] = pack_conv_up2(v, dev)
+                        if bw and v.shape[0] % 64 == 0:
+                            W[k + ":ppT"] = pack_conv_up2_dgrad(v, dev)
             elif v.dim() == 4:                                  # 1x1 conv
                 W[k] = _h(v.reshape(v.shape[0], v.shape[1]), dev)
                 if bw:
@@ -519,8 +540,8 @@ class HipUNet:
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 u = (i + 1) * lpb1
-                # polyphase (16 instead of 36 tap-products per low-res pixel) where its four launches still fill the chip
-                if (p + ".weight:pp") in W and (rows * cur * cur // 128) * (h.shape[1] // 160) >= 200:
+                # polyphase: 16 instead of 36 tap-products per low-res pixel (four launches; one grid on the small maps)
+                if (p + ".weight:pp") in W and (UP2_SMALL_MAPS or (rows * cur * cur // 128) * (h.shape[1] // 160) >= 200):
                     h = ops.conv_up2(h, W[p + ".weight:pp"], rows, cur, cur, out=cats[u][:, :ch_h[u]], bias=W[p + ".bias"])
                 else:
                     h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=cats[u][:, :ch_h[u]],
@@ -827,9 +848,13 @@ class HipUNet:
             if i < nb - 1:
                 # upsampler backward: dgrad at the upsampled size, then 2x2 sum-pool
                 p = f"up_blocks.{i}.upsamplers.0.conv"
-                du = ops.conv3x3(dh, W[p + ".weight:T"], S, cur, cur)
-                cur //= 2
-                dh = ops.sumpool2x2(du, S, cur, cur)
+                if UP2_DGRAD and (p + ".weight:ppT") in W:      # polyphase: one 4 x 4 stride-2 convolution, 16 instead of 36 tap-products
+                    dh = ops.conv4x4s2(dh, W[p + ".weight:ppT"], S, cur, cur)
+                    cur //= 2
+                else:
+                    du = ops.conv3x3(dh, W[p + ".weight:T"], S, cur, cur)
+                    cur //= 2
+                    dh = ops.sumpool2x2(du, S, cur, cur)
             for j in range(lpb, -1, -1):
                 if i > 0:
                     dh = self._tr_bwd(f"up_blocks.{i}.attentions.{j}", dh, S, stash.tr[f"up_blocks.{i}.attentions.{j}"])

@@ -177,6 +177,30 @@ def test_conv_up2_polyphase(ops):
         assert e < 5e-4 and stray == 0
 
 
+def test_conv4x4s2_is_the_dgrad_of_upsample_conv(ops):
+    """skg_conv4x4s2_f16 with unet.pack_conv_up2_dgrad: the data gradient of nearest-2x upsample + 3x3 conv as ONE 4 x 4
+    stride-2 convolution over dY, vs torch autograd of F.interpolate + F.conv2d (fp32), and vs the path it replaces (9-tap
+    dgrad at the upsampled size + 2 x 2 sum-pool); split-K and single-launch shapes, output into a strided view."""
+    from sketch2img_amd.unet import pack_conv_dgrad, pack_conv_up2_dgrad
+    g = torch.Generator().manual_seed(54)
+    for rows, hw, cin, cout in [(2, 8, 64, 128), (8, 32, 640, 640), (8, 8, 1280, 1280), (3, 16, 128, 320)]:
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
+        dy = torch.randn(rows, cout, 2 * hw, 2 * hw, generator=g).half()
+        x = torch.zeros(rows, cin, hw, hw, device=dev(), requires_grad=True)
+        y = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w.float().to(dev()), padding=1)
+        ref, = torch.autograd.grad(y, x, dy.float().to(dev()))
+        ref = ref.permute(0, 2, 3, 1).reshape(-1, cin)
+        dys = nhwc(dy).to(dev())
+        buf = torch.zeros(rows * hw * hw, cin + 16, device=dev(), dtype=torch.float16)
+        ops.conv4x4s2(dys, pack_conv_up2_dgrad(w, dev()), rows, 2 * hw, 2 * hw, out=buf[:, 8:8 + cin])
+        old = ops.sumpool2x2(ops.conv3x3(dys, pack_conv_dgrad(w, dev()), rows, 2 * hw, 2 * hw), rows, hw, hw)
+        e = float((buf[:, 8:8 + cin].float() - ref).norm() / ref.norm())
+        e9 = float((old.float() - ref).norm() / ref.norm())
+        stray = float(buf[:, :8].abs().max() + buf[:, 8 + cin:].abs().max())
+        print(f"conv4x4s2 rows{rows} dY {cout}ch @{2 * hw} -> dX {cin}ch @{hw}: rel {e:.2e} (dgrad + sum-pool {e9:.2e}) stray {stray}")
+        assert e < 5e-4 and stray == 0
+
+
 def test_hilo_pair_epilogue_and_norms(ops):
     """Accuracy mode primitives (skg_*_hilo): a GEMM / conv whose output and residual are (hi, lo) fp16 pairs carries
     ~22 mantissa bits (hi + lo vs an fp64 reference of the same fp16 operands: fp32-accumulation error only), hi alone is
