@@ -120,6 +120,10 @@ class HipSampler:
         self._x0_before: Optional[torch.Tensor] = None      # DPM-Solver++ history (one x0 prediction)
         self._seen = 0
         self.share_cfg_prefix = os.environ.get("SKG_SHARE_CFG", "1") != "0"      # A/B switch (bench.py on one box)
+        # guided steps: LGP + backward-to-input on a second HIP stream from the moment the ninth tap exists, next to the last
+        # up block + conv_out + CFG / DDIM on the launch stream (A/B switch; not under graph capture)
+        self.fork_guidance = os.environ.get("SKG_FORK_GUIDANCE", "1") != "0"
+        self._side: Optional[torch.cuda.Stream] = None
         self._graphs: dict = {}                   # insertion-ordered: least recently used first
         self.max_graph_sets = 4
 
@@ -138,7 +142,34 @@ class HipSampler:
         x32 = ops.nchw_to_nhwc(torch.cat([x, x]).contiguous(), CIN_PAD)
         stash = Stash() if guided else None
         # (the two CFG halves of x32 are the same latents: the text-independent front of the UNet runs once)
-        eps, taps = self.unet.forward(x32, t, 2 * S, h, stash, want_taps=guided, shared_input=self.share_cfg_prefix)
+        fork = guided and self.fork_guidance and not torch.cuda.is_current_stream_capturing()
+        branch: dict = {}
+
+        def guidance_branch(taps):
+            keep = {}
+            out = self.lgp.forward(taps, noise, tab.sigma(t), S, h, keep)
+            tap_grads, loss = self.lgp.backward(out, target, keep)
+            return self.unet.backward(stash, tap_grads), loss
+
+        def on_taps(taps):
+            # every tensor the branch reads exists (the stash of the first three up blocks, the nine taps) and nothing the
+            # launch stream still has to run writes one of them; the tensors stay referenced (stash, `branch`) until the
+            # launch stream has waited for the branch, so neither allocator pool recycles a block the other stream still uses
+            main = torch.cuda.current_stream()
+            if self._side is None or self._side.device != main.device:
+                self._side = torch.cuda.Stream(device=main.device)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ready)
+                branch["grad"], branch["loss"] = guidance_branch(taps)
+                branch["taps"] = taps
+                branch["done"] = torch.cuda.Event()
+                branch["done"].record(self._side)
+
+        eps, taps = self.unet.forward(x32, t, 2 * S, h, stash, want_taps=guided, shared_input=self.share_cfg_prefix,
+                                      on_taps=on_taps if fork else None)
+        fork = fork and "done" in branch          # (a forward without the hook - the accuracy mode - runs the branch in line)
         if isinstance(tab, DPMTables):
             if self._x0_before is None or self._x0_before.shape != x.shape:
                 self._x0_before, self._seen = torch.zeros_like(x), 0
@@ -151,10 +182,11 @@ class HipSampler:
         x_prev, eps_cfg = res if want_eps else (res, None)
         aux = None
         if guided:
-            keep = {}
-            out = self.lgp.forward(taps, noise, tab.sigma(t), S, h, keep)
-            tap_grads, loss = self.lgp.backward(out, target, keep)
-            grad = self.unet.backward(stash, tap_grads)
+            if fork:
+                torch.cuda.current_stream().wait_event(branch["done"])
+                grad, loss = branch["grad"], branch["loss"]
+            else:
+                grad, loss = guidance_branch(taps)
             aux = ops.guidance_update(grad, x, x_prev, S, hw, beta)
             aux[:, 3] = loss
         return x_prev, eps_cfg, aux

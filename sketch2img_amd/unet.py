@@ -391,7 +391,8 @@ class HipUNet:
 
     # ------------------------------------------------------------------ forward
     def forward(self, x32: torch.Tensor, t: int, rows: int, H: int, stash: Optional[Stash] = None,
-                want_taps: bool = True, want_eps: bool = True, down_only: bool = False, shared_input: bool = False):
+                want_taps: bool = True, want_eps: bool = True, down_only: bool = False, shared_input: bool = False,
+                on_taps: Optional[Callable] = None):
         """x32: fp16 [rows*H*H, 32] (latent channels zero-padded).  Returns (eps [rows*H*H, 8] or None,
         taps: list of 9 (tensor [rows*s*s, C], s)).
 
@@ -402,13 +403,19 @@ class HipUNet:
         the full 64 x 64 resolution - is evaluated ONCE on the cond rows and copied to the uncond rows.  Exact in exact
         arithmetic (every kernel's result for a row depends on that row only); bit-identical to the doubled evaluation
         when the half-size launches run the same kernel instantiations, else equal to fp16 rounding noise - another
-        summation order of GroupNorm partial sums / K slices (tests/test_gpu_pipeline.py::test_shared_cfg_prefix_is_bit_identical)."""
+        summation order of GroupNorm partial sums / K slices (tests/test_gpu_pipeline.py::test_shared_cfg_prefix_is_bit_identical).
+
+        on_taps(taps): called as soon as the ninth tap exists (after the third up block), before the last up block and
+        conv_out are launched - the guidance branch (LGP + backward-to-input) depends on nothing later, so the sampler can put
+        it on a second stream while this one finishes eps (sampler.HipSampler.fork_guidance)."""
         cfg, W = self.cfg, self.W
         assert self.ctx is not None and self.ctx["rows"] == rows, "call prepare_context first"
         self.prepare_timesteps([t])
         if self.residual_fp32:
             assert not down_only and self.inject is None, "accuracy mode: the plain UNet (with or without a stash)"
             return self._forward_hp(x32, t, rows, H, want_taps, want_eps, stash)
+        if stash is not None:
+            stash.misc.update(rows=rows, H=H)
         tb = self.tbias[int(t)]
         boc = cfg.block_out_channels
         nb = len(boc)
@@ -550,6 +557,8 @@ class HipUNet:
                 cur *= 2
             if i < 3:
                 taps_up.append((h, cur))
+                if i == 2 and on_taps is not None:
+                    on_taps(taps_down + [tap_at, tap_r0, tap_r1] + taps_up)
         eps = None
         if want_eps:
             n, _ = ops.groupnorm(h, rows, cur * cur, cfg.norm_groups, 1e-5, W["conv_norm_out.weight"],
