@@ -198,6 +198,12 @@ int launch(const GemmParams& p, hipStream_t st) {
 
 template <int MODE>
 int launch_plain(const GemmParams& p, hipStream_t st) {
+#ifdef SKG_LAB      // withdrawn round-3 experiment (tools/lab/gemmws.hip, EXPERIMENTS.md): lab build only, SKG_GEMMWS=1
+  if (skg_gemmws_try_launch(p, MODE, st)) {
+    SKG_CHECK_LAUNCH("skg_gemm (ws)");
+    return SKG_OK;
+  }
+#endif
   if (skg_gemm8_try_launch(p, MODE, st)) {
     SKG_CHECK_LAUNCH("skg_gemm (v8)");
     return SKG_OK;
@@ -269,6 +275,9 @@ extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
   {   // v8 takes plain (fp16 out, no fused GEGLU) launches of eligible shapes
     GemmParams q{};
     q.M = M; q.N = N; q.K = K; q.Cin = Cin; q.lda = q.ldb = K; q.ldc = N; q.OH = q.OW = q.IH = q.IW = 1;
+#ifdef SKG_LAB
+    if (skg_gemmws_eligible(q, mode)) return 7320;      // (plain epilogue only: launches with statistics / GEGLU / fp32 out take v2)
+#endif
     if (const int bn8 = skg_gemm8_tile_n(q, mode)) return 8000 + bn8;
 #ifdef SKG_LAB
     q.C = (void*)16;      // (alignment checks only)

@@ -35,6 +35,9 @@ constexpr unsigned SKG_FLAG_GN_STATS = 0x8000u;      // internal: set by the lau
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st);
 // column width of the tile v2 would use for an M x N output, or 0 if v2 does not take this shape
 int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode, size_t ws_bytes);
+// lab build only (tools/lab/gemmws.hip): weight-stationary streaming kernel for N = K = 320 plain GEMMs with M >= 32768
+bool skg_gemmws_eligible(const GemmParams& p, int mode);
+bool skg_gemmws_try_launch(const GemmParams& p, int mode, hipStream_t st);
 // v8 (gemm8.hip): 256 x 320 tiles, one 8-wave workgroup per CU, ping-pong schedule (S1 convolutions of the 64 x 64 level).
 bool skg_gemm8_eligible(const GemmParams& p, int mode);
 int skg_gemm8_tile_n(const GemmParams& p, int mode);      // 160 / 320, or 0 when v8 does not take the launch

@@ -159,21 +159,22 @@ def test_conv_up2_polyphase(ops):
     vs F.interpolate + F.conv2d, and vs the 9-tap UP2 gather form of skg_conv3x3_f16; output into a strided view."""
     from sketch2img_amd.unet import pack_conv, pack_conv_up2
     g = torch.Generator().manual_seed(53)
-    for rows, hw, cin, cout in [(2, 16, 64, 160), (3, 8, 128, 320), (16, 32, 640, 640),
+    for rows, hw, cin, cout in [(2, 16, 64, 160), (3, 8, 128, 320), (16, 32, 640, 640), (2, (8, 24), 64, 320), (5, (40, 24), 128, 160),
                                 (1, 64, 512, 512), (1, 128, 512, 512), (1, 64, 256, 256)]:      # last three: VAE decoder (128 x 64 / 128 x 128 tiles)
-        x = torch.randn(rows, cin, hw, hw, generator=g).half()
+        ih, iw = hw if isinstance(hw, tuple) else (hw, hw)
+        x = torch.randn(rows, cin, ih, iw, generator=g).half()
         w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
         b = torch.randn(cout, generator=g).half()
         xs = nhwc(x).to(dev())
-        buf = torch.zeros(rows * 4 * hw * hw, cout + 16, device=dev(), dtype=torch.float16)
-        ops.conv_up2(xs, pack_conv_up2(w, dev()), rows, hw, hw, out=buf[:, 8:8 + cout], bias=b.to(dev()))
+        buf = torch.zeros(rows * 4 * ih * iw, cout + 16, device=dev(), dtype=torch.float16)
+        ops.conv_up2(xs, pack_conv_up2(w, dev()), rows, ih, iw, out=buf[:, 8:8 + cout], bias=b.to(dev()))
         ref = F.conv2d(F.interpolate(x.float().to(dev()), scale_factor=2.0, mode="nearest"), w.float().to(dev()), b.float().to(dev()),
                        padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
-        nine = ops.conv3x3(xs, pack_conv(w, dev()), rows, hw, hw, ops.CONV_UP2, bias=b.to(dev()))
+        nine = ops.conv3x3(xs, pack_conv(w, dev()), rows, ih, iw, ops.CONV_UP2, bias=b.to(dev()))
         e = float((buf[:, 8:8 + cout].float() - ref).norm() / ref.norm())
         e9 = float((nine.float() - ref).norm() / ref.norm())
         stray = float(buf[:, :8].abs().max() + buf[:, 8 + cout:].abs().max())
-        print(f"conv_up2 polyphase rows{rows} {cin}->{cout} @{hw}->{2 * hw}: rel {e:.2e} (9-tap form {e9:.2e}) stray {stray}")
+        print(f"conv_up2 polyphase rows{rows} {cin}->{cout} @{ih}x{iw} -> 2x: rel {e:.2e} (9-tap form {e9:.2e}) stray {stray}")
         assert e < 5e-4 and stray == 0
 
 
@@ -183,21 +184,22 @@ def test_conv4x4s2_is_the_dgrad_of_upsample_conv(ops):
     dgrad at the upsampled size + 2 x 2 sum-pool); split-K and single-launch shapes, output into a strided view."""
     from sketch2img_amd.unet import pack_conv_dgrad, pack_conv_up2_dgrad
     g = torch.Generator().manual_seed(54)
-    for rows, hw, cin, cout in [(2, 8, 64, 128), (8, 32, 640, 640), (8, 8, 1280, 1280), (3, 16, 128, 320)]:
+    for rows, hw, cin, cout in [(2, 8, 64, 128), (8, 32, 640, 640), (8, 8, 1280, 1280), (3, 16, 128, 320), (2, (6, 20), 64, 64)]:
+        ih, iw = hw if isinstance(hw, tuple) else (hw, hw)
         w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
-        dy = torch.randn(rows, cout, 2 * hw, 2 * hw, generator=g).half()
-        x = torch.zeros(rows, cin, hw, hw, device=dev(), requires_grad=True)
+        dy = torch.randn(rows, cout, 2 * ih, 2 * iw, generator=g).half()
+        x = torch.zeros(rows, cin, ih, iw, device=dev(), requires_grad=True)
         y = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w.float().to(dev()), padding=1)
         ref, = torch.autograd.grad(y, x, dy.float().to(dev()))
         ref = ref.permute(0, 2, 3, 1).reshape(-1, cin)
         dys = nhwc(dy).to(dev())
-        buf = torch.zeros(rows * hw * hw, cin + 16, device=dev(), dtype=torch.float16)
-        ops.conv4x4s2(dys, pack_conv_up2_dgrad(w, dev()), rows, 2 * hw, 2 * hw, out=buf[:, 8:8 + cin])
-        old = ops.sumpool2x2(ops.conv3x3(dys, pack_conv_dgrad(w, dev()), rows, 2 * hw, 2 * hw), rows, hw, hw)
+        buf = torch.zeros(rows * ih * iw, cin + 16, device=dev(), dtype=torch.float16)
+        ops.conv4x4s2(dys, pack_conv_up2_dgrad(w, dev()), rows, 2 * ih, 2 * iw, out=buf[:, 8:8 + cin])
+        old = ops.sumpool2x2(ops.conv3x3(dys, pack_conv_dgrad(w, dev()), rows, 2 * ih, 2 * iw), rows, ih, iw)
         e = float((buf[:, 8:8 + cin].float() - ref).norm() / ref.norm())
         e9 = float((old.float() - ref).norm() / ref.norm())
         stray = float(buf[:, :8].abs().max() + buf[:, 8 + cin:].abs().max())
-        print(f"conv4x4s2 rows{rows} dY {cout}ch @{2 * hw} -> dX {cin}ch @{hw}: rel {e:.2e} (dgrad + sum-pool {e9:.2e}) stray {stray}")
+        print(f"conv4x4s2 rows{rows} dY {cout}ch @{2 * ih}x{2 * iw} -> dX {cin}ch @{ih}x{iw}: rel {e:.2e} (dgrad + sum-pool {e9:.2e}) stray {stray}")
         assert e < 5e-4 and stray == 0
 
 
