@@ -102,6 +102,7 @@ class LaunchTimer:
     def __init__(self, ops):
         self.ops, self.rec = ops, []
         self._gemm, self._conv, self._attn, self._keep = ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep
+        self._up2, self._c4 = ops.conv_up2, ops.conv4x4s2
 
     def __enter__(self):
         from sketch2img_amd._lib import lib
@@ -156,6 +157,37 @@ class LaunchTimer:
                              f"conv {name} M{M} Cin{Cin} Cout{Cout}" + "+res" * (k.get("residual") is not None)))
             return out
 
+        def v2name(M, N, K, Cin, mode, label, phases=1):
+            """gemm2.hip instantiation of a polyphase launch (gemm8.hip declines them; `phases` grids in one launch)."""
+            var = lib.skg_gemm_variant(M, N, K, Cin, 1 + mode)
+            bn = var % 1000 if 2000 <= var < 8000 or var >= 10000 else 160
+            three = var >= 10000 and phases == 1
+            return f"gemm2_kernel<128, {bn}, 2, 2, {MODES[label]}, {3 if three else 2}, false, false>"
+
+        def conv_up2(X, Wpp, rows, IH, IW, *a, **k):
+            # EXECUTED flops: four 4-tap convolutions over the low-res map (the 9-tap form of the same layer: 36 tap-products)
+            Cin, Cout = X.shape[1], Wpp.shape[1]
+            M = rows * IH * IW
+            e0, e1 = ev()
+            e0.record()
+            out = self._up2(X, Wpp, rows, IH, IW, *a, **k)
+            e1.record()
+            one = ((M + 127) // 128) * ((Cout + 159) // 160) < 200            # the four phases as one grid (gemm.hip)
+            self.rec.append((v2name(M, Cout, 4 * Cin, Cin, 0, "S1", 4 if one else 1), 2.0 * M * Cout * 16 * Cin, e0, e1,
+                             2.0 * (M * Cin + 16 * Cout * Cin + 4 * M * Cout), f"conv UP2 polyphase M{4 * M} Cin{Cin} Cout{Cout}", 1 if one else 4))
+            return out
+
+        def conv4x4s2(X, W16, rows, IH, IW, *a, **k):
+            Cin, Cout = X.shape[1], W16.shape[0]
+            M = rows * (IH // 2) * (IW // 2)
+            e0, e1 = ev()
+            e0.record()
+            out = self._c4(X, W16, rows, IH, IW, *a, **k)
+            e1.record()
+            self.rec.append((v2name(M, Cout, 16 * Cin, Cin, 1, "S2"), 2.0 * M * Cout * 16 * Cin, e0, e1,
+                             2.0 * (4 * M * Cin + 16 * Cout * Cin + M * Cout), f"conv 4x4 S2 (UP2 dgrad) M{M} Cin{Cin} Cout{Cout}"))
+            return out
+
         def attn(Q, K, Vt, batch, heads, Nq, Nkv, kv_stride, dh, scale, *a, **k):
             e0, e1 = ev()
             e0.record()
@@ -183,28 +215,30 @@ class LaunchTimer:
             return out
 
         ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep = gemm, conv, attn, gemm_keep
+        ops.conv_up2, ops.conv4x4s2 = conv_up2, conv4x4s2
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm, self.ops.conv3x3, self.ops.attn_fwd, self.ops.gemm_geglu_keep = self._gemm, self._conv, self._attn, self._keep
+        self.ops.conv_up2, self.ops.conv4x4s2 = self._up2, self._c4
 
     def summary(self):
         """per kernel: [launches, flops, seconds, algorithmic bytes, roofline seconds, seconds of HBM-bound launches];
         a launch's roofline time = max(flops / MFMA peak, algorithmic bytes / HBM peak)."""
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, e0, e1, nb, _ in self.rec:
+        for name, fl, e0, e1, nb, _, *nl in self.rec:      # (nl: kernel launches behind one record - the four polyphase grids)
             a = agg.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0, 0.0])
             t = e0.elapsed_time(e1) * 1e-3
             t_m, t_h = fl / (PEAK_FP16_TFLOPS * 1e12), nb / (PEAK_HBM_TBS * 1e12)
-            a[0] += 1; a[1] += fl; a[2] += t; a[3] += nb; a[4] += max(t_m, t_h); a[5] += t if t_h > t_m else 0.0
+            a[0] += nl[0] if nl else 1; a[1] += fl; a[2] += t; a[3] += nb; a[4] += max(t_m, t_h); a[5] += t if t_h > t_m else 0.0
         return agg
 
     def shape_report(self, path):
         """Per-shape table (launches, total ms, avg us, TFLOP/s, algorithmic TB/s), sorted by total time."""
         torch.cuda.synchronize()
         agg = {}
-        for name, fl, e0, e1, nb, shape in self.rec:
+        for name, fl, e0, e1, nb, shape, *_ in self.rec:
             a = agg.setdefault((shape, name), [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += fl; a[2] += e0.elapsed_time(e1) * 1e-3; a[3] += nb
         rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
@@ -483,10 +517,12 @@ def main():
 
     roof, cpu = None, None
     if rank == 0 and not args.no_roofline:
+        fork, wl["sampler"].fork_guidance = wl["sampler"].fork_guidance, False      # every launch timed ALONE (no second stream)
         with LaunchTimer(ops) as lt:
             wl["sampler"].sample(wl["lat0"], wl["target"], T, tables=wl["tab"], graphs=False)
             if wl["vae"] is not None:
                 wl["vae"].decode_to_u8(wl["sampler"].last_latents)
+        wl["sampler"].fork_guidance = fork
         agg = lt.summary()
         if args.shape_report:
             lt.shape_report(args.shape_report)
@@ -498,7 +534,8 @@ def main():
                     traffic_source=(f"from committed profile {traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes "
                                     "per launch = (2*FETCH + WRITE)*1024), not measured in this run") if traffic_file else None,
                     launches=n, avg_launch_us=sec / n * 1e6, avg_launch_gflop=fl / n / 1e9,
-                    timing="HIP events on the launch stream around every launch (includes the launch gap)",
+                    timing=("HIP events on the launch stream around every launch (includes the launch gap), one instrumented batch after the timed "
+                            "region with the guidance branch in line (the timed region runs it on a second stream beside the last up block)"),
                     all_contraction_tflops=sum(v[1] for v in agg.values()) / tot_sec / 1e12,
                     contraction_share_of_step=tot_sec / (dt / args.steps),
                     # every launch against ITS OWN bound, max(flops / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s): the short-K
