@@ -1,9 +1,10 @@
 cd $GRAFT_REPO_ROOT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-T=gpurun_out/t30
+T=gpurun_out/t31
 mkdir -p $T
-timeout 900 python bench.py --config 2 --shape-report $T/r03_cfg2_shapes.txt > $T/r03_bench_c2.json 2> $T/bench_c2.err; echo rc=$?
-timeout 900 python bench.py --config 4 > $T/r03_bench_c4.json 2> $T/bench_c4.err; echo rc=$?
-timeout 900 python bench.py --config 5 > $T/r03_bench_c5.json 2> $T/bench_c5.err; echo rc=$?
+for i in 1 2; do
+for s in 0 1 2; do
+SKG_STAGGER=$s timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $T/s${s}_$i.json 2> $T/s${s}_$i.err
+done
+done
 grep -o '"value": [0-9.]*' $T/*.json
-tail -3 $T/bench_c2.err
