@@ -1,10 +1,7 @@
 cd $GRAFT_REPO_ROOT
-export HSA_ENABLE_IPC_MODE_LEGACY=0
-T=gpurun_out/t31
+T=gpurun_out/t32
 mkdir -p $T
-for i in 1 2; do
-for s in 0 1 2; do
-SKG_STAGGER=$s timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $T/s${s}_$i.json 2> $T/s${s}_$i.err
-done
-done
-grep -o '"value": [0-9.]*' $T/*.json
+timeout 900 python tools/smallm_bench.py --plain --rounds 3 --iters 20 --pool-mb 640 --out $T/cold.txt > $T/cold.log 2>&1; echo rc=$?
+timeout 900 python tools/smallm_bench.py --plain --rounds 3 --iters 20 --pool-mb 0 --out $T/warm.txt > $T/warm.log 2>&1; echo rc=$?
+paste <(cut -c1-66 $T/cold.txt) <(cut -c49-66 $T/warm.txt) | head -50
+tail -2 $T/cold.txt; tail -2 $T/warm.txt
