@@ -169,7 +169,7 @@ class HipSampler:
 
         eps, taps = self.unet.forward(x32, t, 2 * S, h, stash, want_taps=guided, shared_input=self.share_cfg_prefix,
                                       on_taps=on_taps if fork else None)
-        fork = fork and "done" in branch          # (a forward without the hook - the accuracy mode - runs the branch in line)
+        fork = fork and "done" in branch          # (a forward that never reached the hook runs the branch in line)
         if isinstance(tab, DPMTables):
             if self._x0_before is None or self._x0_before.shape != x.shape:
                 self._x0_before, self._seen = torch.zeros_like(x), 0

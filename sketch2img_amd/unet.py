@@ -413,7 +413,7 @@ class HipUNet:
         self.prepare_timesteps([t])
         if self.residual_fp32:
             assert not down_only and self.inject is None, "accuracy mode: the plain UNet (with or without a stash)"
-            return self._forward_hp(x32, t, rows, H, want_taps, want_eps, stash)
+            return self._forward_hp(x32, t, rows, H, want_taps, want_eps, stash, on_taps)
         if stash is not None:
             stash.misc.update(rows=rows, H=H)
         tb = self.tbias[int(t)]
@@ -658,11 +658,13 @@ class HipUNet:
                  residual=x.hi, residual_lo=x.lo)
         return out
 
-    def _forward_hp(self, x32, t, rows, H, want_taps, want_eps, stash=None):
+    def _forward_hp(self, x32, t, rows, H, want_taps, want_eps, stash=None, on_taps=None):
         """The forward of forward() with the residual stream as (hi, lo) pairs; the same graph, the same kernels for every
         contraction, pair-aware epilogues / norms (skg_*_hilo).  Concatenations [h | skip] are pair buffers
         [h_hi | skip_hi | h_lo | skip_lo], filled in place by their producers."""
         cfg, W = self.cfg, self.W
+        if stash is not None:
+            stash.misc.update(rows=rows, H=H)
         tb = self.tbias[int(t)]
         boc = cfg.block_out_channels
         nb = len(boc)
@@ -747,6 +749,8 @@ class HipUNet:
                 cur *= 2
             if i < 3:
                 taps_up.append((h.hi, cur))
+                if i == 2 and on_taps is not None:
+                    on_taps(taps_down + [tap_at, tap_r0, tap_r1] + taps_up)
         eps = None
         if want_eps:
             n, _ = self._gn_hp(h, rows, cur * cur, 1e-5, "conv_norm_out", True)

@@ -284,11 +284,13 @@ def test_forked_guidance_branch_is_bit_identical(tiny):
     g = torch.Generator().manual_seed(6)
     target = 0.18215 * torch.randn(S, 4, h, h, generator=g)
     big = HipUNet(SD15, synthetic.unet_state_dict(SD15), DEV)
+    acc = HipUNet(SD15, synthetic.unet_state_dict(SD15), DEV, residual_fp32=True)      # accuracy mode: the pair forward forks too
     sdb = synthetic.lgp_state_dict(sum(tap_channels(SD15)) + 40)
     # (the last case is the bench shape, 8 samples at 64 x 64: the two streams then both run the persistent weight-stationary
     # GEMM, gemmws.hip, whose counted waits a second stream once broke)
     cases = [(net, sd, ounet.tap_channels(tiny["cfg"]), tiny["x"], target, None),
              (big, sdb, tap_channels(SD15), synthetic.initial_latents(0, 2, 32), synthetic.sketch_targets(0, 2, 32), 2),
+             (acc, sdb, tap_channels(SD15), synthetic.initial_latents(0, 2, 32), synthetic.sketch_targets(0, 2, 32), 2),
              (big, sdb, tap_channels(SD15), synthetic.initial_latents(0, 8, 64), synthetic.sketch_targets(0, 8, 64), 8)]
     for unet, lsd, chans, x0, tgt, nctx in cases:
         if nctx is not None:

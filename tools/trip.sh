@@ -1,7 +1,10 @@
 cd $GRAFT_REPO_ROOT
-T=gpurun_out/t32
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+T=gpurun_out/t33
 mkdir -p $T
-timeout 900 python tools/smallm_bench.py --plain --rounds 3 --iters 20 --pool-mb 640 --out $T/cold.txt > $T/cold.log 2>&1; echo rc=$?
-timeout 900 python tools/smallm_bench.py --plain --rounds 3 --iters 20 --pool-mb 0 --out $T/warm.txt > $T/warm.log 2>&1; echo rc=$?
-paste <(cut -c1-66 $T/cold.txt) <(cut -c49-66 $T/warm.txt) | head -50
-tail -2 $T/cold.txt; tail -2 $T/warm.txt
+timeout 900 python -m pytest tests/test_gpu_pipeline.py -q -m gpu -k "forked or accuracy" -s > $T/p.log 2>&1; echo "rc=$?"; tail -4 $T/p.log
+for i in 1 2; do
+SKG_FORK_GUIDANCE=0 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --residual-fp32 > $T/off$i.json 2> $T/off$i.err
+SKG_FORK_GUIDANCE=1 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --residual-fp32 > $T/on$i.json 2> $T/on$i.err
+done
+grep -o '"value": [0-9.]*' $T/*.json
