@@ -587,6 +587,7 @@ def main():
                        + (", accuracy mode (hi / lo residual stream)" if args.residual_fp32 else ""),
                        "baseline_config": C, "samples_per_gpu": S, "global_batch": world * S, "ddim_steps": T,
                        "scheduler": args.scheduler, "hip_graphs": bool(args.graph),
+                       "hip_streams": (2 if (C == 2 and not args.no_guidance and wl["sampler"].fork_guidance and not args.graph) else 1),
                        "output": ("decoded uint8 images [S, H, W, 3] (VAE decode on-rank, inside the timed region"
                                   + (", gathered on rank 0)" if world > 1 else ")")) if args.gather == "images"
                        else "fp32 latents (no decode)",
