@@ -1,11 +1,11 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
+# One GPU trip that checks a tree end to end (what the driver runs at round end, plus a bench line):
+#   /usr/local/graft/bin/gpurun --timeout 3000 -- 'bash tools/trip.sh [tag]'
+# Outputs land in gpurun_out/<tag>/ (merged back by gpurun).
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-T=gpurun_out/t35
+T=gpurun_out/${1:-trip}
 mkdir -p $T
-timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $T/one8.json 2> $T/one8.err
-SKG_BENCH_BACKEND=gloo SKG_BENCH_DEVICE=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 2 --samples-per-gpu 4 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $T/two4.json 2> $T/two4.err
-SKG_BENCH_BACKEND=gloo SKG_BENCH_DEVICE=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29656 bench.py --gpus 2 --samples-per-gpu 8 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $T/two8.json 2> $T/two8.err
-timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --samples-per-gpu 16 > $T/one16.json 2> $T/one16.err
-timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $T/one8b.json 2> $T/one8b.err
-grep -o '"value": [0-9.]*' $T/*.json
-tail -2 $T/two4.err
+timeout 2400 python -m pytest tests -q -m gpu -x > $T/gpu_suite.log 2>&1; echo "pytest rc=$?"; tail -3 $T/gpu_suite.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" > $T/smoke.log 2>&1; tail -2 $T/smoke.log
+timeout 900 python bench.py > $T/bench.json 2> $T/bench.err; echo "bench rc=$?"; grep -o '"value": [0-9.]*' $T/bench.json | head -1
