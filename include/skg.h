@@ -133,6 +133,12 @@ int skg_groupnorm_from_partial2(const void* X, int ldx, void* Y, int ldy, int ro
                                 int groups, float eps, const void* gamma, const void* beta, int silu,
                                 float* stats, const float* partialA, int groupsA, const float* partialB,
                                 int groupsB, int nch, void* stream);
+/* C[(m / seg_rows) * seg_stride + m % seg_rows][n] = sum_k A[m][k] * B[n][k] + bias[n]: a GEMM over all batch rows whose output rows
+ * land in per-batch-row slots of a longer buffer - clip_guided_attn concatenates [N image tokens ; 257 sketch tokens] per batch
+ * row (modules/clip_guided_attn.py:111-119), so the image tokens' K / V of row b belong at rows [b L, b L + N) of the K / V
+ * buffer; one launch instead of one per batch row.  M % seg_rows == 0, K % 64 == 0, C 16-byte aligned, ldc % 8 == 0. */
+int skg_gemm_f16_rows(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                      const void* bias, int seg_rows, int seg_stride, void* stream);
 /* Nearest-neighbour 2x upsample followed by a 3x3 convolution (diffusers Upsample2D: the up path of the UNet at
  * modules/pipeline.py:96, the VAE decoder at :118), POLYPHASE: out (2i+a, 2j+b) = sum over the 2 x 2 low-resolution pixels the
  * nine taps land on, with the taps that land on one pixel pre-summed - four 4-tap stride-1 convolutions over the low-res

@@ -31,6 +31,7 @@ SIGNATURES = {
     "skg_gemm_f16": ("i", "pipipiiiippifup"),
     "skg_conv3x3_up2_f16": ("i", "pippiiiiiipp"),
     "skg_conv4x4s2_f16": ("i", "pippiiiiiipp"),
+    "skg_gemm_f16_rows": ("i", "pipipiiiipiip"),
     "skg_gemm_f16_hilo": ("i", "pipippiiiipppifup".replace(" ", "")),
     "skg_conv3x3_f16_hilo": ("i", "pipppiiiiiiipppifup"),
     "skg_groupnorm_apply_hilo": ("i", "ppipiiiiippp ip".replace(" ", "")),

@@ -220,7 +220,7 @@ int launch_plain(const GemmParams& p, hipStream_t st) {
   }
   if (p.flags & SKG_EPI_GEGLU) return SKG_E_UNSUPPORTED;     // fused GEGLU exists in the LDS-DMA kernel only
   if (p.c_lo || p.res_lo) return SKG_E_UNSUPPORTED;          // so does the hi / lo epilogue
-  if (p.ntaps || p.up2) return SKG_E_UNSUPPORTED;            // and the polyphase tap walk
+  if (p.ntaps || p.up2 || p.seg_rows) return SKG_E_UNSUPPORTED;      // and the polyphase tap walk / the output row maps
   const int tm = skg_cdiv(p.M, BM);
   if (use_wide(p.M, p.N)) {
     dim3 grid(p.N / 128, tm);
@@ -325,6 +325,21 @@ extern "C" int skg_gemm_f16(const void* A, int lda, const void* B, int ldb, void
                             int N, int K, const void* bias, const void* residual, int ldr,
                             float alpha, unsigned flags, void* stream) {
   return gemm_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, alpha, flags, nullptr, 0, 0, stream);
+}
+
+extern "C" int skg_gemm_f16_rows(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                                 const void* bias, int seg_rows, int seg_stride, void* stream) {
+  SKG_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && seg_rows > 0 && seg_stride >= seg_rows && M % seg_rows == 0);
+  SKG_REQUIRE(K % 64 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && lda >= K && ldb >= K && ldc >= N);
+  SKG_REQUIRE(skg_aligned(A, 16) && skg_aligned(B, 16) && skg_aligned(C, 16) && (!bias || skg_aligned(bias, 8)));
+  GemmParams p{};
+  p.A = (const half_t*)A; p.lda = lda; p.B = (const half_t*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.bias = (const half_t*)bias; p.M = M; p.N = N; p.K = K; p.alpha = 1.f; p.flags = 0;
+  p.seg_rows = seg_rows; p.seg_stride = seg_stride;
+  ws_attach(p, (hipStream_t)stream);
+  if (!skg_gemm2_try_launch(p, MODE_DIRECT, (hipStream_t)stream)) return SKG_E_UNSUPPORTED;
+  SKG_CHECK_LAUNCH("skg_gemm_f16_rows");
+  return SKG_OK;
 }
 
 static int gemm_impl(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,

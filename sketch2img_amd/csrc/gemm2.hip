@@ -681,6 +681,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
           const int img = m / hw, rr = m - img * hw, i = rr / p.OW, j = rr - i * p.OW;
           const size_t r = (size_t)img * 4 * hw + (size_t)(2 * i + (ph >> 1)) * (2 * p.OW) + 2 * j + (ph & 1);
           crow = reinterpret_cast<half_t*>(p.C) + r * p.ldc + n0 + ec;
+        } else if (p.seg_rows) {      // segmented output rows: batch row b's block goes to rows [b * seg_stride, b * seg_stride + seg_rows)
+          const int m = m0 + sl * HROWS + hr * 64 + er, b = m / p.seg_rows;
+          crow = reinterpret_cast<half_t*>(p.C) + ((size_t)b * p.seg_stride + (m - b * p.seg_rows)) * p.ldc + n0 + ec;
         }
         half8_t hv[IT2];
 #pragma unroll
@@ -989,7 +992,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   operand_bytes(p, MODE, a, b, s);
   const int KT = p.K / BK;
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
-  int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU) && !p.up2) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4, p.ws, p.ws_bytes) : 1;
+  int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU) && !p.up2 && !p.seg_rows) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4, p.ws, p.ws_bytes) : 1;
   constexpr int NTHR = WGM * WGN * 64;
   if constexpr (BM == 128) {
     if (p.c_lo || p.res_lo) {      // accuracy mode: one instantiation per tile, two stages, no split-K, no statistics
@@ -1064,7 +1067,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
 template <int MODE>
 void launch_mode(const GemmParams& p, hipStream_t st) {
   TileCfg t = pick_tile(p.M, p.N, p.K);
-  if (t.bm == 256 && (p.c_lo || p.res_lo || p.up2)) t = TileCfg{128, 160};      // (hi / lo epilogue, polyphase row map: 128-row tiles)
+  if (t.bm == 256 && (p.c_lo || p.res_lo || p.up2 || p.seg_rows)) t = TileCfg{128, 160};      // (hi / lo epilogue, polyphase row map: 128-row tiles)
   if (t.bm == 256) launch_cfg<256, 320, 2, 4, MODE>(p, st);
   else if (t.bn == 160) {
     launch_cfg<128, 160, 2, 2, MODE>(p, st);
@@ -1097,6 +1100,10 @@ void skg_splitk_reduce_launch(const GemmParams& p, const float* ws, int splits, 
 
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
   if (!eligible(p, mode)) return false;
+  if (p.seg_rows &&               // segmented output rows: the plain fp16-staged epilogue, no split-K slabs
+      (mode != MODE_DIRECT || p.res || p.gn_partial || p.c_lo || p.res_lo || p.aux || (p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) ||
+       p.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0))
+    return false;
   if ((p.ntaps || p.up2) &&      // polyphase: stride-1 walk (4 x 4 window: stride 2), the plain fp16-staged epilogue (no residual / statistics)
       ((p.ntaps == 16 ? (mode != MODE_S2 || p.up2) : mode != MODE_S1) || p.res || p.gn_partial || p.c_lo || p.res_lo || (p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) ||
        p.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 || p.M % (p.OH * p.OW) != 0))

@@ -381,7 +381,7 @@ int gemm8_tile(const GemmParams& p, int mode) {
   if (mode == MODE_S1 && p.Cin % BK != 0) return 0;
   if (p.flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) return 0;
   if (p.c_lo || p.res_lo) return 0;      // accuracy mode: gemm2.hip's hi / lo epilogue
-  if (p.ntaps || p.up2) return 0;        // polyphase upsample: gemm2.hip's tap walk / row map
+  if (p.ntaps || p.up2 || p.seg_rows) return 0;        // polyphase upsample / segmented rows: gemm2.hip's tap walk / row map
   if (p.ldc % 4 != 0 || (p.res && p.ldr % 4 != 0)) return 0;
   unsigned long long a, b, s;
   if (!operand_bytes(p, mode, a, b, s)) return 0;

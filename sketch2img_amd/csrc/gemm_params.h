@@ -25,6 +25,9 @@ struct GemmParams {
   // only `ntaps` of the nine taps (tap id of walk position i = (tapmap >> 4 i) & 15; weight pack [Cout][ntaps][Cin]) and stores
   // low-res pixel (i, j) to high-res pixel (2 i + a, 2 j + b) of the output, up2 = 1 + 2 a + b (0 = ordinary conv)
   int ntaps; unsigned tapmap; int up2;
+  // segmented output rows (skg_gemm_f16_rows): row m of the product is stored to row (m / seg_rows) * seg_stride + m % seg_rows
+  // of C - one launch writes the image tokens of every batch row into its slot of a longer per-row buffer (0 = off)
+  int seg_rows, seg_stride;
   // split-K workspace of the launch stream (host side: filled by the entry points from the per-stream registry of
   // skg_set_workspace; the kernels get the slab pointer as an argument)
   float* ws; size_t ws_bytes;

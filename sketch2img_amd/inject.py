@@ -73,6 +73,7 @@ def route_res_samples(res_samples: Sequence[Sequence[torch.Tensor]]) -> List[tor
     return list(down + up[::-1] + mid)
 
 
+_ROWS_KV = os.environ.get("SKG_INJ_ROWS", "1") != "0"        # A/B switch: large maps, K / V of all batch rows in one launch
 _BATCH_KV = os.environ.get("SKG_INJ_BATCH", "1") != "0"      # A/B switch (bench.py on one box)
 
 
@@ -185,8 +186,11 @@ class HipInjector:
             ops.batch_copy(dense[:, C:], N, kvbuf, L, rows, N)
         else:
             q = ops.gemm(zh, w["wq"])
-            for b in range(rows):
-                ops.gemm(zh[b * N:(b + 1) * N], w["wkv"], out=kvbuf[b * L:b * L + N])
+            if _ROWS_KV:      # one launch: row block b of the product -> rows [b L, b L + N) of the K / V buffer
+                ops.gemm_rows(zh, w["wkv"], kvbuf, N, L)
+            else:
+                for b in range(rows):
+                    ops.gemm(zh[b * N:(b + 1) * N], w["wkv"], out=kvbuf[b * L:b * L + N])
         a = ops.attn_fwd(q, kvbuf[:, :C], kvbuf[:, C:], rows, heads, N, N + T, L, dh, scale, v_rows=True)
         o = ops.gemm(a, w["wo"], bias=w["bo"])
         return ops.gemm(o, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)

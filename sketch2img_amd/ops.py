@@ -227,6 +227,18 @@ def conv_up2(X: torch.Tensor, Wpp: torch.Tensor, rows: int, IH: int, IW: int, ou
     return out
 
 
+def gemm_rows(A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, seg_rows: int, seg_stride: int, *, bias=None):
+    """A [M, K] @ B[N, K]^T with product row m stored to row (m // seg_rows) * seg_stride + m % seg_rows of `out`
+    (out: [(M // seg_rows) * seg_stride, >= N] view): every batch row's block into its slot of a longer per-row buffer."""
+    _f16(A, B, out, bias)
+    M, K = A.shape
+    N = B.shape[0]
+    assert B.shape[1] == K and M % seg_rows == 0 and out.shape[0] >= (M // seg_rows - 1) * seg_stride + seg_rows and out.shape[1] >= N
+    check(lib.skg_gemm_f16_rows(_p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out), M, N, K, _p(bias), seg_rows, seg_stride, _stream()),
+          "skg_gemm_f16_rows")
+    return out
+
+
 def conv4x4s2(X: torch.Tensor, W16: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None):
     """4 x 4 stride-2 convolution, padding 1 (the data gradient of conv_up2).  X [rows*IH*IW, Cin] (view), W16 [Cout, 16*Cin]
     (unet.pack_conv_up2_dgrad).  Returns [rows*(IH/2)*(IW/2), Cout]."""

@@ -178,6 +178,25 @@ def test_conv_up2_polyphase(ops):
         assert e < 5e-4 and stray == 0
 
 
+def test_gemm_segmented_output_rows(ops):
+    """skg_gemm_f16_rows: one GEMM over all batch rows, product row m stored to row (m // seg) * stride + m % seg of a longer
+    per-row buffer (the image tokens' K / V of clip_guided_attn) == one GEMM per batch row into its slot, bit for bit; the
+    slots' tails (the sketch tokens' rows) stay untouched; a segment length that is not a multiple of the 128-row tile."""
+    g = torch.Generator().manual_seed(91)
+    for rows, n_img, L, C in [(8, 9216, 9216 + 264, 320), (3, 1000, 1264, 320), (4, 2304, 2568, 640)]:
+        z = torch.randn(rows * n_img, C, generator=g).half().to(dev())
+        w = (torch.randn(2 * C, C, generator=g) * C ** -0.5).half().to(dev())
+        a = torch.full((rows * L, 2 * C + 8), 7.0, device=dev(), dtype=torch.float16)
+        b = a.clone()
+        ops.gemm_rows(z, w, a[:, :2 * C], n_img, L)
+        for r in range(rows):
+            ops.gemm(z[r * n_img:(r + 1) * n_img], w, out=b[r * L:r * L + n_img, :2 * C])
+        ref = z[:n_img].float() @ w.float().t()
+        e = float((a[:n_img, :2 * C].float() - ref).norm() / ref.norm())
+        print(f"gemm_rows rows{rows} seg{n_img} stride{L} C{C}: rel {e:.2e}, equal to the per-row launches: {torch.equal(a, b)}")
+        assert e < 4e-4 and torch.equal(a, b)
+
+
 def test_conv4x4s2_is_the_dgrad_of_upsample_conv(ops):
     """skg_conv4x4s2_f16 with unet.pack_conv_up2_dgrad: the data gradient of nearest-2x upsample + 3x3 conv as ONE 4 x 4
     stride-2 convolution over dY, vs torch autograd of F.interpolate + F.conv2d (fp32), and vs the path it replaces (9-tap
