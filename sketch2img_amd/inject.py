@@ -186,7 +186,7 @@ class HipInjector:
             ops.batch_copy(dense[:, C:], N, kvbuf, L, rows, N)
         else:
             q = ops.gemm(zh, w["wq"])
-            if _ROWS_KV:      # one launch: row block b of the product -> rows [b L, b L + N) of the K / V buffer
+            if _ROWS_KV and C % 64 == 0:      # one launch: row block b of the product -> rows [b L, b L + N) of the K / V buffer
                 ops.gemm_rows(zh, w["wkv"], kvbuf, N, L)
             else:
                 for b in range(rows):
