@@ -361,3 +361,42 @@ def test_binding_loads_torch_before_libskg():
                         "ks = list(sys.modules); assert ks.index('torch') < ks.index('sketch2img_amd._lib'); print('order ok')" % ROOT],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "order ok" in r.stdout, r.stderr[-1500:]
+
+
+def test_polyphase_packs_reproduce_upsample_conv_and_its_gradient():
+    """unet.pack_conv_up2 / pack_conv_up2_dgrad (what skg_conv3x3_up2_f16 / skg_conv4x4s2_f16 consume), emulated with torch on the
+    CPU: four 4-tap convolutions over the low-res map with pre-summed weights == F.interpolate(nearest, 2x) + 3x3 conv, and one
+    4 x 4 stride-2 convolution over dY with the transposed pre-summed weights == its autograd gradient.  Weights on a 1/8
+    grid, so the fp16 rounding of the sums is exact and the identity can be checked to fp32 accuracy."""
+    import torch.nn.functional as F
+    from sketch2img_amd.unet import pack_conv_up2, pack_conv_up2_dgrad
+    g = torch.Generator().manual_seed(3)
+    co, ci, H, W = 6, 5, 4, 7
+    w = torch.randint(-8, 9, (co, ci, 3, 3), generator=g).float() / 8
+    x = torch.randn(2, ci, H, W, generator=g, requires_grad=True)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, padding=1)
+    Wpp = pack_conv_up2(w, "cpu").float()                      # [4 phases 2a+b][co][4 taps * ci]
+    assert Wpp.shape == (4, co, 4 * ci)
+    xp = F.pad(x.detach(), (1, 1, 1, 1))
+    y = torch.zeros_like(ref)
+    for a in (0, 1):
+        for b in (0, 1):
+            acc = 0
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    wt = Wpp[2 * a + b][:, (2 * ty + tx) * ci:(2 * ty + tx + 1) * ci]
+                    acc = acc + torch.einsum("oc,bchw->bohw", wt, xp[:, :, a + ty:a + ty + H, b + tx:b + tx + W])
+            y[:, :, a::2, b::2] = acc
+    assert torch.allclose(y, ref.detach(), atol=1e-5)
+    dy = torch.randn(ref.shape, generator=g)
+    gref, = torch.autograd.grad(ref, x, dy)
+    W16 = pack_conv_up2_dgrad(w, "cpu").float()                # [ci][16 taps ky*4+kx][co]
+    assert W16.shape == (ci, 16 * co)
+    dyp = F.pad(dy, (1, 1, 1, 1))
+    dx = 0
+    for ky in range(4):
+        for kx in range(4):
+            wt = W16[:, (4 * ky + kx) * co:(4 * ky + kx + 1) * co]
+            dx = dx + torch.einsum("co,bohw->bchw", wt, dyp[:, :, ky:ky + 2 * H:2, kx:kx + 2 * W:2])
+    assert torch.allclose(dx, gref, atol=1e-5)
+
