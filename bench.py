@@ -102,7 +102,7 @@ class LaunchTimer:
     def __init__(self, ops):
         self.ops, self.rec = ops, []
         self._gemm, self._conv, self._attn, self._keep = ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep
-        self._up2, self._c4 = ops.conv_up2, ops.conv4x4s2
+        self._up2, self._c4, self._ffb = ops.conv_up2, ops.conv4x4s2, ops.ff_block
 
     def __enter__(self):
         from sketch2img_amd._lib import lib
@@ -214,13 +214,24 @@ class LaunchTimer:
                              2.0 * (M * K + N * K + M * N + M * N // 2), f"gemm M{M} N{N} K{K}+geglu+keep"))
             return out
 
+        def ff_block(X, gamma, beta, eps, pack, *a, **k):       # norm3 + FF1 + gate + FF2 + residual in one launch
+            M, C = X.shape
+            Fh = pack.shape[0] * 32
+            e0, e1 = ev()
+            e0.record()
+            out = self._ffb(X, gamma, beta, eps, pack, *a, **k)
+            e1.record()
+            self.rec.append(("ff_block_kernel<10>", 2.0 * M * C * 3 * Fh, e0, e1, 2.0 * (2 * M * C + 3 * C * Fh),
+                             f"ff_block M{M} C{C} F{Fh} (LN + FF1 + gate + FF2 + res)"))
+            return out
+
         ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep = gemm, conv, attn, gemm_keep
-        ops.conv_up2, ops.conv4x4s2 = conv_up2, conv4x4s2
+        ops.conv_up2, ops.conv4x4s2, ops.ff_block = conv_up2, conv4x4s2, ff_block
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm, self.ops.conv3x3, self.ops.attn_fwd, self.ops.gemm_geglu_keep = self._gemm, self._conv, self._attn, self._keep
-        self.ops.conv_up2, self.ops.conv4x4s2 = self._up2, self._c4
+        self.ops.conv_up2, self.ops.conv4x4s2, self.ops.ff_block = self._up2, self._c4, self._ffb
 
     def summary(self):
         """per kernel: [launches, flops, seconds, algorithmic bytes, roofline seconds, seconds of HBM-bound launches];
@@ -256,6 +267,8 @@ def by_operator(agg):
     def op(name):
         if name.startswith("attn"):
             return "attention_fwd"
+        if name.startswith("ff_block"):
+            return "ff_block"
         args = name[name.index("<") + 1:-1].split(", ")
         mode = int(args[4]) if name.startswith("gemm2") else int(args[1])
         return {0: "gemm", 1: "conv3x3"}.get(mode, "conv3x3_resample")

@@ -200,6 +200,23 @@ int skg_layernorm_bwd(const void* X, int ldx, const void* dY, int lddy, void* dX
 int skg_gemm_f16_geglu_keep(const void* A, int lda, const void* B, int ldb, void* Y, int ldy, void* H, int ldh,
                             int M, int N, int K, const void* bias, void* stream);
 
+/* ---- Row-local fused feed-forward sub-block (round 3) -----------------------------------
+ * Y [M][C] = X + b2 + W2 . geglu(W1 . LayerNorm(X; gamma, beta, eps) + b1)   - ONE launch instead of skg_layernorm_fwd,
+ * skg_gemm_f16 with SKG_EPI_GEGLU and skg_gemm_f16 with a residual; the [M][F] gated tensor never exists in memory.
+ * C == 320 (the 64 x 64 level of SD1.5, the 96 x 96 level of SD2.1), F = hidden width (1280), F % 32 == 0, F <= 1280.
+ * Wpack: fp16 [F/32][60][512] "fragment-major" pack of W1 [2F][C] (diffusers order: value rows, then gate rows) and
+ * W2 [C][F]: chunk c holds the 32 hidden units 32c..32c+31 as 40 W1 pieces (tile t = val 0-15, val 16-31, gate 0-15,
+ * gate 16-31; k-step ks; piece [lane = 16 g + l][8] = W1[row(t, l)][32 ks + 8 g ..]) then 20 W2 pieces (output tile u;
+ * piece [lane][i] = W2[16 u + l][32 c + 16 (i >> 2) + 4 g + (i & 3)]); bias1_pack: fp32 [F/32][4][16] in W1-tile order
+ * (sketch2img_amd.unet.pack_ff_block builds both).  stats (optional): float2 (mean, rstd) per row, as skg_layernorm_fwd.
+ * Y may alias X.  Same roundings as the three-launch path (fp16 LayerNorm output, fp16 FF1 output before the gate,
+ * fp16 gated value, one fp16 rounding of the residual sum).
+ * Replaces: BasicTransformerBlock.norm3 / ff (GEGLU) / residual add ([diffusers] attention.py), reached from
+ * modules/pipeline.py:96. */
+int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma,
+                     const void* beta, float eps, const void* Wpack, const float* bias1_pack,
+                     const void* bias2, float* stats, void* stream);
+
 /* ---- GEGLU: Y[m][j] = a_j * gelu(g_j),  H fp16 [M][2F] -----------------------------------------------
  * interleaved == 0: H = [a (F columns) | g (F columns)] (diffusers' chunk(2));  interleaved == 1: groups of four
  * columns [a_2t a_2t+1 g_2t g_2t+1] (the pack SKG_EPI_GEGLU uses).  bwd writes dH [M][2F] in the same layout from

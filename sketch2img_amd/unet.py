@@ -32,6 +32,7 @@ from .config import UNetConfig, up_block_plan
 _GN_FROM_PRODUCER = os.environ.get("SKG_GN_PRODUCER", "1") != "0"      # A/B switches (bench.py on one box)
 _GEGLU_KEEP = os.environ.get("SKG_GEGLU_KEEP", "1") != "0"
 _GN_CONCAT = os.environ.get("SKG_GN_CONCAT", "1") != "0"
+_FF_BLOCK = os.environ.get("SKG_FF_BLOCK", "1") != "0"              # fused feed-forward sub-block at C = 320 (csrc/ffblock.hip)
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -102,6 +103,31 @@ def pack_conv_up2_dgrad(w: torch.Tensor, dev) -> torch.Tensor:
 UP2_POLYPHASE = os.environ.get("SKG_UP2_POLY", "1") != "0"      # A/B switch (bench.py on one box)
 UP2_SMALL_MAPS = os.environ.get("SKG_UP2_SMALL", "1") != "0"    # A/B: polyphase also where one phase does not fill the chip
 UP2_DGRAD = os.environ.get("SKG_UP2_DGRAD", "1") != "0"         # A/B: the upsampler's backward as one 4 x 4 stride-2 convolution
+
+
+def pack_ff_block(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, dev):
+    """Fragment-major pack of a GEGLU feed-forward (diffusers FeedForward: net.0.proj [2F, C] = value rows then gate rows,
+    net.2 [C, F]) for skg_ff_block_f16 (csrc/ffblock.hip): every 512-half piece is one MFMA A operand in lane order, so
+    the kernel fetches it with one LDS-DMA instruction and reads it with one conflict-free ds_read_b128.
+    Chunk c = hidden units 32c .. 32c+31:
+      40 W1 pieces (t, ks): t = value 0-15, value 16-31, gate 0-15, gate 16-31; [lane = 16 g + l][i] = W1[row(t, l)][32 ks + 8 g + i]
+      20 W2 pieces u:       [lane = 16 g + l][i] = W2[16 u + l][32 c + 16 (i >> 2) + 4 g + (i & 3)]
+    (the hidden-unit order of the second product is the accumulator layout of the first).
+    Returns (pack fp16 [F/32, 60, 512], bias1 fp32 [F/32, 4, 16])."""
+    F2, C = w1.shape
+    F = F2 // 2
+    assert w2.shape == (C, F) and C % 32 == 0 and F % 32 == 0
+    nch, KS, NU = F // 32, C // 32, C // 16
+    w1h, w2h = w1.to(torch.float16), w2.to(torch.float16)
+    rows = torch.stack([w1h[:F].reshape(nch, 2, 16, C), w1h[F:].reshape(nch, 2, 16, C)], 1)     # [c, val|gate, half, l, C]
+    rows = rows.reshape(nch, 4, 16, KS, 4, 8)                                                     # [c, t, l, ks, g, i]
+    p1 = rows.permute(0, 1, 3, 4, 2, 5).reshape(nch, 4 * KS, 512)                                 # [c, (t, ks), (g, l, i)]
+    w2r = w2h.reshape(NU, 16, nch, 2, 4, 4)                                                       # [u, l, c, i_hi, g, i_lo]
+    p2 = w2r.permute(2, 0, 4, 1, 3, 5).reshape(nch, NU, 512)                                      # [c, u, (g, l, i_hi, i_lo)]
+    pack = torch.cat([p1, p2], 1).contiguous().to(dev)
+    b1h = b1.to(torch.float16).float()
+    bias1 = torch.stack([b1h[:F].reshape(nch, 2, 16), b1h[F:].reshape(nch, 2, 16)], 1).reshape(nch, 4, 16).contiguous().to(dev)
+    return pack, bias1
 
 
 def _pad_vec(v: torch.Tensor, n: int) -> torch.Tensor:
@@ -183,6 +209,12 @@ class HipUNet:
                 W[k[:-len("weight")] + "bias"] = _h(sd[k[:-len("weight")] + "bias"][idx], dev)
                 if bw:
                     W[k + ":T"] = _h(sd[k][idx].t(), dev)
+        # 64 x 64 level (C = 320): the whole feed-forward sub-block as ONE row-local launch (csrc/ffblock.hip)
+        for k in list(sd.keys()):
+            if k.endswith(".ff.net.0.proj.weight") and sd[k].shape[1] == 320 and sd[k].shape[0] // 2 <= 1280:
+                t = k[: -len(".ff.net.0.proj.weight")]
+                W[t + ".ff.pack"], W[t + ".ff.bias1"] = pack_ff_block(sd[k], sd[t + ".ff.net.0.proj.bias"],
+                                                                      sd[t + ".ff.net.2.weight"], dev)
         for k in list(sd.keys()):
             if k.endswith(".attn1.to_q.weight"):
                 p = k[: -len(".to_q.weight")]
@@ -341,8 +373,31 @@ class HipUNet:
         o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
                                 want_lse=True, v_rows=True)
         p2 = ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], bias=W[t + ".attn2.to_out.0.bias"], residual=p1)
-        a3, st3 = ops.layernorm(p2, W[t + ".norm3.weight"], W[t + ".norm3.bias"], want_stats=True)
-        if not keep and C % 64 == 0:        # no backward will follow: gate inside the GEMM epilogue (half the bytes)
+        ffb = _FF_BLOCK and (t + ".ff.pack") in W and (not keep or rows % 2 == 0)
+        st3_half = False
+        if ffb:
+            # C = 320: norm3 -> FF1 -> gate -> FF2 + residual of the rows nobody differentiates in ONE row-local launch
+            # (skg_ff_block_f16: the row panel and the output accumulators stay in registers, only weights stream); in a
+            # guided step that is the uncond half, the cond half keeps the launches that stash what its backward reads
+            M0 = (rows // 2) * HW if keep else rows * HW
+            p3 = torch.empty(rows * HW, C, device=x.device, dtype=torch.float16)
+            ops.ff_block(p2[:M0], W[t + ".norm3.weight"], W[t + ".norm3.bias"], 1e-5, W[t + ".ff.pack"], W[t + ".ff.bias1"],
+                         W[t + ".ff.net.2.bias"], out=p3[:M0])
+            f, st3 = None, None
+            if keep:
+                a3, st3 = ops.layernorm(p2[M0:], W[t + ".norm3.weight"], W[t + ".norm3.bias"], want_stats=True)
+                st3_half = True
+                if _GEGLU_KEEP:
+                    ggc, f = ops.gemm_geglu_keep(a3, W[t + ".ff.net.0.proj.weight"], W[t + ".ff.net.0.proj.bias"])
+                else:
+                    f = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"])
+                    ggc = ops.geglu(f, interleaved=True)
+                ops.gemm(ggc, W[t + ".ff.net.2.weight"], p3[M0:], bias=W[t + ".ff.net.2.bias"], residual=p2[M0:])
+        else:
+            a3, st3 = ops.layernorm(p2, W[t + ".norm3.weight"], W[t + ".norm3.bias"], want_stats=True)
+        if ffb:
+            pass
+        elif not keep and C % 64 == 0:        # no backward will follow: gate inside the GEMM epilogue (half the bytes)
             f = None
             gg = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"], geglu=True)
         elif C % 64 == 0 and rows % 2 == 0:
@@ -361,7 +416,8 @@ class HipUNet:
             f = ops.gemm(a3, W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"])
             gg = ops.geglu(f, interleaved=True)
             f = f[(rows // 2) * HW:]
-        p3 = ops.gemm(gg, W[t + ".ff.net.2.weight"], bias=W[t + ".ff.net.2.bias"], residual=p2)
+        if not ffb:
+            p3 = ops.gemm(gg, W[t + ".ff.net.2.weight"], bias=W[t + ".ff.net.2.bias"], residual=p2)
         opart = None
         if want_part and self._gn_from_producer(rows, HW, C):
             out, opart = ops.gemm(p3, W[p + ".proj_out.weight"], out, bias=W[p + ".proj_out.bias"], residual=x,
@@ -371,12 +427,13 @@ class HipUNet:
         if keep:
             # half: the tensors of the text-independent part hold the cond rows only (r1 == rows // 2)
             half = ("x", "gst", "pin", "st1", "qkv", "o1", "lse1", "p1", "st2", "q2") if r1 != rows else ()
+            st3h = ("st3",) if st3_half else ()      # fused FF block: norm3's statistics exist for the cond rows only
             if r1 != rows and self.inject is None:
                 stash.tr[p] = dict(x=x_c, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1_c, st2=st2, q2=q2_c,
-                                   o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=half)
+                                   o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=half + st3h)
             else:
                 stash.tr[p] = dict(x=x, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1, st2=st2, q2=q2,
-                                   o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=())
+                                   o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=st3h)
         return out, opart
 
     @staticmethod
@@ -797,7 +854,7 @@ class HipUNet:
         dgg = ops.gemm(dp3, W[t + ".ff.net.2.weight:T"])
         df = ops.geglu_bwd(st["f"], dgg, interleaved=True)            # f is stashed for the cond rows only
         da3 = ops.gemm(df, W[t + ".ff.net.0.proj.weight:T"])
-        dp2 = ops.layernorm_bwd(c(st["p2"]), da3, W[t + ".norm3.weight"], c(st["st3"]), residual=dp3)
+        dp2 = ops.layernorm_bwd(c(st["p2"]), da3, W[t + ".norm3.weight"], cc("st3"), residual=dp3)
         # cross-attention: only dQ (K/V come from the constant text embeddings)
         do2 = ops.gemm(dp2, W[t + ".attn2.to_out.0.weight:T"])
         cb = self.ctx["blocks"][t + ".attn2"]

@@ -909,3 +909,50 @@ def test_training_helpers_colsum_bn_param_grads_adamw(ops):
     E = ops.lgp_extra_features(torch.ones(2, 4, 4, 4, device=dev()) * 0.25, 2.0, 2, 2, 4, 64).float().cpu()
     assert E.shape == (32, 64) and float(E[:, 40:].abs().max()) == 0.0
     assert abs(float(E[0, 0]) - 0.5) < 1e-3 and abs(float(E[0, 4]) - math.sin(2 * math.pi * 0.5)) < 2e-3
+
+
+# ---------------------------------------------------------------------------------------------- fused FF sub-block
+@pytest.mark.parametrize("M,Fh", [(4096, 1280), (128 * 5 + 37, 1280), (16, 64), (65536, 1280)])
+def test_ff_block_fused(ops, M, Fh):
+    """skg_ff_block_f16 (norm3 -> ff.net.0.proj with the GEGLU gate -> ff.net.2 + residual in ONE launch, C = 320) against
+    (a) the fp32 definition on the same fp16 inputs: one output rounding + the three internal fp16 roundings the unfused
+    path has as well (LayerNorm output, FF1 output, gated value): rel <= 1.5 x FP16_RND on an O(1) residual stream;
+    (b) the three-launch path it replaces (skg_layernorm_fwd, skg_gemm_f16 + SKG_EPI_GEGLU, skg_gemm_f16 + residual), which
+    rounds at the same points: the two differ only by fp32 summation order, i.e. by rare 1-ulp flips - rel <= 2e-4,
+    >= 99 % of the outputs bit-equal; LayerNorm statistics equal to skg_layernorm_fwd's to 1e-6; in place == out of place."""
+    from sketch2img_amd.unet import pack_ff_block
+    d = dev()
+    C = 320
+    x = rnd(M, C, seed=11)
+    gam, bet = (1 + 0.2 * rnd(C, seed=12).float()).half(), (0.1 * rnd(C, seed=13).float()).half()
+    w1, b1 = rnd(2 * Fh, C, seed=14, scale=C ** -0.5), rnd(2 * Fh, seed=15, scale=0.1)
+    w2, b2 = rnd(C, Fh, seed=16, scale=Fh ** -0.5), rnd(C, seed=17, scale=0.1)
+    pack, bias1 = pack_ff_block(w1, b1, w2, d)
+    xd = x.to(d)
+    y, st = ops.ff_block(xd, gam.to(d), bet.to(d), 1e-5, pack, bias1, b2.to(d), want_stats=True)
+    torch.cuda.synchronize()
+    # (a) fp32 definition
+    a = F.layer_norm(x.float(), (C,), gam.float(), bet.float(), 1e-5)
+    hid = a @ w1.float().t() + b1.float()
+    ref = x.float() + (hid[:, :Fh] * F.gelu(hid[:, Fh:])) @ w2.float().t() + b2.float()
+    r, _ = report(f"ff_block M{M} F{Fh} vs fp32", y.float().cpu(), ref)
+    assert r < 1.5 * FP16_RND
+    # (b) the three launches it replaces
+    idx = ops.geglu_interleave_index(Fh)
+    a3, st3 = ops.layernorm(xd, gam.to(d), bet.to(d), 1e-5, want_stats=True)
+    gg = ops.gemm(a3, w1[idx].contiguous().to(d), bias=b1[idx].contiguous().to(d), geglu=True)
+    y3 = ops.gemm(gg, w2.to(d), bias=b2.to(d), residual=xd)
+    r3, _ = report(f"ff_block M{M} F{Fh} vs three launches", y.float().cpu(), y3.float().cpu())
+    same = float((y == y3).float().mean())
+    print(f"[parity] ff_block bit-equal outputs: {same:.5f}")
+    assert r3 < 2e-4 and same > 0.99
+    assert torch.allclose(st, st3, rtol=1e-5, atol=1e-6)
+    y_in = xd.clone()
+    ops.ff_block(y_in, gam.to(d), bet.to(d), 1e-5, pack, bias1, b2.to(d), out=y_in)
+    assert torch.equal(y_in, y)
+    # strided views (the residual stream is sometimes a column slice of a wider buffer)
+    wide = torch.zeros(M, 2 * C, device=d, dtype=torch.float16)
+    wide[:, C:] = xd
+    outw = torch.zeros(M, 2 * C + 8, device=d, dtype=torch.float16)
+    ops.ff_block(wide[:, C:], gam.to(d), bet.to(d), 1e-5, pack, bias1, b2.to(d), out=outw[:, 8:8 + C])
+    assert torch.equal(outw[:, 8:8 + C], y) and float(outw[:, :8].abs().max()) == 0 and float(outw[:, 8 + C:].abs().max()) == 0

@@ -64,6 +64,8 @@ def test_host_side_argument_checks_do_not_need_a_gpu():
     assert lib.skg_gemm_f16(16, 24, 16, 24, 16, 8, 4, 8, 24, None, None, 0, 1.0, 0, None) == -1      # K % 32
     assert lib.skg_attn_fwd(16, 8, 16, 8, 16, 8, 16, 8, None, 1, 1, 8, 8, 8, 24, 1.0, None) == -2      # dh = 24
     assert lib.skg_conv3x3_f16(16, 32, 16, 16, 8, 1, 4, 4, 32, 8, 9, None, None, 0, 1.0, 0, None) == -2  # mode 9
+    assert lib.skg_ff_block_f16(16, 320, 16, 320, 128, 640, 1280, 16, 16, 1e-5, 16, 16, 16, None, None) == -1   # C = 320 only
+    assert lib.skg_ff_block_f16(16, 320, 16, 320, 128, 320, 1296, 16, 16, 1e-5, 16, 16, 16, None, None) == -1   # F % 32
     assert lib.skg_gemm_variant(65536, 320, 2880, 320, 2) == 2160
     assert lib.skg_gemm_variant(4096, 64, 96, 32, 2) == 1064
     # GroupNorm statistics in the producer's epilogue: which launches fuse them (the rest run the stand-alone pass)
@@ -400,3 +402,45 @@ def test_polyphase_packs_reproduce_upsample_conv_and_its_gradient():
             dx = dx + torch.einsum("co,bohw->bchw", wt, dyp[:, :, ky:ky + 2 * H:2, kx:kx + 2 * W:2])
     assert torch.allclose(dx, gref, atol=1e-5)
 
+
+
+def test_ff_block_pack_reproduces_the_geglu_feed_forward():
+    """unet.pack_ff_block (what skg_ff_block_f16 consumes), emulated on the CPU with the kernel's own index arithmetic
+    (csrc/ffblock.hip): a 1 KB piece is an MFMA A operand, lane 16 g + l holds A[l][8 g + i]; the accumulator lane (l, g) holds
+    rows 4 g + r; the gated accumulators of two hidden tiles are the B operand of the second product with k-slot 8 g + i <->
+    hidden unit 16 (i >> 2) + 4 g + (i & 3).  Against diffusers' FeedForward (GEGLU: value, gate = proj(x).chunk(2)) in fp32;
+    weights and inputs on coarse grids so that fp16 storage is exact."""
+    import torch.nn.functional as F
+    from sketch2img_amd.unet import pack_ff_block
+    g = torch.Generator().manual_seed(5)
+    C, Fh, M = 320, 96, 16
+    w1 = torch.randint(-8, 9, (2 * Fh, C), generator=g).float() / 64
+    b1 = torch.randint(-8, 9, (2 * Fh,), generator=g).float() / 8
+    w2 = torch.randint(-8, 9, (C, Fh), generator=g).float() / 64
+    a = torch.randint(-16, 17, (M, C), generator=g).float() / 16
+    pack, bias1 = pack_ff_block(w1, b1, w2, "cpu")
+    nch, KS, NU = Fh // 32, C // 32, C // 16
+    assert pack.shape == (nch, 60, 512) and pack.dtype == torch.float16 and bias1.shape == (nch, 4, 16)
+
+    def a_operand(piece):                       # [512] lane-major -> A [16 rows l][32 k-slots 8 g + i]
+        return piece.float().reshape(4, 16, 8).permute(1, 0, 2).reshape(16, 32)
+
+    y = torch.zeros(C, M)
+    for c in range(nch):
+        h = []
+        for t in range(4):
+            acc = bias1[c, t][:, None].expand(16, M).clone()
+            for ks in range(KS):
+                acc = acc + a_operand(pack[c, t * KS + ks]) @ a[:, 32 * ks:32 * ks + 32].t()
+            h.append(acc)                       # [16 hidden units of tile t][M rows]
+        gated = [h[t] * F.gelu(h[2 + t]) for t in range(2)]
+        # B operand of the second product: k-slot 8 g + i <-> (tile i >> 2, unit 4 g + (i & 3))
+        bop = torch.zeros(32, M)
+        for gg in range(4):
+            for i in range(8):
+                bop[8 * gg + i] = gated[i >> 2][4 * gg + (i & 3)]
+        for u in range(NU):
+            y[16 * u:16 * u + 16] += a_operand(pack[c, 4 * KS + u]) @ bop
+    hidden = a @ w1.t() + b1
+    ref = (hidden[:, :Fh] * F.gelu(hidden[:, Fh:])) @ w2.t()
+    assert torch.allclose(y.t(), ref, atol=2e-4, rtol=1e-5), float((y.t() - ref).abs().max())
