@@ -18,8 +18,11 @@
 //     buffer_load ... lds (1 KB contiguous in memory and in LDS) and read back by ONE conflict-free ds_read_b128.
 //     The 2.4 MB pack stays in every XCD's L2.  Per 128-row workgroup that is 7.8 B of operand traffic per kFLOP through
 //     the L2 -> LDS path - what the 256 x 320 tile of gemm8.hip pays - and no activation traffic at all.
-// One 8-wave workgroup (128 rows) per CU, one barrier per chunk.
+// One 8-wave workgroup (128 rows) per CU, one barrier per chunk; the chunks are software-pipelined (the gate of chunk c
+// under the first product of chunk c + 1: with everything in lockstep behind one barrier the 8 waves were otherwise all
+// in their MFMA phase, then all in their VALU phase - 216 us at M = 65 536 in that form).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -41,30 +44,44 @@ struct FFParams {
 
 constexpr int MAXCH = 40;
 
-template <int KS>
+// PROBE (timing experiments only, results are wrong; SKG_FFB_PROBE): 1 = no weight DMA inside the loop, 2 = no gate arithmetic,
+// 3 = no LDS fragment reads (a register stands in for every A operand), 4 = 1 + 3
+template <int KS, int PROBE = 0>
 __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
-  constexpr int C = 32 * KS, NU = C / 16, NP = 4 * KS + NU, PIECE = 512;
-  constexpr int STAGE = 64 * PIECE;         // 64 slots: every wave issues 8 pieces per chunk, slots >= NP take zero fills
+  constexpr int C = 32 * KS, NU = C / 16, N1 = 4 * KS, NP = N1 + NU, PIECE = 512;
+  constexpr int W1ST = N1 * PIECE, W2ST = NU * PIECE;      // halves per ring stage
+  constexpr int W2OFF = 2 * W1ST, DUMP = W2OFF + 2 * W2ST, RING = DUMP + (64 - NP) * PIECE;
   constexpr int OP = C + 8;                 // pitch of the epilogue staging rows (halves; 16-byte aligned, 2-way on the 8-byte writes)
-  static_assert(KS >= 8 && NP <= 64, "one DMA piece per wave and k-step covers the chunk");
-  static_assert(8 * 16 * OP <= 2 * STAGE, "epilogue staging fits the ring");
-  __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE + MAXCH * 64 * 2];    // ONE object (LDS-DMA + ds_read: see gemm2.hip)
-  float* const bs = reinterpret_cast<float*>(smem + 2 * STAGE);
+  static_assert(KS >= 8 && NP <= 64, "one DMA piece per wave and k-step covers an iteration");
+  static_assert(8 * 16 * OP <= RING, "epilogue staging fits the ring");
+  // ONE object (LDS-DMA + ds_read: see gemm2.hip): [W1 ring 2 x 40 KB | W2 ring 2 x 20 KB | 4 KB for dead pieces | FF1 bias]
+  __shared__ __attribute__((aligned(16))) half_t smem[RING + MAXCH * 64 * 2];
+  float* const bs = reinterpret_cast<float*>(smem + RING);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l16 = lane & 15, g = lane >> 4;
   const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, p.wbytes, 0x00020000);
-  // piece wave + 8 j of chunk c -> the same slot of `stage`.  Unconditional (a branch per piece would cut the MFMA
-  // stream into basic blocks): a dead piece - slot >= NP, or no next chunk - reads out of range = zero fill of its slot
-  auto dma_piece = [&](int c, int stage, int j, bool live) {
-    const int pc = wave + 8 * j;
-    const unsigned voff = (live && pc < NP) ? (unsigned)lane * 16u : 0x80000000u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + stage * STAGE + pc * PIECE), 16, voff,
-                                             (unsigned)(c * NP + pc) * 1024u, 0, 0);
+  // Software pipeline over chunks.  Iteration c computes H(c+1) (W1 ring stage (c+1) & 1) WHILE the gate of chunk c runs on
+  // the VALU, then Y += W2(c) . G(c) (W2 ring stage c & 1); meanwhile W1(c+2) lands in W1 stage c & 1 (H(c) was its last
+  // reader, one iteration ago) and W2(c+1) in W2 stage (c+1) & 1.  Slot q = wave + 8 j of an iteration: q < 40 a W1 piece,
+  // q < 60 a W2 piece, else dead.  Unconditional (a branch per piece would cut the MFMA stream into basic blocks): a dead
+  // piece - no such chunk, or q >= 60 - reads out of range = zero fill of a slot nobody reads.
+  auto dma_slot = [&](int c, int j) {
+    if constexpr (PROBE == 1 || PROBE == 4) return;
+    const int q = wave + 8 * j;
+    const int cs = q < N1 ? c + 2 : c + 1;                                   // source chunk
+    const bool live = q < NP && cs < p.nch;
+    const int dst = q < N1 ? (c & 1) * W1ST + q * PIECE
+                           : (q < NP ? W2OFF + ((c + 1) & 1) * W2ST + (q - N1) * PIECE : DUMP + (q - NP) * PIECE);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + dst), 16, live ? (unsigned)lane * 16u : 0x80000000u,
+                                             (unsigned)(cs * NP + q) * 1024u, 0, 0);
   };
+  // before the loop: W1(0) -> W1 stage 0 (iteration -2 of the slot arithmetic; its W2 slots are dead: chunk -1)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) dma_piece(0, 0, j, true);
+  for (int j = 0; j < 5; ++j)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + (wave + 8 * j) * PIECE), 16, (unsigned)lane * 16u,
+                                             (unsigned)(wave + 8 * j) * 1024u, 0, 0);
   for (int i = tid; i < p.nch * 64; i += 512) bs[i] = p.b1p[i];
 
   // ---- the wave's 16 rows: load, LayerNorm (two passes over registers, as norms.hip), keep as B operands
@@ -108,48 +125,103 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
     y[u] = float4_t{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
   }
 
-  // ---- one chunk of 32 hidden units out of stage `st`; the next chunk's pieces are fetched under the first product
-  auto chunk = [&](const half_t* st, int c, int nstage, bool more) {
-    const half_t* fr = st + lane * 8;
-    float4_t h[4];
+  // H(cn) = W1(cn) . A^T + b1 out of W1 stage cn & 1 (the bias is the initial accumulator), the DMA slots of iteration c
+  // and - GATE - the gate of the previous chunk's accumulators `hin` woven in by hand: after the four MFMAs of k-step ks
+  // (independent accumulators, 64 cycles of matrix-pipe time) every second k-step the wave computes two of its eight gated values (~37 VALU
+  // instructions) and issues one DMA piece, with the next k-step's fragments already on their way.  The order is pinned
+  // with sched_barrier: hipcc alone puts the whole gate in front of (or behind) the MFMAs, and the 8 waves - released
+  // together by the barrier - are then all on the VALU, then all on the matrix pipe (sched_group_barrier plans were
+  // not honoured for this block).
+  // gate: f = fp16(W1 a + b1) (the rounding of the unfused FF1 output), out = fp16(f_val * gelu(f_gate)) as gemm2.hip's
+  // fused epilogue; element 4 t + r of the B operand <-> hidden unit 16 t + 4 g + r of the chunk
+  // Two adjacent elements per call, so that every conversion is a packed one (v_cvt_pk_f16_f32 rounds two values, the
+  // result pair IS one dword of the B operand: no v_and / v_or assembly): ~37 VALU instructions per pair.
+  // (The empty asm statements pin the pair's arithmetic between them: without them the IR optimiser merges all the
+  // independent gate computations into one block before the machine scheduler ever sees the barriers.)
+  auto gate2 = [&](const float4_t (&h)[4], int pr, half8_t& gb) {
+    const int t = pr >> 1, r = 2 * (pr & 1);
+    float2_t hv = {h[t][r], h[t][r + 1]}, hg = {h[2 + t][r], h[2 + t][r + 1]};
+    asm volatile("" : "+v"(hv), "+v"(hg));
+    const half2_t pv = __builtin_convertvector(hv, half2_t), pg = __builtin_convertvector(hg, half2_t);
+    float2_t o = {(float)pv[0] * gelu_fast_f((float)pg[0]), (float)pv[1] * gelu_fast_f((float)pg[1])};
+    if constexpr (PROBE == 2) o = hv + hg;
+    half2_t ph = __builtin_convertvector(o, half2_t);
+    asm volatile("" : "+v"(ph));
+    gb[2 * pr] = ph[0];
+    gb[2 * pr + 1] = ph[1];
+  };
+  auto ff1 = [&](float4_t (&h)[4], int cn, int c, const float4_t (&hin)[4], half8_t& gb, bool GATE) {
+    const half_t* fr = smem + (cn & 1) * W1ST + lane * 8;
+    half8_t fa[4], fb[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) h[t] = *reinterpret_cast<const float4_t*>(bs + c * 64 + t * 16 + 4 * g);
+    for (int t = 0; t < 4; ++t) h[t] = *reinterpret_cast<const float4_t*>(bs + cn * 64 + t * 16 + 4 * g);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fa[t] = (PROBE >= 3) ? xb[t] : ld_half8(fr + (t * KS) * PIECE);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
+      half8_t (&cur)[4] = (ks & 1) ? fb : fa;
+      half8_t (&nxt)[4] = (ks & 1) ? fa : fb;
+      if (ks + 1 < KS) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        h[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(fr + (t * KS + ks) * PIECE), xb[ks], h[t], 0, 0, 0);
-      if (ks < 8) dma_piece(c + 1, nstage, ks, more);
-    }
-    // gate: f = fp16(W1 a + b1) (the rounding of the unfused FF1 output), out = fp16(f_val * gelu(f_gate)) as gemm2.hip's
-    // fused epilogue; element 4 t + r of the B operand <-> hidden unit 16 t + 4 g + r of the chunk
-    half8_t gb;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a = (float)(half_t)h[t][r], gt = (float)(half_t)h[2 + t][r];
-        gb[4 * t + r] = (half_t)(a * gelu_fast_f(gt));
+        for (int t = 0; t < 4; ++t) nxt[t] = (PROBE >= 3) ? xb[(t + ks) % KS] : ld_half8(fr + (t * KS + ks + 1) * PIECE);
       }
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
-      y[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(fr + (4 * KS + u) * PIECE), gb, y[u], 0, 0, 0);
+      for (int t = 0; t < 4; ++t) h[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[t], xb[ks], h[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks < 8) {
+        if (GATE && (ks & 1)) gate2(hin, ks >> 1, gb);
+        dma_slot(c, ks);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
   };
-
-  for (int c = 0; c < p.nch; c += 2) {
+  // (an opaque base register for the W2 ring: its byte offsets lie beyond the 16-bit immediate of ds_read, and hipcc
+  // otherwise rebuilds every fragment address with a VALU instruction)
+  int w2base = W2OFF + lane * 8;
+  asm volatile("" : "+v"(w2base));
+  auto ff2 = [&](half8_t gb, int c) {
+    const half_t* fr = smem + (w2base + (c & 1) * W2ST);
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      y[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16((PROBE >= 3) ? xb[u % KS] : ld_half8(fr + u * PIECE), gb, y[u], 0, 0, 0);
+  };
+  auto iteration = [&](const float4_t (&hin)[4], float4_t (&hout)[4], int c) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
-    chunk(smem, c, 1, c + 1 < p.nch);
-    if (c + 1 < p.nch) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      lds_barrier();
-      chunk(smem + STAGE, c + 1, 0, c + 2 < p.nch);
-    }
+    half8_t gb;
+    ff1(hout, c + 1, c, hin, gb, true);
+    ff2(gb, c);
+  };
+  auto last = [&](const float4_t (&hin)[4], int c) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    half8_t gb;
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) gate2(hin, pr, gb);
+    ff2(gb, c);
+  };
+
+  float4_t hc[4], hn[4];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
+  {
+    half8_t unused;
+    ff1(hc, 0, -1, hc, unused, false);                  // iteration -1: H(0); fetches W1(1) and W2(0)
+  }
+  int c = 0;
+  for (; c + 2 < p.nch; c += 2) {
+    iteration(hc, hn, c);
+    iteration(hn, hc, c + 1);
+  }
+  if (c + 1 < p.nch) {
+    iteration(hc, hn, c);
+    last(hn, c + 1);
+  } else {
+    last(hc, c);
   }
 
   // ---- epilogue: the wave's Y^T tile through its own slice of the (now idle) ring, then whole-row 16-byte pieces:
   // residual read + store are 10 KB contiguous per wave when the rows are dense
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the last chunk's zero fills must not land in the staging rows
   lds_barrier();
   half_t* const stg = smem + wave * (16 * OP);
   {   // the residual is added in fp32 BEFORE staging (lane-local 8-byte reads of X, L2 hits): one fp16 rounding
@@ -189,7 +261,15 @@ extern "C" int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M,
   p.nch = F / 32;
   p.wbytes = (unsigned)p.nch * 60u * 1024u;
   p.stats = stats;
-  hipLaunchKernelGGL((ff_block_kernel<10>), dim3(skg_cdiv(M, 128)), dim3(512), 0, (hipStream_t)stream, p);
+  static const int probe = getenv("SKG_FFB_PROBE") ? atoi(getenv("SKG_FFB_PROBE")) : 0;      // timing experiments only
+  const dim3 grid(skg_cdiv(M, 128));
+  switch (probe) {
+    case 1: hipLaunchKernelGGL((ff_block_kernel<10, 1>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    case 2: hipLaunchKernelGGL((ff_block_kernel<10, 2>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    case 3: hipLaunchKernelGGL((ff_block_kernel<10, 3>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    case 4: hipLaunchKernelGGL((ff_block_kernel<10, 4>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    default: hipLaunchKernelGGL((ff_block_kernel<10>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  }
   SKG_CHECK_LAUNCH("skg_ff_block_f16");
   return SKG_OK;
 }

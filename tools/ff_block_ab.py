@@ -4,7 +4,12 @@ HIP events (alternating, so that both see the same box and clocks).
 
   python tools/ff_block_ab.py [--samples 8] [--reps 6]"""
 import argparse
+import os
+import sys
+
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from sketch2img_amd import synthetic, unet as unet_mod
 from sketch2img_amd.config import SD15, tap_channels

@@ -7,7 +7,12 @@ Inside a UNet evaluation neither the activations nor the weights of a layer are 
 works on another of `--pool` (x, weights) sets (12 sets x (42 MB x + 2.4 MB pack) >> the 32 MB of L2; the 256 MB
 Infinity Cache still helps both sides equally).  Prints per-chain HIP-event times and the fused kernel's TFLOP/s."""
 import argparse
+import os
+import sys
+
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from sketch2img_amd import ops
 from sketch2img_amd.unet import pack_ff_block
