@@ -46,7 +46,9 @@ constexpr int MAXCH = 40;
 
 // PROBE (timing experiments only, results are wrong; SKG_FFB_PROBE): 1 = no weight DMA inside the loop, 2 = no gate arithmetic,
 // 3 = no LDS fragment reads (a register stands in for every A operand), 4 = 1 + 3
-template <int KS, int PROBE = 0>
+// SCHED (SKG_FFB_SCHED, A/B of issue orders): 0 = a gated PAIR after the MFMAs of every second k-step, 1 = the same with the
+// two waves of a SIMD in alternate k-steps, 2 = the pair's arithmetic in four stages spread over the MFMAs of two k-steps
+template <int KS, int PROBE = 0, int SCHED = 0>
 __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
   constexpr int C = 32 * KS, NU = C / 16, N1 = 4 * KS, NP = N1 + NU, PIECE = 512;
   constexpr int W1ST = N1 * PIECE, W2ST = NU * PIECE;      // halves per ring stage
@@ -150,6 +152,55 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
     gb[2 * pr] = ph[0];
     gb[2 * pr + 1] = ph[1];
   };
+  // SCHED 2: gelu_fast_f of a pair in four stages (same expressions), the live values pinned at every stage end
+  float2_t sa, sg, sz, st, se, sp;
+  auto stage = [&](const float4_t (&h)[4], int idx, half8_t& gb) {
+    const int pr = idx >> 2;
+    switch (idx & 3) {
+      case 0: {
+        const int t = pr >> 1, r = 2 * (pr & 1);
+        float2_t hv = {h[t][r], h[t][r + 1]}, hg = {h[2 + t][r], h[2 + t][r + 1]};
+        asm volatile("" : "+v"(hv), "+v"(hg));
+        const half2_t pv = __builtin_convertvector(hv, half2_t), pg = __builtin_convertvector(hg, half2_t);
+        sa = float2_t{(float)pv[0], (float)pv[1]};
+        sg = float2_t{(float)pg[0], (float)pg[1]};
+        sz = float2_t{fabsf(sg[0]) * 0.70710678118654752f, fabsf(sg[1]) * 0.70710678118654752f};
+        asm volatile("" : "+v"(sa), "+v"(sg), "+v"(sz));
+        break;
+      }
+      case 1: {
+        st = float2_t{__builtin_amdgcn_rcpf(fmaf(0.3275911f, sz[0], 1.f)), __builtin_amdgcn_rcpf(fmaf(0.3275911f, sz[1], 1.f))};
+        se = float2_t{__builtin_amdgcn_exp2f(-sz[0] * sz[0] * 1.4426950408889634f), __builtin_amdgcn_exp2f(-sz[1] * sz[1] * 1.4426950408889634f)};
+        asm volatile("" : "+v"(st), "+v"(se));
+        break;
+      }
+      case 2: {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float q = fmaf(1.061405429f, st[j], -1.453152027f);
+          q = fmaf(q, st[j], 1.421413741f);
+          q = fmaf(q, st[j], -0.284496736f);
+          sp[j] = fmaf(q, st[j], 0.254829592f);
+        }
+        asm volatile("" : "+v"(sp));
+        break;
+      }
+      default: {
+        float2_t o;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float e = 1.f - sp[j] * st[j] * se[j];
+          o[j] = sa[j] * (0.5f * sg[j] + 0.5f * fabsf(sg[j]) * e);
+        }
+        if constexpr (PROBE == 2) o = sa + sg;
+        half2_t ph = __builtin_convertvector(o, half2_t);
+        asm volatile("" : "+v"(ph));
+        gb[2 * pr] = ph[0];
+        gb[2 * pr + 1] = ph[1];
+      }
+    }
+  };
+  const int gphase = (wave >> 2) & 1;
   auto ff1 = [&](float4_t (&h)[4], int cn, int c, const float4_t (&hin)[4], half8_t& gb, bool GATE) {
     const half_t* fr = smem + (cn & 1) * W1ST + lane * 8;
     half8_t fa[4], fb[4];
@@ -165,11 +216,27 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) nxt[t] = (PROBE >= 3) ? xb[(t + ks) % KS] : ld_half8(fr + (t * KS + ks + 1) * PIECE);
       }
+      if constexpr (SCHED == 2) {
+        h[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[0], xb[ks], h[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (GATE && ks < 8) stage(hin, 2 * ks, gb);
+        __builtin_amdgcn_sched_barrier(0);
+        h[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[1], xb[ks], h[1], 0, 0, 0);
+        h[2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[2], xb[ks], h[2], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (GATE && ks < 8) stage(hin, 2 * ks + 1, gb);
+        __builtin_amdgcn_sched_barrier(0);
+        h[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[3], xb[ks], h[3], 0, 0, 0);
+      } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) h[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[t], xb[ks], h[t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) h[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[t], xb[ks], h[t], 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (ks < 8) {
-        if (GATE && (ks & 1)) gate2(hin, ks >> 1, gb);
+        // the two waves that share a SIMD (w and w + 4) gate in alternate k-steps: one is on the VALU while the other
+        // feeds the matrix pipe
+        if (SCHED == 0 && GATE && (ks & 1)) gate2(hin, ks >> 1, gb);
+        if (SCHED == 1 && GATE && (ks & 1) == gphase) gate2(hin, ks >> 1, gb);
         dma_slot(c, ks);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -262,12 +329,15 @@ extern "C" int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M,
   p.wbytes = (unsigned)p.nch * 60u * 1024u;
   p.stats = stats;
   static const int probe = getenv("SKG_FFB_PROBE") ? atoi(getenv("SKG_FFB_PROBE")) : 0;      // timing experiments only
+  static const int sched = getenv("SKG_FFB_SCHED") ? atoi(getenv("SKG_FFB_SCHED")) : 0;
   const dim3 grid(skg_cdiv(M, 128));
-  switch (probe) {
-    case 1: hipLaunchKernelGGL((ff_block_kernel<10, 1>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
-    case 2: hipLaunchKernelGGL((ff_block_kernel<10, 2>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
-    case 3: hipLaunchKernelGGL((ff_block_kernel<10, 3>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
-    case 4: hipLaunchKernelGGL((ff_block_kernel<10, 4>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+  switch (probe * 10 + sched) {
+    case 10: hipLaunchKernelGGL((ff_block_kernel<10, 1>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    case 20: hipLaunchKernelGGL((ff_block_kernel<10, 2>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    case 30: hipLaunchKernelGGL((ff_block_kernel<10, 3>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    case 40: hipLaunchKernelGGL((ff_block_kernel<10, 4>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    case 1: hipLaunchKernelGGL((ff_block_kernel<10, 0, 1>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    case 2: hipLaunchKernelGGL((ff_block_kernel<10, 0, 2>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
     default: hipLaunchKernelGGL((ff_block_kernel<10>), grid, dim3(512), 0, (hipStream_t)stream, p);
   }
   SKG_CHECK_LAUNCH("skg_ff_block_f16");
