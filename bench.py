@@ -222,7 +222,7 @@ class LaunchTimer:
             out = self._ffb(X, gamma, beta, eps, pack, *a, **k)
             e1.record()
             self.rec.append(("ff_block_kernel<10>", 2.0 * M * C * 3 * Fh, e0, e1, 2.0 * (2 * M * C + 3 * C * Fh),
-                             f"ff_block M{M} C{C} F{Fh} (LN + FF1 + gate + FF2 + res)"))
+                             f"ff_block M{M} C{C} F{Fh} (LN + FF1 + gate + FF2 + res)" + "+keep" * (k.get("keep_from") is not None)))
             return out
 
         ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep = gemm, conv, attn, gemm_keep

@@ -216,6 +216,13 @@ int skg_gemm_f16_geglu_keep(const void* A, int lda, const void* B, int ldb, void
 int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma,
                      const void* beta, float eps, const void* Wpack, const float* bias1_pack,
                      const void* bias2, float* stats, void* stream);
+/* The same launch, ALSO storing the FF1 output H = fp16(W1 . LayerNorm(X) + b1) of rows >= keep_from to H [M - keep_from][2F]
+ * (row m -> H row m - keep_from) in the interleaved pack order skg_geglu_bwd takes as its saved H (what
+ * skg_gemm_f16_geglu_keep writes): the cond rows of a guided step, whose gate is differentiated.  keep_from % 16 == 0,
+ * ldh % 8 == 0.  H == NULL: plain skg_ff_block_f16. */
+int skg_ff_block_f16_keep(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma,
+                          const void* beta, float eps, const void* Wpack, const float* bias1_pack,
+                          const void* bias2, float* stats, void* H, int ldh, int keep_from, void* stream);
 
 /* ---- GEGLU: Y[m][j] = a_j * gelu(g_j),  H fp16 [M][2F] -----------------------------------------------
  * interleaved == 0: H = [a (F columns) | g (F columns)] (diffusers' chunk(2));  interleaved == 1: groups of four

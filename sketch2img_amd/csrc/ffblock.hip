@@ -40,6 +40,7 @@ struct FFParams {
   int nch;
   unsigned wbytes;
   float* stats;            // optional [M][2]: LayerNorm mean / rstd (what the backward of the norm reads)
+  half_t* keep; int ldkeep; int keep_from;     // optional: rows >= keep_from also store the FF1 output fp16(W1 a + b1), interleaved pack
 };
 
 constexpr int MAXCH = 40;
@@ -252,7 +253,22 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
     for (int u = 0; u < NU; ++u)
       y[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16((PROBE >= 3) ? xb[u % KS] : ld_half8(fr + u * PIECE), gb, y[u], 0, 0, 0);
   };
+  // rows whose gate will be differentiated (the cond rows of a guided step) also store the pre-activation in the
+  // interleaved FF1 pack order skg_geglu_bwd reads: the lane's units j .. j + 3 (j = 32 c + 16 t + 4 g) are the 8
+  // consecutive columns 2 j .. 2 j + 7 = [a a g g a a g g] - one 16-byte store per tile; whole wave tiles (keep_from % 16 == 0)
+  const bool keepw = p.keep != nullptr && m0 >= p.keep_from && m0 < p.M;           // wave-uniform
+  half_t* const keep_row = p.keep ? p.keep + (size_t)(mload - p.keep_from) * p.ldkeep + 8 * g : nullptr;
+  auto store_f = [&](const float4_t (&h)[4], int c) {
+    if (!keepw || mrow >= p.M) return;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const half8_t v = {(half_t)h[t][0], (half_t)h[t][1], (half_t)h[2 + t][0], (half_t)h[2 + t][1],
+                         (half_t)h[t][2], (half_t)h[t][3], (half_t)h[2 + t][2], (half_t)h[2 + t][3]};
+      st_half8(keep_row + 64 * c + 32 * t, v);
+    }
+  };
   auto iteration = [&](const float4_t (&hin)[4], float4_t (&hout)[4], int c) {
+    if (keepw) store_f(hin, c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     half8_t gb;
@@ -260,6 +276,7 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
     ff2(gb, c);
   };
   auto last = [&](const float4_t (&hin)[4], int c) {
+    if (keepw) store_f(hin, c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
     half8_t gb;
@@ -313,10 +330,11 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
 
 }  // namespace
 
-extern "C" int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma,
-                                const void* beta, float eps, const void* Wpack, const float* bias1_pack,
-                                const void* bias2, float* stats, void* stream) {
+extern "C" int skg_ff_block_f16_keep(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma,
+                                     const void* beta, float eps, const void* Wpack, const float* bias1_pack,
+                                     const void* bias2, float* stats, void* H, int ldh, int keep_from, void* stream) {
   SKG_REQUIRE(X && Y && gamma && beta && Wpack && bias1_pack && bias2 && M > 0);
+  SKG_REQUIRE(!H || (ldh % 8 == 0 && ldh >= 2 * F && keep_from >= 0 && keep_from % 16 == 0 && keep_from < M && skg_aligned(H, 16)));
   SKG_REQUIRE(C == 320 && F % 32 == 0 && F / 32 <= MAXCH && F >= 64);
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16) &&
@@ -328,6 +346,7 @@ extern "C" int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M,
   p.nch = F / 32;
   p.wbytes = (unsigned)p.nch * 60u * 1024u;
   p.stats = stats;
+  p.keep = (half_t*)H; p.ldkeep = ldh; p.keep_from = keep_from;
   static const int probe = getenv("SKG_FFB_PROBE") ? atoi(getenv("SKG_FFB_PROBE")) : 0;      // timing experiments only
   static const int sched = getenv("SKG_FFB_SCHED") ? atoi(getenv("SKG_FFB_SCHED")) : 0;
   const dim3 grid(skg_cdiv(M, 128));
@@ -342,4 +361,10 @@ extern "C" int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M,
   }
   SKG_CHECK_LAUNCH("skg_ff_block_f16");
   return SKG_OK;
+}
+
+extern "C" int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma,
+                                const void* beta, float eps, const void* Wpack, const float* bias1_pack,
+                                const void* bias2, float* stats, void* stream) {
+  return skg_ff_block_f16_keep(X, ldx, Y, ldy, M, C, F, gamma, beta, eps, Wpack, bias1_pack, bias2, stats, nullptr, 0, 0, stream);
 }

@@ -176,9 +176,10 @@ def gemm_geglu_keep(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tenso
 
 
 def ff_block(X: torch.Tensor, gamma, beta, eps: float, pack: torch.Tensor, bias1_pack: torch.Tensor, bias2: torch.Tensor,
-             out: Optional[torch.Tensor] = None, want_stats: bool = False):
+             out: Optional[torch.Tensor] = None, want_stats: bool = False, keep_from: Optional[int] = None):
     """Fused feed-forward sub-block at C = 320: out = X + b2 + W2 . geglu(W1 . LayerNorm(X) + b1) in one launch
-    (skg_ff_block_f16; pack / bias1_pack from unet.pack_ff_block).  out may be X."""
+    (skg_ff_block_f16; pack / bias1_pack from unet.pack_ff_block).  out may be X.
+    keep_from=m0: rows >= m0 also store the FF1 output (interleaved pack, what geglu_bwd reads) -> returned last."""
     _f16(X, gamma, beta, pack, bias2)
     M, C = X.shape
     assert pack.is_contiguous() and pack.dim() == 3 and pack.shape[1:] == (60, 512) and bias1_pack.dtype == torch.float32
@@ -186,9 +187,14 @@ def ff_block(X: torch.Tensor, gamma, beta, eps: float, pack: torch.Tensor, bias1
     if out is None:
         out = torch.empty(M, C, device=X.device, dtype=torch.float16)
     stats = torch.empty(M, 2, device=X.device, dtype=torch.float32) if want_stats else None
-    check(lib.skg_ff_block_f16(_p(X), _ld(X), _p(out), _ld(out), M, C, F, _p(gamma), _p(beta), eps, _p(pack), _p(bias1_pack),
-                               _p(bias2), _p(stats), _stream()), "skg_ff_block_f16")
-    return (out, stats) if want_stats else out
+    if keep_from is None:
+        check(lib.skg_ff_block_f16(_p(X), _ld(X), _p(out), _ld(out), M, C, F, _p(gamma), _p(beta), eps, _p(pack), _p(bias1_pack),
+                                   _p(bias2), _p(stats), _stream()), "skg_ff_block_f16")
+        return (out, stats) if want_stats else out
+    pre = torch.empty(M - keep_from, 2 * F, device=X.device, dtype=torch.float16)
+    check(lib.skg_ff_block_f16_keep(_p(X), _ld(X), _p(out), _ld(out), M, C, F, _p(gamma), _p(beta), eps, _p(pack), _p(bias1_pack),
+                                    _p(bias2), _p(stats), _p(pre), _ld(pre), keep_from, _stream()), "skg_ff_block_f16_keep")
+    return (out, stats, pre) if want_stats else (out, pre)
 
 
 def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode: int = CONV_S1,

@@ -33,6 +33,7 @@ _GN_FROM_PRODUCER = os.environ.get("SKG_GN_PRODUCER", "1") != "0"      # A/B swi
 _GEGLU_KEEP = os.environ.get("SKG_GEGLU_KEEP", "1") != "0"
 _GN_CONCAT = os.environ.get("SKG_GN_CONCAT", "1") != "0"
 _FF_BLOCK = os.environ.get("SKG_FF_BLOCK", "1") != "0"              # fused feed-forward sub-block at C = 320 (csrc/ffblock.hip)
+_FF_KEEP = os.environ.get("SKG_FF_KEEP", "1") != "0"                # ... also for the cond rows of a guided step (stashing launch)
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -376,15 +377,19 @@ class HipUNet:
         ffb = _FF_BLOCK and (t + ".ff.pack") in W and (not keep or rows % 2 == 0)
         st3_half = False
         if ffb:
-            # C = 320: norm3 -> FF1 -> gate -> FF2 + residual of the rows nobody differentiates in ONE row-local launch
-            # (skg_ff_block_f16: the row panel and the output accumulators stay in registers, only weights stream); in a
-            # guided step that is the uncond half, the cond half keeps the launches that stash what its backward reads
-            M0 = (rows // 2) * HW if keep else rows * HW
+            # C = 320: norm3 -> FF1 -> gate -> FF2 + residual in ONE row-local launch (skg_ff_block_f16: the row panel and the
+            # output accumulators stay in registers, only weights stream).  In a guided step the same launch also stores what
+            # the backward of the cond rows reads: the FF1 output (interleaved pack) and norm3's statistics
+            M0 = (rows // 2) * HW
             p3 = torch.empty(rows * HW, C, device=x.device, dtype=torch.float16)
-            ops.ff_block(p2[:M0], W[t + ".norm3.weight"], W[t + ".norm3.bias"], 1e-5, W[t + ".ff.pack"], W[t + ".ff.bias1"],
-                         W[t + ".ff.net.2.bias"], out=p3[:M0])
+            ffargs = (W[t + ".norm3.weight"], W[t + ".norm3.bias"], 1e-5, W[t + ".ff.pack"], W[t + ".ff.bias1"], W[t + ".ff.net.2.bias"])
             f, st3 = None, None
-            if keep:
+            if not keep:
+                ops.ff_block(p2, *ffargs, out=p3)
+            elif _FF_KEEP:
+                _, st3, f = ops.ff_block(p2, *ffargs, out=p3, want_stats=True, keep_from=M0)
+            else:       # (A/B switch: the uncond half fused, the cond half on the launches that stash)
+                ops.ff_block(p2[:M0], *ffargs, out=p3[:M0])
                 a3, st3 = ops.layernorm(p2[M0:], W[t + ".norm3.weight"], W[t + ".norm3.bias"], want_stats=True)
                 st3_half = True
                 if _GEGLU_KEEP:

@@ -956,3 +956,31 @@ def test_ff_block_fused(ops, M, Fh):
     outw = torch.zeros(M, 2 * C + 8, device=d, dtype=torch.float16)
     ops.ff_block(wide[:, C:], gam.to(d), bet.to(d), 1e-5, pack, bias1, b2.to(d), out=outw[:, 8:8 + C])
     assert torch.equal(outw[:, 8:8 + C], y) and float(outw[:, :8].abs().max()) == 0 and float(outw[:, 8 + C:].abs().max()) == 0
+
+
+def test_ff_block_keep_stores_the_pre_activation(ops):
+    """skg_ff_block_f16_keep: the cond rows of a guided step (rows >= keep_from) also get the FF1 output in the interleaved pack
+    order - what skg_gemm_f16_geglu_keep writes and skg_geglu_bwd reads.  Same MFMA products and the same fp16 rounding as the
+    GEMM path up to fp32 summation order: rel <= 1e-4, >= 98 % bit-equal; the output is unchanged by the extra stores."""
+    from sketch2img_amd.unet import pack_ff_block
+    d = dev()
+    C, Fh, M, M0 = 320, 1280, 128 * 6 + 48, 128 * 3 + 16
+    x = rnd(M, C, seed=21)
+    gam, bet = (1 + 0.2 * rnd(C, seed=22).float()).half(), (0.1 * rnd(C, seed=23).float()).half()
+    w1, b1 = rnd(2 * Fh, C, seed=24, scale=C ** -0.5), rnd(2 * Fh, seed=25, scale=0.1)
+    w2, b2 = rnd(C, Fh, seed=26, scale=Fh ** -0.5), rnd(C, seed=27, scale=0.1)
+    pack, bias1 = pack_ff_block(w1, b1, w2, d)
+    xd = x.to(d)
+    y0 = ops.ff_block(xd, gam.to(d), bet.to(d), 1e-5, pack, bias1, b2.to(d))
+    y, st, pre = ops.ff_block(xd, gam.to(d), bet.to(d), 1e-5, pack, bias1, b2.to(d), want_stats=True, keep_from=M0)
+    assert torch.equal(y, y0) and pre.shape == (M - M0, 2 * Fh)
+    idx = ops.geglu_interleave_index(Fh)
+    a3 = ops.layernorm(xd[M0:], gam.to(d), bet.to(d), 1e-5)
+    _, f = ops.gemm_geglu_keep(a3, w1[idx].contiguous().to(d), b1[idx].contiguous().to(d))
+    r, _ = report("ff_block keep vs gemm_geglu_keep", pre.float().cpu(), f.float().cpu())
+    same = float((pre == f).float().mean())
+    print(f"[parity] ff_block keep bit-equal: {same:.5f}")
+    assert r < 1e-4 and same > 0.98
+    # and the gate's backward accepts it
+    dy = rnd(M - M0, Fh, seed=28).to(d)
+    assert rel_err(ops.geglu_bwd(pre, dy, interleaved=True), ops.geglu_bwd(f, dy, interleaved=True)) < 2e-4

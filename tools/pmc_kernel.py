@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One kernel shape, a few launches - the target of `rocprofv3 --pmc ...` passes (tools/pmc_kernels.sh).
-    python tools/pmc_kernel.py attn40 | attn64 | conv | gemm_short | gemm_ff1"""
+    python tools/pmc_kernel.py attn40 | attn64 | conv | gemm_short | gemm_ff1 | ffblock"""
 import os
 import sys
 
@@ -20,6 +20,15 @@ if what.startswith("attn"):
     v = torch.randn(B * kvs, H * d, generator=g).half().to(dev)
     vt = ops.transpose(v)
     fn = lambda: ops.attn_fwd(q, k, vt, B, H, N, Nkv, kvs, d, d ** -0.5)
+elif what == "ffblock":
+    from sketch2img_amd.unet import pack_ff_block
+    M, C, Fh = 65536, 320, 1280
+    x = torch.randn(M, C, generator=g).half().to(dev)
+    pack, bias1 = pack_ff_block(torch.randn(2 * Fh, C, generator=g) * C ** -0.5, torch.randn(2 * Fh, generator=g) * 0.1,
+                                torch.randn(C, Fh, generator=g) * Fh ** -0.5, dev)
+    gam, bet, b2 = torch.ones(C).half().to(dev), torch.zeros(C).half().to(dev), torch.zeros(C).half().to(dev)
+    out = torch.empty_like(x)
+    fn = lambda: ops.ff_block(x, gam, bet, 1e-5, pack, bias1, b2, out=out)
 elif what == "conv":
     rows, hw, cin, cout = 16, 32, 1920, 640
     x = torch.randn(rows * hw * hw, cin, generator=g).half().to(dev)

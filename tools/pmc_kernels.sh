@@ -21,7 +21,7 @@ import glob, json
 for f in sorted(glob.glob("gpurun_out/profiles_out/*_waves_*.json")):
     d = json.load(open(f))
     for k, v in d.items():
-        if "SQ_WAVE_CYCLES" not in v or ("gemm" not in k and "attn" not in k):
+        if "SQ_WAVE_CYCLES" not in v or ("gemm" not in k and "attn" not in k and "ff_block" not in k):
             continue
         wc = v["SQ_WAVE_CYCLES"]["sum"] / v["SQ_WAVE_CYCLES"]["launches"]
         print(f, k[:50])
