@@ -224,6 +224,23 @@ int skg_ff_block_f16_keep(const void* X, int ldx, void* Y, int ldy, int M, int C
                           const void* beta, float eps, const void* Wpack, const float* bias1_pack,
                           const void* bias2, float* stats, void* H, int ldh, int keep_from, void* stream);
 
+/* ---- Row-local fused cross-attention sub-block (round 3; VERDICT r2 next #2, first half) ---------------------------
+ * Y [M][C] = X + bo + Wo . Attention(Q = Wq . LayerNorm(X; gamma, beta, eps), K, V) over the Nkv <= 80 text keys of the row's
+ * image - ONE launch instead of skg_layernorm_fwd, skg_gemm_f16 (attn2.to_q), skg_attn_fwd_rowv (77 keys) and skg_gemm_f16 with a
+ * residual (attn2.to_out); q, the attention output and the normalised rows never exist in memory.
+ * C == 320, heads == 8 (head width 40: the 64 x 64 level of SD1.5); rows [b * HW, (b + 1) * HW) belong to image b, HW % 128 == 0,
+ * M % HW == 0; scale = head_width^-0.5.
+ * Wpack: fp16 [heads][60][512], KVpack: fp16 [M / HW][heads][16][512] - fragment-major images of Wq / Wo and of the per-image
+ * text keys / values (layouts: sketch2img_amd.unet.pack_xattn_weights / pack_xattn_kv, which build them; KVpack once per prompt).
+ * Same rounding points as the four-launch path (fp16 LayerNorm output, fp16 q, fp16 scaled q, fp16 probabilities, fp16
+ * attention output, one fp16 rounding of the residual sum).  Y may alias X.  No LSE / q / o outputs: for rows nobody
+ * differentiates (unguided evaluations, the uncond half of guided ones).
+ * Replaces: BasicTransformerBlock.norm2 / attn2 / residual add ([diffusers] attention.py; the op order of
+ * modules/clip_guided_attn.py:127-152), reached from modules/pipeline.py:96. */
+int skg_xattn_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int HW, int C, int heads, int Nkv,
+                        const void* gamma, const void* beta, float eps, const void* Wpack, const void* KVpack,
+                        const void* bias_out, float scale, void* stream);
+
 /* ---- GEGLU: Y[m][j] = a_j * gelu(g_j),  H fp16 [M][2F] -----------------------------------------------
  * interleaved == 0: H = [a (F columns) | g (F columns)] (diffusers' chunk(2));  interleaved == 1: groups of four
  * columns [a_2t a_2t+1 g_2t g_2t+1] (the pack SKG_EPI_GEGLU uses).  bwd writes dH [M][2F] in the same layout from

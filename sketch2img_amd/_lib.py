@@ -41,6 +41,7 @@ SIGNATURES = {
     "skg_gemm_f16_geglu_keep": ("i", "pipipipiiiipp"),
     "skg_ff_block_f16": ("i", "pipiiiippfppppp"),
     "skg_ff_block_f16_keep": ("i", "pipiiiippfpppppiip"),
+    "skg_xattn_block_f16": ("i", "pipiiiiiippfpppfp"),
     "skg_gemm_variant": ("i", "iiiii"),
     "skg_set_workspace": ("i", "pzp"),
     "skg_conv3x3_f16": ("i", "pippiiiiiiippifup"),

@@ -1,0 +1,262 @@
+// Row-local fused cross-attention sub-block of a BasicTransformerBlock at C = 320, 8 heads of 40 (the 64 x 64 level of SD1.5):
+//   Y = X + bo + Wo . Attention(Q = Wq . LayerNorm(X), K, V)      with the <= 80 text keys of the row's image
+// replaces four launches - norm2, attn2.to_q, the 77-key attention, attn2.to_out + residual ([diffusers] attention.py
+// BasicTransformerBlock.forward / CrossAttention, reached from modules/pipeline.py:96; the op order of
+// modules/clip_guided_attn.py:127-152) - and the three [M, 320] tensors between them (first half).
+//
+// Same formulation as ffblock.hip: TRANSPOSED, a wave's 16 rows never leave its registers.  Per head h:
+//   Q^T[48 x 16]  = Wq_h[48 x 320] . A^T            3 tiles x 10 MFMAs; rows 40..47 of the head are zero rows of the pack
+//   S^T[80 x 16]  = K_h[80 x 48] . Q^T              the accumulator lane (l, g) of Q^T holds d = 16 t + 4 g + r: tiles 0, 1
+//                                                   are the B operand of a K = 32 step with k-slot 8 g + i <-> d = 16 (i >> 2) + 4 g + (i & 3),
+//                                                   tile 2 is the B operand of a v_mfma_f32_16x16x16_f16 step in natural order
+//   softmax over the lane's 20 scores and the 4 lanes of a row (exact maximum, as attn_fwd_short_kernel)
+//   O^T[48 x 16]  = V_h^T[48 x 80] . P^T            key tiles (0,1), (2,3) -> two K = 32 steps, tile 4 -> one K = 16 step
+//   Y^T[320 x 16] += Wo[:, head h] . O^T            20 output tiles x (K = 32 step on d 0..31 + K = 16 step on d 32..47)
+// Every A operand is a "fragment-major" piece of a host-side pack (unet.pack_xattn_weights / pack_xattn_kv): the pack IS the
+// LDS image, fetched 1 KB per buffer_load ... lds and read with one conflict-free ds_read_b128 / ds_read_b64 per MFMA.
+// One 8-wave workgroup = 128 rows of ONE image (HW % 128 == 0); LDS: Wq_h (30 KB, single: refilled while S / PV / out of the
+// head run) + two stages of [K_h 8 KB | V_h 8 KB | Wo_h 30 KB]; two barriers per head.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct XAParams {
+  const half_t* X; int ldx;
+  half_t* Y; int ldy;
+  int M, HW;
+  const half_t* gamma; const half_t* beta; float eps;
+  const half_t* Wp;        // [heads][60][512]: Wq_h (30 pieces: tile t, k-step ks) then the Wo_h image (30 pieces)
+  const half_t* KVp;       // [images][heads][16][512]: K_h image (8 pieces) then V_h image (8 pieces)
+  const half_t* bo;        // [C]
+  int heads, nkv;
+  float sc;                // dh^-0.5 * log2(e)
+  unsigned wbytes, kvbytes;
+};
+
+constexpr float XA_NEG = -30000.f;
+
+__global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
+  constexpr int KS = 10, C = 320, NU = 20, PIECE = 512;
+  constexpr int WQ = 0, NWQ = 30;                        // pieces
+  constexpr int STG = NWQ * PIECE, NST = 46;             // stage = [K 8 | V 8 | Wo 30] pieces
+  constexpr int KOFF = 0, VOFF = 8 * PIECE, WOOFF = 16 * PIECE;
+  constexpr int DUMP = STG + 2 * NST * PIECE;            // 2 pieces for dead DMA slots
+  constexpr int LDSH = DUMP + 2 * PIECE;
+  constexpr int OP = C + 8;
+  static_assert(8 * 16 * OP <= LDSH, "epilogue staging fits");
+  __shared__ __attribute__((aligned(16))) half_t smem[LDSH];        // ONE object (LDS-DMA + ds_read: see gemm2.hip)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l16 = lane & 15, g = lane >> 4;
+  const int img = (blockIdx.x * 128) / p.HW;
+  const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, p.wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rKV = __builtin_amdgcn_make_buffer_rsrc((void*)p.KVp, 0, p.kvbytes, 0x00020000);
+  // slot j (0..5) of the stage fetch of head h: piece q = wave + 8 j of [K | V | Wo] -> stage h & 1; dead: q >= 46 or no such head
+  auto dma_stage = [&](int h, int j) {
+    const int q = wave + 8 * j;
+    const bool live = q < NST && h < p.heads;
+    const int dst = q < NST ? STG + (h & 1) * NST * PIECE + q * PIECE : DUMP + (q - NST) * PIECE;
+    const unsigned voff = live ? (unsigned)lane * 16u : 0x80000000u;
+    if (q < 16)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rKV, (lds_ptr_t)(smem + dst), 16, voff,
+                                               (unsigned)(((img * p.heads + h) * 16 + q) * 1024), 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + dst), 16, voff, (unsigned)((h * 60 + 30 + (q - 16)) * 1024), 0, 0);
+  };
+  // slot j (0..3) of the Wq fetch of head h: piece q = wave + 8 j
+  auto dma_wq = [&](int h, int j) {
+    const int q = wave + 8 * j;
+    const bool live = q < NWQ && h < p.heads;
+    const int dst = q < NWQ ? WQ + q * PIECE : DUMP + (q - NWQ) * PIECE;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + dst), 16, live ? (unsigned)lane * 16u : 0x80000000u,
+                                             (unsigned)((h * 60 + q) * 1024), 0, 0);
+  };
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dma_wq(0, j);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) dma_stage(0, j);
+
+  // ---- the wave's 16 rows: load, LayerNorm (as norms.hip), keep as B operands
+  const int m0 = blockIdx.x * 128 + wave * 16;
+  const int mrow = m0 + l16;
+  const int mload = min(mrow, p.M - 1);
+  half8_t xb[KS];
+  {
+    const half_t* xr = p.X + (size_t)mload * p.ldx + 8 * g;
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      xb[ks] = ld_half8(xr + 32 * ks);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += (float)xb[ks][i];
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.f / C);
+    float s2 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = (float)xb[ks][i] - mean; s2 += d * d; }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = rsqrtf(s2 * (1.f / C) + p.eps);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8_t gv = ld_half8(p.gamma + 32 * ks + 8 * g), bv = ld_half8(p.beta + 32 * ks + 8 * g);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xb[ks][i] = (half_t)(((float)xb[ks][i] - mean) * rstd * (float)gv[i] + (float)bv[i]);
+    }
+  }
+  float4_t y[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const half4_t b = ld_half4(p.bo + 16 * u + 4 * g);
+    y[u] = float4_t{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+  }
+  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  for (int h = 0; h < p.heads; ++h) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();                                           // A: Wq_h and stage h landed; every wave is done with head h - 1
+    // ---- Q^T = Wq_h . A^T; the next head's [K | V | Wo] is fetched under it (its stage was head h - 1's)
+    float4_t q[3] = {zero4, zero4, zero4};
+    {
+      const half_t* fr = smem + WQ + lane * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          q[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(fr + (t * KS + ks) * PIECE), xb[ks], q[t], 0, 0, 0);
+        if (ks < 6) dma_stage(h + 1, ks);
+      }
+    }
+    lds_barrier();                                           // B: every wave has read Wq_h - its region takes Wq_{h+1}
+    // q: fp16 (the rounding of the stored to_q output), then scaled and rounded again (attn_fwd_short_kernel's qf)
+    half8_t qb32;
+    half4v qb16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) qb32[i] = (half_t)((float)(half_t)q[i >> 2][i & 3] * p.sc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qb16[i] = (half_t)((float)(half_t)q[2][i] * p.sc);
+    const half_t* st = smem + STG + (h & 1) * NST * PIECE;
+    // ---- S^T = K_h . Q^T: 5 key tiles
+    float4_t s[5];
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt) {
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + KOFF + kt * PIECE + lane * 8), qb32, zero4, 0, 0, 0);
+      s[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(*reinterpret_cast<const half4v*>(st + KOFF + 5 * PIECE + kt * 256 + lane * 4),
+                                                    qb16, s[kt], 0, 0, 0);
+    }
+    dma_wq(h + 1, 0);
+    dma_wq(h + 1, 1);
+    // keys behind nkv are masked (lane holds keys 16 kt + 4 g + r)
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (16 * kt + 4 * g + r >= p.nkv) s[kt][r] = XA_NEG;
+    float mx = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float li = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+        s[kt][r] = e;
+        li += e;
+      }
+    li += __shfl_xor(li, 16, 64);
+    li += __shfl_xor(li, 32, 64);
+    half8_t pb32[2];
+    half4v pb16;
+#pragma unroll
+    for (int sv = 0; sv < 2; ++sv)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pb32[sv][i] = (half_t)s[2 * sv + (i >> 2)][i & 3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pb16[i] = (half_t)s[4][i];
+    dma_wq(h + 1, 2);
+    dma_wq(h + 1, 3);
+    // ---- O^T = V_h^T . P^T: 3 tiles of d
+    float4_t o[3];
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + VOFF + (dt * 2) * PIECE + lane * 8), pb32[0], zero4, 0, 0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + VOFF + (dt * 2 + 1) * PIECE + lane * 8), pb32[1], o[dt], 0, 0, 0);
+      o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(*reinterpret_cast<const half4v*>(st + VOFF + 6 * PIECE + dt * 256 + lane * 4),
+                                                    pb16, o[dt], 0, 0, 0);
+    }
+    const float inv = 1.f / li;
+    half8_t ob32;
+    half4v ob16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ob32[i] = (half_t)(o[i >> 2][i & 3] * inv);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ob16[i] = (half_t)(o[2][i] * inv);
+    // ---- Y^T += Wo[:, head h] . O^T
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      y[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + WOOFF + u * PIECE + lane * 8), ob32, y[u], 0, 0, 0);
+      y[u] = __builtin_amdgcn_mfma_f32_16x16x16f16(*reinterpret_cast<const half4v*>(st + WOOFF + 20 * PIECE + u * 256 + lane * 4),
+                                                   ob16, y[u], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue (as ffblock.hip): residual added in fp32, the tile through the wave's own slice of the idle LDS, whole-row stores
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  lds_barrier();
+  half_t* const stg = smem + wave * (16 * OP);
+  {
+    const half_t* xr = p.X + (size_t)mload * p.ldx + 4 * g;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const half4_t r4 = ld_half4(xr + 16 * u);
+      const half4_t v = {(half_t)(y[u][0] + (float)r4[0]), (half_t)(y[u][1] + (float)r4[1]), (half_t)(y[u][2] + (float)r4[2]),
+                         (half_t)(y[u][3] + (float)r4[3])};
+      st_half4(stg + l16 * OP + 16 * u + 4 * g, v);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  constexpr int PPR = C / 8;
+#pragma unroll
+  for (int j = 0; j < 16 * PPR / 64; ++j) {
+    const int pi = lane + 64 * j;
+    const int row = pi / PPR, pc = pi - row * PPR;
+    if (m0 + row < p.M) st_half8(p.Y + (size_t)(m0 + row) * p.ldy + pc * 8, ld_half8(stg + row * OP + pc * 8));
+  }
+}
+
+}  // namespace
+
+extern "C" int skg_xattn_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int HW, int C, int heads, int Nkv,
+                                   const void* gamma, const void* beta, float eps, const void* Wpack, const void* KVpack,
+                                   const void* bias_out, float scale, void* stream) {
+  SKG_REQUIRE(X && Y && gamma && beta && Wpack && KVpack && bias_out && M > 0);
+  SKG_REQUIRE(C == 320 && heads == 8 && Nkv > 0 && Nkv <= 80 && HW > 0 && HW % 128 == 0 && M % HW == 0);
+  SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16) &&
+              skg_aligned(Wpack, 16) && skg_aligned(KVpack, 16) && skg_aligned(bias_out, 8));
+  XAParams p;
+  p.X = (const half_t*)X; p.ldx = ldx; p.Y = (half_t*)Y; p.ldy = ldy; p.M = M; p.HW = HW;
+  p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.eps = eps;
+  p.Wp = (const half_t*)Wpack; p.KVp = (const half_t*)KVpack; p.bo = (const half_t*)bias_out;
+  p.heads = heads; p.nkv = Nkv;
+  p.sc = scale * 1.4426950408889634f;
+  p.wbytes = (unsigned)heads * 60u * 1024u;
+  p.kvbytes = (unsigned)(M / HW) * (unsigned)heads * 16u * 1024u;
+  hipLaunchKernelGGL(xattn_block_kernel, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+  SKG_CHECK_LAUNCH("skg_xattn_block_f16");
+  return SKG_OK;
+}

@@ -197,6 +197,20 @@ def ff_block(X: torch.Tensor, gamma, beta, eps: float, pack: torch.Tensor, bias1
     return (out, stats, pre) if want_stats else (out, pre)
 
 
+def xattn_block(X: torch.Tensor, HW: int, heads: int, Nkv: int, gamma, beta, eps: float, wpack: torch.Tensor, kvpack: torch.Tensor,
+                bias_out: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None):
+    """Fused cross-attention sub-block at C = 320, 8 heads: out = X + bo + Wo . Attention(Wq . LayerNorm(X), K, V) over the text
+    keys of each row's image, in one launch (skg_xattn_block_f16; packs from unet.pack_xattn_weights / pack_xattn_kv)."""
+    _f16(X, gamma, beta, wpack, kvpack, bias_out)
+    M, C = X.shape
+    assert wpack.is_contiguous() and wpack.shape == (heads, 60, 512) and kvpack.is_contiguous() and kvpack.shape == (M // HW, heads, 16, 512)
+    if out is None:
+        out = torch.empty(M, C, device=X.device, dtype=torch.float16)
+    check(lib.skg_xattn_block_f16(_p(X), _ld(X), _p(out), _ld(out), M, HW, C, heads, Nkv, _p(gamma), _p(beta), eps, _p(wpack),
+                                  _p(kvpack), _p(bias_out), scale, _stream()), "skg_xattn_block_f16")
+    return out
+
+
 def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode: int = CONV_S1,
             out: Optional[torch.Tensor] = None, *, bias=None, residual=None, alpha: float = 1.0,
             relu: bool = False, gn_groups: Optional[int] = None, out_lo=None, residual_lo=None):

@@ -131,6 +131,58 @@ def pack_ff_block(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, dev):
     return pack, bias1
 
 
+def pack_xattn_weights(wq: torch.Tensor, wo: torch.Tensor, heads: int, dev):
+    """Fragment-major pack of attn2.to_q [C, C] and attn2.to_out.0 [C, C] for skg_xattn_block_f16 (csrc/xattn.hip), C = 320,
+    head width 40 padded to 48: per head h 60 pieces of 512 halves = the kernel's LDS image:
+      30 Wq pieces (t, ks):  [lane = 16 g + l][i] = Wq[40 h + 16 t + l][32 ks + 8 g + i]         (rows 40..47 of the head: zeros)
+      Wo image (30 pieces):  20 K = 32 fragments  [lane][i] = Wo[16 u + l][40 h + 16 (i >> 2) + 4 g + (i & 3)]
+                             20 K = 16 fragments  [lane][i < 4] = Wo[16 u + l][40 h + 32 + 4 g + i]   (d >= 40: zeros)
+    Returns fp16 [heads, 60, 512]."""
+    C = wq.shape[0]
+    dh = C // heads
+    assert wq.shape == (C, C) and wo.shape == (C, C) and C == 320 and dh == 40
+    KS, NU = C // 32, C // 16
+    wqh, woh = wq.to(torch.float16), wo.to(torch.float16)
+    out = []
+    for h in range(heads):
+        q = torch.zeros(48, C, dtype=torch.float16)
+        q[:dh] = wqh[h * dh:(h + 1) * dh]
+        pq = q.reshape(3, 16, KS, 4, 8).permute(0, 2, 3, 1, 4).reshape(3 * KS, 512)          # [t, ks][g, l, i]
+        o = torch.zeros(C, 48, dtype=torch.float16)
+        o[:, :dh] = woh[:, h * dh:(h + 1) * dh]
+        o32 = o[:, :32].reshape(NU, 16, 2, 4, 4).permute(0, 3, 1, 2, 4).reshape(-1)             # [u][g, l, i_hi, i_lo]
+        o16 = o[:, 32:].reshape(NU, 16, 4, 4).permute(0, 2, 1, 3).reshape(-1)                   # [u][g, l, i]
+        out.append(torch.cat([pq.reshape(-1), o32, o16]).reshape(60, 512))
+    return torch.stack(out).contiguous().to(dev)
+
+
+def pack_xattn_kv(K: torch.Tensor, V: torch.Tensor, rows: int, Lp: int, L: int, heads: int) -> torch.Tensor:
+    """Fragment-major pack of the text keys / values of every batch row for skg_xattn_block_f16: K, V [rows * Lp, C] (what
+    prepare_context hoists per prompt), L <= 80 valid keys per row.  Per (row, head) 16 pieces of 512 halves:
+      K image: 5 K = 32 fragments [lane = 16 g + l][i] = K[key 16 kt + l][40 h + 16 (i >> 2) + 4 g + (i & 3)], then 5 K = 16
+               fragments [lane][i < 4] = K[key 16 kt + l][40 h + 32 + 4 g + i]                                   (8 pieces)
+      V image: (dt, s) K = 32 fragments [lane][i] = V[key 32 s + 16 (i >> 2) + 4 g + (i & 3)][40 h + 16 dt + l], then 3 K = 16
+               fragments [lane][i < 4] = V[key 64 + 4 g + i][40 h + 16 dt + l]                                   (8 pieces)
+    Keys >= L and head columns >= 40 are zeros.  Returns fp16 [rows, heads, 16, 512] on K's device."""
+    C = K.shape[1]
+    dh = C // heads
+    assert dh == 40 and L <= 80 and K.shape == V.shape == (rows * Lp, C)
+    dev = K.device
+    k = torch.zeros(rows, heads, 80, 48, device=dev, dtype=torch.float16)
+    v = torch.zeros(rows, heads, 80, 48, device=dev, dtype=torch.float16)
+    k[:, :, :L, :dh] = K.reshape(rows, Lp, heads, dh)[:, :L].permute(0, 2, 1, 3)
+    v[:, :, :L, :dh] = V.reshape(rows, Lp, heads, dh)[:, :L].permute(0, 2, 1, 3)
+    R = rows * heads
+    k, v = k.reshape(R, 80, 48), v.reshape(R, 80, 48)
+    k32 = k[:, :, :32].reshape(R, 5, 16, 2, 4, 4).permute(0, 1, 4, 2, 3, 5).reshape(R, 5 * 512)      # [kt][g, l, i_hi, i_lo]
+    k16 = k[:, :, 32:].reshape(R, 5, 16, 4, 4).permute(0, 1, 3, 2, 4).reshape(R, 5 * 256)            # [kt][g, l, i]
+    v32 = v[:, :64].reshape(R, 2, 2, 4, 4, 3, 16).permute(0, 5, 1, 3, 6, 2, 4).reshape(R, 6 * 512)   # [dt, s][g, l, i_hi, i_lo]
+    v16 = v[:, 64:].reshape(R, 4, 4, 3, 16).permute(0, 3, 1, 4, 2).reshape(R, 3 * 256)               # [dt][g, l, i]
+    pad_k = torch.zeros(R, 4096 - 5 * 768, device=dev, dtype=torch.float16)
+    pad_v = torch.zeros(R, 4096 - 6 * 512 - 3 * 256, device=dev, dtype=torch.float16)
+    return torch.cat([k32, k16, pad_k, v32, v16, pad_v], 1).reshape(rows, heads, 16, 512).contiguous()
+
+
 def _pad_vec(v: torch.Tensor, n: int) -> torch.Tensor:
     return torch.nn.functional.pad(v, (0, n - v.shape[0])) if n > v.shape[0] else v
 

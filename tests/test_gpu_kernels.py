@@ -984,3 +984,51 @@ def test_ff_block_keep_stores_the_pre_activation(ops):
     # and the gate's backward accepts it
     dy = rnd(M - M0, Fh, seed=28).to(d)
     assert rel_err(ops.geglu_bwd(pre, dy, interleaved=True), ops.geglu_bwd(f, dy, interleaved=True)) < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------- fused cross-attention sub-block
+@pytest.mark.parametrize("rows,HW,L", [(2, 1024, 77), (16, 4096, 77), (3, 128, 40)])
+def test_xattn_block_fused(ops, rows, HW, L):
+    """skg_xattn_block_f16 (norm2 -> attn2.to_q -> attention over the text keys -> attn2.to_out + residual in ONE launch,
+    C = 320, 8 heads of 40) against (a) the fp32 definition on the same fp16 inputs: the output rounding plus the internal fp16
+    roundings the unfused path has too (LayerNorm output, q, scaled q, probabilities, attention output) - rel <= 2 x FP16_RND
+    on an O(1) residual stream; (b) the four launches it replaces (skg_layernorm_fwd, skg_gemm_f16, skg_attn_fwd_rowv,
+    skg_gemm_f16 + residual), which round at the same points: rel <= 3e-4, >= 95 % of the outputs bit-equal; in place == out of place."""
+    from sketch2img_amd.unet import pack_xattn_kv, pack_xattn_weights
+    d = dev()
+    C, heads, dh, Lp = 320, 8, 40, 80
+    M = rows * HW
+    scale = dh ** -0.5
+    x = rnd(M, C, seed=31)
+    gam, bet = (1 + 0.2 * rnd(C, seed=32).float()).half(), (0.1 * rnd(C, seed=33).float()).half()
+    wq, wo, bo = rnd(C, C, seed=34, scale=C ** -0.5), rnd(C, C, seed=35, scale=C ** -0.5), rnd(C, seed=36, scale=0.1)
+    K, V = rnd(rows * Lp, C, seed=37), rnd(rows * Lp, C, seed=38)
+    wp = pack_xattn_weights(wq, wo, heads, d)
+    kvp = pack_xattn_kv(K.to(d), V.to(d), rows, Lp, L, heads)
+    xd = x.to(d)
+    y = ops.xattn_block(xd, HW, heads, L, gam.to(d), bet.to(d), 1e-5, wp, kvp, bo.to(d), scale)
+    torch.cuda.synchronize()
+    # (b) the four launches
+    a2 = ops.layernorm(xd, gam.to(d), bet.to(d), 1e-5)
+    q2 = ops.gemm(a2, wq.to(d))
+    o2 = ops.attn_fwd(q2, K.to(d), V.to(d), rows, heads, HW, L, Lp, dh, scale, v_rows=True)
+    y4 = ops.gemm(o2, wo.to(d), bias=bo.to(d), residual=xd)
+    r4, _ = report(f"xattn_block rows{rows} HW{HW} L{L} vs four launches", y.float().cpu(), y4.float().cpu())
+    same = float((y == y4).float().mean())
+    print(f"[parity] xattn_block bit-equal outputs: {same:.5f}")
+    # (a) fp32 definition (a subset of the rows at the large size: the CPU reference is the slow part)
+    sel = slice(0, min(M, 8192))
+    b = (torch.arange(M)[sel] // HW)
+    a = F.layer_norm(x.float()[sel], (C,), gam.float(), bet.float(), 1e-5)
+    q = (a @ wq.float().t()).reshape(-1, heads, dh)
+    Kf = K.float().reshape(rows, Lp, heads, dh)[:, :L][b]            # [m, L, heads, dh]
+    Vf = V.float().reshape(rows, Lp, heads, dh)[:, :L][b]
+    att = torch.softmax(torch.einsum("mhd,mlhd->mhl", q, Kf) * scale, -1)
+    o = torch.einsum("mhl,mlhd->mhd", att, Vf).reshape(-1, C)
+    ref = x.float()[sel] + o @ wo.float().t() + bo.float()
+    r, _ = report(f"xattn_block rows{rows} HW{HW} L{L} vs fp32", y.float().cpu()[sel], ref)
+    assert r < 2 * FP16_RND
+    assert r4 < 3e-4 and same > 0.95
+    y_in = xd.clone()
+    ops.xattn_block(y_in, HW, heads, L, gam.to(d), bet.to(d), 1e-5, wp, kvp, bo.to(d), scale, out=y_in)
+    assert torch.equal(y_in, y)

@@ -66,6 +66,8 @@ def test_host_side_argument_checks_do_not_need_a_gpu():
     assert lib.skg_conv3x3_f16(16, 32, 16, 16, 8, 1, 4, 4, 32, 8, 9, None, None, 0, 1.0, 0, None) == -2  # mode 9
     assert lib.skg_ff_block_f16(16, 320, 16, 320, 128, 640, 1280, 16, 16, 1e-5, 16, 16, 16, None, None) == -1   # C = 320 only
     assert lib.skg_ff_block_f16(16, 320, 16, 320, 128, 320, 1296, 16, 16, 1e-5, 16, 16, 16, None, None) == -1   # F % 32
+    assert lib.skg_xattn_block_f16(16, 320, 16, 320, 4096, 4096, 320, 8, 81, 16, 16, 1e-5, 16, 16, 16, 0.158, None) == -1   # Nkv <= 80
+    assert lib.skg_xattn_block_f16(16, 320, 16, 320, 4096, 1000, 320, 8, 77, 16, 16, 1e-5, 16, 16, 16, 0.158, None) == -1  # HW % 128
     assert lib.skg_gemm_variant(65536, 320, 2880, 320, 2) == 2160
     assert lib.skg_gemm_variant(4096, 64, 96, 32, 2) == 1064
     # GroupNorm statistics in the producer's epilogue: which launches fuse them (the rest run the stand-alone pass)
@@ -444,3 +446,67 @@ def test_ff_block_pack_reproduces_the_geglu_feed_forward():
     hidden = a @ w1.t() + b1
     ref = (hidden[:, :Fh] * F.gelu(hidden[:, Fh:])) @ w2.t()
     assert torch.allclose(y.t(), ref, atol=2e-4, rtol=1e-5), float((y.t() - ref).abs().max())
+
+
+def test_xattn_packs_reproduce_cross_attention():
+    """unet.pack_xattn_weights / pack_xattn_kv (what skg_xattn_block_f16 consumes), emulated on the CPU with the kernel's own
+    index arithmetic (csrc/xattn.hip): K = 32 pieces are A operands [16 x 32] with lane 16 g + l holding A[l][8 g + i], K = 16
+    pieces [16 x 16] with A[l][4 g + i]; an accumulator lane (l, g) holds rows 4 g + r, and accumulator tiles feed the next
+    product as B operands with k-slot 8 g + i <-> (tile i >> 2, row 4 g + (i & 3)) resp. 4 g + i <-> (last tile, row 4 g + i).
+    Against to_out(softmax(q k^T / sqrt(d)) v) in fp32 with 77 valid keys; inputs on coarse grids (fp16 storage exact)."""
+    from sketch2img_amd.unet import pack_xattn_kv, pack_xattn_weights
+    g = torch.Generator().manual_seed(9)
+    C, heads, dh, M, Lp, L, rows = 320, 8, 40, 16, 80, 77, 2
+    wq = torch.randint(-8, 9, (C, C), generator=g).float() / 64
+    wo = torch.randint(-8, 9, (C, C), generator=g).float() / 64
+    a = torch.randint(-16, 17, (M, C), generator=g).float() / 16
+    K = torch.randint(-16, 17, (rows * Lp, C), generator=g).float() / 16
+    V = torch.randint(-16, 17, (rows * Lp, C), generator=g).float() / 16
+    wp = pack_xattn_weights(wq, wo, heads, "cpu")
+    kv = pack_xattn_kv(K.half(), V.half(), rows, Lp, L, heads)
+    assert wp.shape == (heads, 60, 512) and kv.shape == (rows, heads, 16, 512)
+    img = 1
+    scale = dh ** -0.5
+
+    def a32(piece):
+        return piece.float().reshape(4, 16, 8).permute(1, 0, 2).reshape(16, 32)
+
+    def a16(piece):
+        return piece.float().reshape(4, 16, 4).permute(1, 0, 2).reshape(16, 16)
+
+    def b32(t0, t1):                            # two accumulator tiles [16, M] -> B operand [32 k-slots, M]
+        out = torch.zeros(32, M)
+        for gg in range(4):
+            for i in range(8):
+                out[8 * gg + i] = (t0, t1)[i >> 2][4 * gg + (i & 3)]
+        return out
+
+    y = torch.zeros(C, M)
+    for h in range(heads):
+        W = wp[h].reshape(-1)
+        q = [sum(a32(W[(t * 10 + ks) * 512:(t * 10 + ks + 1) * 512]) @ a[:, 32 * ks:32 * ks + 32].t() for ks in range(10)) for t in range(3)]
+        q = [t * scale for t in q]
+        kimg, vimg = kv[img, h].reshape(-1)[:4096], kv[img, h].reshape(-1)[4096:]
+        s = []
+        for kt in range(5):
+            acc = a32(kimg[kt * 512:(kt + 1) * 512]) @ b32(q[0], q[1]) + a16(kimg[5 * 512 + kt * 256:5 * 512 + (kt + 1) * 256]) @ q[2]
+            s.append(acc)
+        S = torch.cat(s)                                        # [80 keys, M]
+        S[L:] = float("-inf")
+        P = torch.softmax(S, 0)
+        pt = [P[16 * kt:16 * kt + 16] for kt in range(5)]
+        o = []
+        for dt in range(3):
+            acc = a32(vimg[(dt * 2) * 512:(dt * 2 + 1) * 512]) @ b32(pt[0], pt[1]) + a32(vimg[(dt * 2 + 1) * 512:(dt * 2 + 2) * 512]) @ b32(pt[2], pt[3]) \
+                + a16(vimg[6 * 512 + dt * 256:6 * 512 + (dt + 1) * 256]) @ pt[4]
+            o.append(acc)
+        wo_img = W[30 * 512:]
+        for u in range(20):
+            y[16 * u:16 * u + 16] += a32(wo_img[u * 512:(u + 1) * 512]) @ b32(o[0], o[1]) + a16(wo_img[20 * 512 + u * 256:20 * 512 + (u + 1) * 256]) @ o[2]
+    # reference
+    qr = (a @ wq.t()).reshape(M, heads, dh).permute(1, 0, 2)
+    kr = K[img * Lp:img * Lp + L].reshape(L, heads, dh).permute(1, 0, 2)
+    vr = V[img * Lp:img * Lp + L].reshape(L, heads, dh).permute(1, 0, 2)
+    att = torch.softmax(qr @ kr.transpose(1, 2) * scale, -1) @ vr
+    ref = att.permute(1, 0, 2).reshape(M, C) @ wo.t()
+    assert torch.allclose(y.t(), ref, atol=2e-4, rtol=1e-4), float((y.t() - ref).abs().max())
