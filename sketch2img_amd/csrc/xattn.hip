@@ -39,6 +39,32 @@ struct XAParams {
 
 constexpr float XA_NEG = -30000.f;
 
+// A K = 16 step whose operands are 4 halves per lane.  XA_K16 = 1: v_mfma_f32_16x16x16_f16; 0 (default): the K = 32
+// instruction on zero-extended operands - slot (g, i < 4) of A meets slot (g, i) of B whatever the instruction's
+// internal k order is, the upper slots contribute 0 * 0.
+#ifndef XA_K16
+#define XA_K16 0
+#endif
+__device__ __forceinline__ float4_t mfma_k16(half4v a, half4v b, float4_t c) {
+#if XA_K16
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+#else
+  const half8_t a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, b8 = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, b8, c, 0, 0, 0);
+#endif
+}
+
+// An MFMA that starts a fresh accumulator: its operands stay live past it (the empty asm uses them), so that hipcc cannot
+// allocate the destination on top of a dying A / B fragment.  Found on the device with structured-V probes: a
+// v_mfma_f32_16x16x32_f16 whose destination overlapped its A operand, followed closely by the dependent next k-step of the same
+// accumulator, lost that next step's contribution in accumulator registers 0, 1 for part of the waves (timing dependent).
+// ffblock.hip / attention.hip have such overlaps too, but never a dependent MFMA right behind one.
+__device__ __forceinline__ float4_t mfma32_fresh(half8_t a, half8_t b, float4_t c) {
+  const float4_t d = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  asm volatile("" ::"v"(a), "v"(b));
+  return d;
+}
+
 __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
   constexpr int KS = 10, C = 320, NU = 20, PIECE = 512;
   constexpr int WQ = 0, NWQ = 30;                        // pieces
@@ -119,20 +145,29 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     const half4_t b = ld_half4(p.bo + 16 * u + 4 * g);
     y[u] = float4_t{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
   }
-  const float4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  // Fresh accumulators start from an OPAQUE zero register set, never from the inline constant 0: with C = 0 hipcc may give
+  // v_mfma_f32_16x16x32_f16 a destination that overlaps its own A operand (the LDS fragment dies there), and on gfx950 the
+  // result is then wrong for part of the K range (found with structured-V probes: keys 32..63 lost in accumulator registers
+  // 0, 1 of one tile, timing dependent).  ffblock.hip never hits the pattern - its accumulators start from bias registers.
+  auto fresh = [&]() {
+    float4_t z = {0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(z));
+    return z;
+  };
 
   for (int h = 0; h < p.heads; ++h) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();                                           // A: Wq_h and stage h landed; every wave is done with head h - 1
     // ---- Q^T = Wq_h . A^T; the next head's [K | V | Wo] is fetched under it (its stage was head h - 1's)
-    float4_t q[3] = {zero4, zero4, zero4};
+    float4_t q[3] = {fresh(), fresh(), fresh()};
     {
       const half_t* fr = smem + WQ + lane * 8;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
         for (int t = 0; t < 3; ++t)
-          q[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(fr + (t * KS + ks) * PIECE), xb[ks], q[t], 0, 0, 0);
+          q[t] = ks == 0 ? mfma32_fresh(ld_half8(fr + (t * KS + ks) * PIECE), xb[ks], q[t])
+                         : __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(fr + (t * KS + ks) * PIECE), xb[ks], q[t], 0, 0, 0);
         if (ks < 6) dma_stage(h + 1, ks);
       }
     }
@@ -148,11 +183,10 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     // ---- S^T = K_h . Q^T: 5 key tiles
     float4_t s[5];
 #pragma unroll
-    for (int kt = 0; kt < 5; ++kt) {
-      s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + KOFF + kt * PIECE + lane * 8), qb32, zero4, 0, 0, 0);
-      s[kt] = __builtin_amdgcn_mfma_f32_16x16x16f16(*reinterpret_cast<const half4v*>(st + KOFF + 5 * PIECE + kt * 256 + lane * 4),
-                                                    qb16, s[kt], 0, 0, 0);
-    }
+    for (int kt = 0; kt < 5; ++kt) s[kt] = mfma32_fresh(ld_half8(st + KOFF + kt * PIECE + lane * 8), qb32, fresh());
+#pragma unroll
+    for (int kt = 0; kt < 5; ++kt)
+      s[kt] = mfma_k16(*reinterpret_cast<const half4v*>(st + KOFF + 5 * PIECE + kt * 256 + lane * 4), qb16, s[kt]);
     dma_wq(h + 1, 0);
     dma_wq(h + 1, 1);
     // keys behind nkv are masked (lane holds keys 16 kt + 4 g + r)
@@ -192,12 +226,13 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     // ---- O^T = V_h^T . P^T: 3 tiles of d
     float4_t o[3];
 #pragma unroll
-    for (int dt = 0; dt < 3; ++dt) {
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + VOFF + (dt * 2) * PIECE + lane * 8), pb32[0], zero4, 0, 0, 0);
+    for (int dt = 0; dt < 3; ++dt) o[dt] = mfma32_fresh(ld_half8(st + VOFF + (dt * 2) * PIECE + lane * 8), pb32[0], fresh());
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
       o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + VOFF + (dt * 2 + 1) * PIECE + lane * 8), pb32[1], o[dt], 0, 0, 0);
-      o[dt] = __builtin_amdgcn_mfma_f32_16x16x16f16(*reinterpret_cast<const half4v*>(st + VOFF + 6 * PIECE + dt * 256 + lane * 4),
-                                                    pb16, o[dt], 0, 0, 0);
-    }
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+      o[dt] = mfma_k16(*reinterpret_cast<const half4v*>(st + VOFF + 6 * PIECE + dt * 256 + lane * 4), pb16, o[dt]);
     const float inv = 1.f / li;
     half8_t ob32;
     half4v ob16;
@@ -207,11 +242,10 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     for (int i = 0; i < 4; ++i) ob16[i] = (half_t)(o[2][i] * inv);
     // ---- Y^T += Wo[:, head h] . O^T
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      y[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + WOOFF + u * PIECE + lane * 8), ob32, y[u], 0, 0, 0);
-      y[u] = __builtin_amdgcn_mfma_f32_16x16x16f16(*reinterpret_cast<const half4v*>(st + WOOFF + 20 * PIECE + u * 256 + lane * 4),
-                                                   ob16, y[u], 0, 0, 0);
-    }
+    for (int u = 0; u < NU; ++u) y[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + WOOFF + u * PIECE + lane * 8), ob32, y[u], 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      y[u] = mfma_k16(*reinterpret_cast<const half4v*>(st + WOOFF + 20 * PIECE + u * 256 + lane * 4), ob16, y[u]);
   }
 
   // ---- epilogue (as ffblock.hip): residual added in fp32, the tile through the wave's own slice of the idle LDS, whole-row stores
