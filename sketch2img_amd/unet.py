@@ -33,6 +33,7 @@ _GN_FROM_PRODUCER = os.environ.get("SKG_GN_PRODUCER", "1") != "0"      # A/B swi
 _GEGLU_KEEP = os.environ.get("SKG_GEGLU_KEEP", "1") != "0"
 _GN_CONCAT = os.environ.get("SKG_GN_CONCAT", "1") != "0"
 _FF_BLOCK = os.environ.get("SKG_FF_BLOCK", "1") != "0"              # fused feed-forward sub-block at C = 320 (csrc/ffblock.hip)
+_XATTN_BLOCK = os.environ.get("SKG_XATTN_BLOCK", "1") != "0"        # fused cross-attention sub-block at C = 320, 8 heads (csrc/xattn.hip)
 _FF_KEEP = os.environ.get("SKG_FF_KEEP", "1") != "0"                # ... also for the cond rows of a guided step (stashing launch)
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
@@ -262,6 +263,13 @@ class HipUNet:
                 W[k[:-len("weight")] + "bias"] = _h(sd[k[:-len("weight")] + "bias"][idx], dev)
                 if bw:
                     W[k + ":T"] = _h(sd[k][idx].t(), dev)
+        # 64 x 64 level of SD1.5 (C = 320, 8 heads of 40): norm2 -> to_q -> text attention -> to_out + residual as ONE row-local
+        # launch for the rows nobody differentiates (csrc/xattn.hip); the per-prompt K / V packs are made in prepare_context
+        heads320 = cfg.num_heads[list(cfg.block_out_channels).index(320)] if 320 in cfg.block_out_channels else None
+        for k in list(sd.keys()):
+            if k.endswith(".attn2.to_q.weight") and sd[k].shape == (320, 320) and heads320 == 8:
+                t = k[: -len(".to_q.weight")]
+                W[t + ".xpack"] = pack_xattn_weights(sd[k], sd[t + ".to_out.0.weight"], 8, dev)
         # 64 x 64 level (C = 320): the whole feed-forward sub-block as ONE row-local launch (csrc/ffblock.hip)
         for k in list(sd.keys()):
             if k.endswith(".ff.net.0.proj.weight") and sd[k].shape[1] == 320 and sd[k].shape[0] // 2 <= 1280:
@@ -338,6 +346,8 @@ class HipUNet:
                 Kc = ops.gemm(x, wk)                     # padded token rows are exactly zero (zero input, no bias)
                 Vc = ops.gemm(x, wv)
                 ctx["blocks"][p] = dict(K=Kc, V=Vc)
+                if (p + ".xpack") in W and L <= 80:
+                    ctx["blocks"][p]["kvpack"] = pack_xattn_kv(Kc, Vc, rows, Lp, L, 8)
         self.ctx = ctx
 
     # ------------------------------------------------------------------ modules, forward
@@ -414,18 +424,29 @@ class HipUNet:
                     x, p1, shared = x_full, p1_full, False
                 p1 = self.inject(t, p1, rows, HW, heads)
             p1_c = p1
-        a2, st2 = ops.layernorm(p1, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
-        q2_full = torch.empty(rows * HW, C, device=x.device, dtype=torch.float16) if shared else None
-        q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"], q2_full[M1:] if shared else None)
-        q2_c = q2
-        if shared:      # the text-dependent part needs both halves: one copy each into the uncond half
-            ops.batch_copy(p1, M1, p1_full, M1, 1, M1)
-            ops.batch_copy(q2, M1, q2_full, M1, 1, M1)
-            x, p1, q2 = x_full, p1_full, q2_full
         cb = self.ctx["blocks"][t + ".attn2"]
-        o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
-                                want_lse=True, v_rows=True)
-        p2 = ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], bias=W[t + ".attn2.to_out.0.bias"], residual=p1)
+        xab = _XATTN_BLOCK and not keep and "kvpack" in cb and heads == 8 and HW % 128 == 0
+        if xab:
+            # no backward will follow: norm2 -> to_q -> attention over the text keys -> to_out + residual in ONE row-local launch
+            # (skg_xattn_block_f16); the text-dependent part needs both halves, so a shared front ends here
+            if shared:
+                ops.batch_copy(p1, M1, p1_full, M1, 1, M1)
+                x, p1, shared = x_full, p1_full, False
+            p2 = ops.xattn_block(p1, HW, heads, self.ctx["L"], W[t + ".norm2.weight"], W[t + ".norm2.bias"], 1e-5,
+                                 W[t + ".attn2.xpack"], cb["kvpack"], W[t + ".attn2.to_out.0.bias"], scale)
+            st2 = q2 = q2_c = o2 = lse2 = None                # (only a stash would read them, and there is none)
+        else:
+            a2, st2 = ops.layernorm(p1, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
+            q2_full = torch.empty(rows * HW, C, device=x.device, dtype=torch.float16) if shared else None
+            q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"], q2_full[M1:] if shared else None)
+            q2_c = q2
+            if shared:      # the text-dependent part needs both halves: one copy each into the uncond half
+                ops.batch_copy(p1, M1, p1_full, M1, 1, M1)
+                ops.batch_copy(q2, M1, q2_full, M1, 1, M1)
+                x, p1, q2 = x_full, p1_full, q2_full
+            o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
+                                    want_lse=True, v_rows=True)
+            p2 = ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], bias=W[t + ".attn2.to_out.0.bias"], residual=p1)
         ffb = _FF_BLOCK and (t + ".ff.pack") in W and (not keep or rows % 2 == 0)
         st3_half = False
         if ffb:

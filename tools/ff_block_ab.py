@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--samples", type=int, default=8)
     ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--switch", default="_FF_BLOCK", help="the unet module switch to A/B (_FF_BLOCK, _XATTN_BLOCK, _FF_KEEP)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg, h, S, T = SD15, 64, a.samples, 50
@@ -35,7 +36,7 @@ def main():
     sampler = HipSampler(net, lgp)
 
     def run(i, on):
-        unet_mod._FF_BLOCK = on
+        setattr(unet_mod, a.switch, on)
         sampler.reset_history()
         x, _, aux = sampler.step(x0.clone(), x0.clone(), tgt if i <= 0.5 * T else None, tab, i, 7.5, 1.6)
         return x, aux
@@ -47,7 +48,7 @@ def main():
         torch.cuda.synchronize()
         xa, xb = res[False][0].float(), res[True][0].float()
         rel = float((xa - xb).norm() / xa.norm())
-        print(f"{name}: x_prev fused vs three-launch rel {rel:.3e} max {float((xa - xb).abs().max()):.3e} finite {bool(torch.isfinite(xb).all())}")
+        print(f"[{a.switch}] {name}: x_prev fused vs three-launch rel {rel:.3e} max {float((xa - xb).abs().max()):.3e} finite {bool(torch.isfinite(xb).all())}")
         if res[True][1] is not None:
             print("   aux (|grad| stats, loss) three-launch", res[False][1][0].tolist(), "\n   aux fused", res[True][1][0].tolist())
         times = {False: [], True: []}
