@@ -265,6 +265,7 @@ class HipUNet:
                     W[k + ":T"] = _h(sd[k][idx].t(), dev)
         # 64 x 64 level of SD1.5 (C = 320, 8 heads of 40): norm2 -> to_q -> text attention -> to_out + residual as ONE row-local
         # launch for the rows nobody differentiates (csrc/xattn.hip); the per-prompt K / V packs are made in prepare_context
+        cfg = self.cfg
         heads320 = cfg.num_heads[list(cfg.block_out_channels).index(320)] if 320 in cfg.block_out_channels else None
         for k in list(sd.keys()):
             if k.endswith(".attn2.to_q.weight") and sd[k].shape == (320, 320) and heads320 == 8:

@@ -510,3 +510,18 @@ def test_xattn_packs_reproduce_cross_attention():
     att = torch.softmax(qr @ kr.transpose(1, 2) * scale, -1) @ vr
     ref = att.permute(1, 0, 2).reshape(M, C) @ wo.t()
     assert torch.allclose(y.t(), ref, atol=2e-4, rtol=1e-4), float((y.t() - ref).abs().max())
+
+
+def test_unet_pack_stage_runs_on_cpu_and_builds_the_fused_block_packs():
+    """HipUNet's weight-pack stage is host code: run it on the CPU for the full SD1.5 layout (no kernel is launched) - the five
+    C = 320 transformer blocks get the fragment-major packs of the fused feed-forward and cross-attention launches."""
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import SD15
+    from sketch2img_amd.unet import HipUNet
+    net = HipUNet(SD15, synthetic.unet_state_dict(SD15), "cpu", need_backward=False)
+    xp = sorted(k for k in net.W if k.endswith(".attn2.xpack"))
+    fp = sorted(k for k in net.W if k.endswith(".ff.pack"))
+    assert len(xp) == 5 and len(fp) == 5
+    assert all(net.W[k].shape == (8, 60, 512) and net.W[k].dtype == torch.float16 for k in xp)
+    assert all(net.W[k].shape == (40, 60, 512) for k in fp)
+    assert all(net.W[k[:-len("pack")] + "bias1"].shape == (40, 4, 16) for k in fp)
