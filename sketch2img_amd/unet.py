@@ -120,7 +120,8 @@ def pack_ff_block(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, dev):
     F = F2 // 2
     assert w2.shape == (C, F) and C % 32 == 0 and F % 32 == 0
     nch, KS, NU = F // 32, C // 32, C // 16
-    w1h, w2h = w1.to(torch.float16), w2.to(torch.float16)
+    # (host-side packing: the state dict may live on the device after a broadcast)
+    w1h, w2h, b1 = w1.detach().to("cpu", torch.float16), w2.detach().to("cpu", torch.float16), b1.detach().cpu()
     rows = torch.stack([w1h[:F].reshape(nch, 2, 16, C), w1h[F:].reshape(nch, 2, 16, C)], 1)     # [c, val|gate, half, l, C]
     rows = rows.reshape(nch, 4, 16, KS, 4, 8)                                                     # [c, t, l, ks, g, i]
     p1 = rows.permute(0, 1, 3, 4, 2, 5).reshape(nch, 4 * KS, 512)                                 # [c, (t, ks), (g, l, i)]
@@ -143,7 +144,7 @@ def pack_xattn_weights(wq: torch.Tensor, wo: torch.Tensor, heads: int, dev):
     dh = C // heads
     assert wq.shape == (C, C) and wo.shape == (C, C) and C == 320 and dh == 40
     KS, NU = C // 32, C // 16
-    wqh, woh = wq.to(torch.float16), wo.to(torch.float16)
+    wqh, woh = wq.detach().to("cpu", torch.float16), wo.detach().to("cpu", torch.float16)      # host-side packing
     out = []
     for h in range(heads):
         q = torch.zeros(48, C, dtype=torch.float16)
