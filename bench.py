@@ -102,7 +102,7 @@ class LaunchTimer:
     def __init__(self, ops):
         self.ops, self.rec = ops, []
         self._gemm, self._conv, self._attn, self._keep = ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep
-        self._up2, self._c4, self._ffb = ops.conv_up2, ops.conv4x4s2, ops.ff_block
+        self._up2, self._c4, self._ffb, self._xab = ops.conv_up2, ops.conv4x4s2, ops.ff_block, ops.xattn_block
 
     def __enter__(self):
         from sketch2img_amd._lib import lib
@@ -225,13 +225,25 @@ class LaunchTimer:
                              f"ff_block M{M} C{C} F{Fh} (LN + FF1 + gate + FF2 + res)" + "+keep" * (k.get("keep_from") is not None)))
             return out
 
+        def xattn_block(X, HW, heads, Nkv, *a, **k):            # norm2 + to_q + text attention + to_out + residual in one launch
+            M, C = X.shape
+            e0, e1 = ev()
+            e0.record()
+            out = self._xab(X, HW, heads, Nkv, *a, **k)
+            e1.record()
+            # algorithmic flops (unpadded head width): to_q + to_out + QK^T + PV
+            self.rec.append(("xattn_block_kernel", 4.0 * M * C * C + 4.0 * M * Nkv * C, e0, e1,
+                             2.0 * (2 * M * C + 2 * C * C + 2 * (M // HW) * Nkv * C),
+                             f"xattn_block M{M} C{C} H{heads} Nkv{Nkv} (LN + to_q + attention + to_out + res)"))
+            return out
+
         ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep = gemm, conv, attn, gemm_keep
-        ops.conv_up2, ops.conv4x4s2, ops.ff_block = conv_up2, conv4x4s2, ff_block
+        ops.conv_up2, ops.conv4x4s2, ops.ff_block, ops.xattn_block = conv_up2, conv4x4s2, ff_block, xattn_block
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm, self.ops.conv3x3, self.ops.attn_fwd, self.ops.gemm_geglu_keep = self._gemm, self._conv, self._attn, self._keep
-        self.ops.conv_up2, self.ops.conv4x4s2, self.ops.ff_block = self._up2, self._c4, self._ffb
+        self.ops.conv_up2, self.ops.conv4x4s2, self.ops.ff_block, self.ops.xattn_block = self._up2, self._c4, self._ffb, self._xab
 
     def summary(self):
         """per kernel: [launches, flops, seconds, algorithmic bytes, roofline seconds, seconds of HBM-bound launches];
@@ -269,6 +281,8 @@ def by_operator(agg):
             return "attention_fwd"
         if name.startswith("ff_block"):
             return "ff_block"
+        if name.startswith("xattn_block"):
+            return "xattn_block"
         args = name[name.index("<") + 1:-1].split(", ")
         mode = int(args[4]) if name.startswith("gemm2") else int(args[1])
         return {0: "gemm", 1: "conv3x3"}.get(mode, "conv3x3_resample")
