@@ -30,7 +30,7 @@ extern "C" {
 #define SKG_E_UNSUPPORTED (-2)
 #define SKG_E_LAUNCH (-3)    /* hipGetLastError() != hipSuccess after the launch */
 
-#define SKG_ABI_VERSION 2
+#define SKG_ABI_VERSION 3
 int skg_abi_version(void);
 /* Human-readable text of the last SKG_E_LAUNCH on this thread ("" if none). */
 const char* skg_last_error(void);
@@ -169,6 +169,25 @@ int skg_gemm_f16_hilo(const void* A, int lda, const void* B, int ldb, void* C, v
 int skg_conv3x3_f16_hilo(const void* X, int ldx, const void* Wp, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW,
                          int Cin, int Cout, int mode, const void* bias, const void* residual, const void* residual_lo,
                          int ldr, float alpha, unsigned flags, void* stream);
+/* The same launches leaving the GroupNorm partial sums of the output's hi part behind (format of skg_gemm_f16_gn /
+ * skg_conv3x3_f16_gn): from the producer's own epilogue where its tile can (256 x 320, 128 x 160), else the stand-alone pass. */
+int skg_gemm_f16_hilo_gn(const void* A, int lda, const void* B, int ldb, void* C, void* C_lo, int ldc, int M, int N, int K,
+                         const void* bias, const void* residual, const void* residual_lo, int ldr, float alpha,
+                         unsigned flags, float* gn_partial, int HW, int groups, void* stream);
+int skg_conv3x3_f16_hilo_gn(const void* X, int ldx, const void* Wp, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW,
+                            int Cin, int Cout, int mode, const void* bias, const void* residual, const void* residual_lo,
+                            int ldr, float alpha, unsigned flags, float* gn_partial, int groups, void* stream);
+/* GroupNorm(+SiLU) of a pair X + X_lo (one pitch), mirrors of skg_groupnorm_fwd (own statistics pass over the hi part; small
+ * maps: one launch on the pair's sum) and of skg_groupnorm_from_partial / _from_partial2 (partialB == NULL: one producer and
+ * groupsA == groups; else the concatenation [A (CA channels) | B]).  The reference's GroupNorm layers (diffusers ResnetBlock2D /
+ * Transformer2DModel under modules/pipeline.py:96) evaluated on the fp32-accurate stream. */
+int skg_groupnorm_fwd_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
+                           float eps, const void* gamma, const void* beta, int silu, float* stats, float* partial,
+                           void* stream);
+int skg_groupnorm_from_partial_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int rows, int HW, int C, int CA,
+                                    int groups, float eps, const void* gamma, const void* beta, int silu, float* stats,
+                                    const float* partialA, int groupsA, const float* partialB, int groupsB, int nch,
+                                    void* stream);
 /* GroupNorm(+SiLU) apply and LayerNorm of a pair (statistics [rows][groups][2] from skg_groupnorm_stats on the hi part). */
 int skg_groupnorm_apply_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int rows, int HW, int C,
                              int groups, const float* stats, const void* gamma, const void* beta, int silu,

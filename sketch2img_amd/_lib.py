@@ -20,9 +20,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SKG_LIB") or os.path.join(_HERE, "libskg.so")
 
 # include/skg.h SKG_ABI_VERSION: bumped whenever an entry point changes its signature (2: skg_attn_bwd_dq / _dkv lost
-# their transposed-operand pointers, skg_set_workspace became per stream), so that a stale build selected through
+# their transposed-operand pointers, skg_set_workspace became per stream; 3: the accuracy-mode entry points with GroupNorm
+# statistics - skg_*_hilo_gn, skg_groupnorm_fwd_hilo / _from_partial_hilo), so that a stale build selected through
 # SKG_LIB fails at load instead of receiving shifted arguments
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # spec letters: p = device/host pointer, i = int, f = float, u = unsigned, z = size_t (return only)
 SIGNATURES = {
@@ -34,6 +35,10 @@ SIGNATURES = {
     "skg_gemm_f16_rows": ("i", "pipipiiiipiip"),
     "skg_gemm_f16_hilo": ("i", "pipippiiiipppifup".replace(" ", "")),
     "skg_conv3x3_f16_hilo": ("i", "pipppiiiiiiipppifup"),
+    "skg_gemm_f16_hilo_gn": ("i", "pipippiiiipppifupiip"),
+    "skg_conv3x3_f16_hilo_gn": ("i", "pipppiiiiiiipppifupip"),
+    "skg_groupnorm_fwd_hilo": ("i", "ppipiiiiifppippp"),
+    "skg_groupnorm_from_partial_hilo": ("i", "ppipiiiiiifppippipiip"),
     "skg_groupnorm_apply_hilo": ("i", "ppipiiiiippp ip".replace(" ", "")),
     "skg_layernorm_fwd_hilo": ("i", "ppipiiippfpp"),
     "skg_gemm_f16_gn": ("i", "pipipiiiippifupiip"),

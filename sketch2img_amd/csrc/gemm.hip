@@ -460,6 +460,33 @@ extern "C" int skg_conv3x3_f16_hilo(const void* X, int ldx, const void* Wp, void
                    Y_lo, residual_lo);
 }
 
+// ... and the GroupNorm partial sums of the OUTPUT's hi part with it (what skg_groupnorm_from_partial_hilo folds): from the
+// epilogue of the kernel that runs where its tile can (256 x 320, 128 x 160), else from the stand-alone pass
+extern "C" int skg_gemm_f16_hilo_gn(const void* A, int lda, const void* B, int ldb, void* C, void* C_lo, int ldc, int M, int N,
+                                    int K, const void* bias, const void* residual, const void* residual_lo, int ldr,
+                                    float alpha, unsigned flags, float* gn_partial, int HW, int groups, void* stream) {
+  SKG_REQUIRE((C_lo || residual_lo) && !(flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) && K % 64 == 0 && ldc % 8 == 0);
+  SKG_REQUIRE(skg_aligned(C, 16) && (!C_lo || skg_aligned(C_lo, 16)) && (!residual_lo || skg_aligned(residual_lo, 16)) &&
+              (!residual || skg_aligned(residual, 16)) && ((!residual && !residual_lo) || ldr % 8 == 0));
+  SKG_REQUIRE(gn_args_ok(gn_partial, M, N, HW, groups, ldc, flags));
+  return gemm_impl(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, alpha, flags, gn_partial, HW, groups, stream, C_lo,
+                   residual_lo);
+}
+
+extern "C" int skg_conv3x3_f16_hilo_gn(const void* X, int ldx, const void* Wp, void* Y, void* Y_lo, int ldy, int rows, int IH,
+                                       int IW, int Cin, int Cout, int mode, const void* bias, const void* residual,
+                                       const void* residual_lo, int ldr, float alpha, unsigned flags, float* gn_partial,
+                                       int groups, void* stream) {
+  SKG_REQUIRE((Y_lo || residual_lo) && !(flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) && Cin % 64 == 0 && ldy % 8 == 0);
+  SKG_REQUIRE(skg_aligned(Y, 16) && (!Y_lo || skg_aligned(Y_lo, 16)) && (!residual_lo || skg_aligned(residual_lo, 16)) &&
+              (!residual || skg_aligned(residual, 16)) && ((!residual && !residual_lo) || ldr % 8 == 0));
+  const int up = (mode == SKG_CONV_UP2 || mode == SKG_CONV_S2T), dn = (mode == SKG_CONV_S2 || mode == SKG_CONV_S2A);
+  const int OH = up ? IH * 2 : dn ? IH / 2 : IH, OW = up ? IW * 2 : dn ? IW / 2 : IW;
+  SKG_REQUIRE(rows > 0 && OH > 0 && OW > 0 && gn_args_ok(gn_partial, rows * OH * OW, Cout, OH * OW, groups, ldy, flags));
+  return conv_impl(X, ldx, Wp, Y, ldy, rows, IH, IW, Cin, Cout, mode, bias, residual, ldr, alpha, flags, gn_partial, groups,
+                   stream, Y_lo, residual_lo);
+}
+
 extern "C" int skg_conv3x3_f16(const void* X, int ldx, const void* Wp, void* Y, int ldy, int rows,
                                int IH, int IW, int Cin, int Cout, int mode, const void* bias,
                                const void* residual, int ldr, float alpha, unsigned flags,

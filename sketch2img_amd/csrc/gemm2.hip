@@ -875,6 +875,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
       const half4_t r = ld_half4(p.res + m * p.ldr + n);
       v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
     }
+    if (p.res_lo) {      // accuracy mode: pair residual
+      const half4_t r = ld_half4(p.res_lo + m * p.ldr + n);
+      v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+    }
     if (p.flags & SKG_EPI_RELU) {
       v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
     }
@@ -883,6 +887,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     } else {
       half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
       st_half4(reinterpret_cast<half_t*>(p.C) + m * p.ldc + n, o);
+      if (p.c_lo) {      // accuracy mode: pair output, lo = fp16(v - hi)
+        half4_t l = {(half_t)(v[0] - (float)o[0]), (half_t)(v[1] - (float)o[1]), (half_t)(v[2] - (float)o[2]), (half_t)(v[3] - (float)o[3])};
+        st_half4(p.c_lo + m * p.ldc + n, l);
+      }
     }
   }
 }
@@ -967,7 +975,9 @@ constexpr size_t STREAM_OUT_BYTES = (size_t)32 << 20;      // the aggregate L2 (
 inline bool gn_fusable(const GemmParams& p, int mode) {
   if (!p.gn_partial || p.gn_groups <= 0 || p.gn_hw <= 0 || !eligible(p, mode)) return false;
   if (p.flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) return false;
-  const TileCfg t = pick_tile(p.M, p.N, p.K);
+  const bool hilo = p.c_lo || p.res_lo;      // accuracy mode: 128-row tiles only (launch_mode)
+  TileCfg t = pick_tile(p.M, p.N, p.K);
+  if (hilo && t.bm == 256) t = TileCfg{128, 160};
   if (t.bm != 128 || t.bn != 160) return false;
   if (p.M % 128 != 0 || p.N % 160 != 0 || p.gn_hw % 128 != 0 || p.M % p.gn_hw != 0 || p.N % p.gn_groups != 0) return false;
   const int cpg = p.N / p.gn_groups;
@@ -994,13 +1004,6 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
   int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU) && !p.up2 && !p.seg_rows) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4, p.ws, p.ws_bytes) : 1;
   constexpr int NTHR = WGM * WGN * 64;
-  if constexpr (BM == 128) {
-    if (p.c_lo || p.res_lo) {      // accuracy mode: one instantiation per tile, two stages, no split-K, no statistics
-      hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 2, false, true>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n,
-                         ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
-      return;
-    }
-  }
   if (BM == 128 && BN == 160 && splits == 1 && gn_fusable(p, MODE)) p.flags |= SKG_FLAG_GN_STATS;
   // XCDs per K slice: all 8 without split-K; 8 / ns when the slices line up with XCD boundaries
   const int ns_eff = splits > 1 ? skg_cdiv(KT, skg_cdiv(KT, splits)) : 1;
@@ -1028,20 +1031,26 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
                        (const float*)p.ws, ns);
     return;
   }
+  // accuracy mode (p.c_lo / p.res_lo): the same decision tree on the instantiations with the hi / lo epilogue (split-K launches
+  // above: the slabs are raw accumulators, the pair epilogue is splitk_reduce_kernel's)
+  const bool hilo = p.c_lo || p.res_lo;
+  constexpr bool HILO_OK = BM == 128 && (MODE == MODE_DIRECT || MODE == MODE_S1 || MODE == MODE_S2 || MODE == MODE_UP2);
+  const bool gns = (p.flags & SKG_FLAG_GN_STATS) != 0;
+#define G2_LAUNCH(NS_, GNS_, HILO_)                                                                                            \
+  hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, NS_, GNS_, HILO_>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles, \
+                     (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr)
   // three stages: the 128 x 160 tile when the launch has at most one workgroup per CU anyway (110 KB of LDS), the
   // 128 x 64 tile always (74 KB: two workgroups per CU still fit)
   if constexpr (BM == 128 && (BN == 160 || BN == 64) && (MODE == MODE_DIRECT || MODE == MODE_S1)) {
     static const bool off = getenv("SKG_NO_NS3") != nullptr;        // A/B switch (tools/gemm_bench.py)
     if (!off && KT >= 4 && (BN == 64 || ntiles <= 256)) {
       if constexpr (BN == 160) {
-        if (p.flags & SKG_FLAG_GN_STATS) {
-          hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 3, true>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n,
-                             ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
+        if (gns) {
+          if (hilo) G2_LAUNCH(3, true, true); else G2_LAUNCH(3, true, false);
           return;
         }
       }
-      hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 3>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles,
-                         (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
+      if (hilo) G2_LAUNCH(3, false, true); else G2_LAUNCH(3, false, false);
       return;
     }
   }
@@ -1053,13 +1062,19 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
     return;
   }
 #endif
-  if constexpr (BM == 128 && BN == 160) {
-    if (p.flags & SKG_FLAG_GN_STATS) {
-      hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 2, true>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n,
-                         ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
+  if constexpr (HILO_OK) {
+    if (hilo) {
+      if constexpr (BN == 160 && MODE != MODE_UP2) {
+        if (gns) { G2_LAUNCH(2, true, true); return; }
+      }
+      G2_LAUNCH(2, false, true);
       return;
     }
   }
+  if constexpr (BM == 128 && BN == 160) {
+    if (gns) { G2_LAUNCH(2, true, false); return; }
+  }
+#undef G2_LAUNCH
   hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles, NTHR)), dim3(NTHR), 0, st,
                      p, tiles_n, ntiles, (unsigned)a, (unsigned)b, (unsigned)s, KT, (float*)nullptr);
 }
@@ -1109,7 +1124,8 @@ bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
        p.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 || p.M % (p.OH * p.OW) != 0))
     return false;
   if ((p.c_lo || p.res_lo) &&
-      ((p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) || p.gn_partial || p.aux || p.ldc % 8 != 0 ||
+      ((p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) || p.aux || p.ldc % 8 != 0 ||
+       (mode != MODE_DIRECT && mode != MODE_S1 && mode != MODE_S2 && mode != MODE_UP2) || (mode == MODE_UP2 && p.gn_partial) ||
        (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 || (p.c_lo && (reinterpret_cast<uintptr_t>(p.c_lo) & 15) != 0) ||
        ((p.res || p.res_lo) && p.ldr % 8 != 0) || (p.res && (reinterpret_cast<uintptr_t>(p.res) & 15) != 0) ||
        (p.res_lo && (reinterpret_cast<uintptr_t>(p.res_lo) & 15) != 0)))

@@ -43,7 +43,9 @@ __device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); 
 
 // EXP: probe builds (SKG_G8_EXP; compute on stale / missing data, timing only): 1 = no DMA in the loop, 2 = no
 // fragment reads in the loop, 4 = no priority raise, 8 = no stagger between the two groups
-template <int BN, int MODE, int EXP = 0, bool GNS = false>
+// HILO: the accuracy-mode epilogue (skg_*_hilo): the residual is the pair p.res + p.res_lo, the output the pair
+// hi = fp16(v) -> p.C, lo = fp16(v - hi) -> p.c_lo (same leading dimensions); statistics (GNS) are those of hi
+template <int BN, int MODE, int EXP = 0, bool GNS = false, bool HILO = false>
 __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int tiles_n, int nwg, unsigned a_bytes,
                                                         unsigned b_bytes, unsigned a_shift) {
   constexpr int NS = BN == 160 ? 3 : 2;            // LDS stages
@@ -266,46 +268,61 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
   float gs[NT][2][2];
 #pragma unroll
   for (int j = 0; j < NT; ++j) gs[j][0][0] = gs[j][0][1] = gs[j][1][0] = gs[j][1][1] = 0.f;
+  constexpr int RG = HILO ? 2 : 4;      // 16-row groups per pass (pair residual: twice the registers per group)
 #pragma unroll
-  for (int i0 = 0; i0 < MT; i0 += 4) {
-    if (p.res) {
-      half4_t rv[4][NT];
+  for (int i0 = 0; i0 < MT; i0 += RG) {
+    if (p.res) {      // (HILO: the launcher takes the launch only when p.res and p.res_lo are both there or both absent)
+      half4_t rv[RG][NT], rl[RG][NT];
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii) {
+      for (int ii = 0; ii < RG; ++ii) {
         const int m = min(mrow + (i0 + ii) * 16, p.M - 1);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) rv[ii][j] = ld_half4(p.res + (size_t)m * p.ldr + n0 + wn * WN + j * 16 + g * 4);
+        for (int j = 0; j < NT; ++j) {
+          const size_t off = (size_t)m * p.ldr + n0 + wn * WN + j * 16 + g * 4;
+          rv[ii][j] = ld_half4(p.res + off);
+          if (HILO) rl[ii][j] = ld_half4(p.res_lo + off);
+        }
       }
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
+      for (int ii = 0; ii < RG; ++ii)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const half4_t r = rv[ii][j];
           acc[i0 + ii][j] = (acc[i0 + ii][j] + bv[j]) * p.alpha + float4_t{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+          if (HILO) {
+            const half4_t l = rl[ii][j];
+            acc[i0 + ii][j] += float4_t{(float)l[0], (float)l[1], (float)l[2], (float)l[3]};
+          }
         }
     } else {
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
+      for (int ii = 0; ii < RG; ++ii)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i0 + ii][j] = (acc[i0 + ii][j] + bv[j]) * p.alpha;
     }
     if (relu) {
 #pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
+      for (int ii = 0; ii < RG; ++ii)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[i0 + ii][j][e] = fmaxf(acc[i0 + ii][j][e], 0.f);
     }
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
+    for (int ii = 0; ii < RG; ++ii) {
       const int m = mrow + (i0 + ii) * 16;
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const float4_t v = acc[i0 + ii][j];
         const half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-        st_half4(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n0 + wn * WN + j * 16 + g * 4, o);
+        const size_t off = (size_t)m * p.ldc + n0 + wn * WN + j * 16 + g * 4;
+        st_half4(reinterpret_cast<half_t*>(p.C) + off, o);
+        if (HILO) {
+          const half4_t lo = {(half_t)(v[0] - (float)o[0]), (half_t)(v[1] - (float)o[1]), (half_t)(v[2] - (float)o[2]),
+                              (half_t)(v[3] - (float)o[3])};
+          st_half4(p.c_lo + off, lo);
+        }
         if (gn) {
           typedef _Float16 h2 __attribute__((ext_vector_type(2)));
           const h2 one = {(_Float16)1.f, (_Float16)1.f}, lo = {o[0], o[1]}, hi = {o[2], o[3]};
@@ -380,7 +397,8 @@ int gemm8_tile(const GemmParams& p, int mode) {
   if (p.K % BK != 0 || p.K < 2 * BK || p.M < 1) return 0;
   if (mode == MODE_S1 && p.Cin % BK != 0) return 0;
   if (p.flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) return 0;
-  if (p.c_lo || p.res_lo) return 0;      // accuracy mode: gemm2.hip's hi / lo epilogue
+  const bool hilo = p.c_lo || p.res_lo;      // accuracy mode: the 256 x 320 tile has the hi / lo epilogue, the rest is gemm2.hip's
+  if (hilo && (mode != MODE_S1 || !p.c_lo || (p.res != nullptr) != (p.res_lo != nullptr))) return 0;
   if (p.ntaps || p.up2 || p.seg_rows) return 0;        // polyphase upsample / segmented rows: gemm2.hip's tap walk / row map
   if (p.ldc % 4 != 0 || (p.res && p.ldr % 4 != 0)) return 0;
   unsigned long long a, b, s;
@@ -392,7 +410,7 @@ int gemm8_tile(const GemmParams& p, int mode) {
     const long t = tm * (p.N / 320);
     if (t >= 224 && (t <= 256 || t >= 480)) return 320;
   }
-  if (md == 1 && p.N % 160 == 0 && tm * (p.N / 160) >= 224) return 160;
+  if (md == 1 && !hilo && p.N % 160 == 0 && tm * (p.N / 160) >= 224) return 160;
   return 0;
 }
 
@@ -438,6 +456,15 @@ void launch8(const GemmParams& p_in, int mode, hipStream_t st) {
 #endif
       default:
         if constexpr (BN == 320) {
+          if (p.c_lo || p.res_lo) {      // accuracy mode
+            if (p.flags & SKG_FLAG_GN_STATS)
+              hipLaunchKernelGGL((gemm8_kernel<BN, MODE_S1, 0, true, true>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles,
+                                 (unsigned)a, (unsigned)b, (unsigned)s);
+            else
+              hipLaunchKernelGGL((gemm8_kernel<BN, MODE_S1, 0, false, true>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles,
+                                 (unsigned)a, (unsigned)b, (unsigned)s);
+            break;
+          }
           if (p.flags & SKG_FLAG_GN_STATS) {
             hipLaunchKernelGGL((gemm8_kernel<BN, MODE_S1, 0, true>), dim3(ntiles), dim3(NTHR), 0, st, p, tiles_n, ntiles,
                                (unsigned)a, (unsigned)b, (unsigned)s);

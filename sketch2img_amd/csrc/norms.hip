@@ -4,6 +4,7 @@
 // on global memory, so results do not depend on workgroup scheduling).
 #include "common.h"
 #include "gemm_params.h"
+#include <type_traits>
 
 namespace {
 
@@ -166,8 +167,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // fixed-order fold into LDS; chunk 0 also publishes (mean, rstd) for the backward pass) - this removes the separate
 // finalize launch (4.7 us of an otherwise ~15-40 us GroupNorm).
 struct GnSrc { const float* partialB; int split, unused, ratioA, ratioB; };
-template <bool FOLD>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ X, int ldx,
+// HILO (accuracy mode, include/skg.h): the input is the PAIR X + Xl of fp16 tensors with one pitch (what the hi / lo epilogues
+// of gemm2.hip / gemm8.hip write); the statistics are those of the hi part (the producer's epilogue sums, or gn_partial_kernel
+// on X): the mean of >= 640 rounding errors of relative size 2^-12 is far below fp32 resolution.
+template <bool FOLD, bool HILO = false>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ X, const half_t* __restrict__ Xl, int ldx,
                                                        half_t* __restrict__ Y, int ldy, int HW, int C, int groups,
                                                        const float* __restrict__ stats,
                                                        const half_t* __restrict__ gamma,
@@ -234,18 +238,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
       sh[j] = (float)bv[j] - (lo ? mlo : mhi) * a[j];
     }
     const half_t* xp = X + ((size_t)b * HW) * ldx + c0;
+    const half_t* lp = HILO ? Xl + ((size_t)b * HW) * ldx + c0 : nullptr;
     half_t* yp = Y + ((size_t)b * HW) * ldy + c0;
     int p = p0 + pl;
-    for (; p + 3 * P < p1; p += 4 * P) {
-      half8_t xv[4];
+    constexpr int U = HILO ? 2 : 4;      // independent pixels per iteration: four 16-byte loads in flight either way
+    for (; p + (U - 1) * P < p1; p += U * P) {
+      half8_t xv[U], lv[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) xv[u] = ld_half8(xp + (size_t)(p + u * P) * ldx);
+      for (int u = 0; u < U; ++u) {
+        xv[u] = ld_half8(xp + (size_t)(p + u * P) * ldx);
+        if (HILO) lv[u] = ld_half8(lp + (size_t)(p + u * P) * ldx);
+      }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         half8_t o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float v = fmaf((float)xv[u][j], a[j], sh[j]);
+          float v = fmaf(HILO ? (float)xv[u][j] + (float)lv[u][j] : (float)xv[u][j], a[j], sh[j]);
           if (silu) v = silu_f(v);
           o[j] = (half_t)v;
         }
@@ -254,10 +263,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     }
     for (; p < p1; p += P) {
       const half8_t xv = ld_half8(xp + (size_t)p * ldx);
+      const half8_t lv = HILO ? ld_half8(lp + (size_t)p * ldx) : zero_half8();
       half8_t o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        float v = fmaf((float)xv[j], a[j], sh[j]);
+        float v = fmaf(HILO ? (float)xv[j] + (float)lv[j] : (float)xv[j], a[j], sh[j]);
         if (silu) v = silu_f(v);
         o[j] = (half_t)v;
       }
@@ -332,9 +342,9 @@ constexpr int LN_MAXP = 4;   // 16-byte pieces per lane -> C <= 2048
 
 // NQ 16-byte pieces per lane cover a row (C <= NQ*512), RW rows per wave are processed together so that NQ*RW = 4
 // independent loads are in flight per lane (one load per lane caps a streaming kernel at ~4 TB/s, see gn_apply_kernel)
-template <int NQ, int RW>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const half_t* __restrict__ X, int ldx, half_t* __restrict__ Y,
-                                                     int ldy, int M, int C, const half_t* __restrict__ gamma,
+template <int NQ, int RW, bool HILO = false>      // HILO: the input is the pair X + Xl (accuracy mode)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const half_t* __restrict__ X, const half_t* __restrict__ Xl, int ldx,
+                                                     half_t* __restrict__ Y, int ldy, int M, int C, const half_t* __restrict__ gamma,
                                                      const half_t* __restrict__ beta, float eps,
                                                      float* __restrict__ stats) {
   const int lane = threadIdx.x & 63;
@@ -349,10 +359,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const half_t* __restrict__ 
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int pc = lane + q * 64;
-      half8_t x = zero_half8();
-      if (pc < C8 && row0 + r < M) x = ld_half8(X + (size_t)(row0 + r) * ldx + pc * 8);
+      half8_t x = zero_half8(), xl = zero_half8();
+      if (pc < C8 && row0 + r < M) {
+        x = ld_half8(X + (size_t)(row0 + r) * ldx + pc * 8);
+        if (HILO) xl = ld_half8(Xl + (size_t)(row0 + r) * ldx + pc * 8);
+      }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { v[r][q][j] = (float)x[j]; s[r] += v[r][q][j]; }
+      for (int j = 0; j < 8; ++j) { v[r][q][j] = HILO ? (float)x[j] + (float)xl[j] : (float)x[j]; s[r] += v[r][q][j]; }
     }
   }
   float mean[RW], rstd[RW];
@@ -466,26 +479,41 @@ extern "C" int skg_groupnorm_stats(const void* X, int ldx, int rows, int HW, int
   return SKG_OK;
 }
 
-extern "C" int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C,
-                                   int groups, const float* stats, const void* gamma, const void* beta,
-                                   int silu, void* stream) {
+static int gn_apply_impl(const void* X, const void* Xl, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
+                         const float* stats, const void* gamma, const void* beta, int silu, void* stream) {
   SKG_REQUIRE(X && Y && stats && gamma && beta && rows > 0 && HW > 0);
   SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
   SKG_REQUIRE((C / groups) >= 4 && C <= GN_MAX_C);      // an 8-channel piece spans at most two groups
-  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
-  hipLaunchKernelGGL((gn_apply_kernel<false>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, groups, stats, (const half_t*)gamma,
-                     (const half_t*)beta, silu, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16) && skg_aligned(Xl, 16));
+#define SKG_GN_APPLY(H)                                                                                                       \
+  hipLaunchKernelGGL((gn_apply_kernel<false, H>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,      \
+                     (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, ldy, HW, C, groups, stats, (const half_t*)gamma,   \
+                     (const half_t*)beta, silu, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr)
+  if (Xl) SKG_GN_APPLY(true); else SKG_GN_APPLY(false);
+#undef SKG_GN_APPLY
   SKG_CHECK_LAUNCH("skg_groupnorm_apply");
   return SKG_OK;
+}
+
+extern "C" int skg_groupnorm_apply(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C,
+                                   int groups, const float* stats, const void* gamma, const void* beta,
+                                   int silu, void* stream) {
+  return gn_apply_impl(X, nullptr, ldx, Y, ldy, rows, HW, C, groups, stats, gamma, beta, silu, stream);
+}
+
+extern "C" int skg_groupnorm_apply_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int rows, int HW, int C,
+                                        int groups, const float* stats, const void* gamma, const void* beta, int silu,
+                                        void* stream) {
+  SKG_REQUIRE(X_lo);
+  return gn_apply_impl(X, X_lo, ldx, Y, ldy, rows, HW, C, groups, stats, gamma, beta, silu, stream);
 }
 
 // Small maps (16x16 / 8x8 levels): ONE workgroup per (row, group) keeps the group's whole slice in registers - X is
 // read once, mean and the CENTRED variance come from two block reductions, the statistics are published for the
 // backward pass.  The chunked path is launch-latency bound there (two launches, 14-20 us for 2.6-10 MB).
-template <int NP>   // 16-byte pieces per thread
-__global__ __launch_bounds__(256) void gn_small_kernel(const half_t* __restrict__ X, int ldx, half_t* __restrict__ Y,
-                                                       int ldy, int HW, int C, int groups,
+template <int NP, bool HILO = false>   // 16-byte pieces per thread; HILO: the input is the pair X + Xl (see gn_apply_kernel)
+__global__ __launch_bounds__(256) void gn_small_kernel(const half_t* __restrict__ X, const half_t* __restrict__ Xl, int ldx,
+                                                       half_t* __restrict__ Y, int ldy, int HW, int C, int groups,
                                                        const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
                                                        int silu, float eps, float* __restrict__ stats) {
   __shared__ float red[8];
@@ -494,7 +522,9 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const half_t* __restrict_
   const int npieces = HW * ppp;
   const half_t* xb = X + (size_t)row * HW * ldx + g * cpg;
   half_t* yb = Y + (size_t)row * HW * ldy + g * cpg;
-  half8_t v[NP];
+  typedef float float8_t __attribute__((ext_vector_type(8)));
+  typedef typename std::conditional<HILO, float8_t, half8_t>::type val8_t;      // the pair's sum needs fp32 registers
+  val8_t v[NP];
   int off[NP];                                             // pixel * ld is recomputed for the store; keep (px, pc)
   float s = 0.f;
 #pragma unroll
@@ -502,9 +532,14 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const half_t* __restrict_
     const int pi = tid + k * 256;
     const int px = pi / ppp, pc = pi - px * ppp;
     off[k] = pi < npieces ? (px << 8) | pc : -1;           // ppp <= 255
-    v[k] = pi < npieces ? ld_half8(xb + (size_t)px * ldx + pc * 8) : zero_half8();
+    const half8_t h = pi < npieces ? ld_half8(xb + (size_t)px * ldx + pc * 8) : zero_half8();
+    const half8_t l = (HILO && pi < npieces) ? ld_half8(Xl + (size_t)row * HW * ldx + g * cpg + (size_t)px * ldx + pc * 8) : zero_half8();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += (float)v[k][j];
+    for (int j = 0; j < 8; ++j) {
+      if constexpr (HILO) v[k][j] = (float)h[j] + (float)l[j];
+      else v[k][j] = h[j];
+      s += (float)v[k][j];
+    }
   }
   const float inv_n = 1.f / ((float)HW * cpg);
   const float mean = block_sum<256>(s, red) * inv_n;
@@ -587,25 +622,27 @@ __global__ __launch_bounds__(256) void gn_bwd_small_kernel(
   }
 }
 
-extern "C" int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
-                                 float eps, const void* gamma, const void* beta, int silu, float* stats,
-                                 float* partial, void* stream) {
+static int gn_fwd_impl(const void* X, const void* Xl, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
+                       float eps, const void* gamma, const void* beta, int silu, float* stats, float* partial, void* stream) {
   SKG_REQUIRE(X && Y && stats && partial && gamma && beta && rows > 0 && HW > 0 && groups > 0 && groups <= 64);
   SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && (C / groups) % 2 == 0 && (C / groups) >= 4 && C <= GN_MAX_C);
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
-  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16) && skg_aligned(Xl, 16));
   hipStream_t st = (hipStream_t)stream;
   const int cpg = C / groups;
   if (cpg % 8 == 0 && (cpg >> 3) <= 255 && (long)HW * (cpg >> 3) <= 2560) {      // the slice fits 256 threads' registers
     const int np = skg_cdiv(HW * (cpg >> 3), 256);
     const dim3 grid(groups, rows);
-#define SKG_GN_SMALL(NP)                                                                                          \
-    hipLaunchKernelGGL((gn_small_kernel<NP>), grid, dim3(256), 0, st, (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, \
-                       groups, (const half_t*)gamma, (const half_t*)beta, silu, eps, stats)
-    if (np <= 2) SKG_GN_SMALL(2);
-    else if (np <= 3) SKG_GN_SMALL(3);
-    else if (np <= 5) SKG_GN_SMALL(5);
-    else SKG_GN_SMALL(10);
+#define SKG_GN_SMALL(NP, H)                                                                                                    \
+    hipLaunchKernelGGL((gn_small_kernel<NP, H>), grid, dim3(256), 0, st, (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, \
+                       ldy, HW, C, groups, (const half_t*)gamma, (const half_t*)beta, silu, eps, stats)
+#define SKG_GN_SMALL_NP(H)                \
+    if (np <= 2) SKG_GN_SMALL(2, H);      \
+    else if (np <= 3) SKG_GN_SMALL(3, H); \
+    else if (np <= 5) SKG_GN_SMALL(5, H); \
+    else SKG_GN_SMALL(10, H)
+    if (Xl) { SKG_GN_SMALL_NP(true); } else { SKG_GN_SMALL_NP(false); }
+#undef SKG_GN_SMALL_NP
 #undef SKG_GN_SMALL
     SKG_CHECK_LAUNCH("skg_groupnorm_fwd (small)");
     return SKG_OK;
@@ -614,12 +651,29 @@ extern "C" int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int r
   hipLaunchKernelGGL((gn_partial_kernel<0>), dim3(nch, rows), dim3(256), 0, st, (const half_t*)X, ldx,
                      (const half_t*)nullptr, 0, HW, C, groups, (const float*)nullptr, (const half_t*)nullptr,
                      (const half_t*)nullptr, 0, partial);
-  hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, st,
-                     (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, groups, (const float*)nullptr,
-                     (const half_t*)gamma, (const half_t*)beta, silu, (const float*)partial, nch,
-                     1.f / ((float)HW * (C / groups)), eps, stats);
+#define SKG_GN_FOLD(H)                                                                                                \
+  hipLaunchKernelGGL((gn_apply_kernel<true, H>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, st,               \
+                     (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, ldy, HW, C, groups, (const float*)nullptr, \
+                     (const half_t*)gamma, (const half_t*)beta, silu, (const float*)partial, nch,                    \
+                     1.f / ((float)HW * (C / groups)), eps, stats)
+  if (Xl) SKG_GN_FOLD(true); else SKG_GN_FOLD(false);
+#undef SKG_GN_FOLD
   SKG_CHECK_LAUNCH("skg_groupnorm_fwd");
   return SKG_OK;
+}
+
+extern "C" int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
+                                 float eps, const void* gamma, const void* beta, int silu, float* stats,
+                                 float* partial, void* stream) {
+  return gn_fwd_impl(X, nullptr, ldx, Y, ldy, rows, HW, C, groups, eps, gamma, beta, silu, stats, partial, stream);
+}
+
+// accuracy mode: GroupNorm(+SiLU) of the pair X + X_lo (one pitch) in one or two launches, statistics published
+extern "C" int skg_groupnorm_fwd_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int rows, int HW, int C,
+                                      int groups, float eps, const void* gamma, const void* beta, int silu, float* stats,
+                                      float* partial, void* stream) {
+  SKG_REQUIRE(X_lo);
+  return gn_fwd_impl(X, X_lo, ldx, Y, ldy, rows, HW, C, groups, eps, gamma, beta, silu, stats, partial, stream);
 }
 
 // the statistics pass alone, nch chunks per sample (the fallback behind skg_gemm_f16_gn / skg_conv3x3_f16_gn when the
@@ -632,46 +686,63 @@ void skg_gn_partial_launch(const half_t* X, int ldx, int rows, int HW, int C, in
 
 // GroupNorm forward from partial sums somebody else produced (a producer epilogue: skg_gemm_f16_gn, skg_conv3x3_f16_gn):
 // one launch - the apply kernel folds the nch chunk partials per (row, group) itself and publishes (mean, rstd).
-extern "C" int skg_groupnorm_from_partial(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
-                                          float eps, const void* gamma, const void* beta, int silu, float* stats,
-                                          const float* partial, int nch, void* stream) {
-  SKG_REQUIRE(X && Y && stats && partial && gamma && beta && rows > 0 && HW > 0 && groups > 0 && groups <= 64);
+// partialB != NULL: GroupNorm of a concatenation [A (CA channels) | B (C - CA channels)] whose halves were written by two
+// producers that each left partial sums behind (groupsA / groupsB groups per chunk over their own channels).  The
+// concatenation's group width must be a multiple of both source group widths and CA a multiple of it (e.g. 320 + 320 or
+// 640 + 640 channels with 32 groups each way: two source groups per output group); otherwise SKG_E_UNSUPPORTED.
+static int gn_from_partial_impl(const void* X, const void* Xl, int ldx, void* Y, int ldy, int rows, int HW, int C, int CA,
+                                int groups, float eps, const void* gamma, const void* beta, int silu, float* stats,
+                                const float* partialA, int groupsA, const float* partialB, int groupsB, int nch,
+                                void* stream) {
+  SKG_REQUIRE(X && Y && stats && partialA && gamma && beta && rows > 0 && HW > 0 && groups > 0 && groups <= 64);
   SKG_REQUIRE(nch > 0 && nch <= GN_MAX_CHUNKS);
   SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && (C / groups) % 2 == 0 && (C / groups) >= 4 && C <= GN_MAX_C);
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
-  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
-  hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, groups, (const float*)nullptr,
-                     (const half_t*)gamma, (const half_t*)beta, silu, partial, nch,
-                     1.f / ((float)HW * (C / groups)), eps, stats);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16) && skg_aligned(Xl, 16));
+  const int cpg = C / groups;
+  GnSrc src{nullptr, 0, 0, 1, 1};
+  if (partialB) {
+    SKG_REQUIRE(CA > 0 && CA < C && groupsA > 0 && groupsB > 0);
+    const int CB = C - CA;
+    if (CA % cpg != 0 || CA % groupsA != 0 || CB % groupsB != 0) return SKG_E_UNSUPPORTED;
+    const int cpgA = CA / groupsA, cpgB = CB / groupsB;
+    if (cpg % cpgA != 0 || cpg % cpgB != 0) return SKG_E_UNSUPPORTED;
+    src = GnSrc{partialB, CA / cpg, 0, cpg / cpgA, cpg / cpgB};
+  }
+#define SKG_GN_FOLD(H)                                                                                                          \
+  hipLaunchKernelGGL((gn_apply_kernel<true, H>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,        \
+                     (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, ldy, HW, C, groups, (const float*)nullptr,           \
+                     (const half_t*)gamma, (const half_t*)beta, silu, partialA, nch, 1.f / ((float)HW * cpg), eps, stats, src)
+  if (Xl) SKG_GN_FOLD(true); else SKG_GN_FOLD(false);
+#undef SKG_GN_FOLD
   SKG_CHECK_LAUNCH("skg_groupnorm_from_partial");
   return SKG_OK;
 }
 
-// GroupNorm of a concatenation [A (CA channels) | B (C - CA channels)] whose halves were written by two producers that
-// each left partial sums behind (groupsA / groupsB groups per chunk over their own channels).  The concatenation's group
-// width must be a multiple of both source group widths and CA a multiple of it (e.g. 320 + 320 or 640 + 640 channels with
-// 32 groups each way: two source groups per output group); otherwise SKG_E_UNSUPPORTED - run the stand-alone pass.
+extern "C" int skg_groupnorm_from_partial(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
+                                          float eps, const void* gamma, const void* beta, int silu, float* stats,
+                                          const float* partial, int nch, void* stream) {
+  return gn_from_partial_impl(X, nullptr, ldx, Y, ldy, rows, HW, C, 0, groups, eps, gamma, beta, silu, stats, partial, groups,
+                              nullptr, 0, nch, stream);
+}
+
 extern "C" int skg_groupnorm_from_partial2(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int CA,
                                            int groups, float eps, const void* gamma, const void* beta, int silu,
                                            float* stats, const float* partialA, int groupsA, const float* partialB,
                                            int groupsB, int nch, void* stream) {
-  SKG_REQUIRE(X && Y && stats && partialA && partialB && gamma && beta && rows > 0 && HW > 0 && groups > 0 && groups <= 64);
-  SKG_REQUIRE(nch > 0 && nch <= GN_MAX_CHUNKS && CA > 0 && CA < C && groupsA > 0 && groupsB > 0);
-  SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && (C / groups) % 2 == 0 && (C / groups) >= 4 && C <= GN_MAX_C);
-  SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
-  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
-  const int cpg = C / groups, CB = C - CA;
-  if (CA % cpg != 0 || CA % groupsA != 0 || CB % groupsB != 0) return SKG_E_UNSUPPORTED;
-  const int cpgA = CA / groupsA, cpgB = CB / groupsB;
-  if (cpg % cpgA != 0 || cpg % cpgB != 0) return SKG_E_UNSUPPORTED;
-  const GnSrc src{partialB, CA / cpg, 0, cpg / cpgA, cpg / cpgB};
-  hipLaunchKernelGGL((gn_apply_kernel<true>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)X, ldx, (half_t*)Y, ldy, HW, C, groups, (const float*)nullptr,
-                     (const half_t*)gamma, (const half_t*)beta, silu, partialA, nch,
-                     1.f / ((float)HW * cpg), eps, stats, src);
-  SKG_CHECK_LAUNCH("skg_groupnorm_from_partial2");
-  return SKG_OK;
+  SKG_REQUIRE(partialB);
+  return gn_from_partial_impl(X, nullptr, ldx, Y, ldy, rows, HW, C, CA, groups, eps, gamma, beta, silu, stats, partialA, groupsA,
+                              partialB, groupsB, nch, stream);
+}
+
+// accuracy mode: the same for a pair X + X_lo (partialB == NULL: one producer; else the concatenation form)
+extern "C" int skg_groupnorm_from_partial_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int rows, int HW,
+                                               int C, int CA, int groups, float eps, const void* gamma, const void* beta,
+                                               int silu, float* stats, const float* partialA, int groupsA,
+                                               const float* partialB, int groupsB, int nch, void* stream) {
+  SKG_REQUIRE(X_lo && (partialB || groupsA == groups));
+  return gn_from_partial_impl(X, X_lo, ldx, Y, ldy, rows, HW, C, CA, groups, eps, gamma, beta, silu, stats, partialA, groupsA,
+                              partialB, groupsB, nch, stream);
 }
 
 extern "C" int skg_groupnorm_bwd(const void* X, int ldx, const void* dY, int lddy, void* dX, int lddx,
@@ -715,21 +786,39 @@ extern "C" int skg_groupnorm_bwd(const void* X, int ldx, const void* dY, int ldd
   return SKG_OK;
 }
 
-extern "C" int skg_layernorm_fwd(const void* X, int ldx, void* Y, int ldy, int M, int C, const void* gamma,
-                                 const void* beta, float eps, float* stats, void* stream) {
+static int ln_fwd_impl(const void* X, const void* Xl, int ldx, void* Y, int ldy, int M, int C, const void* gamma,
+                       const void* beta, float eps, float* stats, void* stream) {
   SKG_REQUIRE(X && Y && gamma && beta && M > 0 && C % 8 == 0 && C <= LN_MAXP * 64 * 8);
-  SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && skg_aligned(X, 16) && skg_aligned(Y, 16) &&
+  SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(Xl, 16) &&
               skg_aligned(gamma, 16) && skg_aligned(beta, 16));
   hipStream_t st = (hipStream_t)stream;
-  const half_t *x = (const half_t*)X, *g = (const half_t*)gamma, *b = (const half_t*)beta;
-  if (C <= 512)
-    hipLaunchKernelGGL((ln_fwd_kernel<1, 4>), dim3(skg_cdiv(M, 16)), dim3(256), 0, st, x, ldx, (half_t*)Y, ldy, M, C, g, b, eps, stats);
-  else if (C <= 1024)
-    hipLaunchKernelGGL((ln_fwd_kernel<2, 2>), dim3(skg_cdiv(M, 8)), dim3(256), 0, st, x, ldx, (half_t*)Y, ldy, M, C, g, b, eps, stats);
-  else
-    hipLaunchKernelGGL((ln_fwd_kernel<LN_MAXP, 1>), dim3(skg_cdiv(M, 4)), dim3(256), 0, st, x, ldx, (half_t*)Y, ldy, M, C, g, b, eps, stats);
+  const half_t *x = (const half_t*)X, *xl = (const half_t*)Xl, *g = (const half_t*)gamma, *b = (const half_t*)beta;
+  // RW rows per wave so that four independent 16-byte loads are in flight per lane (pair input: two tensors per row)
+#define SKG_LN(NQ, RW, H) \
+  hipLaunchKernelGGL((ln_fwd_kernel<NQ, RW, H>), dim3(skg_cdiv(M, 4 * RW)), dim3(256), 0, st, x, xl, ldx, (half_t*)Y, ldy, M, C, g, b, eps, stats)
+  if (Xl) {
+    if (C <= 512) SKG_LN(1, 2, true);
+    else if (C <= 1024) SKG_LN(2, 1, true);
+    else SKG_LN(LN_MAXP, 1, true);
+  } else {
+    if (C <= 512) SKG_LN(1, 4, false);
+    else if (C <= 1024) SKG_LN(2, 2, false);
+    else SKG_LN(LN_MAXP, 1, false);
+  }
+#undef SKG_LN
   SKG_CHECK_LAUNCH("skg_layernorm_fwd");
   return SKG_OK;
+}
+
+extern "C" int skg_layernorm_fwd(const void* X, int ldx, void* Y, int ldy, int M, int C, const void* gamma,
+                                 const void* beta, float eps, float* stats, void* stream) {
+  return ln_fwd_impl(X, nullptr, ldx, Y, ldy, M, C, gamma, beta, eps, stats, stream);
+}
+
+extern "C" int skg_layernorm_fwd_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int M, int C,
+                                      const void* gamma, const void* beta, float eps, float* stats, void* stream) {
+  SKG_REQUIRE(X_lo);
+  return ln_fwd_impl(X, X_lo, ldx, Y, ldy, M, C, gamma, beta, eps, stats, stream);
 }
 
 extern "C" int skg_layernorm_bwd(const void* X, int ldx, const void* dY, int lddy, void* dX, int lddx,

@@ -140,15 +140,28 @@ class HipInjector:
             self.per_image[path] = dict(K=kv[:, :C], V=kv[:, C:], rows=rows, N=hh * ww)
 
     # ---- per UNet evaluation ------------------------------------------------------------------------------
-    def __call__(self, path: str, h: torch.Tensor, rows: int, N: int, heads: int, cond_only: bool = False,
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """cond_only (sketch variant, halves_equal): h holds the cond rows only (rows // 2 of them); K / V of the cond half."""
+    def __call__(self, path: str, h, rows: int, N: int, heads: int, cond_only: bool = False, out=None):
+        """cond_only (sketch variant, halves_equal): h holds the cond rows only (rows // 2 of them); K / V of the cond half.
+        h (and out) may be ops.Pair objects - HipUNet's accuracy mode: the stream enters sketch_norm as hi + lo and the scaled
+        injection is added to the pair in fp32 (the result is a pair again)."""
+        pair = isinstance(h, ops.Pair)
         pi = self.per_image.get(path)
         if pi is None:
             if out is not None:
-                ops.batch_copy(h, h.shape[0], out, h.shape[0], 1, h.shape[0])
+                for src, dst in ((h.hi, out.hi), (h.lo, out.lo)) if pair else ((h, out),):
+                    ops.batch_copy(src, src.shape[0], dst, src.shape[0], 1, src.shape[0])
                 return out
             return h
+        if pair:
+            hp, h = h, h.hi
+            res = out or ops.Pair.empty(h.shape[0], h.shape[1], self.dev)
+            norm = lambda g, b: ops.layernorm_hilo(hp.hi, hp.lo, g, b)
+            # h + scale * conv1x1(o) in fp32 on the pair
+            last = lambda o, wc, bc: (ops.gemm(o, wc, out=res.hi, out_lo=res.lo, bias=bc, residual=hp.hi, residual_lo=hp.lo,
+                                               alpha=self.scale), res)[1]
+        else:
+            norm = lambda g, b: ops.layernorm(h, g, b)
+            last = lambda o, wc, bc: ops.gemm(o, wc, out, bias=bc, residual=h, alpha=self.scale)
         w = self.W[path]
         C = w["C"]
         dh = C // heads
@@ -160,11 +173,11 @@ class HipInjector:
                 assert self.halves_equal
                 r = rows // 2
                 K, V = K[r * N:], V[r * N:]
-            z = ops.layernorm(h, w["ng"], w["nb"])
+            z = norm(w["ng"], w["nb"])
             q = ops.gemm(z, w["wq"])
             a = ops.attn_fwd(q, K, V, r, heads, N, N, N, dh, scale, v_rows=True)
             o = ops.gemm(a, w["wo"], bias=w["bo"])
-            return ops.gemm(o, w["wc"], out, bias=w["bc"], residual=h, alpha=self.scale)
+            return last(o, w["wc"], w["bc"])
         # CLIP variant: self-attention of the N image-token queries over [N image tokens ; T sketch tokens]
         assert pi["rows"] == rows
         T = pi["T"]
@@ -174,7 +187,7 @@ class HipInjector:
             kvbuf = torch.zeros(rows * L, 2 * C, device=self.dev, dtype=torch.float16)
             ops.batch_copy(pi["kvs"], T, kvbuf[N:], L, rows, T)     # K / V of the normalised sketch tokens, once per image
             pi["bufs"][N] = kvbuf
-        zh = ops.layernorm(h, w["ng"], w["nb"])
+        zh = norm(w["ng"], w["nb"])
         # K / V of the image tokens go to rows [b L, b L + N) of the [rows * L, 2C] buffer (the sketch tokens sit behind them).
         # Large maps: one GEMM per batch row straight into place (each launch fills the chip).  Small maps - a batch row is
         # under 256 tiles of 128 x 160 - : ONE GEMM over all rows for q, k and v into a dense buffer + one strided copy of the
@@ -193,4 +206,4 @@ class HipInjector:
                     ops.gemm(zh[b * N:(b + 1) * N], w["wkv"], out=kvbuf[b * L:b * L + N])
         a = ops.attn_fwd(q, kvbuf[:, :C], kvbuf[:, C:], rows, heads, N, N + T, L, dh, scale, v_rows=True)
         o = ops.gemm(a, w["wo"], bias=w["bo"])
-        return ops.gemm(o, w["wc"], bias=w["bc"], residual=h, alpha=self.scale)
+        return last(o, w["wc"], w["bc"])

@@ -36,8 +36,9 @@ from .latent_predictor import LatentEdgePredictor, hook_unet
 class UNetFacade:
     """Stands where ``pipe.unet`` is: the attributes app.py / the reference pipeline touch, plus the engine."""
 
-    def __init__(self, cfg: UNetConfig, state_dict, device):
+    def __init__(self, cfg: UNetConfig, state_dict, device, residual_fp32: bool = False):
         self.cfg = cfg
+        self.residual_fp32 = bool(residual_fp32)      # HipUNet's accuracy mode (see AntiGradientPipeline.from_pretrained)
         self.config = SimpleNamespace(sample_size=cfg.sample_size, in_channels=cfg.in_channels,
                                       cross_attention_dim=cfg.cross_attention_dim)
         self.in_channels = cfg.in_channels
@@ -65,7 +66,7 @@ class UNetFacade:
             if self._device.type != "cuda":
                 raise RuntimeError("sketch2img_amd computes on the GPU only: call pipe.to('cuda') first")
             from ..unet import HipUNet
-            self._hip = HipUNet(self.cfg, self._state_dict, self._device)
+            self._hip = HipUNet(self.cfg, self._state_dict, self._device, residual_fp32=self.residual_fp32)
         return self._hip
 
     def state_dict(self):
@@ -194,11 +195,19 @@ class AntiGradientPipeline:
     # ------------------------------------------------------------------ construction (app.py:32-46,67-70)
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path=None, vae=None, torch_dtype=None, scheduler=None,
-                        text_encoder=None, unet_config: Optional[UNetConfig] = None, synthetic: bool = False, **kwargs):
+                        text_encoder=None, unet_config: Optional[UNetConfig] = None, synthetic: bool = False,
+                        residual_fp32: bool = False, **kwargs):
         """``pretrained_model_name_or_path``: a local diffusers-layout folder (``unet/``, optionally ``tokenizer/`` +
         ``text_encoder/``).  ``None`` or ``synthetic=True`` is the explicit opt-in to seeded synthetic UNet weights and
         seeded pseudo text embeddings (boxes without checkpoints, tests, bench.py); any other path that does not
-        resolve to weights raises FileNotFoundError instead of sampling noise from random weights."""
+        resolve to weights raises FileNotFoundError instead of sampling noise from random weights.
+
+        ``residual_fp32=True`` (also reachable as ``torch_dtype=torch.float32``, what a caller who wants the fp32 reference's
+        numbers passes to the reference, app.py:34 being ``torch.float16``): the UNet keeps its residual stream and the
+        convolution outputs that feed a norm as (hi, lo) fp16 pairs - max eps deviation from the fp32 reference <= 1e-3
+        (north_star's bound; the all-fp16 default, like the reference's own fp16 GPU path, is ~1.7e-3 away).  Works with
+        ``setup_lgp`` guidance and with both SatMixin injections."""
+        residual_fp32 = bool(residual_fp32) or torch_dtype == torch.float32
         root = pretrained_model_name_or_path
         synthetic = synthetic or root is None
         cfg = unet_config or _config_from_folder(root)
@@ -207,8 +216,8 @@ class AntiGradientPipeline:
                 and os.path.isdir(os.path.join(root, "text_encoder")):
             from ..clip_text import PromptEncoder
             text_encoder = PromptEncoder.from_pretrained(root)
-        return cls(UNetFacade(cfg, sd, "cpu"), vae=vae, scheduler=scheduler, text_encoder=text_encoder,
-                   allow_pseudo_text=synthetic)
+        return cls(UNetFacade(cfg, sd, "cpu", residual_fp32=residual_fp32), vae=vae, scheduler=scheduler,
+                   text_encoder=text_encoder, allow_pseudo_text=synthetic)
 
     def to(self, device):
         self.unet.to(device)

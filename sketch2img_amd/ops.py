@@ -108,6 +108,20 @@ class GNPartial:
         self.buf = torch.empty(rows * self.nch * groups * 2, device=dev, dtype=torch.float32)
 
 
+class Pair:
+    """Accuracy mode: a tensor kept as (hi, lo) fp16 views with one pitch, value = hi + lo; `full` = the [M, 2C] tensor
+    [hi | lo] when the two are its halves (then the pair is directly a K-doubled matmul operand)."""
+    __slots__ = ("hi", "lo", "full")
+
+    def __init__(self, hi, lo, full=None):
+        self.hi, self.lo, self.full = hi, lo, full
+
+    @staticmethod
+    def empty(M: int, C: int, dev) -> "Pair":
+        buf = torch.empty(M, 2 * C, device=dev, dtype=torch.float16)
+        return Pair(buf[:, :C], buf[:, C:], buf)
+
+
 def gn_fusable(M: int, N: int, HW: int, groups: int) -> bool:
     """Shapes the `gn_stats=` form of gemm / conv3x3 accepts (whole 128-row chunks per sample, even group width)."""
     return (HW % 128 == 0 and HW // 128 <= 128 and M % HW == 0 and N % groups == 0 and N % 8 == 0 and
@@ -136,10 +150,17 @@ def gemm(A: torch.Tensor, B: torch.Tensor, out: Optional[torch.Tensor] = None, *
     N = B.shape[0]
     assert B.shape[1] == K
     if out_lo is not None or residual_lo is not None:
-        assert out is not None and not (out_f32 or geglu) and gn_stats is None
+        assert out is not None and not (out_f32 or geglu)
         assert out_lo is None or _ld(out_lo) == _ld(out)
         assert residual_lo is None or residual is None or _ld(residual_lo) == _ld(residual)
         r_any = residual if residual is not None else residual_lo
+        if gn_stats is not None:      # the partial sums of the output's hi part come with it
+            HW, groups = gn_stats
+            part = GNPartial(M // HW, HW, groups, A.device)
+            check(lib.skg_gemm_f16_hilo_gn(_p(A), _ld(A), _p(B), _ld(B), _p(out), _p(out_lo), _ld(out), M, N, K, _p(bias),
+                                           _p(residual), _p(residual_lo), _ld(r_any) if r_any is not None else 0, alpha,
+                                           EPI_RELU if relu else 0, _p(part.buf), HW, groups, _stream()), "skg_gemm_f16_hilo_gn")
+            return out, part
         check(lib.skg_gemm_f16_hilo(_p(A), _ld(A), _p(B), _ld(B), _p(out), _p(out_lo), _ld(out), M, N, K, _p(bias),
                                     _p(residual), _p(residual_lo), _ld(r_any) if r_any is not None else 0, alpha,
                                     EPI_RELU if relu else 0, _stream()), "skg_gemm_f16_hilo")
@@ -230,9 +251,16 @@ def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode
     if out is None:
         out = torch.empty(rows * OH * OW, Cout, device=X.device, dtype=torch.float16)
     if out_lo is not None or residual_lo is not None:
-        assert gn_groups is None and (out_lo is None or _ld(out_lo) == _ld(out))
+        assert out_lo is None or _ld(out_lo) == _ld(out)
         assert residual_lo is None or residual is None or _ld(residual_lo) == _ld(residual)
         r_any = residual if residual is not None else residual_lo
+        if gn_groups is not None:
+            part = GNPartial(rows, OH * OW, gn_groups, X.device)
+            check(lib.skg_conv3x3_f16_hilo_gn(_p(X), _ld(X), _p(Wp), _p(out), _p(out_lo), _ld(out), rows, IH, IW, Cin, Cout, mode,
+                                              _p(bias), _p(residual), _p(residual_lo), _ld(r_any) if r_any is not None else 0,
+                                              alpha, EPI_RELU if relu else 0, _p(part.buf), gn_groups, _stream()),
+                  "skg_conv3x3_f16_hilo_gn")
+            return out, part
         check(lib.skg_conv3x3_f16_hilo(_p(X), _ld(X), _p(Wp), _p(out), _p(out_lo), _ld(out), rows, IH, IW, Cin, Cout, mode,
                                        _p(bias), _p(residual), _p(residual_lo), _ld(r_any) if r_any is not None else 0,
                                        alpha, EPI_RELU if relu else 0, _stream()), "skg_conv3x3_f16_hilo")
@@ -360,16 +388,27 @@ def groupnorm(X, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, parti
     return out, st
 
 
-def groupnorm_hilo(X, X_lo, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, want_stats=False):
-    """GroupNorm(+SiLU) of the pair X + X_lo (accuracy mode): statistics from the hi part, apply on the sum."""
+def groupnorm_hilo(X, X_lo, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, want_stats=False, partial=None):
+    """GroupNorm(+SiLU) of the pair X + X_lo (accuracy mode): statistics from the hi part (the producer's epilogue sums when
+    `partial` - a GNPartial, or (GNPartial of A, channels of A, GNPartial of B) for a concatenation - is given, else an own
+    pass; small maps: one launch on the pair's sum), apply on the sum."""
     _f16(X, X_lo, gamma, beta)
     assert _ld(X) == _ld(X_lo)
     C = X.shape[1]
-    st = groupnorm_stats(X, rows, HW, groups, eps)
     if out is None:
         out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
-    check(lib.skg_groupnorm_apply_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _ld(out), rows, HW, C, groups, _p(st), _p(gamma),
-                                       _p(beta), int(silu), _stream()), "skg_groupnorm_apply_hilo")
+    st = torch.empty(rows, groups, 2, device=X.device, dtype=torch.float32)
+    if partial is not None:
+        pa, CA, pb = partial if isinstance(partial, tuple) else (partial, 0, None)
+        assert pa.rows == rows and pa.nch == HW // 128 and (pb is not None or pa.groups == groups)
+        check(lib.skg_groupnorm_from_partial_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _ld(out), rows, HW, C, CA, groups, eps,
+                                                  _p(gamma), _p(beta), int(silu), _p(st), _p(pa.buf), pa.groups,
+                                                  None if pb is None else _p(pb.buf), 0 if pb is None else pb.groups, pa.nch,
+                                                  _stream()), "skg_groupnorm_from_partial_hilo")
+    else:
+        check(lib.skg_groupnorm_fwd_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _ld(out), rows, HW, C, groups, eps, _p(gamma),
+                                         _p(beta), int(silu), _p(st), _p(_gn_scratch(rows, groups, X.device)), _stream()),
+              "skg_groupnorm_fwd_hilo")
     return (out, st) if want_stats else out
 
 

@@ -549,8 +549,8 @@ class HipUNet:
         assert self.ctx is not None and self.ctx["rows"] == rows, "call prepare_context first"
         self.prepare_timesteps([t])
         if self.residual_fp32:
-            assert not down_only and self.inject is None, "accuracy mode: the plain UNet (with or without a stash)"
-            return self._forward_hp(x32, t, rows, H, want_taps, want_eps, stash, on_taps)
+            assert not down_only, "accuracy mode: the whole UNet (with or without a stash, with or without an injector)"
+            return self._forward_hp(x32, t, rows, H, want_taps, want_eps, stash, on_taps, shared_input)
         if stash is not None:
             stash.misc.update(rows=rows, H=H)
         tb = self.tbias[int(t)]
@@ -708,32 +708,33 @@ class HipUNet:
 
 
     # ------------------------------------------------------------------ accuracy mode (residual_fp32)
-    class _Pair:
-        """(hi, lo) views with one pitch; `full` = the [M, 2C] tensor [hi | lo] when the two are its halves."""
-        __slots__ = ("hi", "lo", "full")
+    _Pair = ops.Pair      # (hi, lo) views with one pitch; `full` = the [M, 2C] tensor [hi | lo] when the two are its halves
 
-        def __init__(self, hi, lo, full=None):
-            self.hi, self.lo, self.full = hi, lo, full
+    def _pair(self, M: int, C: int) -> ops.Pair:
+        return ops.Pair.empty(M, C, self.dev)
 
-    def _pair(self, M: int, C: int) -> "HipUNet._Pair":
-        buf = torch.empty(M, 2 * C, device=self.dev, dtype=torch.float16)
-        return HipUNet._Pair(buf[:, :C], buf[:, C:], buf)
-
-    def _gn_hp(self, x, rows, HW, eps, name, silu):
-        """-> (normalised fp16 tensor, statistics [rows, groups, 2])"""
+    def _gn_hp(self, x, rows, HW, eps, name, silu, partial=None):
+        """-> (normalised fp16 tensor, statistics [rows, groups, 2]); partial: the producer's epilogue sums (see ops.groupnorm_hilo)"""
         return ops.groupnorm_hilo(x.hi, x.lo, rows, HW, self.cfg.norm_groups, eps, self.W[name + ".weight"],
-                                  self.W[name + ".bias"], silu, want_stats=True)
+                                  self.W[name + ".bias"], silu, want_stats=True, partial=partial)
 
-    def _res_fwd_hp(self, p, x, rows, H, tb, out=None, full_of=None, stash=None):
+    def _res_fwd_hp(self, p, x, rows, H, tb, out=None, full_of=None, stash=None, xpart=None, want_part=False, half=False):
+        """As _res_fwd on pairs.  Returns (out pair, GroupNorm partial sums of out or None)."""
         W = self.W
+        G = self.cfg.norm_groups
         HW, M = H * H, rows * H * H
         Cout = W[p + ".conv1.weight"].shape[0]
-        n1, st1 = self._gn_hp(x, rows, HW, 1e-5, p + ".norm1", True)
+        n1, st1 = self._gn_hp(x, rows, HW, 1e-5, p + ".norm1", True, partial=xpart)
         h1 = self._pair(M, Cout)                                    # conv1 output feeds norm2: kept as a pair ("lin_n")
-        ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p])
-        n2, st2 = self._gn_hp(h1, rows, HW, 1e-5, p + ".norm2", True)
+        fuse = self._gn_from_producer(rows, HW, Cout)
+        part1 = None
+        if fuse:
+            _, part1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p], gn_groups=G)
+        else:
+            ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p])
+        n2, st2 = self._gn_hp(h1, rows, HW, 1e-5, p + ".norm2", True, partial=part1)
         if stash is not None:      # the backward differentiates the fp16 (hi) values, as in the default mode
-            stash.res[p] = dict(x=x.hi, st1=st1, h1=h1.hi, st2=st2, H=H, half=False)
+            stash.res[p] = dict(x=x.hi, st1=st1, h1=h1.hi, st2=st2, H=H, half=half)
         if (p + ".conv_shortcut.weight") in W:
             sc = self._pair(M, Cout)                                 # the stream as a matmul operand: [hi | lo] . [W | W]
             xf = x.full if x.full is not None else full_of(x, x.hi.shape[1])
@@ -741,11 +742,17 @@ class HipUNet:
         else:
             sc = x
         out = out or self._pair(M, Cout)
-        ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
-                    residual=sc.hi, residual_lo=sc.lo)
-        return out
+        opart = None
+        if want_part and fuse:
+            _, opart = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
+                                   residual=sc.hi, residual_lo=sc.lo, gn_groups=G)
+        else:
+            ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
+                        residual=sc.hi, residual_lo=sc.lo)
+        return out, opart
 
-    def _tr_fwd_hp(self, p, x, rows, H, heads, out=None, stash=None):
+    def _tr_fwd_hp(self, p, x, rows, H, heads, out=None, stash=None, xpart=None, want_part=False, shared=False, x_full=None):
+        """As _tr_fwd on pairs (shared / x_full: the shared CFG front, see _tr_fwd: x holds the cond rows only)."""
         W = self.W
         HW, M = H * H, rows * H * H
         C = x.hi.shape[1]
@@ -753,18 +760,41 @@ class HipUNet:
         scale = dh ** -0.5
         t = p + ".transformer_blocks.0"
         keep = stash is not None
-        g, gst = self._gn_hp(x, rows, HW, 1e-6, p + ".norm", False)
-        pin = self._pair(M, C)
+        r1 = rows // 2 if shared else rows
+        M1 = r1 * HW
+        g, gst = self._gn_hp(x, r1, HW, 1e-6, p + ".norm", False, partial=xpart)
+        pin = self._pair(M1, C)
         ops.gemm(g, W[p + ".proj_in.weight"], out=pin.hi, out_lo=pin.lo, bias=W[p + ".proj_in.bias"])
         a1, st1 = ops.layernorm_hilo(pin.hi, pin.lo, W[t + ".norm1.weight"], W[t + ".norm1.bias"], want_stats=True)
         qkv = ops.gemm(a1, W[t + ".attn1.qkv"])
-        o1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], rows, heads, HW, HW, HW, dh, scale,
+        o1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], r1, heads, HW, HW, HW, dh, scale,
                                 want_lse=True, v_rows=True)
-        p1 = self._pair(M, C)
+        P = HipUNet._Pair
+        p1_full = self._pair(M, C) if shared else None
+        p1 = P(p1_full.hi[M1:], p1_full.lo[M1:], p1_full.full[M1:]) if shared else self._pair(M, C)
         ops.gemm(o1, W[t + ".attn1.to_out.0.weight"], out=p1.hi, out_lo=p1.lo, bias=W[t + ".attn1.to_out.0.bias"],
                  residual=pin.hi, residual_lo=pin.lo)
+        x_c, p1_c = x, p1
+        if self.inject is not None:
+            if shared and getattr(self.inject, "halves_equal", False):
+                nf = self._pair(M, C)
+                p1 = self.inject(t, p1, rows, HW, heads, cond_only=True, out=P(nf.hi[M1:], nf.lo[M1:], nf.full[M1:]))
+                p1_full = nf
+            else:
+                if shared:                                    # the injected K / V differ between the halves: diverge here
+                    ops.batch_copy(p1.full, M1, p1_full.full, M1, 1, M1)
+                    x, p1, shared = x_full, p1_full, False
+                p1 = self.inject(t, p1, rows, HW, heads)
+            p1_c = p1
+        r2 = rows // 2 if shared else rows
         a2, st2 = ops.layernorm_hilo(p1.hi, p1.lo, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
-        q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"])
+        q2_full = torch.empty(M, C, device=self.dev, dtype=torch.float16) if shared else None
+        q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"], q2_full[M1:] if shared else None)
+        q2_c = q2
+        if shared:      # the text-dependent part needs both halves: one copy each into the uncond half
+            ops.batch_copy(p1.full, M1, p1_full.full, M1, 1, M1)
+            ops.batch_copy(q2, M1, q2_full, M1, 1, M1)
+            x, p1, q2 = x_full, p1_full, q2_full
         cb = self.ctx["blocks"][t + ".attn2"]
         o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
                                 want_lse=True, v_rows=True)
@@ -785,26 +815,39 @@ class HipUNet:
             gg = ops.geglu(ff, interleaved=True)
             f = ff[(rows // 2) * HW:]
         if keep:
-            stash.tr[p] = dict(x=x.hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1.hi, st2=st2, q2=q2,
-                               o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=())
+            # half: the tensors of the text-independent part hold the cond rows only (as _tr_fwd stashes them)
+            half = ("x", "gst", "pin", "st1", "qkv", "o1", "lse1", "p1", "st2", "q2") if r1 != rows else ()
+            if r1 != rows and self.inject is None:
+                stash.tr[p] = dict(x=x_c.hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1_c.hi, st2=st2, q2=q2_c,
+                                   o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=half)
+            else:
+                stash.tr[p] = dict(x=x.hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1.hi, st2=st2, q2=q2,
+                                   o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=())
         p3 = self._pair(M, C)
         ops.gemm(gg, W[t + ".ff.net.2.weight"], out=p3.hi, out_lo=p3.lo, bias=W[t + ".ff.net.2.bias"],
                  residual=p2.hi, residual_lo=p2.lo)
         out = out or self._pair(M, C)
-        ops.gemm(p3.full, W[p + ".proj_out.weight:2"], out=out.hi, out_lo=out.lo, bias=W[p + ".proj_out.bias"],
-                 residual=x.hi, residual_lo=x.lo)
-        return out
+        opart = None
+        if want_part and self._gn_from_producer(rows, HW, C):
+            _, opart = ops.gemm(p3.full, W[p + ".proj_out.weight:2"], out=out.hi, out_lo=out.lo, bias=W[p + ".proj_out.bias"],
+                                residual=x.hi, residual_lo=x.lo, gn_stats=(HW, self.cfg.norm_groups))
+        else:
+            ops.gemm(p3.full, W[p + ".proj_out.weight:2"], out=out.hi, out_lo=out.lo, bias=W[p + ".proj_out.bias"],
+                     residual=x.hi, residual_lo=x.lo)
+        return out, opart
 
-    def _forward_hp(self, x32, t, rows, H, want_taps, want_eps, stash=None, on_taps=None):
+    def _forward_hp(self, x32, t, rows, H, want_taps, want_eps, stash=None, on_taps=None, shared_input=False):
         """The forward of forward() with the residual stream as (hi, lo) pairs; the same graph, the same kernels for every
-        contraction, pair-aware epilogues / norms (skg_*_hilo).  Concatenations [h | skip] are pair buffers
-        [h_hi | skip_hi | h_lo | skip_lo], filled in place by their producers."""
+        contraction, pair-aware epilogues / norms (skg_*_hilo), the same GroupNorm statistics from the producers' epilogues and
+        the same shared CFG front.  Concatenations [h | skip] are pair buffers [h_hi | skip_hi | h_lo | skip_lo], filled in
+        place by their producers."""
         cfg, W = self.cfg, self.W
         if stash is not None:
             stash.misc.update(rows=rows, H=H)
         tb = self.tbias[int(t)]
         boc = cfg.block_out_channels
         nb = len(boc)
+        G = cfg.norm_groups
         lpb1 = cfg.layers_per_block + 1
         rev = list(reversed(boc))
         n_skips = 1 + sum(cfg.layers_per_block + (1 if i < nb - 1 else 0) for i in range(nb))
@@ -812,6 +855,7 @@ class HipUNet:
         cats: List[Optional[torch.Tensor]] = [None] * (nb * lpb1)
         P = HipUNet._Pair
         n_made = [0]
+        skip_parts: List[Optional[ops.GNPartial]] = []       # partial sums of each skip, when its producer left them
 
         def skip_slot(ch_s: int, size: int):
             """The pair view inside the concat buffer that will consume the skip produced next."""
@@ -830,51 +874,96 @@ class HipUNet:
             ops.axpby(pv.lo, None, out=buf[:, C:])
             return buf
 
-        h = skip_slot(boc[0], H)
-        ops.conv3x3(x32, W["conv_in.weight"], rows, H, H, out=h.hi, out_lo=h.lo, bias=W["conv_in.bias"])
-        taps_down = []
+        def rows_of(pv, m0, m1):
+            return P(pv.hi[m0:m1], pv.lo[m0:m1], None if pv.full is None else pv.full[m0:m1])
+
+        def conv_pair(x, wkey, bkey, size, mode, o, r=rows, want=False):
+            """conv with a pair output (+ the GroupNorm sums of its hi part where the level takes them from the producers)"""
+            osz = size // 2 if mode == ops.CONV_S2 else size
+            if want and self._gn_from_producer(r, osz * osz, o.hi.shape[1]):
+                return ops.conv3x3(x, W[wkey], r, size, size, mode, out=o.hi, out_lo=o.lo, bias=W[bkey], gn_groups=G)[1]
+            ops.conv3x3(x, W[wkey], r, size, size, mode, out=o.hi, out_lo=o.lo, bias=W[bkey])
+            return None
+
+        shared = shared_input and rows % 2 == 0 and rows >= 2 and nb > 1 and cfg.layers_per_block >= 1
         cur = H
+        taps_down = []
+        h = skip_slot(boc[0], H)
+        if shared:
+            S1, M1 = rows // 2, (rows // 2) * H * H
+            hc = rows_of(h, M1, 2 * M1)
+            hp1 = conv_pair(x32[M1:], "conv_in.weight", "conv_in.bias", H, ops.CONV_S1, hc, r=S1, want=True)
+            ops.batch_copy(hc.hi, M1, h.hi, M1, 1, M1)
+            ops.batch_copy(hc.lo, M1, h.lo, M1, 1, M1)
+            skip_parts.append(self._dup_partial(hp1))
+            x_full = self._pair(rows * H * H, boc[0])
+            h1, hp1 = self._res_fwd_hp("down_blocks.0.resnets.0", hc, S1, cur, tb, out=rows_of(x_full, M1, 2 * M1), full_of=full_of,
+                                       stash=stash, xpart=hp1, want_part=True, half=True)
+            ops.batch_copy(h1.full, M1, x_full.full, M1, 1, M1)
+            h, hp = self._tr_fwd_hp("down_blocks.0.attentions.0", h1, rows, cur, cfg.num_heads[0], out=skip_slot(boc[0], cur),
+                                    stash=stash, xpart=hp1, want_part=0 < cfg.layers_per_block - 1, shared=True, x_full=x_full)
+            skip_parts.append(hp)
+        else:
+            hp = conv_pair(x32, "conv_in.weight", "conv_in.bias", H, ops.CONV_S1, h, want=True)
+            skip_parts.append(hp)
         for i in range(nb):
             for j in range(cfg.layers_per_block):
+                if shared and i == 0 and j == 0:
+                    continue
                 if i < nb - 1:
-                    h = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, full_of=full_of, stash=stash)
-                    h = self._tr_fwd_hp(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i], out=skip_slot(boc[i], cur), stash=stash)
+                    h, hp = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, full_of=full_of, stash=stash,
+                                             xpart=hp, want_part=True)
+                    h, hp = self._tr_fwd_hp(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i],
+                                            out=skip_slot(boc[i], cur), stash=stash, xpart=hp,
+                                            want_part=j < cfg.layers_per_block - 1)
                 else:
-                    h = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, out=skip_slot(boc[i], cur),
-                                         full_of=full_of, stash=stash)
+                    h, hp = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, out=skip_slot(boc[i], cur),
+                                             full_of=full_of, stash=stash, xpart=hp, want_part=True)
+                skip_parts.append(hp)
             if i < nb - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
-                half = cur // 2
-                o = skip_slot(boc[i], half)
-                ops.conv3x3(full_of(h, boc[i]), W[p + ".weight:2"], rows, cur, cur, ops.CONV_S2, out=o.hi, out_lo=o.lo, bias=W[p + ".bias"])
+                o = skip_slot(boc[i], cur // 2)
+                hp = conv_pair(full_of(h, boc[i]), p + ".weight:2", p + ".bias", cur, ops.CONV_S2, o, want=True)
                 h = o
                 cur //= 2
+                skip_parts.append(hp)
             if i < 3:
                 taps_down.append((h.hi, cur))
-        h = self._res_fwd_hp("mid_block.resnets.0", h, rows, cur, tb, full_of=full_of, stash=stash)
+        h, hp = self._res_fwd_hp("mid_block.resnets.0", h, rows, cur, tb, full_of=full_of, stash=stash, xpart=hp, want_part=True)
         tap_r0 = (h.hi, cur)
-        h = self._tr_fwd_hp("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash=stash)
+        h, hp = self._tr_fwd_hp("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash=stash, xpart=hp, want_part=True)
         tap_at = (h.hi, cur)
         ct0 = cats[0].shape[1] // 2
-        h = self._res_fwd_hp("mid_block.resnets.1", h, rows, cur, tb, out=P(cats[0][:, :ch_h[0]], cats[0][:, ct0:ct0 + ch_h[0]]),
-                             stash=stash)
+        h, _ = self._res_fwd_hp("mid_block.resnets.1", h, rows, cur, tb, out=P(cats[0][:, :ch_h[0]], cats[0][:, ct0:ct0 + ch_h[0]]),
+                                stash=stash, xpart=hp)
         tap_r1 = (h.hi, cur)
+        hp = None
         taps_up = []
         rev_heads = tuple(reversed(cfg.num_heads))
+        last_needed = 2 if not want_eps else nb - 1
         for i in range(nb):
+            if i > last_needed:
+                break
             for j in range(lpb1):
                 u = i * lpb1 + j
                 ct = cats[u].shape[1] // 2
                 cat = P(cats[u][:, :ct], cats[u][:, ct:], cats[u])
+                sp = skip_parts.pop() if skip_parts else None
+                cpart = None
+                if _GN_CONCAT and hp is not None and sp is not None and ops.gn_concat_ok(ch_h[u], ct - ch_h[u], G, hp.groups, sp.groups):
+                    cpart = (hp, ch_h[u], sp)
                 nxt = None
                 if j < lpb1 - 1:
                     ctn = cats[u + 1].shape[1] // 2
                     nxt = P(cats[u + 1][:, :ch_h[u + 1]], cats[u + 1][:, ctn:ctn + ch_h[u + 1]])
                 if i > 0:
-                    h = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash=stash)
-                    h = self._tr_fwd_hp(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], out=nxt, stash=stash)
+                    h, hp = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash=stash, xpart=cpart, want_part=True)
+                    keepp = (want_eps and i == nb - 1 and j == lpb1 - 1) or j < lpb1 - 1
+                    h, hp = self._tr_fwd_hp(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], out=nxt, stash=stash,
+                                            xpart=hp, want_part=keepp)
                 else:
-                    h = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, out=nxt, stash=stash)
+                    h, hp = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, out=nxt, stash=stash, xpart=cpart,
+                                             want_part=j < lpb1 - 1)
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 u = (i + 1) * lpb1
@@ -883,6 +972,7 @@ class HipUNet:
                 ops.conv3x3(full_of(h, h.hi.shape[1]), W[p + ".weight:2"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo,
                             bias=W[p + ".bias"])
                 h = o
+                hp = None
                 cur *= 2
             if i < 3:
                 taps_up.append((h.hi, cur))
@@ -890,7 +980,7 @@ class HipUNet:
                     on_taps(taps_down + [tap_at, tap_r0, tap_r1] + taps_up)
         eps = None
         if want_eps:
-            n, _ = self._gn_hp(h, rows, cur * cur, 1e-5, "conv_norm_out", True)
+            n, _ = self._gn_hp(h, rows, cur * cur, 1e-5, "conv_norm_out", True, partial=hp)
             eps = ops.conv3x3(n, W["conv_out.weight"], rows, cur, cur, bias=W["conv_out.bias"])
         taps = taps_down + [tap_at, tap_r0, tap_r1] + taps_up
         if stash is not None:

@@ -288,6 +288,70 @@ def test_hilo_pair_epilogue_and_norms(ops):
     assert e < 4e-4
 
 
+@pytest.mark.parametrize("kind,rows,H,Cin,Cout,res", [
+    ("conv", 16, 64, 320, 320, True),      # 256 x 320 ping-pong tile (gemm8.hip) with the pair epilogue + statistics
+    ("conv", 16, 64, 320, 320, False),
+    ("conv", 4, 32, 640, 640, True),       # 128 x 160 two-stage tile + statistics
+    ("conv", 2, 32, 640, 640, False),      # <= 256 tiles: the three-stage instantiation
+    ("conv", 2, 16, 1280, 1280, True),     # split-K: the pair epilogue lives in the reduce kernel, statistics from the stand-alone pass
+    ("conv", 2, 8, 1280, 1280, True),
+    ("down", 4, 64, 640, 320, False),      # stride 2 on a K-doubled pair operand
+    ("gemm", 4, 64, 640, 320, True),       # proj_out: [hi | lo] x [W | W] + pair residual + statistics
+    ("gemm", 2, 16, 1280, 1280, True)])
+def test_hilo_producers_with_groupnorm_sums(ops, kind, rows, H, Cin, Cout, res):
+    """Accuracy mode on every instantiation the default mode uses: pair output (+ pair residual) carries fp32 accuracy
+    (hi + lo vs fp64), hi equals the plain launch's fp16 output, the GroupNorm partial sums are those of hi, and
+    groupnorm_hilo(partial=) equals torch on hi + lo."""
+    d = dev()
+    G = 32
+    mode = {"conv": ops.CONV_S1, "down": ops.CONV_S2}.get(kind)
+    OH = H // 2 if kind == "down" else H
+    M, HW = rows * OH * OH, OH * OH
+    x = (rnd(rows * H * H, Cin, seed=1).float() * 0.5).half().to(d)
+    b = rnd(Cout, seed=3).to(d)
+    rp = None
+    if res:
+        r32 = torch.randn(M, Cout, generator=torch.Generator().manual_seed(4)).to(d)
+        rp = ops.Pair.empty(M, Cout, d)
+        rp.hi.copy_(r32.half()); rp.lo.copy_((r32 - rp.hi.float()).half())
+    out = ops.Pair.empty(M, Cout, d)
+    kw = dict(bias=b, residual=rp.hi if res else None, residual_lo=rp.lo if res else None)
+    if kind == "gemm":
+        w = (rnd(Cout, Cin, seed=2).float() * Cin ** -0.5).half().to(d)
+        _, part = ops.gemm(x, w, out=out.hi, out_lo=out.lo, gn_stats=(HW, G), **kw)
+        plain = ops.gemm(x, w, bias=b, residual=rp.hi.contiguous() if res else None)
+        ref = x.double() @ w.double().t() + b.double()
+    else:
+        w4 = (torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(2)) * (9 * Cin) ** -0.5).half()
+        w = w4.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(d)
+        _, part = ops.conv3x3(x, w, rows, H, H, mode, out=out.hi, out_lo=out.lo, gn_groups=G, **kw)
+        plain = ops.conv3x3(x, w, rows, H, H, mode, bias=b, residual=rp.hi.contiguous() if res else None)
+        xs = x.double().reshape(rows, H, H, Cin).permute(0, 3, 1, 2)
+        ref = F.conv2d(xs, w4.double().to(d), padding=1, stride=2 if kind == "down" else 1).permute(0, 2, 3, 1).reshape(M, Cout) + b.double()
+    if res:
+        ref = ref + rp.hi.double() + rp.lo.double()
+    e = float(((out.hi.double() + out.lo.double()) - ref).norm() / ref.norm())
+    e_hi = float((out.hi.double() - ref).norm() / ref.norm())
+    print(f"hilo {kind} rows{rows} H{H} {Cin}->{Cout} res={res}: pair rel {e:.2e}, hi alone {e_hi:.2e}")
+    assert e < 3e-6 and 1e-4 < e_hi < 6e-4
+    # hi is the plain launch's output (up to the last bit where the residual's lo part moves a rounding)
+    assert float((out.hi.float() - plain.float()).abs().max()) <= 2.0 ** -9 * float(plain.float().abs().max())
+    cpg = Cout // G
+    yf = out.hi.float().reshape(rows, HW // 128, 128, G, cpg)
+    sref = torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1)
+    got = part.buf.view(rows, HW // 128, G, 2)
+    err = ((got - sref).abs() / (sref.abs().amax(dim=(1, 2), keepdim=True) + 1e-6)).max().item()
+    assert err < 2e-5, err
+    ga, be = (1 + 0.2 * rnd(Cout, seed=5).float()).half().to(d), (0.2 * rnd(Cout, seed=6).float()).half().to(d)
+    n1, st1 = ops.groupnorm_hilo(out.hi, out.lo, rows, HW, G, 1e-5, ga, be, True, want_stats=True, partial=part)
+    n0, st0 = ops.groupnorm_hilo(out.hi, out.lo, rows, HW, G, 1e-5, ga, be, True, want_stats=True)
+    vs = (out.hi.float() + out.lo.float()).reshape(rows, HW, Cout).permute(0, 2, 1)
+    nref = F.silu(F.group_norm(vs, G, ga.float(), be.float(), 1e-5)).permute(0, 2, 1).reshape(M, Cout)
+    for n in (n1, n0):
+        assert float((n.float() - nref).norm() / nref.norm()) < 4e-4
+    assert (st1 - st0).abs().max().item() < 2e-4 * (1 + st0.abs().max().item())
+
+
 def test_split_k_workspace_is_per_stream(ops):
     """the split-K slab used to be ONE process-global pointer.  Since ABI 2 libskg.so keeps one slab per (device,
     stream) and hands it to the kernel as an argument: split-K launches issued alternately on two streams - free to overlap on

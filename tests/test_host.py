@@ -51,7 +51,7 @@ def test_library_exports_every_declared_symbol_with_matching_signature():
     for name, sig in decl.items():
         assert _lib.SIGNATURES[name] == sig, (name, _lib.SIGNATURES[name], sig)
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.skg_abi_version() == _lib.ABI_VERSION == 2
+    assert _lib.lib.skg_abi_version() == _lib.ABI_VERSION == 3
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (skg_\w+)", nm))
     assert set(decl) <= exported
