@@ -21,7 +21,8 @@ LIB_PATH = os.environ.get("SKG_LIB") or os.path.join(_HERE, "libskg.so")
 
 # include/skg.h SKG_ABI_VERSION: bumped whenever an entry point changes its signature (2: skg_attn_bwd_dq / _dkv lost
 # their transposed-operand pointers, skg_set_workspace became per stream; 3: the accuracy-mode entry points with GroupNorm
-# statistics - skg_*_hilo_gn, skg_groupnorm_fwd_hilo / _from_partial_hilo), so that a stale build selected through
+# statistics - skg_*_hilo_gn, skg_groupnorm_fwd_hilo / _from_partial_hilo, skg_ff_block_f16_hilo - and the pair offset of
+# skg_cfg_ddim_step / skg_cfg_dpmpp2m_step), so that a stale build selected through
 # SKG_LIB fails at load instead of receiving shifted arguments
 ABI_VERSION = 3
 
@@ -31,14 +32,16 @@ SIGNATURES = {
     "skg_last_error": ("s", ""),
     "skg_gemm_f16": ("i", "pipipiiiippifup"),
     "skg_conv3x3_up2_f16": ("i", "pippiiiiiipp"),
+    "skg_conv3x3_up2_f16_hilo": ("i", "pipppiiiiiipp"),
     "skg_conv4x4s2_f16": ("i", "pippiiiiiipp"),
     "skg_gemm_f16_rows": ("i", "pipipiiiipiip"),
     "skg_gemm_f16_hilo": ("i", "pipippiiiipppifup".replace(" ", "")),
     "skg_conv3x3_f16_hilo": ("i", "pipppiiiiiiipppifup"),
     "skg_gemm_f16_hilo_gn": ("i", "pipippiiiipppifupiip"),
     "skg_conv3x3_f16_hilo_gn": ("i", "pipppiiiiiiipppifupip"),
-    "skg_groupnorm_fwd_hilo": ("i", "ppipiiiiifppippp"),
-    "skg_groupnorm_from_partial_hilo": ("i", "ppipiiiiiifppippipiip"),
+    "skg_groupnorm_fwd_hilo": ("i", "ppippiiiiifppippp"),
+    "skg_groupnorm_from_partial_hilo": ("i", "ppippiiiiiifppippipiip"),
+    "skg_ff_block_f16_hilo": ("i", "ppippiiiippfpppppiip"),
     "skg_groupnorm_apply_hilo": ("i", "ppipiiiiippp ip".replace(" ", "")),
     "skg_layernorm_fwd_hilo": ("i", "ppipiiippfpp"),
     "skg_gemm_f16_gn": ("i", "pipipiiiippifupiip"),
@@ -47,6 +50,7 @@ SIGNATURES = {
     "skg_ff_block_f16": ("i", "pipiiiippfppppp"),
     "skg_ff_block_f16_keep": ("i", "pipiiiippfpppppiip"),
     "skg_xattn_block_f16": ("i", "pipiiiiiippfpppfp"),
+    "skg_xattn_block_f16_hilo": ("i", "ppippiiiiiippfpppfp"),
     "skg_gemm_variant": ("i", "iiiii"),
     "skg_set_workspace": ("i", "pzp"),
     "skg_conv3x3_f16": ("i", "pippiiiiiiippifup"),
@@ -91,12 +95,12 @@ SIGNATURES = {
     "skg_lgp_mse_train": ("i", "pippipiifp"),
     "skg_adamw_step": ("i", "pppppzfffffifp"),
     "skg_lgp_mse_seed": ("i", "pippipiifp"),
-    "skg_cfg_ddim_step": ("i", "ppipppiifffffp"),
+    "skg_cfg_ddim_step": ("i", "ppiipppiifffffp"),
     "skg_softmax_rows_f16": ("i", "pipiiip"),
     "skg_image_postprocess": ("i", "pipziffp"),
     "skg_image_to_u8": ("i", "pipziffp"),
     "skg_gaussian_sample": ("i", "pippiiifp"),
-    "skg_cfg_dpmpp2m_step": ("i", "ppippppiiffffffp"),
+    "skg_cfg_dpmpp2m_step": ("i", "ppiippppiiffffffp"),
     "skg_guidance_update": ("i", "pipppiifp"),
 }
 

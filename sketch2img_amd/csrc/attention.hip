@@ -661,6 +661,278 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 2 : (KS >= 3 ? 3 : 4))) void attn_f
   }
 }
 
+// ---- forward, 8 waves, PING-PONG between the two waves of a SIMD (round 4) ------------------------------------------------
+// attn_fwd_kernel above runs four independent 4-wave workgroups per CU and hopes that one wave's softmax lands under another
+// wave's MFMAs; the counters say they do not overlap (matrix pipe 0.43 busy at d = 40: 448 MFMA + ~316 VALU cycles per tile
+// and wave against ~1 040 measured, EXPERIMENTS.md round 3).  Here the overlap is constructed, as gemm8.hip does for the GEMM
+// and MI355X_MICROARCH.md "Two waves per SIMD" describes for attention: ONE 8-wave workgroup per CU owns 256 queries (32 per
+// wave); waves w and w + 4 share a SIMD; both groups run the same sequence of segments, separated by s_barrier,
+//     L(t): softmax of S(t) -> P(t) (VALU), LDS fragment reads of V(t) and K(t + 1) into registers, staging of tile t + 2
+//     M(t): O^T += V(t)^T P(t)^T, then S(t + 1)^T = K(t + 1) Q^T - m           (MFMAs out of registers only)
+// with group 1 one barrier behind group 0: on every SIMD one wave is in its MFMA segment while its partner does softmax,
+// fragment reads and staging.
+// Formulation (swapped products as above, other instruction shapes):
+//   * S^T[64 keys x 32 queries] = K Q^T with v_mfma_f32_32x32x16_f16: K = 16 steps, so d = 40 pads to 48 (3 steps) instead of
+//     64 and every K fragment read feeds a 32 x 32 tile.  In the C layout lane (q = lane & 31, hi = lane >> 5) holds
+//     S^T[key = 32 kt + (r & 3) + 8 (r >> 2) + 4 hi][q] in register r of key tile kt: 32 scores of ONE query per lane.
+//   * O^T[d x 16 queries] += V^T P^T stays on v_mfma_f32_16x16x32_f16 (d pads to 16 ND, not to a multiple of 32).  Its B
+//     operand wants lane (n = lane & 15, g = lane >> 4) = query n of a 16-query tile; the packed probabilities sit in lanes
+//     (q = lane & 31): four v_permlane16_swap_b32 per key tile (rows 1, 3 of the first operand <-> rows 0, 2 of the second)
+//     turn {regs 0..7, regs 8..15} of all 32 queries into the B operands of the two 16-query tiles.  k-slot (g, i) of a 32-key
+//     step then means key (i & 3) + 8 (i >> 2) + 4 (g >> 1) + 16 (g & 1); the V tile is staged with key bits 2 and 4 swapped so
+//     that the transposing LDS read of group g starts at row 16 (g >> 1) + 4 (g & 1) (+ 8 for its second half) - the same
+//     conflict-free pattern as tfrag_rows.
+//   * online softmax as above: scale folded into Q, minus the reference maximum as the MFMA C operand, re-based only when a
+//     tile beats it by more than 2^8 (wave-uniform ballot); d = 40: the denominator is row 40 of O^T (ones column of V).
+// K / V tiles: registers -> LDS (three stages each; the loads of tile t + 3 are issued in L(t), written in L(t + 1)), pitches
+// KP8 (odd number of 16-byte pieces: conflict-free ds_read_b128 with row = lane & 31) and vrow_pitch.
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kp8_pitch(int d16) { return (2 * d16) | 1; }      // 16-byte pieces per K row: >= 2 d16, odd
+
+template <int D16, int ND, bool ONES>
+__global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(const AttnParams p) {
+  constexpr int NS = 3;                              // LDS stages
+  constexpr int KP = kp8_pitch(D16) * 8;             // halves
+  constexpr int VP = vrow_pitch(ND);
+  constexpr int KSZ = 64 * KP, VSZ = 64 * VP;
+  __shared__ __attribute__((aligned(16))) half_t lds[NS * (KSZ + VSZ)];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                         // waves w and w + 4 share a SIMD: one of each group
+  const int l32 = lane & 31, hi = lane >> 5, l16 = lane & 15, g = lane >> 4;
+  const BlkMap bm = attn_block_map(p);
+  const int b = bm.b, h = bm.h, dh = p.dh;
+  const int PK = dh >> 3;                            // 16-byte pieces per K / V row in memory
+  const int q0 = bm.bx * 256 + wave * 32;
+
+  // ---- Q^T fragments (B operand of 32x32x16: lane (n = l32, hi) holds d = 16 ks + 8 hi .. + 7 of query n), pre-scaled
+  const int qrow = min(q0 + l32, p.Nq - 1);
+  half8_t qf[D16];
+  {
+    const half_t* qp = p.Q + (size_t)(b * p.Nq + qrow) * p.ldq + h * dh + 8 * hi;
+    const float sc = p.scale * LOG2E;
+#pragma unroll
+    for (int ks = 0; ks < D16; ++ks) {
+      qf[ks] = (16 * ks + 8 * hi < dh) ? ld_half8(qp + 16 * ks) : zero_half8();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)qf[ks][j] * sc);
+    }
+  }
+
+  // ---- staging: piece pi of a tile = (K | V, key row, 16-byte column piece); a thread owns pieces tid + 512 j
+  constexpr int MAXPC = (2 * 64 * 2 * ND + 511) / 512;       // >= 2 * 64 * PK / 512 for every head width this instantiation takes
+  const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
+  const half_t* Vb = p.Vt + (size_t)b * p.kv_stride * p.ldvt + h * dh;
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (unsigned)(((size_t)(p.kv_stride - 1) * p.ldk + dh) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (unsigned)(((size_t)(p.kv_stride - 1) * p.ldvt + dh) * 2), 0x00020000);
+  unsigned soff[MAXPC];      // byte offset inside a tile in memory, or ATT_OOB
+  int sdst[MAXPC];           // half offset inside a stage (K part, or KSZ + V part)
+  bool sisv[MAXPC];          // wave-uniform: 64 * PK is a multiple of 64
+#pragma unroll
+  for (int j = 0; j < MAXPC; ++j) {
+    const int pi = tid + 512 * j;
+    const int npk = 64 * PK;
+    const bool isv = pi >= npk;
+    const int pj = isv ? pi - npk : pi;
+    const int row = pj / PK, pc = pj - row * PK;
+    const bool ok = pi < 2 * npk;
+    sisv[j] = __builtin_amdgcn_readfirstlane((int)isv) != 0;
+    // V rows are stored with key bits 2 and 4 swapped (see above)
+    const int vrow = (row & ~20) | ((row & 4) << 2) | ((row & 16) >> 2);
+    soff[j] = ok ? (unsigned)(row * (isv ? p.ldvt : p.ldk) + pc * 8) * 2u : ATT_OOB;
+    sdst[j] = ok ? (isv ? KSZ + vrow * VP + pc * 8 : row * KP + pc * 8) : -1;
+  }
+  half8_t sreg[MAXPC];
+  auto stage_load = [&](int t) {      // global -> registers (rows behind the last key of this batch row read as zero)
+    const unsigned sk = (unsigned)t * 64u * (unsigned)p.ldk * 2u, sv = (unsigned)t * 64u * (unsigned)p.ldvt * 2u;
+#pragma unroll
+    for (int j = 0; j < MAXPC; ++j) sreg[j] = sisv[j] ? buf_half8(rv, soff[j], sv) : buf_half8(rk, soff[j], sk);
+  };
+  auto stage_store = [&](int t) {     // registers -> LDS stage t % NS
+    half_t* st = lds + (t % NS) * (KSZ + VSZ);
+#pragma unroll
+    for (int j = 0; j < MAXPC; ++j)
+      if (sdst[j] >= 0) st_half8(st + sdst[j], sreg[j]);
+  };
+  // constant pieces of every stage, written once: the zero columns d >= dh of K that the last k-step reads, and (ONES) the
+  // piece [1, 0 x 7] at column dh of every V row - the register staging never touches them
+  for (int i = tid; i < NS * 64; i += 512) {
+    half_t* st = lds + (i >> 6) * (KSZ + VSZ);
+    const int row = i & 63;
+    for (int c = PK * 8; c < D16 * 16; c += 8) st_half8(st + row * KP + c, zero_half8());
+    if (ONES) {
+      const half8_t one = {(half_t)1.f, 0, 0, 0, 0, 0, 0, 0};
+      st_half8(st + KSZ + row * VP + PK * 8, one);
+    } else {
+      for (int c = PK * 8; c < ND * 16; c += 8) st_half8(st + KSZ + row * VP + c, zero_half8());
+    }
+  }
+  const int nt = (p.Nkv + 63) >> 6;
+  stage_load(0);
+  stage_store(0);
+  if (nt > 1) { stage_load(1); stage_store(1); }
+  if (nt > 2) stage_load(2);
+
+  // ---- per-wave state
+  float16_t s[2];                    // S^T of the current tile: key tiles 0, 1
+  float4_t o[2][ND];                 // O^T: query tile (queries 0-15, 16-31 of the wave) x d tile
+  float nm = 0.f, l = 0.f;           // minus the reference maximum (log2 domain) / denominator partial (S layout: query l32)
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int u = 0; u < ND; ++u) o[qt][u] = float4_t{0.f, 0.f, 0.f, 0.f};
+  half8_t kf[2][D16];                // K fragments of the next QK^T
+  half8_t vf[ND][2];                 // V^T fragments of the next PV
+  uint4_t pb[2][2];                  // P^T as B operands: [query tile][32-key step]
+  constexpr float REF_SLACK = 8.f;
+  const int vlane = (16 * (g >> 1) + 4 * (g & 1) + (l16 >> 2)) * VP + 4 * (l16 & 3);
+
+  auto read_k = [&](int t) {
+    const half_t* Ks = lds + (t % NS) * (KSZ + VSZ) + l32 * KP + 8 * hi;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < D16; ++ks) kf[kt][ks] = ld_half8(Ks + 32 * kt * KP + 16 * ks);
+  };
+  auto read_v = [&](int t) {
+    const half_t* Vs = lds + (t % NS) * (KSZ + VSZ) + KSZ + vlane;
+#pragma unroll
+    for (int u = 0; u < ND; ++u)
+#pragma unroll
+      for (int sv = 0; sv < 2; ++sv) {
+        const half4_t lo = tr_read(Vs + (32 * sv) * VP + 16 * u), hh = tr_read(Vs + (32 * sv + 8) * VP + 16 * u);
+        vf[u][sv] = half8_t{lo[0], lo[1], lo[2], lo[3], hh[0], hh[1], hh[2], hh[3]};
+      }
+  };
+  auto qk = [&]() {                  // S^T = K Q^T - m: the two key tiles alternate (dependent MFMAs one apart)
+    const float16_t init = {nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm};
+#pragma unroll
+    for (int ks = 0; ks < D16; ++ks)
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[ks], ks == 0 ? init : s[kt], 0, 0, 0);
+  };
+  auto pv = [&]() {
+#pragma unroll
+    for (int sv = 0; sv < 2; ++sv)
+#pragma unroll
+      for (int u = 0; u < ND; ++u)
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+          o[qt][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[u][sv], __builtin_bit_cast(half8_t, pb[qt][sv]), o[qt][u], 0, 0, 0);
+  };
+  auto softmax = [&](int t) {
+    const int kv0 = t * 64;
+    if (kv0 + 64 > p.Nkv) {            // ragged last tile only (wave-uniform)
+      int lim = p.Nkv - kv0 - 4 * hi;
+      asm volatile("" : "+v"(lim));
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (32 * kt + (r & 3) + 8 * (r >> 2) >= lim) s[kt][r] = NEG_BIG;
+    }
+    float mx = max3f(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = max3f(mx, s[0][r], s[0][r + 1]);
+    mx = max3f(mx, s[0][15], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 15; r += 2) mx = max3f(mx, s[1][r], s[1][r + 1]);
+    mx = max3f(mx, s[1][15], mx);
+    const bool first = t == 0;         // the reference starts at 0: the first tile always re-bases it
+    if (__builtin_amdgcn_ballot_w64(first || mx > REF_SLACK) != 0) {      // wave-uniform, rare after tile 0
+      mx = max3f(mx, __shfl_xor(mx, 32, 64), mx);                         // the query's maximum over the tile
+      const float delta = (first || mx > REF_SLACK) ? mx : 0.f;
+      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // (o, l are still zero in tile 0)
+      nm -= delta;
+      l *= alpha;
+      const float aA = __shfl(alpha, l16, 64), aB = __shfl(alpha, 16 + l16, 64);      // O layout: query l16 of each 16-query tile
+#pragma unroll
+      for (int u = 0; u < ND; ++u) { o[0][u] *= aA; o[1][u] *= aB; }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) s[kt] -= delta;
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      unsigned pk[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e0 = __builtin_amdgcn_exp2f(s[kt][2 * j]), e1 = __builtin_amdgcn_exp2f(s[kt][2 * j + 1]);
+        if (!ONES) ps += e0 + e1;
+        const half2_t h2 = {(half_t)e0, (half_t)e1};
+        pk[j] = __builtin_bit_cast(unsigned, h2);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const auto r = __builtin_amdgcn_permlane16_swap(pk[j], pk[j + 4], false, false);
+        pb[0][kt][j] = r[0];
+        pb[1][kt][j] = r[1];
+      }
+    }
+    if (!ONES) l += ps;
+  };
+
+  __syncthreads();                      // tiles 0, 1 and the constant pieces are in LDS
+  read_k(0);
+  qk();                                 // S(0)
+  if (grp == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+  for (int t = 0; t < nt; ++t) {
+    // ---- L(t)
+    softmax(t);
+    read_v(t);
+    if (t + 1 < nt) read_k(t + 1);
+    if (t + 2 < nt) stage_store(t + 2);
+    if (t + 3 < nt) stage_load(t + 3);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- M(t)
+    __builtin_amdgcn_s_setprio(1);
+    pv();
+    if (t + 1 < nt) qk();
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (grp == 0) { asm volatile("s_barrier" ::: "memory"); }
+
+  // ---- epilogue: O^T tiles -> O rows (lane (l16, g): d = 16 u + 4 g .. + 3 of query l16 of each 16-query tile)
+  float liA, liB;
+  if (ONES) {      // denominator = row dh = 40 of O^T: tile 2, row 8 -> lanes g == 2, element 0
+    liA = __shfl(o[0][ND - 1][0], 32 + l16, 64);
+    liB = __shfl(o[1][ND - 1][0], 32 + l16, 64);
+  } else {
+    const float ls = l + __shfl_xor(l, 32, 64);
+    liA = __shfl(ls, l16, 64);
+    liB = __shfl(ls, 16 + l16, 64);
+  }
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + 16 * qt + l16;
+    const float inv = 1.f / (qt ? liB : liA);
+    if (q < p.Nq) {
+      half_t* orow = p.O + (size_t)(b * p.Nq + q) * p.ldo + h * dh;
+#pragma unroll
+      for (int u = 0; u < ND; ++u) {
+        const int d = 16 * u + 4 * g;
+        if (d < dh) {
+          const half4_t v = {(half_t)(o[qt][u][0] * inv), (half_t)(o[qt][u][1] * inv), (half_t)(o[qt][u][2] * inv), (half_t)(o[qt][u][3] * inv)};
+          st_half4(orow + d, v);
+        }
+      }
+    }
+  }
+  if (p.lse) {       // S layout: lanes 0..31 own query q0 + lane
+    const float li = (lane & 16) ? liB : liA;
+    if (hi == 0 && q0 + l32 < p.Nq) p.lse[((size_t)b * p.heads + h) * p.Nq + q0 + l32] = (log2f(li) - nm) * LN2;
+  }
+}
+
 // dQ: per 64-query block, loop over key tiles.  dS^T = P^T o (dP^T - delta);  dQ^T += K^T dS^T.
 template <int KS, int ND, int QT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
@@ -1012,6 +1284,19 @@ static int attn_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const v
       default: hipLaunchKernelGGL((attn_fwd_short_kernel<5, 10>), gs, dim3(256), 0, st, p, (int)qch); break;
     }
     SKG_CHECK_LAUNCH("skg_attn_fwd (short keys)");
+    return SKG_OK;
+  }
+  // self-attention of the 64 x 64 / 32 x 32 levels (and SD2.1's 96 x 96 ... 24 x 24): the 8-wave ping-pong kernel, 256 queries
+  // per workgroup, where that still gives every CU a workgroup (SKG_NO_ATTN8: A/B switch, default is the product)
+  static const bool no8 = getenv("SKG_NO_ATTN8") != nullptr || getenv("SKG_ATTN8") == nullptr;      // (round 4, first form: correct, 29 % slower - off)
+  if (vrow && !causal && !no8 && (dh == 40 || dh == 64) && (long)skg_cdiv(Nq, 256) * heads * batch >= 192) {
+    p.nx = skg_cdiv(Nq, 256);
+    dim3 g8((unsigned)p.nx * heads * batch);
+    switch (dh) {
+      case 40: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true>), g8, dim3(512), 0, st, p); break;
+      default: hipLaunchKernelGGL((attn_fwd8_kernel<4, 4, false>), g8, dim3(512), 0, st, p); break;
+    }
+    SKG_CHECK_LAUNCH("skg_attn_fwd (8 waves)");
     return SKG_OK;
   }
   p.nx = skg_cdiv(Nq, dh == 160 ? 64 : 128);       // query tiles per workgroup: see SKG_ATTN_FWD_DISPATCH

@@ -32,6 +32,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 struct FFParams {
   const half_t* X; int ldx;
   half_t* Y; int ldy;
+  const half_t* Xl; half_t* Yl;      // accuracy mode (HILO): input and output are PAIRS X + Xl, Y + Yl of fp16 tensors (pitches ldx / ldy)
   int M;
   const half_t* gamma; const half_t* beta; float eps;
   const half_t* Wp;        // [nch][60][512]: chunk c = 40 W1 pieces (tile t = val0, val1, gate0, gate1; k-step ks) then 20 W2 pieces
@@ -49,7 +50,9 @@ constexpr int MAXCH = 40;
 // 3 = no LDS fragment reads (a register stands in for every A operand), 4 = 1 + 3
 // SCHED (SKG_FFB_SCHED, A/B of issue orders): 0 = a gated PAIR after the MFMAs of every second k-step, 1 = the same with the
 // two waves of a SIMD in alternate k-steps, 2 = the pair's arithmetic in four stages spread over the MFMAs of two k-steps
-template <int KS, int PROBE = 0, int SCHED = 0>
+// HILO (accuracy mode, skg_ff_block_f16_hilo): LayerNorm reads hi + lo, the residual sum is formed in fp32 on the pair and
+// stored as hi = fp16(v), lo = fp16(v - hi); everything between is the same kernel
+template <int KS, int PROBE = 0, int SCHED = 0, bool HILO = false>
 __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
   constexpr int C = 32 * KS, NU = C / 16, N1 = 4 * KS, NP = N1 + NU, PIECE = 512;
   constexpr int W1ST = N1 * PIECE, W2ST = NU * PIECE;      // halves per ring stage
@@ -92,6 +95,45 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
   const int mrow = m0 + l16;
   const int mload = min(mrow, p.M - 1);
   half8_t xb[KS];
+  if constexpr (HILO)
+  {
+    // the lo parts are NOT kept in registers across the three passes (40 more live registers spill into the main loop):
+    // each pass re-reads them through a pointer the compiler cannot see through (L1 / L2 hits)
+    const half_t* xr = p.X + (size_t)mload * p.ldx + 8 * g;
+    const half_t* xlr = p.Xl + (size_t)mload * p.ldx + 8 * g;
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      xb[ks] = ld_half8(xr + 32 * ks);
+      const half8_t xl = ld_half8(xlr + 32 * ks);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += (float)xb[ks][i] + (float)xl[i];
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.f / C);
+    asm volatile("" : "+v"(xlr));
+    float s2 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8_t xl = ld_half8(xlr + 32 * ks);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = (float)xb[ks][i] + (float)xl[i] - mean; s2 += d * d; }
+    }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = rsqrtf(s2 * (1.f / C) + p.eps);
+    asm volatile("" : "+v"(xlr));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8_t gv = ld_half8(p.gamma + 32 * ks + 8 * g), bv = ld_half8(p.beta + 32 * ks + 8 * g);
+      const half8_t xl = ld_half8(xlr + 32 * ks);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xb[ks][i] = (half_t)(((float)xb[ks][i] + (float)xl[i] - mean) * rstd * (float)gv[i] + (float)bv[i]);
+    }
+    if (p.stats && g == 0 && mrow < p.M) { p.stats[(size_t)mrow * 2] = mean; p.stats[(size_t)mrow * 2 + 1] = rstd; }
+  }
+  else
   {
     const half_t* xr = p.X + (size_t)mload * p.ldx + 8 * g;
     float s = 0.f;
@@ -307,6 +349,38 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
   // ---- epilogue: the wave's Y^T tile through its own slice of the (now idle) ring, then whole-row 16-byte pieces:
   // residual read + store are 10 KB contiguous per wave when the rows are dense
   lds_barrier();
+  if constexpr (HILO) {
+  half_t* const stg = smem + wave * (16 * OP);
+  constexpr int PPR = C / 8;                              // 16-byte pieces per row
+  {   // the pair residual joins the accumulators first (ONE read of X: Y may alias X), then hi and lo are staged and stored in
+      // two passes through the same wave-private slice (LDS operations of a wave execute in order)
+    const half_t* xr = p.X + (size_t)mload * p.ldx + 4 * g;
+    const half_t* xlr = p.Xl + (size_t)mload * p.ldx + 4 * g;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const half4_t r4 = ld_half4(xr + 16 * u), l4 = ld_half4(xlr + 16 * u);
+      y[u] += float4_t{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]} + float4_t{(float)l4[0], (float)l4[1], (float)l4[2], (float)l4[3]};
+    }
+  }
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const float4_t f = y[u];
+      half4_t v = {(half_t)f[0], (half_t)f[1], (half_t)f[2], (half_t)f[3]};
+      if (part == 1) v = half4_t{(half_t)(f[0] - (float)v[0]), (half_t)(f[1] - (float)v[1]), (half_t)(f[2] - (float)v[2]), (half_t)(f[3] - (float)v[3])};
+      st_half4(stg + l16 * OP + 16 * u + 4 * g, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // wave-private staging: no workgroup barrier
+    half_t* const dst = part == 0 ? p.Y : p.Yl;
+#pragma unroll
+    for (int j = 0; j < 16 * PPR / 64; ++j) {
+      const int pi = lane + 64 * j;
+      const int row = pi / PPR, pc = pi - row * PPR;
+      if (m0 + row < p.M) st_half8(dst + (size_t)(m0 + row) * p.ldy + pc * 8, ld_half8(stg + row * OP + pc * 8));
+    }
+  }
+  } else {
   half_t* const stg = smem + wave * (16 * OP);
   {   // the residual is added in fp32 BEFORE staging (lane-local 8-byte reads of X, L2 hits): one fp16 rounding
     const half_t* xr = p.X + (size_t)mload * p.ldx + 4 * g;
@@ -326,45 +400,68 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
     const int row = pi / PPR, pc = pi - row * PPR;
     if (m0 + row < p.M) st_half8(p.Y + (size_t)(m0 + row) * p.ldy + pc * 8, ld_half8(stg + row * OP + pc * 8));
   }
+  }
 }
 
 }  // namespace
 
-extern "C" int skg_ff_block_f16_keep(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma,
-                                     const void* beta, float eps, const void* Wpack, const float* bias1_pack,
-                                     const void* bias2, float* stats, void* H, int ldh, int keep_from, void* stream) {
-  SKG_REQUIRE(X && Y && gamma && beta && Wpack && bias1_pack && bias2 && M > 0);
+static int ff_block_impl(const void* X, const void* Xl, int ldx, void* Y, void* Yl, int ldy, int M, int C, int F, const void* gamma,
+                         const void* beta, float eps, const void* Wpack, const float* bias1_pack, const void* bias2,
+                         float* stats, void* H, int ldh, int keep_from, void* stream) {
+  SKG_REQUIRE(X && Y && gamma && beta && Wpack && bias1_pack && bias2 && M > 0 && (Xl != nullptr) == (Yl != nullptr));
   SKG_REQUIRE(!H || (ldh % 8 == 0 && ldh >= 2 * F && keep_from >= 0 && keep_from % 16 == 0 && keep_from < M && skg_aligned(H, 16)));
   SKG_REQUIRE(C == 320 && F % 32 == 0 && F / 32 <= MAXCH && F >= 64);
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
-  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16) &&
-              skg_aligned(Wpack, 16) && skg_aligned(bias1_pack, 16) && skg_aligned(bias2, 8));
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(Xl, 16) && skg_aligned(Yl, 16) && skg_aligned(gamma, 16) &&
+              skg_aligned(beta, 16) && skg_aligned(Wpack, 16) && skg_aligned(bias1_pack, 16) && skg_aligned(bias2, 8));
   FFParams p;
   p.X = (const half_t*)X; p.ldx = ldx; p.Y = (half_t*)Y; p.ldy = ldy; p.M = M;
+  p.Xl = (const half_t*)Xl; p.Yl = (half_t*)Yl;
   p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.eps = eps;
   p.Wp = (const half_t*)Wpack; p.b1p = bias1_pack; p.b2 = (const half_t*)bias2;
   p.nch = F / 32;
   p.wbytes = (unsigned)p.nch * 60u * 1024u;
   p.stats = stats;
   p.keep = (half_t*)H; p.ldkeep = ldh; p.keep_from = keep_from;
-  static const int probe = getenv("SKG_FFB_PROBE") ? atoi(getenv("SKG_FFB_PROBE")) : 0;      // timing experiments only
-  static const int sched = getenv("SKG_FFB_SCHED") ? atoi(getenv("SKG_FFB_SCHED")) : 0;
   const dim3 grid(skg_cdiv(M, 128));
-  switch (probe * 10 + sched) {
-    case 10: hipLaunchKernelGGL((ff_block_kernel<10, 1>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
-    case 20: hipLaunchKernelGGL((ff_block_kernel<10, 2>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
-    case 30: hipLaunchKernelGGL((ff_block_kernel<10, 3>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
-    case 40: hipLaunchKernelGGL((ff_block_kernel<10, 4>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
-    case 1: hipLaunchKernelGGL((ff_block_kernel<10, 0, 1>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
-    case 2: hipLaunchKernelGGL((ff_block_kernel<10, 0, 2>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
-    default: hipLaunchKernelGGL((ff_block_kernel<10>), grid, dim3(512), 0, (hipStream_t)stream, p);
+#ifdef SKG_LAB      // lab build only (make lab): probe instantiations compute WRONG results (timing experiments, EXPERIMENTS.md round 3)
+  static const int probe = getenv("SKG_FFB_PROBE") ? atoi(getenv("SKG_FFB_PROBE")) : 0;
+  static const int sched = getenv("SKG_FFB_SCHED") ? atoi(getenv("SKG_FFB_SCHED")) : 0;
+  if (!Xl && probe * 10 + sched) {
+    switch (probe * 10 + sched) {
+      case 10: hipLaunchKernelGGL((ff_block_kernel<10, 1>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+      case 20: hipLaunchKernelGGL((ff_block_kernel<10, 2>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+      case 30: hipLaunchKernelGGL((ff_block_kernel<10, 3>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+      case 40: hipLaunchKernelGGL((ff_block_kernel<10, 4>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+      case 1: hipLaunchKernelGGL((ff_block_kernel<10, 0, 1>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+      default: hipLaunchKernelGGL((ff_block_kernel<10, 0, 2>), grid, dim3(512), 0, (hipStream_t)stream, p); break;
+    }
+    SKG_CHECK_LAUNCH("skg_ff_block_f16 (probe)");
+    return SKG_OK;
   }
+#endif
+  if (Xl) hipLaunchKernelGGL((ff_block_kernel<10, 0, 0, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((ff_block_kernel<10>), grid, dim3(512), 0, (hipStream_t)stream, p);
   SKG_CHECK_LAUNCH("skg_ff_block_f16");
   return SKG_OK;
+}
+
+extern "C" int skg_ff_block_f16_keep(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma,
+                                     const void* beta, float eps, const void* Wpack, const float* bias1_pack,
+                                     const void* bias2, float* stats, void* H, int ldh, int keep_from, void* stream) {
+  return ff_block_impl(X, nullptr, ldx, Y, nullptr, ldy, M, C, F, gamma, beta, eps, Wpack, bias1_pack, bias2, stats, H, ldh, keep_from, stream);
 }
 
 extern "C" int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma,
                                 const void* beta, float eps, const void* Wpack, const float* bias1_pack,
                                 const void* bias2, float* stats, void* stream) {
-  return skg_ff_block_f16_keep(X, ldx, Y, ldy, M, C, F, gamma, beta, eps, Wpack, bias1_pack, bias2, stats, nullptr, 0, 0, stream);
+  return ff_block_impl(X, nullptr, ldx, Y, nullptr, ldy, M, C, F, gamma, beta, eps, Wpack, bias1_pack, bias2, stats, nullptr, 0, 0, stream);
+}
+
+// accuracy mode: the same launch on a pair input X + X_lo (pitch ldx) with a pair output Y + Y_lo (pitch ldy); H / keep_from as _keep
+extern "C" int skg_ff_block_f16_hilo(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int M, int C, int F,
+                                     const void* gamma, const void* beta, float eps, const void* Wpack, const float* bias1_pack,
+                                     const void* bias2, float* stats, void* H, int ldh, int keep_from, void* stream) {
+  SKG_REQUIRE(X_lo && Y_lo);
+  return ff_block_impl(X, X_lo, ldx, Y, Y_lo, ldy, M, C, F, gamma, beta, eps, Wpack, bias1_pack, bias2, stats, H, ldh, keep_from, stream);
 }

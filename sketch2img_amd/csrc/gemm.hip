@@ -390,11 +390,11 @@ extern "C" int skg_conv3x3_f16_gn(const void* X, int ldx, const void* Wp, void* 
 // (a = 1) x the same for columns, with the three taps of the 3 x 3 filter that land on one low-res row / column pre-summed:
 // four stride-1 convolutions with FOUR taps each over the low-res input (16 tap-products per low-res pixel) instead of nine
 // taps at every high-res pixel (36).  Wpp: [4 phases (2 a + b)][Cout][4 taps (row-major over the phase's 2 x 2)][Cin].
-extern "C" int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void* Y, int ldy, int rows, int IH, int IW,
-                                   int Cin, int Cout, const void* bias, void* stream) {
+static int conv_up2_impl(const void* X, int ldx, const void* Wpp, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW, int Cin,
+                         int Cout, int a_wrap, const void* bias, void* stream) {
   SKG_REQUIRE(X && Wpp && Y && rows > 0 && IH > 0 && IW > 0 && Cin % 64 == 0 && Cout % 8 == 0);
-  SKG_REQUIRE(ldx % 8 == 0 && ldx >= Cin && ldy % 8 == 0 && ldy >= Cout && skg_aligned(X, 16) && skg_aligned(Wpp, 16) &&
-              skg_aligned(Y, 16) && (!bias || skg_aligned(bias, 8)));
+  SKG_REQUIRE(ldx % 8 == 0 && ldx >= (a_wrap ? a_wrap : Cin) && ldy % 8 == 0 && ldy >= Cout && skg_aligned(X, 16) && skg_aligned(Wpp, 16) &&
+              skg_aligned(Y, 16) && skg_aligned(Y_lo, 16) && (!bias || skg_aligned(bias, 8)));
   hipStream_t st = (hipStream_t)stream;
   // a phase that does not fill the chip by itself (the 8 -> 16 / 12 -> 24 maps): the four phases as ONE grid
   const bool one_grid = (long)skg_cdiv(rows * IH * IW, 128) * skg_cdiv(Cout, 160) < 200;
@@ -403,10 +403,11 @@ extern "C" int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void
     GemmParams p{};
     p.A = (const half_t*)X; p.lda = ldx;
     p.B = (const half_t*)Wpp + (size_t)ph * Cout * 4 * Cin; p.ldb = 4 * Cin;
-    p.C = Y; p.ldc = ldy; p.bias = (const half_t*)bias;
+    p.C = Y; p.ldc = ldy; p.bias = (const half_t*)bias; p.c_lo = (half_t*)Y_lo;
     p.N = Cout; p.K = 4 * Cin; p.alpha = 1.f; p.flags = 0;
     p.IH = IH; p.IW = IW; p.OH = IH; p.OW = IW; p.Cin = Cin; p.M = rows * IH * IW;
     p.ntaps = 4; p.up2 = one_grid ? 5 : 1 + ph;
+    p.a_wrap = a_wrap;
     // low-res rows (ky) / columns (kx) this phase reads, as stride-1 tap ids ky * 3 + kx with ky, kx in {0: -1, 1: 0, 2: +1}
     const int ky0 = a ? 1 : 0, kx0 = b ? 1 : 0;
     p.tapmap = (unsigned)(ky0 * 3 + kx0) | (unsigned)(ky0 * 3 + kx0 + 1) << 4 | (unsigned)((ky0 + 1) * 3 + kx0) << 8 |
@@ -416,6 +417,21 @@ extern "C" int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void
     SKG_CHECK_LAUNCH("skg_conv3x3_up2_f16");
   }
   return SKG_OK;
+}
+
+extern "C" int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void* Y, int ldy, int rows, int IH, int IW,
+                                   int Cin, int Cout, const void* bias, void* stream) {
+  return conv_up2_impl(X, ldx, Wpp, Y, nullptr, ldy, rows, IH, IW, Cin, Cout, 0, bias, stream);
+}
+
+// Accuracy mode: the input is the pair buffer [x_hi | x_lo] (2 C channels per pixel, pitch ldx), the pre-summed polyphase weights
+// are (hi, lo) pairs too - their fp16 rounding would otherwise cost the margin of the eps bound (EXPERIMENTS.md round 3) - and a
+// tap's K axis is [x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo] (x_lo . W_lo is dropped: 2^-22): Wpp3 [4][Cout][4 taps][3 C];
+// the output is the pair Y + Y_lo.  12 tap-products of C channels per low-res pixel and phase against 18 for the 9-tap pair form.
+extern "C" int skg_conv3x3_up2_f16_hilo(const void* X2, int ldx, const void* Wpp3, void* Y, void* Y_lo, int ldy, int rows, int IH,
+                                        int IW, int C, int Cout, const void* bias, void* stream) {
+  SKG_REQUIRE(Y_lo && C % 64 == 0);
+  return conv_up2_impl(X2, ldx, Wpp3, Y, Y_lo, ldy, rows, IH, IW, 3 * C, Cout, 2 * C, bias, stream);
 }
 
 // dX of the polyphase upsample + conv above = ONE 4 x 4 stride-2 convolution (padding 1) over dY at the upsampled size with

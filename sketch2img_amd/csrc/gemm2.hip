@@ -308,7 +308,8 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
         ky = tap / 3;
         kx = tap - ky * 3;
       }
-      soff = (unsigned)((ky * p.IW + kx) * p.lda + c0) * 2u;
+      const int ca = (p.a_wrap && c0 >= p.a_wrap) ? c0 - p.a_wrap : c0;      // (accuracy-mode polyphase: the x_hi block is read twice)
+      soff = (unsigned)((ky * p.IW + kx) * p.lda + ca) * 2u;
     }
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
@@ -764,7 +765,16 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
       if (!RES_UP_FRONT) load_res(sl);
       if (m0 + sl * SROWS + er < p.M) {
         const float* const srow = stg + er * OPF + ec;
-        half_t* const crow = crow0 + (size_t)sl * SROWS * p.ldc;
+        half_t* crow = crow0 + (size_t)sl * SROWS * p.ldc;
+        size_t lo_row = (size_t)(m0 + er + sl * SROWS);
+        if constexpr (HILO) {
+          if (p.up2) {      // polyphase upsample: low-res pixel (i, j) of image b -> high-res pixel (2 i + a, 2 j + b)
+            const int m = m0 + sl * SROWS + er, hw = p.OH * p.OW;
+            const int img = m / hw, rr = m - img * hw, i = rr / p.OW, j = rr - i * p.OW;
+            lo_row = (size_t)img * 4 * hw + (size_t)(2 * i + (ph >> 1)) * (2 * p.OW) + 2 * j + (ph & 1);
+            crow = reinterpret_cast<half_t*>(p.C) + lo_row * p.ldc + n0 + ec;
+          }
+        }
         float4_t v0[ITER], v1[ITER];
 #pragma unroll
         for (int k = 0; k < ITER; ++k) {
@@ -801,7 +811,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
                 half8_t lo;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) lo[e] = (half_t)(v[e] - (float)o[e]);
-                st_half8(p.c_lo + (size_t)(m0 + er + sl * SROWS) * p.ldc + n0 + ec + k * TPR * 8, lo);
+                st_half8(p.c_lo + lo_row * p.ldc + n0 + ec + k * TPR * 8, lo);
               }
             }
             half8_t* dst8 = reinterpret_cast<half8_t*>(crow + k * TPR * 8);
@@ -1119,8 +1129,8 @@ bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
       (mode != MODE_DIRECT || p.res || p.gn_partial || p.c_lo || p.res_lo || p.aux || (p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) ||
        p.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0))
     return false;
-  if ((p.ntaps || p.up2) &&      // polyphase: stride-1 walk (4 x 4 window: stride 2), the plain fp16-staged epilogue (no residual / statistics)
-      ((p.ntaps == 16 ? (mode != MODE_S2 || p.up2) : mode != MODE_S1) || p.res || p.gn_partial || p.c_lo || p.res_lo || (p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) ||
+  if ((p.ntaps || p.up2) &&      // polyphase: stride-1 walk (4 x 4 window: stride 2), the plain fp16-staged epilogue (no residual / statistics) or the pair one
+      ((p.ntaps == 16 ? (mode != MODE_S2 || p.up2 || p.c_lo) : mode != MODE_S1) || p.res || p.gn_partial || p.res_lo || (p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) ||
        p.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0 || p.M % (p.OH * p.OW) != 0))
     return false;
   if ((p.c_lo || p.res_lo) &&

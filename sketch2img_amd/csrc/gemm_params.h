@@ -25,6 +25,9 @@ struct GemmParams {
   // only `ntaps` of the nine taps (tap id of walk position i = (tapmap >> 4 i) & 15; weight pack [Cout][ntaps][Cin]) and stores
   // low-res pixel (i, j) to high-res pixel (2 i + a, 2 j + b) of the output, up2 = 1 + 2 a + b (0 = ordinary conv)
   int ntaps; unsigned tapmap; int up2;
+  // accuracy-mode polyphase upsample (skg_conv3x3_up2_f16_hilo): the K axis of a tap is [x_hi | x_lo | x_hi] against
+  // [W_hi | W_hi | W_lo] but the operand only holds [x_hi | x_lo]: channel offsets >= a_wrap wrap around to the start (0 = off)
+  int a_wrap;
   // segmented output rows (skg_gemm_f16_rows): row m of the product is stored to row (m / seg_rows) * seg_stride + m % seg_rows
   // of C - one launch writes the image tokens of every batch row into its slot of a longer per-row buffer (0 = off)
   int seg_rows, seg_stride;

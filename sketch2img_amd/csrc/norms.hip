@@ -172,7 +172,7 @@ struct GnSrc { const float* partialB; int split, unused, ratioA, ratioB; };
 // on X): the mean of >= 640 rounding errors of relative size 2^-12 is far below fp32 resolution.
 template <bool FOLD, bool HILO = false>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ X, const half_t* __restrict__ Xl, int ldx,
-                                                       half_t* __restrict__ Y, int ldy, int HW, int C, int groups,
+                                                       half_t* __restrict__ Y, half_t* __restrict__ Yl, int ldy, int HW, int C, int groups,
                                                        const float* __restrict__ stats,
                                                        const half_t* __restrict__ gamma,
                                                        const half_t* __restrict__ beta, int silu,
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     const half_t* xp = X + ((size_t)b * HW) * ldx + c0;
     const half_t* lp = HILO ? Xl + ((size_t)b * HW) * ldx + c0 : nullptr;
     half_t* yp = Y + ((size_t)b * HW) * ldy + c0;
+    half_t* ylp = (HILO && Yl) ? Yl + ((size_t)b * HW) * ldy + c0 : nullptr;      // HILO: optional PAIR output (lo = fp16(v - fp16(v)))
     int p = p0 + pl;
     constexpr int U = HILO ? 2 : 4;      // independent pixels per iteration: four 16-byte loads in flight either way
     for (; p + (U - 1) * P < p1; p += U * P) {
@@ -251,27 +252,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        half8_t o;
+        half8_t o, ol;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float v = fmaf(HILO ? (float)xv[u][j] + (float)lv[u][j] : (float)xv[u][j], a[j], sh[j]);
           if (silu) v = silu_f(v);
           o[j] = (half_t)v;
+          if (HILO) ol[j] = (half_t)(v - (float)o[j]);
         }
         st_half8(yp + (size_t)(p + u * P) * ldy, o);
+        if (HILO) { if (ylp) st_half8(ylp + (size_t)(p + u * P) * ldy, ol); }
       }
     }
     for (; p < p1; p += P) {
       const half8_t xv = ld_half8(xp + (size_t)p * ldx);
       const half8_t lv = HILO ? ld_half8(lp + (size_t)p * ldx) : zero_half8();
-      half8_t o;
+      half8_t o, ol;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float v = fmaf(HILO ? (float)xv[j] + (float)lv[j] : (float)xv[j], a[j], sh[j]);
         if (silu) v = silu_f(v);
         o[j] = (half_t)v;
+        if (HILO) ol[j] = (half_t)(v - (float)o[j]);
       }
       st_half8(yp + (size_t)p * ldy, o);
+      if (HILO) { if (ylp) st_half8(ylp + (size_t)p * ldy, ol); }
     }
   }
 }
@@ -487,7 +492,7 @@ static int gn_apply_impl(const void* X, const void* Xl, int ldx, void* Y, int ld
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16) && skg_aligned(Xl, 16));
 #define SKG_GN_APPLY(H)                                                                                                       \
   hipLaunchKernelGGL((gn_apply_kernel<false, H>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,      \
-                     (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, ldy, HW, C, groups, stats, (const half_t*)gamma,   \
+                     (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, (half_t*)nullptr, ldy, HW, C, groups, stats, (const half_t*)gamma,   \
                      (const half_t*)beta, silu, (const float*)nullptr, 0, 0.f, 0.f, (float*)nullptr)
   if (Xl) SKG_GN_APPLY(true); else SKG_GN_APPLY(false);
 #undef SKG_GN_APPLY
@@ -513,7 +518,7 @@ extern "C" int skg_groupnorm_apply_hilo(const void* X, const void* X_lo, int ldx
 // backward pass.  The chunked path is launch-latency bound there (two launches, 14-20 us for 2.6-10 MB).
 template <int NP, bool HILO = false>   // 16-byte pieces per thread; HILO: the input is the pair X + Xl (see gn_apply_kernel)
 __global__ __launch_bounds__(256) void gn_small_kernel(const half_t* __restrict__ X, const half_t* __restrict__ Xl, int ldx,
-                                                       half_t* __restrict__ Y, int ldy, int HW, int C, int groups,
+                                                       half_t* __restrict__ Y, half_t* __restrict__ Yl, int ldy, int HW, int C, int groups,
                                                        const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
                                                        int silu, float eps, float* __restrict__ stats) {
   __shared__ float red[8];
@@ -556,14 +561,16 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const half_t* __restrict_
     if (off[k] < 0) continue;
     const int px = off[k] >> 8, pc = off[k] & 255;
     const half8_t gv = ld_half8(gamma + g * cpg + pc * 8), bv = ld_half8(beta + g * cpg + pc * 8);
-    half8_t o;
+    half8_t o, ol;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float y = ((float)v[k][j] - mean) * rstd * (float)gv[j] + (float)bv[j];
       if (silu) y = silu_f(y);
       o[j] = (half_t)y;
+      if (HILO) ol[j] = (half_t)(y - (float)o[j]);
     }
     st_half8(yb + (size_t)px * ldy + pc * 8, o);
+    if (HILO) { if (Yl) st_half8(Yl + (size_t)row * HW * ldy + g * cpg + (size_t)px * ldy + pc * 8, ol); }
   }
 }
 
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(256) void gn_bwd_small_kernel(
   }
 }
 
-static int gn_fwd_impl(const void* X, const void* Xl, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
+static int gn_fwd_impl(const void* X, const void* Xl, int ldx, void* Y, void* Yl, int ldy, int rows, int HW, int C, int groups,
                        float eps, const void* gamma, const void* beta, int silu, float* stats, float* partial, void* stream) {
   SKG_REQUIRE(X && Y && stats && partial && gamma && beta && rows > 0 && HW > 0 && groups > 0 && groups <= 64);
   SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && (C / groups) % 2 == 0 && (C / groups) >= 4 && C <= GN_MAX_C);
@@ -635,7 +642,7 @@ static int gn_fwd_impl(const void* X, const void* Xl, int ldx, void* Y, int ldy,
     const dim3 grid(groups, rows);
 #define SKG_GN_SMALL(NP, H)                                                                                                    \
     hipLaunchKernelGGL((gn_small_kernel<NP, H>), grid, dim3(256), 0, st, (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, \
-                       ldy, HW, C, groups, (const half_t*)gamma, (const half_t*)beta, silu, eps, stats)
+                       (half_t*)Yl, ldy, HW, C, groups, (const half_t*)gamma, (const half_t*)beta, silu, eps, stats)
 #define SKG_GN_SMALL_NP(H)                \
     if (np <= 2) SKG_GN_SMALL(2, H);      \
     else if (np <= 3) SKG_GN_SMALL(3, H); \
@@ -653,7 +660,7 @@ static int gn_fwd_impl(const void* X, const void* Xl, int ldx, void* Y, int ldy,
                      (const half_t*)nullptr, 0, partial);
 #define SKG_GN_FOLD(H)                                                                                                \
   hipLaunchKernelGGL((gn_apply_kernel<true, H>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, st,               \
-                     (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, ldy, HW, C, groups, (const float*)nullptr, \
+                     (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, (half_t*)Yl, ldy, HW, C, groups, (const float*)nullptr, \
                      (const half_t*)gamma, (const half_t*)beta, silu, (const float*)partial, nch,                    \
                      1.f / ((float)HW * (C / groups)), eps, stats)
   if (Xl) SKG_GN_FOLD(true); else SKG_GN_FOLD(false);
@@ -665,15 +672,16 @@ static int gn_fwd_impl(const void* X, const void* Xl, int ldx, void* Y, int ldy,
 extern "C" int skg_groupnorm_fwd(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
                                  float eps, const void* gamma, const void* beta, int silu, float* stats,
                                  float* partial, void* stream) {
-  return gn_fwd_impl(X, nullptr, ldx, Y, ldy, rows, HW, C, groups, eps, gamma, beta, silu, stats, partial, stream);
+  return gn_fwd_impl(X, nullptr, ldx, Y, nullptr, ldy, rows, HW, C, groups, eps, gamma, beta, silu, stats, partial, stream);
 }
 
-// accuracy mode: GroupNorm(+SiLU) of the pair X + X_lo (one pitch) in one or two launches, statistics published
-extern "C" int skg_groupnorm_fwd_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int rows, int HW, int C,
+// accuracy mode: GroupNorm(+SiLU) of the pair X + X_lo (one pitch) in one or two launches, statistics published; Y_lo != NULL:
+// the OUTPUT is a pair too (pitch ldy) - the normalised activation in front of conv_out, whose rounding would reach eps 1 : 1
+extern "C" int skg_groupnorm_fwd_hilo(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int rows, int HW, int C,
                                       int groups, float eps, const void* gamma, const void* beta, int silu, float* stats,
                                       float* partial, void* stream) {
   SKG_REQUIRE(X_lo);
-  return gn_fwd_impl(X, X_lo, ldx, Y, ldy, rows, HW, C, groups, eps, gamma, beta, silu, stats, partial, stream);
+  return gn_fwd_impl(X, X_lo, ldx, Y, Y_lo, ldy, rows, HW, C, groups, eps, gamma, beta, silu, stats, partial, stream);
 }
 
 // the statistics pass alone, nch chunks per sample (the fallback behind skg_gemm_f16_gn / skg_conv3x3_f16_gn when the
@@ -690,7 +698,7 @@ void skg_gn_partial_launch(const half_t* X, int ldx, int rows, int HW, int C, in
 // producers that each left partial sums behind (groupsA / groupsB groups per chunk over their own channels).  The
 // concatenation's group width must be a multiple of both source group widths and CA a multiple of it (e.g. 320 + 320 or
 // 640 + 640 channels with 32 groups each way: two source groups per output group); otherwise SKG_E_UNSUPPORTED.
-static int gn_from_partial_impl(const void* X, const void* Xl, int ldx, void* Y, int ldy, int rows, int HW, int C, int CA,
+static int gn_from_partial_impl(const void* X, const void* Xl, int ldx, void* Y, void* Yl, int ldy, int rows, int HW, int C, int CA,
                                 int groups, float eps, const void* gamma, const void* beta, int silu, float* stats,
                                 const float* partialA, int groupsA, const float* partialB, int groupsB, int nch,
                                 void* stream) {
@@ -711,7 +719,7 @@ static int gn_from_partial_impl(const void* X, const void* Xl, int ldx, void* Y,
   }
 #define SKG_GN_FOLD(H)                                                                                                          \
   hipLaunchKernelGGL((gn_apply_kernel<true, H>), dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, (hipStream_t)stream,        \
-                     (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, ldy, HW, C, groups, (const float*)nullptr,           \
+                     (const half_t*)X, (const half_t*)Xl, ldx, (half_t*)Y, (half_t*)Yl, ldy, HW, C, groups, (const float*)nullptr, \
                      (const half_t*)gamma, (const half_t*)beta, silu, partialA, nch, 1.f / ((float)HW * cpg), eps, stats, src)
   if (Xl) SKG_GN_FOLD(true); else SKG_GN_FOLD(false);
 #undef SKG_GN_FOLD
@@ -722,7 +730,7 @@ static int gn_from_partial_impl(const void* X, const void* Xl, int ldx, void* Y,
 extern "C" int skg_groupnorm_from_partial(const void* X, int ldx, void* Y, int ldy, int rows, int HW, int C, int groups,
                                           float eps, const void* gamma, const void* beta, int silu, float* stats,
                                           const float* partial, int nch, void* stream) {
-  return gn_from_partial_impl(X, nullptr, ldx, Y, ldy, rows, HW, C, 0, groups, eps, gamma, beta, silu, stats, partial, groups,
+  return gn_from_partial_impl(X, nullptr, ldx, Y, nullptr, ldy, rows, HW, C, 0, groups, eps, gamma, beta, silu, stats, partial, groups,
                               nullptr, 0, nch, stream);
 }
 
@@ -731,17 +739,17 @@ extern "C" int skg_groupnorm_from_partial2(const void* X, int ldx, void* Y, int 
                                            float* stats, const float* partialA, int groupsA, const float* partialB,
                                            int groupsB, int nch, void* stream) {
   SKG_REQUIRE(partialB);
-  return gn_from_partial_impl(X, nullptr, ldx, Y, ldy, rows, HW, C, CA, groups, eps, gamma, beta, silu, stats, partialA, groupsA,
+  return gn_from_partial_impl(X, nullptr, ldx, Y, nullptr, ldy, rows, HW, C, CA, groups, eps, gamma, beta, silu, stats, partialA, groupsA,
                               partialB, groupsB, nch, stream);
 }
 
 // accuracy mode: the same for a pair X + X_lo (partialB == NULL: one producer; else the concatenation form)
-extern "C" int skg_groupnorm_from_partial_hilo(const void* X, const void* X_lo, int ldx, void* Y, int ldy, int rows, int HW,
+extern "C" int skg_groupnorm_from_partial_hilo(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int rows, int HW,
                                                int C, int CA, int groups, float eps, const void* gamma, const void* beta,
                                                int silu, float* stats, const float* partialA, int groupsA,
                                                const float* partialB, int groupsB, int nch, void* stream) {
   SKG_REQUIRE(X_lo && (partialB || groupsA == groups));
-  return gn_from_partial_impl(X, X_lo, ldx, Y, ldy, rows, HW, C, CA, groups, eps, gamma, beta, silu, stats, partialA, groupsA,
+  return gn_from_partial_impl(X, X_lo, ldx, Y, Y_lo, ldy, rows, HW, C, CA, groups, eps, gamma, beta, silu, stats, partialA, groupsA,
                               partialB, groupsB, nch, stream);
 }
 

@@ -27,6 +27,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 struct XAParams {
   const half_t* X; int ldx;
   half_t* Y; int ldy;
+  const half_t* Xl; half_t* Yl;      // accuracy mode (HILO): input and output are PAIRS X + Xl, Y + Yl (pitches ldx / ldy)
   int M, HW;
   const half_t* gamma; const half_t* beta; float eps;
   const half_t* Wp;        // [heads][60][512]: Wq_h (30 pieces: tile t, k-step ks) then the Wo_h image (30 pieces)
@@ -65,6 +66,9 @@ __device__ __forceinline__ float4_t mfma32_fresh(half8_t a, half8_t b, float4_t 
   return d;
 }
 
+// HILO (accuracy mode, skg_xattn_block_f16_hilo): LayerNorm reads hi + lo, the residual sum is formed in fp32 on the pair and stored
+// as hi = fp16(v), lo = fp16(v - hi); everything between is the same kernel
+template <bool HILO>
 __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
   constexpr int KS = 10, C = 320, NU = 20, PIECE = 512;
   constexpr int WQ = 0, NWQ = 30;                        // pieces
@@ -112,6 +116,43 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
   const int mrow = m0 + l16;
   const int mload = min(mrow, p.M - 1);
   half8_t xb[KS];
+  if constexpr (HILO)
+  {
+    // (the lo parts are re-read in each of the three passes through a pointer the compiler cannot see through: see ffblock.hip)
+    const half_t* xr = p.X + (size_t)mload * p.ldx + 8 * g;
+    const half_t* xlr = p.Xl + (size_t)mload * p.ldx + 8 * g;
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      xb[ks] = ld_half8(xr + 32 * ks);
+      const half8_t xl = ld_half8(xlr + 32 * ks);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += (float)xb[ks][i] + (float)xl[i];
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.f / C);
+    asm volatile("" : "+v"(xlr));
+    float s2 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8_t xl = ld_half8(xlr + 32 * ks);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = (float)xb[ks][i] + (float)xl[i] - mean; s2 += d * d; }
+    }
+    s2 += __shfl_xor(s2, 16, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float rstd = rsqrtf(s2 * (1.f / C) + p.eps);
+    asm volatile("" : "+v"(xlr));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const half8_t gv = ld_half8(p.gamma + 32 * ks + 8 * g), bv = ld_half8(p.beta + 32 * ks + 8 * g);
+      const half8_t xl = ld_half8(xlr + 32 * ks);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xb[ks][i] = (half_t)(((float)xb[ks][i] + (float)xl[i] - mean) * rstd * (float)gv[i] + (float)bv[i]);
+    }
+  }
+  else
   {
     const half_t* xr = p.X + (size_t)mload * p.ldx + 8 * g;
     float s = 0.f;
@@ -251,6 +292,37 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
   // ---- epilogue (as ffblock.hip): residual added in fp32, the tile through the wave's own slice of the idle LDS, whole-row stores
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   lds_barrier();
+  if constexpr (HILO) {
+    half_t* const stg = smem + wave * (16 * OP);
+    constexpr int PPR = C / 8;
+    {   // the pair residual joins the accumulators first (ONE read of X: Y may alias X); hi, then lo, through the same slice
+      const half_t* xr = p.X + (size_t)mload * p.ldx + 4 * g;
+      const half_t* xlr = p.Xl + (size_t)mload * p.ldx + 4 * g;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const half4_t r4 = ld_half4(xr + 16 * u), l4 = ld_half4(xlr + 16 * u);
+        y[u] += float4_t{(float)r4[0], (float)r4[1], (float)r4[2], (float)r4[3]} + float4_t{(float)l4[0], (float)l4[1], (float)l4[2], (float)l4[3]};
+      }
+    }
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const float4_t f = y[u];
+        half4_t v = {(half_t)f[0], (half_t)f[1], (half_t)f[2], (half_t)f[3]};
+        if (part == 1) v = half4_t{(half_t)(f[0] - (float)v[0]), (half_t)(f[1] - (float)v[1]), (half_t)(f[2] - (float)v[2]), (half_t)(f[3] - (float)v[3])};
+        st_half4(stg + l16 * OP + 16 * u + 4 * g, v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      half_t* const dst = part == 0 ? p.Y : p.Yl;
+#pragma unroll
+      for (int j = 0; j < 16 * PPR / 64; ++j) {
+        const int pi = lane + 64 * j;
+        const int row = pi / PPR, pc = pi - row * PPR;
+        if (m0 + row < p.M) st_half8(dst + (size_t)(m0 + row) * p.ldy + pc * 8, ld_half8(stg + row * OP + pc * 8));
+      }
+    }
+  } else {
   half_t* const stg = smem + wave * (16 * OP);
   {
     const half_t* xr = p.X + (size_t)mload * p.ldx + 4 * g;
@@ -270,27 +342,44 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     const int row = pi / PPR, pc = pi - row * PPR;
     if (m0 + row < p.M) st_half8(p.Y + (size_t)(m0 + row) * p.ldy + pc * 8, ld_half8(stg + row * OP + pc * 8));
   }
+  }
 }
 
 }  // namespace
 
-extern "C" int skg_xattn_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int HW, int C, int heads, int Nkv,
-                                   const void* gamma, const void* beta, float eps, const void* Wpack, const void* KVpack,
-                                   const void* bias_out, float scale, void* stream) {
-  SKG_REQUIRE(X && Y && gamma && beta && Wpack && KVpack && bias_out && M > 0);
+static int xattn_block_impl(const void* X, const void* Xl, int ldx, void* Y, void* Yl, int ldy, int M, int HW, int C, int heads,
+                            int Nkv, const void* gamma, const void* beta, float eps, const void* Wpack, const void* KVpack,
+                            const void* bias_out, float scale, void* stream) {
+  SKG_REQUIRE(X && Y && gamma && beta && Wpack && KVpack && bias_out && M > 0 && (Xl != nullptr) == (Yl != nullptr));
   SKG_REQUIRE(C == 320 && heads == 8 && Nkv > 0 && Nkv <= 80 && HW > 0 && HW % 128 == 0 && M % HW == 0);
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
-  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16) &&
-              skg_aligned(Wpack, 16) && skg_aligned(KVpack, 16) && skg_aligned(bias_out, 8));
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(Xl, 16) && skg_aligned(Yl, 16) && skg_aligned(gamma, 16) &&
+              skg_aligned(beta, 16) && skg_aligned(Wpack, 16) && skg_aligned(KVpack, 16) && skg_aligned(bias_out, 8));
   XAParams p;
   p.X = (const half_t*)X; p.ldx = ldx; p.Y = (half_t*)Y; p.ldy = ldy; p.M = M; p.HW = HW;
+  p.Xl = (const half_t*)Xl; p.Yl = (half_t*)Yl;
   p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.eps = eps;
   p.Wp = (const half_t*)Wpack; p.KVp = (const half_t*)KVpack; p.bo = (const half_t*)bias_out;
   p.heads = heads; p.nkv = Nkv;
   p.sc = scale * 1.4426950408889634f;
   p.wbytes = (unsigned)heads * 60u * 1024u;
   p.kvbytes = (unsigned)(M / HW) * (unsigned)heads * 16u * 1024u;
-  hipLaunchKernelGGL(xattn_block_kernel, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+  if (Xl) hipLaunchKernelGGL(xattn_block_kernel<true>, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(xattn_block_kernel<false>, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
   SKG_CHECK_LAUNCH("skg_xattn_block_f16");
   return SKG_OK;
+}
+
+extern "C" int skg_xattn_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int HW, int C, int heads, int Nkv,
+                                   const void* gamma, const void* beta, float eps, const void* Wpack, const void* KVpack,
+                                   const void* bias_out, float scale, void* stream) {
+  return xattn_block_impl(X, nullptr, ldx, Y, nullptr, ldy, M, HW, C, heads, Nkv, gamma, beta, eps, Wpack, KVpack, bias_out, scale, stream);
+}
+
+// accuracy mode: pair input X + X_lo (pitch ldx), pair output Y + Y_lo (pitch ldy)
+extern "C" int skg_xattn_block_f16_hilo(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int M, int HW, int C,
+                                        int heads, int Nkv, const void* gamma, const void* beta, float eps, const void* Wpack,
+                                        const void* KVpack, const void* bias_out, float scale, void* stream) {
+  SKG_REQUIRE(X_lo && Y_lo);
+  return xattn_block_impl(X, X_lo, ldx, Y, Y_lo, ldy, M, HW, C, heads, Nkv, gamma, beta, eps, Wpack, KVpack, bias_out, scale, stream);
 }

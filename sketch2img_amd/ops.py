@@ -196,37 +196,56 @@ def gemm_geglu_keep(A: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tenso
     return out, pre
 
 
-def ff_block(X: torch.Tensor, gamma, beta, eps: float, pack: torch.Tensor, bias1_pack: torch.Tensor, bias2: torch.Tensor,
-             out: Optional[torch.Tensor] = None, want_stats: bool = False, keep_from: Optional[int] = None):
+def ff_block(X, gamma, beta, eps: float, pack: torch.Tensor, bias1_pack: torch.Tensor, bias2: torch.Tensor,
+             out=None, want_stats: bool = False, keep_from: Optional[int] = None):
     """Fused feed-forward sub-block at C = 320: out = X + b2 + W2 . geglu(W1 . LayerNorm(X) + b1) in one launch
     (skg_ff_block_f16; pack / bias1_pack from unet.pack_ff_block).  out may be X.
-    keep_from=m0: rows >= m0 also store the FF1 output (interleaved pack, what geglu_bwd reads) -> returned last."""
-    _f16(X, gamma, beta, pack, bias2)
-    M, C = X.shape
+    keep_from=m0: rows >= m0 also store the FF1 output (interleaved pack, what geglu_bwd reads) -> returned last.
+    X (and out) may be ops.Pair objects (accuracy mode: skg_ff_block_f16_hilo)."""
+    pair = isinstance(X, Pair)
+    Xh = X.hi if pair else X
+    _f16(Xh, gamma, beta, pack, bias2)
+    M, C = Xh.shape
     assert pack.is_contiguous() and pack.dim() == 3 and pack.shape[1:] == (60, 512) and bias1_pack.dtype == torch.float32
     F = pack.shape[0] * 32
     if out is None:
-        out = torch.empty(M, C, device=X.device, dtype=torch.float16)
-    stats = torch.empty(M, 2, device=X.device, dtype=torch.float32) if want_stats else None
-    if keep_from is None:
+        out = Pair.empty(M, C, Xh.device) if pair else torch.empty(M, C, device=Xh.device, dtype=torch.float16)
+    stats = torch.empty(M, 2, device=Xh.device, dtype=torch.float32) if want_stats else None
+    pre = None if keep_from is None else torch.empty(M - keep_from, 2 * F, device=Xh.device, dtype=torch.float16)
+    if pair:
+        assert _ld(X.lo) == _ld(X.hi) and _ld(out.lo) == _ld(out.hi)
+        check(lib.skg_ff_block_f16_hilo(_p(X.hi), _p(X.lo), _ld(X.hi), _p(out.hi), _p(out.lo), _ld(out.hi), M, C, F, _p(gamma), _p(beta),
+                                        eps, _p(pack), _p(bias1_pack), _p(bias2), _p(stats), _p(pre), _ld(pre) if pre is not None else 0,
+                                        keep_from or 0, _stream()), "skg_ff_block_f16_hilo")
+    elif keep_from is None:
         check(lib.skg_ff_block_f16(_p(X), _ld(X), _p(out), _ld(out), M, C, F, _p(gamma), _p(beta), eps, _p(pack), _p(bias1_pack),
                                    _p(bias2), _p(stats), _stream()), "skg_ff_block_f16")
+    else:
+        check(lib.skg_ff_block_f16_keep(_p(X), _ld(X), _p(out), _ld(out), M, C, F, _p(gamma), _p(beta), eps, _p(pack), _p(bias1_pack),
+                                        _p(bias2), _p(stats), _p(pre), _ld(pre), keep_from, _stream()), "skg_ff_block_f16_keep")
+    if keep_from is None:
         return (out, stats) if want_stats else out
-    pre = torch.empty(M - keep_from, 2 * F, device=X.device, dtype=torch.float16)
-    check(lib.skg_ff_block_f16_keep(_p(X), _ld(X), _p(out), _ld(out), M, C, F, _p(gamma), _p(beta), eps, _p(pack), _p(bias1_pack),
-                                    _p(bias2), _p(stats), _p(pre), _ld(pre), keep_from, _stream()), "skg_ff_block_f16_keep")
     return (out, stats, pre) if want_stats else (out, pre)
 
 
-def xattn_block(X: torch.Tensor, HW: int, heads: int, Nkv: int, gamma, beta, eps: float, wpack: torch.Tensor, kvpack: torch.Tensor,
-                bias_out: torch.Tensor, scale: float, out: Optional[torch.Tensor] = None):
+def xattn_block(X, HW: int, heads: int, Nkv: int, gamma, beta, eps: float, wpack: torch.Tensor, kvpack: torch.Tensor,
+                bias_out: torch.Tensor, scale: float, out=None):
     """Fused cross-attention sub-block at C = 320, 8 heads: out = X + bo + Wo . Attention(Wq . LayerNorm(X), K, V) over the text
-    keys of each row's image, in one launch (skg_xattn_block_f16; packs from unet.pack_xattn_weights / pack_xattn_kv)."""
-    _f16(X, gamma, beta, wpack, kvpack, bias_out)
-    M, C = X.shape
+    keys of each row's image, in one launch (skg_xattn_block_f16; packs from unet.pack_xattn_weights / pack_xattn_kv).
+    X (and out) may be ops.Pair objects (accuracy mode: skg_xattn_block_f16_hilo)."""
+    pair = isinstance(X, Pair)
+    Xh = X.hi if pair else X
+    _f16(Xh, gamma, beta, wpack, kvpack, bias_out)
+    M, C = Xh.shape
     assert wpack.is_contiguous() and wpack.shape == (heads, 60, 512) and kvpack.is_contiguous() and kvpack.shape == (M // HW, heads, 16, 512)
     if out is None:
-        out = torch.empty(M, C, device=X.device, dtype=torch.float16)
+        out = Pair.empty(M, C, Xh.device) if pair else torch.empty(M, C, device=Xh.device, dtype=torch.float16)
+    if pair:
+        assert _ld(X.lo) == _ld(X.hi) and _ld(out.lo) == _ld(out.hi)
+        check(lib.skg_xattn_block_f16_hilo(_p(X.hi), _p(X.lo), _ld(X.hi), _p(out.hi), _p(out.lo), _ld(out.hi), M, HW, C, heads, Nkv,
+                                           _p(gamma), _p(beta), eps, _p(wpack), _p(kvpack), _p(bias_out), scale, _stream()),
+              "skg_xattn_block_f16_hilo")
+        return out
     check(lib.skg_xattn_block_f16(_p(X), _ld(X), _p(out), _ld(out), M, HW, C, heads, Nkv, _p(gamma), _p(beta), eps, _p(wpack),
                                   _p(kvpack), _p(bias_out), scale, _stream()), "skg_xattn_block_f16")
     return out
@@ -288,6 +307,17 @@ def conv_up2(X: torch.Tensor, Wpp: torch.Tensor, rows: int, IH: int, IW: int, ou
         out = torch.empty(rows * 4 * IH * IW, Cout, device=X.device, dtype=torch.float16)
     check(lib.skg_conv3x3_up2_f16(_p(X), _ld(X), _p(Wpp), _p(out), _ld(out), rows, IH, IW, Cin, Cout, _p(bias), _stream()),
           "skg_conv3x3_up2_f16")
+    return out
+
+
+def conv_up2_hilo(X2: torch.Tensor, Wpp3: torch.Tensor, rows: int, IH: int, IW: int, out: Pair, *, bias=None):
+    """Accuracy mode: conv_up2 on the pair buffer X2 = [x_hi | x_lo] ([rows*IH*IW, 2C]) with (hi, lo) pre-summed weights
+    Wpp3 [4, Cout, 4 * 3C] (unet.pack_conv_up2_hilo); the output is the pair `out`."""
+    _f16(X2, Wpp3, bias, out.hi, out.lo)
+    C, Cout = X2.shape[1] // 2, Wpp3.shape[1]
+    assert Wpp3.shape == (4, Cout, 12 * C) and Wpp3.is_contiguous() and X2.shape[0] == rows * IH * IW and _ld(out.hi) == _ld(out.lo)
+    check(lib.skg_conv3x3_up2_f16_hilo(_p(X2), _ld(X2), _p(Wpp3), _p(out.hi), _p(out.lo), _ld(out.hi), rows, IH, IW, C, Cout, _p(bias),
+                                       _stream()), "skg_conv3x3_up2_f16_hilo")
     return out
 
 
@@ -388,12 +418,12 @@ def groupnorm(X, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, parti
     return out, st
 
 
-def groupnorm_hilo(X, X_lo, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, want_stats=False, partial=None):
+def groupnorm_hilo(X, X_lo, rows, HW, groups, eps, gamma, beta, silu: bool, out=None, want_stats=False, partial=None, out_lo=None):
     """GroupNorm(+SiLU) of the pair X + X_lo (accuracy mode): statistics from the hi part (the producer's epilogue sums when
     `partial` - a GNPartial, or (GNPartial of A, channels of A, GNPartial of B) for a concatenation - is given, else an own
-    pass; small maps: one launch on the pair's sum), apply on the sum."""
-    _f16(X, X_lo, gamma, beta)
-    assert _ld(X) == _ld(X_lo)
+    pass; small maps: one launch on the pair's sum), apply on the sum.  out_lo: the output as a pair too (pitch of `out`)."""
+    _f16(X, X_lo, gamma, beta, out_lo)
+    assert _ld(X) == _ld(X_lo) and (out_lo is None or (out is not None and _ld(out_lo) == _ld(out)))
     C = X.shape[1]
     if out is None:
         out = torch.empty(X.shape[0], C, device=X.device, dtype=torch.float16)
@@ -401,12 +431,12 @@ def groupnorm_hilo(X, X_lo, rows, HW, groups, eps, gamma, beta, silu: bool, out=
     if partial is not None:
         pa, CA, pb = partial if isinstance(partial, tuple) else (partial, 0, None)
         assert pa.rows == rows and pa.nch == HW // 128 and (pb is not None or pa.groups == groups)
-        check(lib.skg_groupnorm_from_partial_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _ld(out), rows, HW, C, CA, groups, eps,
+        check(lib.skg_groupnorm_from_partial_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _p(out_lo), _ld(out), rows, HW, C, CA, groups, eps,
                                                   _p(gamma), _p(beta), int(silu), _p(st), _p(pa.buf), pa.groups,
                                                   None if pb is None else _p(pb.buf), 0 if pb is None else pb.groups, pa.nch,
                                                   _stream()), "skg_groupnorm_from_partial_hilo")
     else:
-        check(lib.skg_groupnorm_fwd_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _ld(out), rows, HW, C, groups, eps, _p(gamma),
+        check(lib.skg_groupnorm_fwd_hilo(_p(X), _p(X_lo), _ld(X), _p(out), _p(out_lo), _ld(out), rows, HW, C, groups, eps, _p(gamma),
                                          _p(beta), int(silu), _p(st), _p(_gn_scratch(rows, groups, X.device)), _stream()),
               "skg_groupnorm_fwd_hilo")
     return (out, st) if want_stats else out
@@ -562,7 +592,9 @@ def nchw_to_nhwc(X: torch.Tensor, Cpad: int, out=None):
     return out
 
 
-def nhwc_to_nchw(X: torch.Tensor, rows: int, C: int, H: int, W: int):
+def nhwc_to_nchw(X, rows: int, C: int, H: int, W: int):
+    if isinstance(X, Pair):      # accuracy mode: hi + lo in fp32
+        return nhwc_to_nchw(X.hi, rows, C, H, W) + nhwc_to_nchw(X.lo, rows, C, H, W)
     _f16(X)
     out = torch.empty(rows, C, H, W, device=X.device, dtype=torch.float32)
     check(lib.skg_nhwc_f16_to_nchw_f32(_p(X), _ld(X), _p(out), rows, C, H * W, _stream()),
@@ -776,25 +808,36 @@ def gaussian_sample(moments, samples: int, L: int, HW: int, noise=None, scale: f
     return out
 
 
+def eps_halves(eps, samples, HW):
+    """(uncond rows, cond rows, pair offset) of the UNet's eps for cfg_*_step: fp16 [2 S HW, >= 4], or - accuracy mode - a
+    Pair whose lo part sits a fixed number of columns to the right of the hi part in the same buffer."""
+    if isinstance(eps, Pair):
+        off = (eps.lo.data_ptr() - eps.hi.data_ptr()) // 2
+        assert _ld(eps.hi) == _ld(eps.lo) and 0 < off <= _ld(eps.hi) - 4
+        return eps.hi[:samples * HW], eps.hi[samples * HW:], off
+    return eps[:samples * HW], eps[samples * HW:], 0
+
+
 def cfg_ddim_step(eps_u, eps_c, x, samples, HW, g, coeffs: Tuple[float, float, float, float],
-                  want_eps=False):
+                  want_eps=False, lo_off: int = 0):
+    """lo_off != 0: eps_u / eps_c are the hi parts of pairs whose lo parts sit lo_off columns to the right (eps_halves)."""
     _f16(eps_u, eps_c)
     x_prev = torch.empty_like(x)
     eps_out = torch.empty_like(x) if want_eps else None
     c0, c1, c2, c3 = coeffs
-    check(lib.skg_cfg_ddim_step(_p(eps_u), _p(eps_c), _ld(eps_u), _p(x), _p(x_prev), _p(eps_out), samples, HW,
+    check(lib.skg_cfg_ddim_step(_p(eps_u), _p(eps_c), _ld(eps_u), lo_off, _p(x), _p(x_prev), _p(eps_out), samples, HW,
                                 g, c0, c1, c2, c3, _stream()), "skg_cfg_ddim_step")
     return (x_prev, eps_out) if want_eps else x_prev
 
 
 def cfg_dpmpp2m_step(eps_u, eps_c, x, x0_io, samples, HW, g, coeffs: Tuple[float, float, float, float, float],
-                     want_eps=False):
+                     want_eps=False, lo_off: int = 0):
     """coeffs = (alpha_s, sigma_s, a, b, c); x0_io is updated in place (previous x0 in, this step's x0 out)."""
     _f16(eps_u, eps_c)
     x_prev = torch.empty_like(x)
     eps_out = torch.empty_like(x) if want_eps else None
     al, sg, a, b, c = coeffs
-    check(lib.skg_cfg_dpmpp2m_step(_p(eps_u), _p(eps_c), _ld(eps_u), _p(x), _p(x0_io), _p(x_prev), _p(eps_out),
+    check(lib.skg_cfg_dpmpp2m_step(_p(eps_u), _p(eps_c), _ld(eps_u), lo_off, _p(x), _p(x0_io), _p(x_prev), _p(eps_out),
                                    samples, HW, g, al, sg, a, b, c, _stream()), "skg_cfg_dpmpp2m_step")
     return (x_prev, eps_out) if want_eps else x_prev
 

@@ -170,15 +170,15 @@ class HipSampler:
         eps, taps = self.unet.forward(x32, t, 2 * S, h, stash, want_taps=guided, shared_input=self.share_cfg_prefix,
                                       on_taps=on_taps if fork else None)
         fork = fork and "done" in branch          # (a forward that never reached the hook runs the branch in line)
+        eu, ec, lo_off = ops.eps_halves(eps, S, hw)      # (accuracy mode: eps is a (hi, lo) pair, combined in fp32 by the step kernel)
         if isinstance(tab, DPMTables):
             if self._x0_before is None or self._x0_before.shape != x.shape:
                 self._x0_before, self._seen = torch.zeros_like(x), 0
             order = tab.order(i, self._seen)
-            res = ops.cfg_dpmpp2m_step(eps[:S * hw], eps[S * hw:], x, self._x0_before, S, hw, guidance_scale,
-                                       tab.coeffs(i, order), want_eps)
+            res = ops.cfg_dpmpp2m_step(eu, ec, x, self._x0_before, S, hw, guidance_scale, tab.coeffs(i, order), want_eps, lo_off=lo_off)
             self._seen = min(self._seen + 1, tab.solver_order)
         else:
-            res = ops.cfg_ddim_step(eps[:S * hw], eps[S * hw:], x, S, hw, guidance_scale, tab.coeffs(t), want_eps)
+            res = ops.cfg_ddim_step(eu, ec, x, S, hw, guidance_scale, tab.coeffs(t), want_eps, lo_off=lo_off)
         x_prev, eps_cfg = res if want_eps else (res, None)
         aux = None
         if guided:

@@ -85,6 +85,25 @@ def pack_conv_up2(w: torch.Tensor, dev) -> torch.Tensor:
     return _h(torch.stack(phases, 0), dev)
 
 
+def pack_conv_up2_hilo(w: torch.Tensor, dev) -> torch.Tensor:
+    """Accuracy-mode polyphase pack (ops.conv_up2_hilo): the pre-summed weights of pack_conv_up2 kept as (hi, lo) fp16 pairs,
+    per phase and tap [W_hi | W_hi | W_lo] against the operand blocks [x_hi | x_lo | x_hi]: [4][Cout][4 taps][3 Cin]."""
+    w = w.detach().float()
+    co, ci = w.shape[:2]
+    phases = []
+    for a in (0, 1):
+        rws = (w[:, :, 0], w[:, :, 1] + w[:, :, 2]) if a == 0 else (w[:, :, 0] + w[:, :, 1], w[:, :, 2])      # [co, ci, kx]
+        for b in (0, 1):
+            taps = []
+            for r in rws:
+                taps += [r[:, :, 0], r[:, :, 1] + r[:, :, 2]] if b == 0 else [r[:, :, 0] + r[:, :, 1], r[:, :, 2]]
+            t = torch.stack(taps, 1)                                                                           # [co][tap][ci] fp32
+            hi = t.half()
+            lo = (t - hi.float()).half()
+            phases.append(torch.cat([hi, hi, lo], 2).reshape(co, 12 * ci))
+    return torch.stack(phases, 0).contiguous().to(dev)
+
+
 def pack_conv_up2_dgrad(w: torch.Tensor, dev) -> torch.Tensor:
     """Data gradient of the polyphase upsample + conv (ops.conv4x4s2): [Cin][16 taps ky*4+kx][Cout], the transposed pre-summed
     weights of pack_conv_up2.  dX[p] = sum over phases a and taps ty of Wpp[a][ty]^T dY[2 (p - oy(a, ty)) + a] with
@@ -295,7 +314,12 @@ class HipUNet:
                 w = v.reshape(v.shape[0], v.shape[1])
                 W[k + ":2"] = _h(torch.cat([w, w], 1), dev)
             elif ".downsamplers." in k and k.endswith(".weight") or ".upsamplers." in k and k.endswith(".weight"):
-                W[k + ":2"] = pack_conv(torch.cat([v, v], 1), dev)
+                if ".upsamplers." in k and UP2_POLYPHASE and v.shape[1] % 64 == 0:
+                    W[k + ":pp3"] = pack_conv_up2_hilo(v, dev)      # polyphase with (hi, lo) pre-summed weights
+                else:
+                    W[k + ":2"] = pack_conv(torch.cat([v, v], 1), dev)
+            elif k == "conv_out.weight":      # its operand - the last normalised activation - reaches eps one to one: a pair too
+                W[k + ":2"] = pack_conv(torch.cat([v, v], 1), dev, cout_pad=COUT_PAD)
 
     # ------------------------------------------------------------------ hoisted precompute
     def prepare_timesteps(self, timesteps: Sequence[int]):
@@ -786,24 +810,46 @@ class HipUNet:
                     x, p1, shared = x_full, p1_full, False
                 p1 = self.inject(t, p1, rows, HW, heads)
             p1_c = p1
-        r2 = rows // 2 if shared else rows
-        a2, st2 = ops.layernorm_hilo(p1.hi, p1.lo, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
-        q2_full = torch.empty(M, C, device=self.dev, dtype=torch.float16) if shared else None
-        q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"], q2_full[M1:] if shared else None)
-        q2_c = q2
-        if shared:      # the text-dependent part needs both halves: one copy each into the uncond half
-            ops.batch_copy(p1.full, M1, p1_full.full, M1, 1, M1)
-            ops.batch_copy(q2, M1, q2_full, M1, 1, M1)
-            x, p1, q2 = x_full, p1_full, q2_full
         cb = self.ctx["blocks"][t + ".attn2"]
-        o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
-                                want_lse=True, v_rows=True)
-        p2 = self._pair(M, C)
-        ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], out=p2.hi, out_lo=p2.lo, bias=W[t + ".attn2.to_out.0.bias"],
-                 residual=p1.hi, residual_lo=p1.lo)
-        a3, st3 = ops.layernorm_hilo(p2.hi, p2.lo, W[t + ".norm3.weight"], W[t + ".norm3.bias"], want_stats=True)
+        xab = _XATTN_BLOCK and not keep and "kvpack" in cb and heads == 8 and HW % 128 == 0
+        if xab:
+            # no backward will follow: norm2 -> to_q -> text attention -> to_out + residual in ONE row-local launch on the pair
+            if shared:
+                ops.batch_copy(p1.full, M1, p1_full.full, M1, 1, M1)
+                x, p1, shared = x_full, p1_full, False
+            p2 = ops.xattn_block(p1, HW, heads, self.ctx["L"], W[t + ".norm2.weight"], W[t + ".norm2.bias"], 1e-5,
+                                 W[t + ".attn2.xpack"], cb["kvpack"], W[t + ".attn2.to_out.0.bias"], scale)
+            st2 = q2 = q2_c = o2 = lse2 = None
+        else:
+            a2, st2 = ops.layernorm_hilo(p1.hi, p1.lo, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
+            q2_full = torch.empty(M, C, device=self.dev, dtype=torch.float16) if shared else None
+            q2 = ops.gemm(a2, W[t + ".attn2.to_q.weight"], q2_full[M1:] if shared else None)
+            q2_c = q2
+            if shared:      # the text-dependent part needs both halves: one copy each into the uncond half
+                ops.batch_copy(p1.full, M1, p1_full.full, M1, 1, M1)
+                ops.batch_copy(q2, M1, q2_full, M1, 1, M1)
+                x, p1, q2 = x_full, p1_full, q2_full
+            o2, lse2 = ops.attn_fwd(q2, cb["K"], cb["V"], rows, heads, HW, self.ctx["L"], self.ctx["Lp"], dh, scale,
+                                    want_lse=True, v_rows=True)
+            p2 = self._pair(M, C)
+            ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], out=p2.hi, out_lo=p2.lo, bias=W[t + ".attn2.to_out.0.bias"],
+                     residual=p1.hi, residual_lo=p1.lo)
+        ffb = _FF_BLOCK and (t + ".ff.pack") in W and (not keep or (rows % 2 == 0 and _FF_KEEP))
         f = None
-        if keep and C % 64 == 0 and rows % 2 == 0:     # guided step: the cond half's gate also keeps its pre-activation
+        if ffb:
+            # C = 320: norm3 -> FF1 -> gate -> FF2 + residual in ONE row-local launch on the pair (guided steps: the same launch
+            # stores the cond rows' FF1 output and norm3's statistics for the backward)
+            ffargs = (W[t + ".norm3.weight"], W[t + ".norm3.bias"], 1e-5, W[t + ".ff.pack"], W[t + ".ff.bias1"], W[t + ".ff.net.2.bias"])
+            st3 = None
+            if keep:
+                p3, st3, f = ops.ff_block(p2, *ffargs, want_stats=True, keep_from=(rows // 2) * HW)
+            else:
+                p3 = ops.ff_block(p2, *ffargs)
+        else:
+            a3, st3 = ops.layernorm_hilo(p2.hi, p2.lo, W[t + ".norm3.weight"], W[t + ".norm3.bias"], want_stats=True)
+        if ffb:
+            pass
+        elif keep and C % 64 == 0 and rows % 2 == 0:     # guided step: the cond half's gate also keeps its pre-activation
             M0 = (rows // 2) * HW
             gg = torch.empty(M, 4 * C, device=self.dev, dtype=torch.float16)
             ops.gemm(a3[:M0], W[t + ".ff.net.0.proj.weight"], bias=W[t + ".ff.net.0.proj.bias"], geglu=True, out=gg[:M0])
@@ -823,9 +869,10 @@ class HipUNet:
             else:
                 stash.tr[p] = dict(x=x.hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1.hi, st2=st2, q2=q2,
                                    o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=())
-        p3 = self._pair(M, C)
-        ops.gemm(gg, W[t + ".ff.net.2.weight"], out=p3.hi, out_lo=p3.lo, bias=W[t + ".ff.net.2.bias"],
-                 residual=p2.hi, residual_lo=p2.lo)
+        if not ffb:
+            p3 = self._pair(M, C)
+            ops.gemm(gg, W[t + ".ff.net.2.weight"], out=p3.hi, out_lo=p3.lo, bias=W[t + ".ff.net.2.bias"],
+                     residual=p2.hi, residual_lo=p2.lo)
         out = out or self._pair(M, C)
         opart = None
         if want_part and self._gn_from_producer(rows, HW, C):
@@ -969,8 +1016,11 @@ class HipUNet:
                 u = (i + 1) * lpb1
                 ctn = cats[u].shape[1] // 2
                 o = P(cats[u][:, :ch_h[u]], cats[u][:, ctn:ctn + ch_h[u]])
-                ops.conv3x3(full_of(h, h.hi.shape[1]), W[p + ".weight:2"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo,
-                            bias=W[p + ".bias"])
+                if (p + ".weight:pp3") in W:      # polyphase, K axis [x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo]: 12 instead of 18 tap-products
+                    ops.conv_up2_hilo(full_of(h, h.hi.shape[1]), W[p + ".weight:pp3"], rows, cur, cur, o, bias=W[p + ".bias"])
+                else:
+                    ops.conv3x3(full_of(h, h.hi.shape[1]), W[p + ".weight:2"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo,
+                                bias=W[p + ".bias"])
                 h = o
                 hp = None
                 cur *= 2
@@ -980,8 +1030,14 @@ class HipUNet:
                     on_taps(taps_down + [tap_at, tap_r0, tap_r1] + taps_up)
         eps = None
         if want_eps:
-            n, _ = self._gn_hp(h, rows, cur * cur, 1e-5, "conv_norm_out", True, partial=hp)
-            eps = ops.conv3x3(n, W["conv_out.weight"], rows, cur, cur, bias=W["conv_out.bias"])
+            # conv_norm_out -> SiLU -> conv_out: both the normalised activation (the K-doubled operand [hi | lo] . [W | W]) and eps
+            # itself (a (hi, lo) pair in one [M, 2 * 8] buffer, combined in fp32 by the CFG / scheduler kernel) keep fp32 accuracy -
+            # their fp16 roundings would reach eps one to one (2.8e-4 relative each)
+            n = self._pair(rows * cur * cur, boc[0])
+            ops.groupnorm_hilo(h.hi, h.lo, rows, cur * cur, G, 1e-5, W["conv_norm_out.weight"], W["conv_norm_out.bias"], True,
+                               out=n.hi, out_lo=n.lo, partial=hp)
+            eps = self._pair(rows * cur * cur, COUT_PAD)
+            ops.conv3x3(n.full, W["conv_out.weight:2"], rows, cur, cur, out=eps.hi, out_lo=eps.lo, bias=W["conv_out.bias"])
         taps = taps_down + [tap_at, tap_r0, tap_r1] + taps_up
         if stash is not None:
             stash.misc.update(rows=rows, H=H)

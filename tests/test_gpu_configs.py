@@ -102,7 +102,7 @@ def test_sd15_accuracy_mode_meets_north_star_eps_bound():
     cfg = ounet.SD15
     W = ounet.init_weights(cfg)
     net = HipUNet(SD15, W, DEV, need_backward=False, residual_fp32=True)
-    worst = 0.0
+    worst = worst_rel = 0.0
     for t in (981, 501, 21):
         for seeds in ((7, 11), (23, 101)):
             g = torch.Generator().manual_seed(seeds[0] * 1000 + t)
@@ -114,8 +114,7 @@ def test_sd15_accuracy_mode_meets_north_star_eps_bound():
                 C, _ = ounet.unet_forward(cfg, W, xx, t, ehs)
             for row in range(2):
                 rAC, mAC = report(f"sd15 eps  HIP accuracy mode vs fp32 oracle, t = {t}, seed {seeds[row]}", A[row], C[row])
-                worst = max(worst, mAC)
-                assert mAC <= 1e-3 and rAC <= 7e-4
+                worst, worst_rel = max(worst, mAC), max(worst_rel, rAC)
             if t == 981 and seeds == (7, 11):
                 with torch.no_grad(), ounet.fp16_storage(skip=("res", "lin_n", "rop")):
                     B, _ = ounet.unet_forward(cfg, W, xx, t, ehs)
@@ -123,7 +122,8 @@ def test_sd15_accuracy_mode_meets_north_star_eps_bound():
                 rBC, mBC = report("sd15 eps  oracle emulation of the accuracy mode vs fp32 oracle", B, C)
                 report("sd15 eps  HIP accuracy mode vs its oracle emulation", A, B)
                 assert mAC < 1.35 * mBC and rAC < 1.25 * rBC + 5e-5
-    print(f"[parity] accuracy mode, 3 timesteps x 4 seeds: worst max |eps - eps_fp32| = {worst:.2e} (north_star bound 1e-3)")
+    print(f"[parity] accuracy mode, 3 timesteps x 4 seeds: worst max |eps - eps_fp32| = {worst:.2e} (north_star bound 1e-3), worst rel {worst_rel:.2e}")
+    assert worst <= 1e-3 and worst_rel <= 7e-4
 
 
 # ------------------------------------------------------------------------------------------------------ config 4

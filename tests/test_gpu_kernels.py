@@ -307,6 +307,7 @@ def test_hilo_producers_with_groupnorm_sums(ops, kind, rows, H, Cin, Cout, res):
     mode = {"conv": ops.CONV_S1, "down": ops.CONV_S2}.get(kind)
     OH = H // 2 if kind == "down" else H
     M, HW = rows * OH * OH, OH * OH
+    want_gn = HW % 128 == 0                  # (8 x 8 maps: the one-launch GroupNorm keeps its own statistics)
     x = (rnd(rows * H * H, Cin, seed=1).float() * 0.5).half().to(d)
     b = rnd(Cout, seed=3).to(d)
     rp = None
@@ -318,13 +319,15 @@ def test_hilo_producers_with_groupnorm_sums(ops, kind, rows, H, Cin, Cout, res):
     kw = dict(bias=b, residual=rp.hi if res else None, residual_lo=rp.lo if res else None)
     if kind == "gemm":
         w = (rnd(Cout, Cin, seed=2).float() * Cin ** -0.5).half().to(d)
-        _, part = ops.gemm(x, w, out=out.hi, out_lo=out.lo, gn_stats=(HW, G), **kw)
+        part = ops.gemm(x, w, out=out.hi, out_lo=out.lo, gn_stats=(HW, G) if want_gn else None, **kw)
+        part = part[1] if want_gn else None
         plain = ops.gemm(x, w, bias=b, residual=rp.hi.contiguous() if res else None)
         ref = x.double() @ w.double().t() + b.double()
     else:
         w4 = (torch.randn(Cout, Cin, 3, 3, generator=torch.Generator().manual_seed(2)) * (9 * Cin) ** -0.5).half()
         w = w4.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(d)
-        _, part = ops.conv3x3(x, w, rows, H, H, mode, out=out.hi, out_lo=out.lo, gn_groups=G, **kw)
+        part = ops.conv3x3(x, w, rows, H, H, mode, out=out.hi, out_lo=out.lo, gn_groups=G if want_gn else None, **kw)
+        part = part[1] if want_gn else None
         plain = ops.conv3x3(x, w, rows, H, H, mode, bias=b, residual=rp.hi.contiguous() if res else None)
         xs = x.double().reshape(rows, H, H, Cin).permute(0, 3, 1, 2)
         ref = F.conv2d(xs, w4.double().to(d), padding=1, stride=2 if kind == "down" else 1).permute(0, 2, 3, 1).reshape(M, Cout) + b.double()
@@ -337,19 +340,106 @@ def test_hilo_producers_with_groupnorm_sums(ops, kind, rows, H, Cin, Cout, res):
     # hi is the plain launch's output (up to the last bit where the residual's lo part moves a rounding)
     assert float((out.hi.float() - plain.float()).abs().max()) <= 2.0 ** -9 * float(plain.float().abs().max())
     cpg = Cout // G
-    yf = out.hi.float().reshape(rows, HW // 128, 128, G, cpg)
-    sref = torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1)
-    got = part.buf.view(rows, HW // 128, G, 2)
-    err = ((got - sref).abs() / (sref.abs().amax(dim=(1, 2), keepdim=True) + 1e-6)).max().item()
-    assert err < 2e-5, err
     ga, be = (1 + 0.2 * rnd(Cout, seed=5).float()).half().to(d), (0.2 * rnd(Cout, seed=6).float()).half().to(d)
-    n1, st1 = ops.groupnorm_hilo(out.hi, out.lo, rows, HW, G, 1e-5, ga, be, True, want_stats=True, partial=part)
-    n0, st0 = ops.groupnorm_hilo(out.hi, out.lo, rows, HW, G, 1e-5, ga, be, True, want_stats=True)
     vs = (out.hi.float() + out.lo.float()).reshape(rows, HW, Cout).permute(0, 2, 1)
-    nref = F.silu(F.group_norm(vs, G, ga.float(), be.float(), 1e-5)).permute(0, 2, 1).reshape(M, Cout)
-    for n in (n1, n0):
-        assert float((n.float() - nref).norm() / nref.norm()) < 4e-4
-    assert (st1 - st0).abs().max().item() < 2e-4 * (1 + st0.abs().max().item())
+    nref = F.silu(F.group_norm(vs.double(), G, ga.double(), be.double(), 1e-5)).permute(0, 2, 1).reshape(M, Cout)
+    n0, st0 = ops.groupnorm_hilo(out.hi, out.lo, rows, HW, G, 1e-5, ga, be, True, want_stats=True)
+    assert float((n0.double() - nref).norm() / nref.norm()) < 4e-4
+    # pair OUTPUT of the norm (conv_norm_out in front of conv_out): hi + lo carries fp32 accuracy, hi is the fp16 output
+    npair = ops.Pair.empty(M, Cout, d)
+    ops.groupnorm_hilo(out.hi, out.lo, rows, HW, G, 1e-5, ga, be, True, out=npair.hi, out_lo=npair.lo, partial=part)
+    assert float(((npair.hi.double() + npair.lo.double()) - nref).norm() / nref.norm()) < 3e-5
+    assert float((npair.hi.double() - nref).norm() / nref.norm()) < 4e-4
+    if want_gn:
+        yf = out.hi.float().reshape(rows, HW // 128, 128, G, cpg)
+        sref = torch.stack([yf.sum(dim=(2, 4)), (yf * yf).sum(dim=(2, 4))], dim=-1)
+        got = part.buf.view(rows, HW // 128, G, 2)
+        err = ((got - sref).abs() / (sref.abs().amax(dim=(1, 2), keepdim=True) + 1e-6)).max().item()
+        assert err < 2e-5, err
+        n1, st1 = ops.groupnorm_hilo(out.hi, out.lo, rows, HW, G, 1e-5, ga, be, True, want_stats=True, partial=part)
+        assert float((n1.double() - nref).norm() / nref.norm()) < 4e-4
+        assert (st1 - st0).abs().max().item() < 2e-4 * (1 + st0.abs().max().item())
+
+
+def _as_pair(ops, v32):
+    pr = ops.Pair.empty(v32.shape[0], v32.shape[1], v32.device)
+    pr.hi.copy_(v32.half())
+    pr.lo.copy_((v32 - pr.hi.float()).half())
+    return pr
+
+
+def test_fused_blocks_on_pairs(ops):
+    """Accuracy mode: skg_ff_block_f16_hilo / skg_xattn_block_f16_hilo take the residual stream as a (hi, lo) pair and return a
+    pair.  Against the unfused pair launches they replace (same rounding points: LayerNorm output, FF1 output, gated value / q,
+    probabilities, attention output): hi + lo within 1e-4 relative; the stashed FF1 output and the LayerNorm statistics equal
+    the unfused ones; in place == out of place."""
+    from sketch2img_amd.unet import pack_ff_block, pack_xattn_kv, pack_xattn_weights
+    d = dev()
+    C, Fh, M = 320, 1280, 128 * 9 + 48
+    g = torch.Generator().manual_seed(51)
+    xp = _as_pair(ops, (torch.randn(M, C, generator=g) * 1.5 + 0.3).to(d))
+    gam, bet = (1 + 0.2 * rnd(C, seed=52).float()).half().to(d), (0.1 * rnd(C, seed=53).float()).half().to(d)
+    w1, b1 = rnd(2 * Fh, C, seed=54, scale=C ** -0.5), rnd(2 * Fh, seed=55, scale=0.1)
+    w2, b2 = rnd(C, Fh, seed=56, scale=Fh ** -0.5), rnd(C, seed=57, scale=0.1)
+    pack, bias1 = pack_ff_block(w1, b1, w2, d)
+    M0 = 128 * 4 + 16
+    y, st, pre = ops.ff_block(xp, gam, bet, 1e-5, pack, bias1, b2.to(d), want_stats=True, keep_from=M0)
+    idx = ops.geglu_interleave_index(Fh)
+    a3, st3 = ops.layernorm_hilo(xp.hi, xp.lo, gam, bet, 1e-5, want_stats=True)
+    gg, f = ops.gemm_geglu_keep(a3, w1[idx].contiguous().to(d), b1[idx].contiguous().to(d))
+    y3 = ops.Pair.empty(M, C, d)
+    ops.gemm(gg, w2.to(d), out=y3.hi, out_lo=y3.lo, bias=b2.to(d), residual=xp.hi, residual_lo=xp.lo)
+    s, s3 = y.hi.double() + y.lo.double(), y3.hi.double() + y3.lo.double()
+    r = float((s - s3).norm() / s3.norm())
+    print(f"[parity] ff_block on a pair vs the unfused pair launches: rel {r:.2e}")
+    assert r < 1e-4 and torch.allclose(st, st3, rtol=1e-5, atol=1e-6)
+    assert float((pre.float() - f[M0:].float()).norm() / f[M0:].float().norm()) < 1e-4
+    assert float(y.lo.abs().max()) > 0 and float((y.hi.float() - s.float()).abs().max()) <= 2.0 ** -10 * float(s.abs().max())
+    xin = ops.Pair.empty(M, C, d)
+    xin.full.copy_(xp.full)
+    ops.ff_block(xin, gam, bet, 1e-5, pack, bias1, b2.to(d), out=xin)
+    y0 = ops.ff_block(xp, gam, bet, 1e-5, pack, bias1, b2.to(d))
+    assert torch.equal(xin.full, y0.full) and torch.equal(y0.full, y.full)
+    # cross-attention block
+    rows, HW, L, heads, dh, Lp = 3, 512, 77, 8, 40, 80
+    M = rows * HW
+    xp = _as_pair(ops, (torch.randn(M, C, generator=g) * 1.5 - 0.2).to(d))
+    wq, wo, bo = rnd(C, C, seed=64, scale=C ** -0.5), rnd(C, C, seed=65, scale=C ** -0.5), rnd(C, seed=66, scale=0.1)
+    K, V = rnd(rows * Lp, C, seed=67).to(d), rnd(rows * Lp, C, seed=68).to(d)
+    wp, kvp = pack_xattn_weights(wq, wo, heads, d), pack_xattn_kv(K, V, rows, Lp, L, heads)
+    y = ops.xattn_block(xp, HW, heads, L, gam, bet, 1e-5, wp, kvp, bo.to(d), dh ** -0.5)
+    a2 = ops.layernorm_hilo(xp.hi, xp.lo, gam, bet, 1e-5)
+    o2 = ops.attn_fwd(ops.gemm(a2, wq.to(d)), K, V, rows, heads, HW, L, Lp, dh, dh ** -0.5, v_rows=True)
+    y4 = ops.Pair.empty(M, C, d)
+    ops.gemm(o2, wo.to(d), out=y4.hi, out_lo=y4.lo, bias=bo.to(d), residual=xp.hi, residual_lo=xp.lo)
+    s, s4 = y.hi.double() + y.lo.double(), y4.hi.double() + y4.lo.double()
+    r = float((s - s4).norm() / s4.norm())
+    print(f"[parity] xattn_block on a pair vs the unfused pair launches: rel {r:.2e}")
+    assert r < 1e-4 and float((y.hi.float() - s.float()).abs().max()) <= 2.0 ** -10 * float(s.abs().max())
+
+
+def test_cfg_steps_on_a_pair_eps(ops):
+    """Accuracy mode: eps arrives as a (hi, lo) pair in one buffer; the CFG + scheduler kernels add the halves in fp32."""
+    from sketch2img_amd.sampler import DDIMTables, DPMTables
+    d = dev()
+    S, hw = 2, 256
+    g = torch.Generator().manual_seed(71)
+    e32 = torch.randn(2 * S * hw, 8, generator=g).to(d)
+    x = torch.randn(S, 4, 16, 16, generator=g).to(d)
+    ep = _as_pair(ops, e32)
+    eu, ec, off = ops.eps_halves(ep, S, hw)
+    assert off == 8
+    tab = DDIMTables.make(10)
+    t = int(tab.timesteps[3])
+    xp, e = ops.cfg_ddim_step(eu, ec, x, S, hw, 7.5, tab.coeffs(t), want_eps=True, lo_off=off)
+    es = (ep.hi.float() + ep.lo.float())[:, :4].reshape(2, S, hw, 4).permute(0, 1, 3, 2).reshape(2, S, 4, 16, 16)
+    eref = es[0] + 7.5 * (es[1] - es[0])
+    c0, c1, c2, c3 = tab.coeffs(t)
+    assert torch.allclose(e, eref, rtol=1e-6, atol=1e-6) and torch.allclose(xp, c2 * (x - c1 * eref) / c0 + c3 * eref, rtol=1e-5, atol=1e-5)
+    dt = DPMTables.make(10)
+    x0 = torch.zeros_like(x)
+    xp2, e2 = ops.cfg_dpmpp2m_step(eu, ec, x, x0, S, hw, 7.5, dt.coeffs(0, 1), want_eps=True, lo_off=off)
+    assert torch.allclose(e2, eref, rtol=1e-6, atol=1e-6)
 
 
 def test_split_k_workspace_is_per_stream(ops):
@@ -666,7 +756,8 @@ def ref_attention(q, k, v, heads, scale):
 @pytest.mark.parametrize("dh,heads,Nq,Nkv", [(40, 8, 256, 256), (80, 8, 128, 128), (160, 8, 64, 64), (64, 5, 200, 200),
                                             (16, 2, 72, 72), (32, 2, 1024, 1024), (40, 8, 4096, 4096),
                                             (40, 8, 256, 77), (160, 8, 64, 77), (64, 5, 144, 401), (80, 8, 1000, 77),
-                                            (64, 5, 300, 77), (40, 8, 200, 50), (40, 8, 4096, 77)])
+                                            (64, 5, 300, 77), (40, 8, 200, 50), (40, 8, 4096, 77),
+                                            (40, 8, 3000, 3000), (64, 10, 2560, 2817)])
 def test_attention_forward(ops, dh, heads, Nq, Nkv):
     B, C = 2, heads * dh
     kvs = (Nkv + 7) // 8 * 8
@@ -690,6 +781,14 @@ def test_attention_forward(ops, dh, heads, Nq, Nkv):
         # another kernel, so not bit-equal to the flash kernel - checked against the reference like it, and deterministic
         assert report(f"attn fwd short-key kernel dh{dh} {Nq}x{Nkv}", o2.float().cpu().view(B, Nq, C), ro)[0] < 2e-3
         assert report("attn lse short-key kernel", lse2.cpu(), rl)[1] < 2e-3
+        o3, lse3 = ops.attn_fwd(Q, K, V, B, heads, Nq, Nkv, kvs, dh, scale, want_lse=True, v_rows=True)
+        assert torch.equal(o2, o3) and torch.equal(lse2, lse3)
+    elif dh in (40, 64) and ((Nq + 255) // 256) * heads * B >= 192:
+        # large self-attentions with row-major V take the 8-wave ping-pong kernel (attn_fwd8_kernel: 32 x 32 x 16 QK^T tiles,
+        # v_permlane16_swap relayout of P, ragged last key tile / ragged last query block here): another kernel, checked against
+        # the reference like the first one, and bit-repeatable
+        assert report(f"attn fwd 8-wave kernel dh{dh} {Nq}x{Nkv}", o2.float().cpu().view(B, Nq, C), ro)[0] < 2e-3
+        assert report("attn lse 8-wave kernel", lse2.cpu(), rl)[1] < 2e-3
         o3, lse3 = ops.attn_fwd(Q, K, V, B, heads, Nq, Nkv, kvs, dh, scale, want_lse=True, v_rows=True)
         assert torch.equal(o2, o3) and torch.equal(lse2, lse3)
     else:
@@ -732,6 +831,41 @@ def test_attention_forward_strided_qkv_and_online_rescale(ops):
     assert report("attn fwd strided+spike", o.float().cpu().view(B, N, C), ro)[0] < 2e-3
     o2 = ops.attn_fwd(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], B, heads, N, N, N, dh, dh ** -0.5, v_rows=True)
     assert torch.equal(o2, o)                        # V as the third column block of the fused buffer, no transpose
+
+
+def test_attention_forward_8wave_online_rescale_and_structure(ops):
+    """attn_fwd8_kernel: (a) spiked keys in late tiles force the reference maximum to move (the rescale branch: alpha crosses
+    from the score layout, query = lane & 31, to the output layout, query = lane & 15 of two tiles); (b) structured probes with
+    exact answers: K = 0 makes the softmax uniform, V = one-hot on single keys / single head columns, so every output
+    is an exactly known value - a lost k-step, a wrong key <-> k-slot map or a wrong V row permutation shows as an O(1) error."""
+    B, heads, dh, N = 2, 8, 40, 3072
+    C = heads * dh
+    d = dev()
+    qkv = rnd(B * N, 3 * C, seed=1)
+    qkv[B * N // 2 + 2900, C:2 * C] *= 12.0          # one key with a huge norm in the 46th kv tile of row 1
+    qkv[1700, C:2 * C] *= -9.0
+    t = qkv.to(d)
+    o = ops.attn_fwd(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], B, heads, N, N, N, dh, dh ** -0.5, v_rows=True)
+    q, k, v = (qkv[:, i * C:(i + 1) * C].float().view(B, N, C) for i in range(3))
+    ro, _ = ref_attention(q, k, v, heads, dh ** -0.5)
+    assert report("attn fwd 8-wave strided + spike", o.float().cpu().view(B, N, C), ro)[0] < 2e-3
+    # (b) K = 0: uniform softmax, O[q][c] = mean over keys of V[:, c]
+    Q = rnd(B * N, C, seed=2).to(d)
+    K0 = torch.zeros(B * N, C, device=d, dtype=torch.float16)
+    for key in (0, 5, 17, 31, 36, 63, 64 + 21, N - 1):          # one key carries 1.0 in every column, all others 0
+        V = torch.zeros(B * N, C, device=d, dtype=torch.float16)
+        V[key] = 1.0
+        V[N + key] = 2.0
+        o = ops.attn_fwd(Q, K0, V, B, heads, N, N, N, dh, dh ** -0.5, v_rows=True).float().view(B, N, C)
+        assert float((o[0] - 1.0 / N).abs().max()) < 1e-6 and float((o[1] - 2.0 / N).abs().max()) < 2e-6, key
+    V = torch.zeros(B * N, C, device=d, dtype=torch.float16)      # every key carries its (small-integer) code in one head column
+    code = (torch.arange(N) % 61 + 1).half()
+    for col in (0, 7, 16, 33, 39):
+        V.zero_()
+        V.view(B, N, heads, dh)[:, :, :, col] = code.to(d)[None, :, None]
+        o = ops.attn_fwd(Q, K0, V, B, heads, N, N, N, dh, dh ** -0.5, v_rows=True).float().view(B, N, heads, dh)
+        want = float(code.float().mean())
+        assert float((o[..., col] - want).abs().max()) < 2e-2 * want / 31 and float(o[..., [c for c in range(dh) if c != col]].abs().max()) == 0.0, col
 
 
 @pytest.mark.parametrize("dh,heads,Nq,Nkv,cross", [(40, 8, 256, 256, False), (80, 8, 64, 64, False),
