@@ -22,6 +22,7 @@
 // [d][72] read with ds_read_b64 pairs (two 32-lane groups: conflict-free at 72).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -592,13 +593,24 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 2 : (KS >= 3 ? 3 : 4))) void attn_f
 #pragma unroll
       for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)qn[ks][j] * sc);
     if (q0 + 64 < q_end) load_q(qn, q0 + 64);               // in flight under this tile's work
+    // (the accumulators start from an opaque zero REGISTER, the operands of an accumulator-starting MFMA stay live past
+    // it, and the k-steps of one accumulator are separated by the other tiles' MFMAs - the treatment xattn.hip got after its
+    // first build lost half an accumulator; tools/ubench/mfma_fresh_overlap.hip could not make the pattern fail in isolation,
+    // profiles/r04_mfma_fresh_overlap.txt, so this is belt and braces)
     float4_t s[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
+      for (int t = 0; t < NT; ++t) {
         const half8_t kf = ld_half8(Ks + (16 * t + l16) * KP + 32 * ks + 8 * g);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], ks == 0 ? float4_t{0.f, 0.f, 0.f, 0.f} : s[t], 0, 0, 0);
+        if (ks == 0) {
+          float4_t z = {0.f, 0.f, 0.f, 0.f};
+          asm volatile("" : "+v"(z));
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], z, 0, 0, 0);
+          asm volatile("" ::"v"(kf), "v"(qf[ks]));
+        } else {
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[ks], s[t], 0, 0, 0);
+        }
       }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -638,12 +650,19 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 2 : (KS >= 3 ? 3 : 4))) void attn_f
       }
     float4_t o[ND];
 #pragma unroll
-    for (int u = 0; u < ND; ++u) {
-      o[u] = float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int sv = 0; sv < NSV; ++sv)
 #pragma unroll
-      for (int sv = 0; sv < NSV; ++sv)
-        o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(tfrag_rows<VP>(Vs + vlane, u, sv), pb[sv], o[u], 0, 0, 0);
-    }
+      for (int u = 0; u < ND; ++u) {
+        const half8_t vfr = tfrag_rows<VP>(Vs + vlane, u, sv);
+        if (sv == 0) {
+          float4_t z = {0.f, 0.f, 0.f, 0.f};
+          asm volatile("" : "+v"(z));
+          o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr, pb[sv], z, 0, 0, 0);
+          asm volatile("" ::"v"(vfr), "v"(pb[sv]));
+        } else {
+          o[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vfr, pb[sv], o[u], 0, 0, 0);
+        }
+      }
     const int q = q0 + l16;
     if (q < q_end) {
       const float inv = 1.f / li;
@@ -661,16 +680,16 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 2 : (KS >= 3 ? 3 : 4))) void attn_f
   }
 }
 
-// ---- forward, 8 waves, PING-PONG between the two waves of a SIMD (round 4) ------------------------------------------------
-// attn_fwd_kernel above runs four independent 4-wave workgroups per CU and hopes that one wave's softmax lands under another
-// wave's MFMAs; the counters say they do not overlap (matrix pipe 0.43 busy at d = 40: 448 MFMA + ~316 VALU cycles per tile
-// and wave against ~1 040 measured, EXPERIMENTS.md round 3).  Here the overlap is constructed, as gemm8.hip does for the GEMM
-// and MI355X_MICROARCH.md "Two waves per SIMD" describes for attention: ONE 8-wave workgroup per CU owns 256 queries (32 per
-// wave); waves w and w + 4 share a SIMD; both groups run the same sequence of segments, separated by s_barrier,
-//     L(t): softmax of S(t) -> P(t) (VALU), LDS fragment reads of V(t) and K(t + 1) into registers, staging of tile t + 2
-//     M(t): O^T += V(t)^T P(t)^T, then S(t + 1)^T = K(t + 1) Q^T - m           (MFMAs out of registers only)
-// with group 1 one barrier behind group 0: on every SIMD one wave is in its MFMA segment while its partner does softmax,
-// fragment reads and staging.
+// ---- forward, 8 waves, 32 queries per wave, MFMA and softmax of DIFFERENT tiles in one instruction stream (round 4) --------
+// attn_fwd_kernel above runs QK^T -> softmax -> PV of one tile as one dependency chain per wave and hopes that another wave's
+// MFMAs land under this wave's softmax; the counters say they do not (matrix pipe 0.43 busy at d = 40: 448 MFMA + ~316 VALU
+// cycles per tile and wave against ~1 040 measured, EXPERIMENTS.md round 3).  Measured on the way to this kernel (EXPERIMENTS.md
+// round 4): a lone wave issues one VALU instruction per ~8.5 cycles whatever the instruction, so a softmax SEGMENT of ~100
+// instructions is ~1 500 cycles long and a barrier-separated ping-pong (MFMA segment | softmax segment, as gemm8.hip) is bound by
+// it (784 us against 608).  What a wave can do is put its MFMAs INTO that cadence: here every iteration issues
+//     O^T += V(t-1)^T P(t-1)^T      and      S(t+1)^T = K(t+1) Q^T - m      (18 MFMAs at d = 40, 384 matrix-pipe cycles)
+// beside  P(t) = exp2(S(t))  (VALU) - three different tiles, no dependency between them inside the iteration (S and P are double
+// buffered in registers) - so the matrix pipe works under the wave's own softmax and the partner wave of the SIMD fills the rest.
 // Formulation (swapped products as above, other instruction shapes):
 //   * S^T[64 keys x 32 queries] = K Q^T with v_mfma_f32_32x32x16_f16: K = 16 steps, so d = 40 pads to 48 (3 steps) instead of
 //     64 and every K fragment read feeds a 32 x 32 tile.  In the C layout lane (q = lane & 31, hi = lane >> 5) holds
@@ -683,29 +702,40 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 2 : (KS >= 3 ? 3 : 4))) void attn_f
 //     that the transposing LDS read of group g starts at row 16 (g >> 1) + 4 (g & 1) (+ 8 for its second half) - the same
 //     conflict-free pattern as tfrag_rows.
 //   * online softmax as above: scale folded into Q, minus the reference maximum as the MFMA C operand, re-based only when a
-//     tile beats it by more than 2^8 (wave-uniform ballot); d = 40: the denominator is row 40 of O^T (ones column of V).
-// K / V tiles: registers -> LDS (three stages each; the loads of tile t + 3 are issued in L(t), written in L(t + 1)), pitches
-// KP8 (odd number of 16-byte pieces: conflict-free ds_read_b128 with row = lane & 31) and vrow_pitch.
+//     tile beats it by more than 2^8 (wave-uniform ballot): at a re-base everything still at the old reference - O, the
+//     denominator AND the probabilities of tile t that wait for their PV - is scaled exactly once (cdna_hip_programming.md T13).
+//     d = 40: the denominator is row 40 of O^T (ones column of V).
+// K / V tiles: registers -> LDS, one barrier per tile: tile t + 2 is written in iteration t (K ring of 2: K(t + 2) replaces
+// K(t), last read in iteration t - 1; V ring of 4: V(t + 2) replaces V(t - 2), and V(t - 1) is being read), its loads were issued in
+// iteration t - 1; pitches kp8_pitch (odd number of 16-byte pieces: conflict-free ds_read_b128 with row = lane & 31) / vrow_pitch.
 typedef float float16_t __attribute__((ext_vector_type(16)));
 typedef unsigned uint4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kp8_pitch(int d16) { return (2 * d16) | 1; }      // 16-byte pieces per K row: >= 2 d16, odd
 
-template <int D16, int ND, bool ONES>
-__global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(const AttnParams p) {
-  constexpr int NS = 3;                              // LDS stages
+// NW waves per workgroup (32 NW queries), OCC = waves per SIMD the register allocation is bounded for: <8, 2> = one 8-wave
+// workgroup per CU; <4, 3> = three independent 4-wave workgroups per CU (their phases drift apart by themselves)
+// PROBE (profiling build only, make phases + SKG_ATTN8_PROBE; results are WRONG): 1 = no exponentials, 2 = no MFMAs, 4 = no staging,
+// 8 = no barrier, 16 = no LDS fragment reads
+template <int D16, int ND, bool ONES, int NW = 8, int OCC = 2, int PROBE = 0>
+__global__ __launch_bounds__(64 * NW, OCC) void attn_fwd8_kernel(const AttnParams p) {
+  constexpr int NTHR = 64 * NW;
+  // DEEP (the 8-wave form: 256 registers per wave): every latency is covered by software pipelining instead of by other waves -
+  // the fragments of iteration t + 1 are read from LDS during iteration t (two register sets), tile t + 3 is written in
+  // iteration t and its global loads were issued two iterations earlier (two staging sets)
+  constexpr bool DEEP = NW == 8;
+  constexpr int NK = 2, NV = 4;                      // ring depths
   constexpr int KP = kp8_pitch(D16) * 8;             // halves
   constexpr int VP = vrow_pitch(ND);
-  constexpr int KSZ = 64 * KP, VSZ = 64 * VP;
-  __shared__ __attribute__((aligned(16))) half_t lds[NS * (KSZ + VSZ)];
+  constexpr int KSZ = 64 * KP, VSZ = 64 * VP, VBASE = NK * KSZ;
+  __shared__ __attribute__((aligned(16))) half_t lds[NK * KSZ + NV * VSZ];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;                         // waves w and w + 4 share a SIMD: one of each group
   const int l32 = lane & 31, hi = lane >> 5, l16 = lane & 15, g = lane >> 4;
   const BlkMap bm = attn_block_map(p);
   const int b = bm.b, h = bm.h, dh = p.dh;
   const int PK = dh >> 3;                            // 16-byte pieces per K / V row in memory
-  const int q0 = bm.bx * 256 + wave * 32;
+  const int q0 = bm.bx * (32 * NW) + wave * 32;
 
   // ---- Q^T fragments (B operand of 32x32x16: lane (n = l32, hi) holds d = 16 ks + 8 hi .. + 7 of query n), pre-scaled
   const int qrow = min(q0 + l32, p.Nq - 1);
@@ -721,92 +751,100 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(const AttnParams p) {
     }
   }
 
-  // ---- staging: piece pi of a tile = (K | V, key row, 16-byte column piece); a thread owns pieces tid + 512 j
-  constexpr int MAXPC = (2 * 64 * 2 * ND + 511) / 512;       // >= 2 * 64 * PK / 512 for every head width this instantiation takes
+  // ---- staging: piece pi of a tile = (K | V, key row, 16-byte column piece); a thread owns pieces tid + NTHR j
+  constexpr int MAXPC = (2 * 64 * 2 * ND + NTHR - 1) / NTHR;       // >= 2 * 64 * PK / 512 for every head width this instantiation takes
   const half_t* Kb = p.K + (size_t)b * p.kv_stride * p.ldk + h * dh;
   const half_t* Vb = p.Vt + (size_t)b * p.kv_stride * p.ldvt + h * dh;
   const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (unsigned)(((size_t)(p.kv_stride - 1) * p.ldk + dh) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, (unsigned)(((size_t)(p.kv_stride - 1) * p.ldvt + dh) * 2), 0x00020000);
   unsigned soff[MAXPC];      // byte offset inside a tile in memory, or ATT_OOB
-  int sdst[MAXPC];           // half offset inside a stage (K part, or KSZ + V part)
+  int sdst[MAXPC];           // half offset inside its ring slot, or -1
   bool sisv[MAXPC];          // wave-uniform: 64 * PK is a multiple of 64
 #pragma unroll
   for (int j = 0; j < MAXPC; ++j) {
-    const int pi = tid + 512 * j;
+    const int pi = tid + NTHR * j;
     const int npk = 64 * PK;
     const bool isv = pi >= npk;
     const int pj = isv ? pi - npk : pi;
     const int row = pj / PK, pc = pj - row * PK;
     const bool ok = pi < 2 * npk;
     sisv[j] = __builtin_amdgcn_readfirstlane((int)isv) != 0;
-    // V rows are stored with key bits 2 and 4 swapped (see above)
-    const int vrow = (row & ~20) | ((row & 4) << 2) | ((row & 16) >> 2);
+    const int vrow = (row & ~20) | ((row & 4) << 2) | ((row & 16) >> 2);      // V rows: key bits 2 and 4 swapped (see above)
     soff[j] = ok ? (unsigned)(row * (isv ? p.ldvt : p.ldk) + pc * 8) * 2u : ATT_OOB;
-    sdst[j] = ok ? (isv ? KSZ + vrow * VP + pc * 8 : row * KP + pc * 8) : -1;
+    sdst[j] = ok ? (isv ? vrow * VP + pc * 8 : row * KP + pc * 8) : -1;
   }
-  half8_t sreg[MAXPC];
-  auto stage_load = [&](int t) {      // global -> registers (rows behind the last key of this batch row read as zero)
+  half8_t sreg[MAXPC], sreg2[DEEP ? MAXPC : 1];
+  auto stage_load_to = [&](half8_t (&r)[MAXPC], int t) {      // global -> registers (rows behind the last key of this batch row read as zero)
     const unsigned sk = (unsigned)t * 64u * (unsigned)p.ldk * 2u, sv = (unsigned)t * 64u * (unsigned)p.ldvt * 2u;
 #pragma unroll
-    for (int j = 0; j < MAXPC; ++j) sreg[j] = sisv[j] ? buf_half8(rv, soff[j], sv) : buf_half8(rk, soff[j], sk);
+    for (int j = 0; j < MAXPC; ++j) r[j] = sisv[j] ? buf_half8(rv, soff[j], sv) : buf_half8(rk, soff[j], sk);
   };
-  auto stage_store = [&](int t) {     // registers -> LDS stage t % NS
-    half_t* st = lds + (t % NS) * (KSZ + VSZ);
+  auto stage_store_from = [&](const half8_t (&r)[MAXPC], int t) {     // registers -> K ring slot t % NK / V ring slot t % NV
+    half_t* const ks = lds + (t & (NK - 1)) * KSZ;
+    half_t* const vs = lds + VBASE + (t & (NV - 1)) * VSZ;
 #pragma unroll
     for (int j = 0; j < MAXPC; ++j)
-      if (sdst[j] >= 0) st_half8(st + sdst[j], sreg[j]);
+      if (sdst[j] >= 0) st_half8((sisv[j] ? vs : ks) + sdst[j], r[j]);
   };
-  // constant pieces of every stage, written once: the zero columns d >= dh of K that the last k-step reads, and (ONES) the
+  auto stage_load = [&](int t) { stage_load_to(sreg, t); };
+  auto stage_store = [&](int t) { stage_store_from(sreg, t); };
+  // constant pieces of every ring slot, written once: the zero columns d >= dh of K that the last k-step reads, and (ONES) the
   // piece [1, 0 x 7] at column dh of every V row - the register staging never touches them
-  for (int i = tid; i < NS * 64; i += 512) {
-    half_t* st = lds + (i >> 6) * (KSZ + VSZ);
-    const int row = i & 63;
-    for (int c = PK * 8; c < D16 * 16; c += 8) st_half8(st + row * KP + c, zero_half8());
-    if (ONES) {
-      const half8_t one = {(half_t)1.f, 0, 0, 0, 0, 0, 0, 0};
-      st_half8(st + KSZ + row * VP + PK * 8, one);
+  for (int i = tid; i < (NK + NV) * 64; i += NTHR) {
+    const int slot = i >> 6, row = i & 63;
+    if (slot < NK) {
+      for (int c = PK * 8; c < D16 * 16; c += 8) st_half8(lds + slot * KSZ + row * KP + c, zero_half8());
     } else {
-      for (int c = PK * 8; c < ND * 16; c += 8) st_half8(st + KSZ + row * VP + c, zero_half8());
+      half_t* const vr = lds + VBASE + (slot - NK) * VSZ + row * VP;
+      if (ONES) {
+        const half8_t one = {(half_t)1.f, 0, 0, 0, 0, 0, 0, 0};
+        st_half8(vr + PK * 8, one);
+      } else {
+        for (int c = PK * 8; c < ND * 16; c += 8) st_half8(vr + c, zero_half8());
+      }
     }
   }
   const int nt = (p.Nkv + 63) >> 6;
   stage_load(0);
   stage_store(0);
   if (nt > 1) { stage_load(1); stage_store(1); }
-  if (nt > 2) stage_load(2);
+  if (nt > 2) stage_load(2);             // (DEEP: written after K(0)'s fragments have been read, below)
 
   // ---- per-wave state
-  float16_t s[2];                    // S^T of the current tile: key tiles 0, 1
+  float16_t sA[2], sB[2];            // S^T of two tiles in flight: key tiles 0, 1
+  uint4_t pA[2][2], pB[2][2];        // P^T of two tiles as B operands: [query tile][32-key step]
   float4_t o[2][ND];                 // O^T: query tile (queries 0-15, 16-31 of the wave) x d tile
   float nm = 0.f, l = 0.f;           // minus the reference maximum (log2 domain) / denominator partial (S layout: query l32)
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
     for (int u = 0; u < ND; ++u) o[qt][u] = float4_t{0.f, 0.f, 0.f, 0.f};
-  half8_t kf[2][D16];                // K fragments of the next QK^T
-  half8_t vf[ND][2];                 // V^T fragments of the next PV
-  uint4_t pb[2][2];                  // P^T as B operands: [query tile][32-key step]
   constexpr float REF_SLACK = 8.f;
   const int vlane = (16 * (g >> 1) + 4 * (g & 1) + (l16 >> 2)) * VP + 4 * (l16 & 3);
+  const int klane = l32 * KP + 8 * hi;
 
-  auto read_k = [&](int t) {
-    const half_t* Ks = lds + (t % NS) * (KSZ + VSZ) + l32 * KP + 8 * hi;
+  // fragment reads of one iteration, all issued up front (two waves per SIMD: nobody else covers an exposed LDS latency)
+  auto read_k = [&](int t, half8_t (&kf)[2][D16]) {
+    const half_t* Ks = lds + (t & (NK - 1)) * KSZ + klane;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int ks = 0; ks < D16; ++ks) kf[kt][ks] = ld_half8(Ks + 32 * kt * KP + 16 * ks);
+      for (int ks = 0; ks < D16; ++ks) kf[kt][ks] = (PROBE & 16) ? qf[ks] : ld_half8(Ks + 32 * kt * KP + 16 * ks);
   };
-  auto read_v = [&](int t) {
-    const half_t* Vs = lds + (t % NS) * (KSZ + VSZ) + KSZ + vlane;
+  auto read_v = [&](int t, half8_t (&vf)[ND][2]) {
+    const half_t* Vs = lds + VBASE + (t & (NV - 1)) * VSZ + vlane;
 #pragma unroll
     for (int u = 0; u < ND; ++u)
 #pragma unroll
       for (int sv = 0; sv < 2; ++sv) {
+        if (PROBE & 16) { vf[u][sv] = qf[(u + sv) % D16]; continue; }
         const half4_t lo = tr_read(Vs + (32 * sv) * VP + 16 * u), hh = tr_read(Vs + (32 * sv + 8) * VP + 16 * u);
         vf[u][sv] = half8_t{lo[0], lo[1], lo[2], lo[3], hh[0], hh[1], hh[2], hh[3]};
       }
   };
-  auto qk = [&]() {                  // S^T = K Q^T - m: the two key tiles alternate (dependent MFMAs one apart)
+  // S^T = K Q^T - m: the two key tiles alternate (dependent MFMAs one apart)
+  auto qk = [&](const half8_t (&kf)[2][D16], float16_t (&s)[2]) {
+    if (PROBE & 2) { asm volatile("" : "+v"(s[0]), "+v"(s[1])); return; }
     const float16_t init = {nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm, nm};
 #pragma unroll
     for (int ks = 0; ks < D16; ++ks)
@@ -814,7 +852,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(const AttnParams p) {
       for (int kt = 0; kt < 2; ++kt)
         s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kt][ks], qf[ks], ks == 0 ? init : s[kt], 0, 0, 0);
   };
-  auto pv = [&]() {
+  // O^T += V^T P^T
+  auto pv = [&](const half8_t (&vf)[ND][2], const uint4_t (&pb)[2][2]) {
+    if (PROBE & 2) return;
 #pragma unroll
     for (int sv = 0; sv < 2; ++sv)
 #pragma unroll
@@ -823,44 +863,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(const AttnParams p) {
         for (int qt = 0; qt < 2; ++qt)
           o[qt][u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[u][sv], __builtin_bit_cast(half8_t, pb[qt][sv]), o[qt][u], 0, 0, 0);
   };
-  auto softmax = [&](int t) {
-    const int kv0 = t * 64;
-    if (kv0 + 64 > p.Nkv) {            // ragged last tile only (wave-uniform)
-      int lim = p.Nkv - kv0 - 4 * hi;
-      asm volatile("" : "+v"(lim));
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (32 * kt + (r & 3) + 8 * (r >> 2) >= lim) s[kt][r] = NEG_BIG;
-    }
-    float mx = max3f(s[0][0], s[0][1], s[0][2]);
-#pragma unroll
-    for (int r = 3; r < 15; r += 2) mx = max3f(mx, s[0][r], s[0][r + 1]);
-    mx = max3f(mx, s[0][15], s[1][0]);
-#pragma unroll
-    for (int r = 1; r < 15; r += 2) mx = max3f(mx, s[1][r], s[1][r + 1]);
-    mx = max3f(mx, s[1][15], mx);
-    const bool first = t == 0;         // the reference starts at 0: the first tile always re-bases it
-    if (__builtin_amdgcn_ballot_w64(first || mx > REF_SLACK) != 0) {      // wave-uniform, rare after tile 0
-      mx = max3f(mx, __shfl_xor(mx, 32, 64), mx);                         // the query's maximum over the tile
-      const float delta = (first || mx > REF_SLACK) ? mx : 0.f;
-      const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);   // (o, l are still zero in tile 0)
-      nm -= delta;
-      l *= alpha;
-      const float aA = __shfl(alpha, l16, 64), aB = __shfl(alpha, 16 + l16, 64);      // O layout: query l16 of each 16-query tile
-#pragma unroll
-      for (int u = 0; u < ND; ++u) { o[0][u] *= aA; o[1][u] *= aB; }
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt) s[kt] -= delta;
-    }
+  // P = exp2(S) -> packed fp16 -> B operands of the two 16-query tiles
+  auto expo = [&](const float16_t (&s)[2], uint4_t (&pb)[2][2]) {
     float ps = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
       unsigned pk[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float e0 = __builtin_amdgcn_exp2f(s[kt][2 * j]), e1 = __builtin_amdgcn_exp2f(s[kt][2 * j + 1]);
+        const float e0 = (PROBE & 1) ? s[kt][2 * j] : __builtin_amdgcn_exp2f(s[kt][2 * j]);
+        const float e1 = (PROBE & 1) ? s[kt][2 * j + 1] : __builtin_amdgcn_exp2f(s[kt][2 * j + 1]);
         if (!ONES) ps += e0 + e1;
         const half2_t h2 = {(half_t)e0, (half_t)e1};
         pk[j] = __builtin_bit_cast(unsigned, h2);
@@ -874,33 +886,175 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(const AttnParams p) {
     }
     if (!ONES) l += ps;
   };
+  // the lane's maximum over its 32 scores of tile t (ragged last tile masked first)
+  auto tile_max = [&](auto is_last, int t, float16_t (&s)[2]) {
+    const int kv0 = t * 64;
+    if (decltype(is_last)::value && kv0 + 64 > p.Nkv) {      // ragged last tile (only the iterations without a next tile test for it)
+      int lim = p.Nkv - kv0 - 4 * hi;
+      asm volatile("" : "+v"(lim));
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (32 * kt + (r & 3) + 8 * (r >> 2) >= lim) s[kt][r] = NEG_BIG;
+    }
+    float m8[8];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) m8[j] = max3f(s[0][3 * j], s[0][3 * j + 1], s[0][3 * j + 2]);
+    m8[5] = max3f(s[0][15], s[1][0], s[1][1]);
+    m8[6] = max3f(s[1][2], s[1][3], s[1][4]);
+    m8[7] = max3f(s[1][5], s[1][6], s[1][7]);
+    float mx = max3f(max3f(m8[0], m8[1], m8[2]), max3f(m8[3], m8[4], m8[5]), max3f(m8[6], m8[7], s[1][8]));
+    mx = max3f(mx, max3f(s[1][9], s[1][10], s[1][11]), max3f(s[1][12], s[1][13], s[1][14]));
+    return max3f(mx, s[1][15], mx);
+  };
+  // the reference moves (rare after tile 0; wave-uniform): O and the denominator hold every tile before t - in program order
+  // the PV MFMAs of tile t - 1 are BEHIND us here - so nothing else is at the old reference (cdna_hip_programming.md T13)
+  auto rebase = [&](bool first, float mx, float16_t (&s)[2]) {
+    mx = max3f(mx, __shfl_xor(mx, 32, 64), mx);                           // the query's maximum over the tile
+    const float delta = (first || mx > REF_SLACK) ? mx : 0.f;
+    const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);     // (o, l are still zero in tile 0)
+    nm -= delta;
+    l *= alpha;
+    const float aA = __shfl(alpha, l16, 64), aB = __shfl(alpha, 16 + l16, 64);        // O layout: query l16 of each 16-query tile
+#pragma unroll
+    for (int u = 0; u < ND; ++u) { o[0][u] *= aA; o[1][u] *= aB; }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) s[kt] -= delta;
+  };
+  // One iteration = tile t's softmax on the VALU beside the MFMAs of two OTHER tiles:
+  //   block 1:  O^T += V(t-1)^T P(t-1)^T   ||  lane maxima of S(t)          (then the rare re-base)
+  //   block 2:  S(t+1)^T = K(t+1) Q^T - m  ||  P(t) = exp2(S(t)), packing, relayout
+#ifdef SKG_PHASES
+  unsigned long long att_acc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+  auto step = [&](auto has_pv, auto has_qk, int t, float16_t (&sc)[2], float16_t (&sn)[2], uint4_t (&pp)[2][2], uint4_t (&pc)[2][2]) {
+    constexpr bool HAS_PV = decltype(has_pv)::value, HAS_QK = decltype(has_qk)::value;
+    ATT_T(ta);
+    half8_t vf[ND][2], kf[2][D16];
+    if constexpr (HAS_PV) read_v(t - 1, vf);
+    if constexpr (HAS_QK) read_k(t + 1, kf);
+    if constexpr (HAS_PV) pv(vf, pp);
+    const float mx = tile_max(std::integral_constant<bool, !HAS_QK>{}, t, sc);
+    ATT_T(tb);
+    if (__builtin_amdgcn_ballot_w64(t == 0 || mx > REF_SLACK) != 0) rebase(t == 0, mx, sc);
+    ATT_T(tc);
+    if constexpr (HAS_QK) qk(kf, sn);
+    expo(sc, pc);
+    ATT_T(td);
+    if (!(PROBE & 4)) {
+      if (t + 2 < nt) stage_store(t + 2);
+      if (t + 3 < nt) stage_load(t + 3);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ATT_T(te);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(PROBE & 8)) asm volatile("s_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    ATT_T(tf);
+    ATT_ACC(0, ta, tb); ATT_ACC(1, tb, tc); ATT_ACC(2, tc, td); ATT_ACC(3, td, te); ATT_ACC(4, te, tf); ATT_ACC(5, ta, tf);
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  if constexpr (DEEP) {
+    half8_t kfA[2][D16], kfB[2][D16], vfA[ND][2], vfB[ND][2];      // fragments of K(j) / V(j) live in set j & 1
+    // iteration t: MFMAs PV(t - 1) [vfu, pp] and QK(t + 1) [kfu]  ||  softmax of S(t)  ||  fragment reads V(t) -> vff, K(t + 2) -> kff
+    // ||  tile t + 3 -> LDS from staging set sst, loads of tile t + 5 into it
+    auto dstep = [&](auto has_pv, auto has_qk, int t, float16_t (&sc)[2], float16_t (&sn)[2], uint4_t (&pp)[2][2], uint4_t (&pc)[2][2],
+                     half8_t (&kfu)[2][D16], half8_t (&kff)[2][D16], half8_t (&vfu)[ND][2], half8_t (&vff)[ND][2], half8_t (&sst)[MAXPC]) {
+      constexpr bool HAS_PV = decltype(has_pv)::value, HAS_QK = decltype(has_qk)::value;
+      ATT_T(ta);
+      if (t + 2 < nt) read_k(t + 2, kff);
+      read_v(t, vff);
+      if constexpr (HAS_PV) pv(vfu, pp);
+      const float mx = tile_max(std::integral_constant<bool, !HAS_QK>{}, t, sc);
+      ATT_T(tb);
+      if (__builtin_amdgcn_ballot_w64(t == 0 || mx > REF_SLACK) != 0) rebase(t == 0, mx, sc);
+      ATT_T(tc);
+      if constexpr (HAS_QK) qk(kfu, sn);
+      expo(sc, pc);
+      ATT_T(td);
+      if (!(PROBE & 4)) {
+        if (t + 3 < nt) stage_store_from(sst, t + 3);
+        if (t + 5 < nt) stage_load_to(sst, t + 5);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ATT_T(te);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(PROBE & 8)) asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      ATT_T(tf);
+      ATT_ACC(0, ta, tb); ATT_ACC(1, tb, tc); ATT_ACC(2, tc, td); ATT_ACC(3, td, te); ATT_ACC(4, te, tf); ATT_ACC(5, ta, tf);
+    };
+#define DSTEP_EVEN(PV_, QK_, t_) dstep(PV_{}, QK_{}, t_, sA, sB, pB, pA, kfB, kfA, vfB, vfA, sreg2)
+#define DSTEP_ODD(PV_, QK_, t_) dstep(PV_{}, QK_{}, t_, sB, sA, pA, pB, kfA, kfB, vfA, vfB, sreg)
+    __syncthreads();                    // tiles 0, 1 and the constant pieces are in LDS
+    read_k(0, kfA);
+    qk(kfA, sA);
+    if (nt > 1) read_k(1, kfB);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // K(0)'s slot takes K(2)
+    if (nt > 2) stage_store(2);
+    if (nt > 3) stage_load_to(sreg2, 3);      // tile j travels in staging set (j & 1): sreg2 = odd tiles
+    if (nt > 4) stage_load_to(sreg, 4);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (nt > 1) DSTEP_EVEN(F_, T_, 0); else DSTEP_EVEN(F_, F_, 0);
+    int t = 1;
+    for (; t + 2 < nt; t += 2) {
+      DSTEP_ODD(T_, T_, t);
+      DSTEP_EVEN(T_, T_, t + 1);
+    }
+    if (nt > 1) {
+      if (t + 1 < nt) {
+        DSTEP_ODD(T_, T_, t);
+        DSTEP_EVEN(T_, F_, t + 1);
+        pv(vfA, pA);                     // tile nt - 1 (even): its V fragments were read in the last iteration
+      } else {
+        DSTEP_ODD(T_, F_, t);
+        pv(vfB, pB);
+      }
+    } else {
+      pv(vfA, pA);
+    }
+#undef DSTEP_EVEN
+#undef DSTEP_ODD
+  } else {
 
   __syncthreads();                      // tiles 0, 1 and the constant pieces are in LDS
-  read_k(0);
-  qk();                                 // S(0)
-  if (grp == 1) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_barrier" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
-  for (int t = 0; t < nt; ++t) {
-    // ---- L(t)
-    softmax(t);
-    read_v(t);
-    if (t + 1 < nt) read_k(t + 1);
-    if (t + 2 < nt) stage_store(t + 2);
-    if (t + 3 < nt) stage_load(t + 3);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- M(t)
-    __builtin_amdgcn_s_setprio(1);
-    pv();
-    if (t + 1 < nt) qk();
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
+  {
+    half8_t kf[2][D16];
+    read_k(0, kf);
+    qk(kf, sA);
   }
-  if (grp == 0) { asm volatile("s_barrier" ::: "memory"); }
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // K(0)'s slot is refilled in iteration 0
+  if (nt > 1) step(F_{}, T_{}, 0, sA, sB, pB, pA); else step(F_{}, F_{}, 0, sA, sB, pB, pA);
+  int t = 1;                             // t odd: S / P of tile t are sB / pB
+  for (; t + 2 < nt; t += 2) {
+    step(T_{}, T_{}, t, sB, sA, pA, pB);
+    step(T_{}, T_{}, t + 1, sA, sB, pB, pA);
+  }
+  bool last_in_a = true;                 // where P of the last tile ends up
+  if (nt > 1) {
+    if (t + 1 < nt) {                    // t = nt - 2 (odd): one more full iteration, then the last tile (even)
+      step(T_{}, T_{}, t, sB, sA, pA, pB);
+      step(T_{}, F_{}, t + 1, sA, sB, pB, pA);
+    } else {                             // t = nt - 1 (odd)
+      step(T_{}, F_{}, t, sB, sA, pA, pB);
+      last_in_a = false;
+    }
+  }
+  {
+    half8_t vf[ND][2];
+    read_v(nt - 1, vf);
+    if (last_in_a) pv(vf, pA); else pv(vf, pB);
+  }
 
+  }
+#ifdef SKG_PHASES
+  if (lane == 0 && blockIdx.x < (1 << 13)) {
+    for (int j = 0; j < 6; ++j) g_attn_phase[blockIdx.x * NW + wave][j] = att_acc[j];
+    g_attn_phase[blockIdx.x * NW + wave][6] = nt;
+  }
+#endif
   // ---- epilogue: O^T tiles -> O rows (lane (l16, g): d = 16 u + 4 g .. + 3 of query l16 of each 16-query tile)
   float liA, liB;
   if (ONES) {      // denominator = row dh = 40 of O^T: tile 2, row 8 -> lanes g == 2, element 0
@@ -1288,13 +1442,36 @@ static int attn_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const v
   }
   // self-attention of the 64 x 64 / 32 x 32 levels (and SD2.1's 96 x 96 ... 24 x 24): the 8-wave ping-pong kernel, 256 queries
   // per workgroup, where that still gives every CU a workgroup (SKG_NO_ATTN8: A/B switch, default is the product)
-  static const bool no8 = getenv("SKG_NO_ATTN8") != nullptr || getenv("SKG_ATTN8") == nullptr;      // (round 4, first form: correct, 29 % slower - off)
+  static const bool no8 = getenv("SKG_NO_ATTN8") != nullptr || getenv("SKG_ATTN8") == nullptr;      // (round 4: off until it wins)
+  static const int form8 = getenv("SKG_ATTN8") ? atoi(getenv("SKG_ATTN8")) : 0;      // 1: one 8-wave workgroup per CU, 2: three 4-wave ones
   if (vrow && !causal && !no8 && (dh == 40 || dh == 64) && (long)skg_cdiv(Nq, 256) * heads * batch >= 192) {
-    p.nx = skg_cdiv(Nq, 256);
+    const int qpw = form8 == 2 ? 128 : 256;
+    p.nx = skg_cdiv(Nq, qpw);
     dim3 g8((unsigned)p.nx * heads * batch);
-    switch (dh) {
-      case 40: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true>), g8, dim3(512), 0, st, p); break;
-      default: hipLaunchKernelGGL((attn_fwd8_kernel<4, 4, false>), g8, dim3(512), 0, st, p); break;
+#ifdef SKG_PHASES
+    static const int probe8 = getenv("SKG_ATTN8_PROBE") ? atoi(getenv("SKG_ATTN8_PROBE")) : 0;
+    if (probe8 && dh == 40 && form8 == 2) {
+      switch (probe8) {
+        case 1: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true, 4, 3, 1>), g8, dim3(256), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true, 4, 3, 2>), g8, dim3(256), 0, st, p); break;
+        case 4: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true, 4, 3, 4>), g8, dim3(256), 0, st, p); break;
+        case 8: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true, 4, 3, 8>), g8, dim3(256), 0, st, p); break;
+        case 12: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true, 4, 3, 12>), g8, dim3(256), 0, st, p); break;
+        case 16: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true, 4, 3, 16>), g8, dim3(256), 0, st, p); break;
+        case 28: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true, 4, 3, 28>), g8, dim3(256), 0, st, p); break;
+        case 29: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true, 4, 3, 29>), g8, dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true, 4, 3, 30>), g8, dim3(256), 0, st, p); break;
+      }
+      SKG_CHECK_LAUNCH("skg_attn_fwd (8 waves, probe)");
+      return SKG_OK;
+    }
+#endif
+    if (form8 == 2) {
+      if (dh == 40) hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true, 4, 3>), g8, dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((attn_fwd8_kernel<4, 4, false, 4, 2>), g8, dim3(256), 0, st, p);
+    } else {
+      if (dh == 40) hipLaunchKernelGGL((attn_fwd8_kernel<3, 3, true>), g8, dim3(512), 0, st, p);
+      else hipLaunchKernelGGL((attn_fwd8_kernel<4, 4, false>), g8, dim3(512), 0, st, p);
     }
     SKG_CHECK_LAUNCH("skg_attn_fwd (8 waves)");
     return SKG_OK;

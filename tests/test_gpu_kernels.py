@@ -418,6 +418,29 @@ def test_fused_blocks_on_pairs(ops):
     assert r < 1e-4 and float((y.hi.float() - s.float()).abs().max()) <= 2.0 ** -10 * float(s.abs().max())
 
 
+@pytest.mark.parametrize("rows,ih,cin,cout", [(2, 16, 128, 320), (4, 32, 640, 640), (2, 8, 1280, 1280)])
+def test_conv_up2_polyphase_on_pairs(ops, rows, ih, cin, cout):
+    """Accuracy mode: nearest-2x upsample + 3x3 conv, polyphase, on a pair input with (hi, lo) pre-summed weights and a pair
+    output (skg_conv3x3_up2_f16_hilo; per tap [x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo]): hi + lo against fp64
+    F.interpolate + F.conv2d of the pair's sum carries fp32 accuracy - the pre-summed weights' fp16 rounding (1.4e-4 at kernel
+    level, what cost the plain-weight form its eps margin in round 3) is gone; incl. the one-grid form of the small maps."""
+    from sketch2img_amd.unet import pack_conv_up2_hilo
+    d = dev()
+    g = torch.Generator().manual_seed(61)
+    x32 = torch.randn(rows * ih * ih, cin, generator=g).to(d)
+    xp = _as_pair(ops, x32)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
+    b = rnd(cout, seed=62).to(d)
+    out = ops.Pair.empty(rows * 4 * ih * ih, cout, d)
+    ops.conv_up2_hilo(xp.full, pack_conv_up2_hilo(w, d), rows, ih, ih, out, bias=b)
+    xs = (xp.hi.double() + xp.lo.double()).reshape(rows, ih, ih, cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), w.double().to(d), padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + b.double()
+    e = float(((out.hi.double() + out.lo.double()) - ref).norm() / ref.norm())
+    e_hi = float((out.hi.double() - ref).norm() / ref.norm())
+    print(f"[parity] polyphase upsample on a pair rows{rows} {cin}->{cout} @{ih}: pair rel {e:.2e}, hi alone {e_hi:.2e}")
+    assert e < 3e-6 and e_hi < 6e-4
+
+
 def test_cfg_steps_on_a_pair_eps(ops):
     """Accuracy mode: eps arrives as a (hi, lo) pair in one buffer; the CFG + scheduler kernels add the halves in fp32."""
     from sketch2img_amd.sampler import DDIMTables, DPMTables
