@@ -113,7 +113,7 @@ class SkgTap(ctypes.Structure):
 
 
 class SkgError(RuntimeError):
-    pass
+    rc = 0                      # the C ABI's return code (-2 = SKG_E_UNSUPPORTED: nothing was launched)
 
 
 def _load():
@@ -144,4 +144,6 @@ _ERR = {-1: "SKG_E_BADARG (shape/alignment precondition violated)", -2: "SKG_E_U
 def check(rc: int, what: str):
     if rc != 0:
         detail = lib.skg_last_error().decode() if rc == -3 else ""
-        raise SkgError(f"{what}: {_ERR.get(rc, rc)} {detail}")
+        err = SkgError(f"{what}: {_ERR.get(rc, rc)} {detail}")
+        err.rc = rc
+        raise err

@@ -244,7 +244,12 @@ namespace {
 struct WsEntry { int dev; hipStream_t st; float* ws; size_t bytes; };
 std::mutex g_ws_mu;
 std::vector<WsEntry> g_ws_tab;
-size_t g_ws_last_bytes = 0;        // what the shape queries (skg_gemm_variant, skg_gemm_gn_fused) assume
+size_t g_ws_last_bytes = 0;        // what the shape queries (skg_gemm_variant, skg_gemm_gn_fused) assume; guarded by g_ws_mu
+
+size_t ws_query_bytes() {          // the slab size the shape queries plan with: the most recent registration still standing, 0 with none
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  return g_ws_last_bytes;
+}
 
 void ws_attach(GemmParams& p, hipStream_t st) {
   int dev = 0;
@@ -264,7 +269,10 @@ extern "C" int skg_set_workspace(void* ws, size_t bytes, void* stream) {
   for (size_t i = 0; i < g_ws_tab.size(); ++i)
     if (g_ws_tab[i].dev == dev && g_ws_tab[i].st == (hipStream_t)stream) {
       if (ws) { g_ws_tab[i].ws = (float*)ws; g_ws_tab[i].bytes = bytes; g_ws_last_bytes = bytes; }
-      else g_ws_tab.erase(g_ws_tab.begin() + i);
+      else {
+        g_ws_tab.erase(g_ws_tab.begin() + i);
+        g_ws_last_bytes = g_ws_tab.empty() ? 0 : g_ws_tab.back().bytes;      // (a query must not plan with a slab nobody holds any more)
+      }
       return SKG_OK;
     }
   if (ws) { g_ws_tab.push_back({dev, (hipStream_t)stream, (float*)ws, bytes}); g_ws_last_bytes = bytes; }
@@ -284,7 +292,7 @@ extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
     if (skg_gemmk_eligible(q, mode)) return 9160;
 #endif
   }
-  const int v2 = skg_gemm2_tile_n(M, N, K, Cin, mode, g_ws_last_bytes);
+  const int v2 = skg_gemm2_tile_n(M, N, K, Cin, mode, ws_query_bytes());
   return v2 ? 2000 + v2 : 1000 + (use_wide(M, N) ? 128 : 64);
 }
 
@@ -317,7 +325,8 @@ extern "C" int skg_gemm_gn_fused(int M, int N, int K, int Cin, int mode, int HW,
   GemmParams q{};
   q.M = M; q.N = N; q.K = K; q.Cin = Cin; q.lda = q.ldb = K; q.ldc = N; q.OH = q.OW = q.IH = q.IW = 1;
   q.gn_partial = &dummy; q.gn_hw = HW; q.gn_groups = groups;
-  q.ws = g_ws_last_bytes ? (float*)&dummy : nullptr; q.ws_bytes = g_ws_last_bytes;
+  const size_t wsb = ws_query_bytes();
+  q.ws = wsb ? (float*)&dummy : nullptr; q.ws_bytes = wsb;
   return (skg_gemm8_eligible(q, mode) ? skg_gemm8_fuses_gn(q, mode) : skg_gemm2_fuses_gn(q, mode)) ? 1 : 0;
 }
 

@@ -7,17 +7,19 @@ stream; all arithmetic happens inside libskg.so.  A 2-D "matrix view" is any ten
 from __future__ import annotations
 
 import ctypes
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import SkgTap, check, lib
+from ._lib import SkgError, SkgTap, check, lib
 
 EPI_RELU, EPI_OUT_F32, EPI_GEGLU = 1, 2, 4
 CONV_S1, CONV_S2, CONV_UP2, CONV_S2T, CONV_S2A = 0, 1, 2, 3, 4
 
 
 _workspace = {}
+_workspace_lock = threading.Lock()      # (two host threads on one stream: allocate + register is one step)
 WORKSPACE_BYTES = 128 << 20
 _capture_owner = None      # set by private_buffers(): scratch / workspace owned by one hipGraph set
 
@@ -30,10 +32,24 @@ def _stream() -> int:
     st = torch.cuda.current_stream()
     key = (st.device.index, st.cuda_stream)
     if key not in _workspace:
-        with torch.cuda.device(st.device):
-            _workspace[key] = torch.empty(WORKSPACE_BYTES // 4, device=st.device, dtype=torch.float32)
-            check(lib.skg_set_workspace(_workspace[key].data_ptr(), WORKSPACE_BYTES, st.cuda_stream), "skg_set_workspace")
+        with _workspace_lock:
+            if key not in _workspace:
+                with torch.cuda.device(st.device):
+                    ws = torch.empty(WORKSPACE_BYTES // 4, device=st.device, dtype=torch.float32)
+                    check(lib.skg_set_workspace(ws.data_ptr(), WORKSPACE_BYTES, st.cuda_stream), "skg_set_workspace")
+                    _workspace[key] = ws
     return st.cuda_stream
+
+
+def release_stream(stream: "torch.cuda.Stream"):
+    """Drop the split-K slab, the library's registry entry and the scratch buffers of a stream that will not launch again (a
+    sampler's side stream, a retired graph set): they are otherwise held for the life of the process."""
+    key = (stream.device.index, stream.cuda_stream)
+    with _workspace_lock:
+        if _workspace.pop(key, None) is not None:
+            check(lib.skg_set_workspace(None, 0, stream.cuda_stream), "skg_set_workspace")
+    for k in [k for k in _scratch if isinstance(k, tuple) and len(k) > 1 and isinstance(k[1], tuple) and k[1][1] == stream.cuda_stream]:
+        _scratch.pop(k, None)
 
 
 class private_buffers:
@@ -297,16 +313,22 @@ def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode
     return out
 
 
-def conv_up2(X: torch.Tensor, Wpp: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None):
+def conv_up2(X: torch.Tensor, Wpp: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None, W9=None):
     """Nearest-2x upsample + 3x3 conv, polyphase (four 4-tap convs over the low-res input).  X [rows*IH*IW, Cin] (view),
-    Wpp [4, Cout, 4*Cin] (unet.pack_conv_up2).  Returns [rows*2IH*2IW, Cout]."""
+    Wpp [4, Cout, 4*Cin] (unet.pack_conv_up2).  Returns [rows*2IH*2IW, Cout].  W9: the layer's ordinary 9-tap pack - the
+    fall-back when the launch is declined (SKG_E_UNSUPPORTED)."""
     _f16(X, Wpp, bias)
     Cin, Cout = X.shape[1], Wpp.shape[1]
     assert Wpp.shape == (4, Cout, 4 * Cin) and Wpp.is_contiguous() and X.shape[0] == rows * IH * IW
     if out is None:
         out = torch.empty(rows * 4 * IH * IW, Cout, device=X.device, dtype=torch.float16)
-    check(lib.skg_conv3x3_up2_f16(_p(X), _ld(X), _p(Wpp), _p(out), _ld(out), rows, IH, IW, Cin, Cout, _p(bias), _stream()),
-          "skg_conv3x3_up2_f16")
+    try:
+        check(lib.skg_conv3x3_up2_f16(_p(X), _ld(X), _p(Wpp), _p(out), _ld(out), rows, IH, IW, Cin, Cout, _p(bias), _stream()),
+              "skg_conv3x3_up2_f16")
+    except SkgError as e:      # the LDS-DMA kernel declined the launch (an operand >= 2 GiB): the 9-tap gather form, when the caller has its pack
+        if e.rc != -2 or W9 is None:
+            raise
+        return conv3x3(X, W9, rows, IH, IW, CONV_UP2, out=out, bias=bias)
     return out
 
 
@@ -328,12 +350,18 @@ def gemm_rows(A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, seg_rows: int
     M, K = A.shape
     N = B.shape[0]
     assert B.shape[1] == K and M % seg_rows == 0 and out.shape[0] >= (M // seg_rows - 1) * seg_stride + seg_rows and out.shape[1] >= N
-    check(lib.skg_gemm_f16_rows(_p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out), M, N, K, _p(bias), seg_rows, seg_stride, _stream()),
-          "skg_gemm_f16_rows")
+    try:
+        check(lib.skg_gemm_f16_rows(_p(A), _ld(A), _p(B), _ld(B), _p(out), _ld(out), M, N, K, _p(bias), seg_rows, seg_stride, _stream()),
+              "skg_gemm_f16_rows")
+    except SkgError as e:      # declined: one GEMM per batch row straight into its slot
+        if e.rc != -2:
+            raise
+        for b in range(M // seg_rows):
+            gemm(A[b * seg_rows:(b + 1) * seg_rows], B, out=out[b * seg_stride:b * seg_stride + seg_rows, :N], bias=bias)
     return out
 
 
-def conv4x4s2(X: torch.Tensor, W16: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None):
+def conv4x4s2(X: torch.Tensor, W16: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None, W9T=None):
     """4 x 4 stride-2 convolution, padding 1 (the data gradient of conv_up2).  X [rows*IH*IW, Cin] (view), W16 [Cout, 16*Cin]
     (unet.pack_conv_up2_dgrad).  Returns [rows*(IH/2)*(IW/2), Cout]."""
     _f16(X, W16, bias)
@@ -341,8 +369,13 @@ def conv4x4s2(X: torch.Tensor, W16: torch.Tensor, rows: int, IH: int, IW: int, o
     assert W16.shape == (Cout, 16 * Cin) and W16.is_contiguous() and X.shape[0] == rows * IH * IW
     if out is None:
         out = torch.empty(rows * (IH // 2) * (IW // 2), Cout, device=X.device, dtype=torch.float16)
-    check(lib.skg_conv4x4s2_f16(_p(X), _ld(X), _p(W16), _p(out), _ld(out), rows, IH, IW, Cin, Cout, _p(bias), _stream()),
-          "skg_conv4x4s2_f16")
+    try:
+        check(lib.skg_conv4x4s2_f16(_p(X), _ld(X), _p(W16), _p(out), _ld(out), rows, IH, IW, Cin, Cout, _p(bias), _stream()),
+              "skg_conv4x4s2_f16")
+    except SkgError as e:      # declined: the 9-tap dgrad at the upsampled size + 2 x 2 sum-pool it replaced
+        if e.rc != -2 or W9T is None or bias is not None:
+            raise
+        return sumpool2x2(conv3x3(X, W9T, rows, IH, IW, bias=bias), rows, IH // 2, IW // 2, out=out)
     return out
 
 

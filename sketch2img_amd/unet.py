@@ -530,14 +530,17 @@ class HipUNet:
             out = ops.gemm(p3, W[p + ".proj_out.weight"], out, bias=W[p + ".proj_out.bias"], residual=x)
         if keep:
             # half: the tensors of the text-independent part hold the cond rows only (r1 == rows // 2)
-            half = ("x", "gst", "pin", "st1", "qkv", "o1", "lse1", "p1", "st2", "q2") if r1 != rows else ()
+            # (`half` is derived from what each tensor actually holds - r1 rows or all of them - whatever the injector did, so that
+            # a backward through an injected block could never slice an M1-row tensor a second time: ADVICE r3)
             st3h = ("st3",) if st3_half else ()      # fused FF block: norm3's statistics exist for the cond rows only
-            if r1 != rows and self.inject is None:
-                stash.tr[p] = dict(x=x_c, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1_c, st2=st2, q2=q2_c,
-                                   o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=half + st3h)
-            else:
-                stash.tr[p] = dict(x=x, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1, st2=st2, q2=q2,
-                                   o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=st3h)
+            ent = dict(x=x_c, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1_c, st2=st2, q2=q2_c)
+            half = ()
+            if r1 != rows:
+                M1_ = r1 * HW
+                half = tuple(k for k, v in ent.items() if v is not None and v.shape[0] == (r1 if k in ("gst", "lse1") else M1_))
+                if "x" not in half:      # the front diverged before p1 (an injector with differing halves): x is full size
+                    ent["x"] = x
+            stash.tr[p] = dict(ent, o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=half + st3h)
         return out, opart
 
     @staticmethod
@@ -710,7 +713,7 @@ class HipUNet:
                 u = (i + 1) * lpb1
                 # polyphase: 16 instead of 36 tap-products per low-res pixel (four launches; one grid on the small maps)
                 if (p + ".weight:pp") in W and (UP2_SMALL_MAPS or (rows * cur * cur // 128) * (h.shape[1] // 160) >= 200):
-                    h = ops.conv_up2(h, W[p + ".weight:pp"], rows, cur, cur, out=cats[u][:, :ch_h[u]], bias=W[p + ".bias"])
+                    h = ops.conv_up2(h, W[p + ".weight:pp"], rows, cur, cur, out=cats[u][:, :ch_h[u]], bias=W[p + ".bias"], W9=W[p + ".weight"])
                 else:
                     h = ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=cats[u][:, :ch_h[u]],
                                     bias=W[p + ".bias"])
@@ -1145,7 +1148,7 @@ class HipUNet:
                 # upsampler backward: dgrad at the upsampled size, then 2x2 sum-pool
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 if UP2_DGRAD and (p + ".weight:ppT") in W:      # polyphase: one 4 x 4 stride-2 convolution, 16 instead of 36 tap-products
-                    dh = ops.conv4x4s2(dh, W[p + ".weight:ppT"], S, cur, cur)
+                    dh = ops.conv4x4s2(dh, W[p + ".weight:ppT"], S, cur, cur, W9T=W[p + ".weight:T"])
                     cur //= 2
                 else:
                     du = ops.conv3x3(dh, W[p + ".weight:T"], S, cur, cur)

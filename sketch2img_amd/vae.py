@@ -148,7 +148,7 @@ class HipVAEDecoder(_HipVAEBlocks):
             if up:
                 u = f"decoder.up_blocks.{i}.upsamplers.0.conv"
                 if (u + ".weight:pp") in W:      # polyphase: 16 instead of 36 tap-products per low-res pixel
-                    x = ops.conv_up2(x, W[u + ".weight:pp"], S, H, H, bias=W[u + ".bias"])
+                    x = ops.conv_up2(x, W[u + ".weight:pp"], S, H, H, bias=W[u + ".bias"], W9=W.get(u + ".weight"))
                 else:
                     x = ops.conv3x3(x, W[u + ".weight"], S, H, H, ops.CONV_UP2, bias=W[u + ".bias"])
                 H *= 2

@@ -222,6 +222,55 @@ def test_conv4x4s2_is_the_dgrad_of_upsample_conv(ops):
         assert e < 5e-4 and stray == 0
 
 
+def test_declined_launches_fall_back_to_the_forms_they_replaced(ops, monkeypatch):
+    """SKG_E_UNSUPPORTED from the three LDS-DMA-only entry points (an operand of 2 GiB or more) is not an error of the caller:
+    ops.conv_up2 falls back to the 9-tap UP2 gather form, ops.conv4x4s2 to the 9-tap dgrad + 2 x 2 sum-pool, ops.gemm_rows to one
+    GEMM per batch row - the entry points return -2 here by substitution, the results are those of the replaced paths; any other
+    error code still raises; release_stream drops a side stream's slab and the library's entry."""
+    from sketch2img_amd import _lib
+    from sketch2img_amd.unet import pack_conv, pack_conv_dgrad, pack_conv_up2, pack_conv_up2_dgrad
+    g = torch.Generator().manual_seed(57)
+    rows, ih, iw, cin, cout = 2, 16, 16, 64, 160
+    x = nhwc(torch.randn(rows, cin, ih, iw, generator=g).half()).to(dev())
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
+    b = torch.randn(cout, generator=g).half().to(dev())
+    dy = nhwc(torch.randn(rows, cout, 2 * ih, 2 * iw, generator=g).half()).to(dev())
+    z = torch.randn(3 * 1000, 320, generator=g).half().to(dev())
+    wz = (torch.randn(640, 320, generator=g) * 320 ** -0.5).half().to(dev())
+    nine = ops.conv3x3(x, pack_conv(w, dev()), rows, ih, iw, ops.CONV_UP2, bias=b)
+    old = ops.sumpool2x2(ops.conv3x3(dy, pack_conv_dgrad(w, dev()), rows, 2 * ih, 2 * iw), rows, ih, iw)
+    seg = torch.full((3 * 1264, 640), 7.0, device=dev(), dtype=torch.float16)
+    ops.gemm_rows(z, wz, seg, 1000, 1264)
+    for name in ("skg_conv3x3_up2_f16", "skg_conv4x4s2_f16", "skg_gemm_f16_rows"):
+        monkeypatch.setattr(ops.lib, name, lambda *a: -2)
+    up = ops.conv_up2(x, pack_conv_up2(w, dev()), rows, ih, iw, bias=b, W9=pack_conv(w, dev()))
+    dx = ops.conv4x4s2(dy, pack_conv_up2_dgrad(w, dev()), rows, 2 * ih, 2 * iw, W9T=pack_conv_dgrad(w, dev()))
+    seg2 = torch.full_like(seg, 7.0)
+    ops.gemm_rows(z, wz, seg2, 1000, 1264)
+    assert torch.equal(up, nine) and torch.equal(dx, old) and torch.equal(seg, seg2)
+    with pytest.raises(_lib.SkgError) as ei:      # without the caller's 9-tap pack there is nothing to fall back to
+        ops.conv_up2(x, pack_conv_up2(w, dev()), rows, ih, iw, bias=b)
+    assert ei.value.rc == -2
+    monkeypatch.setattr(ops.lib, "skg_gemm_f16_rows", lambda *a: -1)
+    with pytest.raises(_lib.SkgError) as ei:
+        ops.gemm_rows(z, wz, seg2, 1000, 1264)
+    assert ei.value.rc == -1
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ops.groupnorm_stats(x, rows, ih * iw, 32, 1e-5)
+        ops.gemm(z, wz)
+    side.synchronize()
+    key = (side.device.index, side.cuda_stream)
+    assert key in ops._workspace
+    ops.release_stream(side)
+    assert key not in ops._workspace and not any(k[1][1] == side.cuda_stream for k in ops._scratch)
+    with torch.cuda.stream(side):      # and the stream is usable again afterwards (a new slab is registered)
+        again = ops.gemm(z, wz)
+    side.synchronize()
+    assert torch.equal(again, ops.gemm(z, wz))
+    ops.release_stream(side)
+
+
 def test_hilo_pair_epilogue_and_norms(ops):
     """Accuracy mode primitives (skg_*_hilo): a GEMM / conv whose output and residual are (hi, lo) fp16 pairs carries
     ~22 mantissa bits (hi + lo vs an fp64 reference of the same fp16 operands: fp32-accumulation error only), hi alone is
