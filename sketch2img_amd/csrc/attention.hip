@@ -1376,7 +1376,19 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
 // (tools/attn_var_bench.py; the other variants measured in round 2 - all fragments of a tile requested up front, four
 // query tiles per wave - lost and are not instantiated: profiles/r02_attn_variants.txt).
 #define SKG_ATTN_VARIANTS(KS_, ND_, grid2, VROW_)                                                                \
-  if (ND_ == 4 && attn_var() != 7)                                                                               \
+  if (attn_var() == 8) {      /* four query tiles per wave, two waves per SIMD */                                \
+    p.nx = skg_cdiv(p.Nq, 256);                                                                                  \
+    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, 2 | (2 << 2), VROW_>), dim3((unsigned)p.nx * p.heads * p.batch), dim3(256), 0, st, p); \
+  } else if (attn_var() == 10) {      /* var 8 with two register prefetch sets */                                \
+    p.nx = skg_cdiv(p.Nq, 256);                                                                                  \
+    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, (2 << 2), VROW_>), dim3((unsigned)p.nx * p.heads * p.batch), dim3(256), 0, st, p); \
+  } else if (attn_var() == 11) {      /* var 8 with every fragment of a tile requested up front */               \
+    p.nx = skg_cdiv(p.Nq, 256);                                                                                  \
+    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, 3 | (2 << 2), VROW_>), dim3((unsigned)p.nx * p.heads * p.batch), dim3(256), 0, st, p); \
+  } else if (attn_var() == 9) {      /* three query tiles per wave, three waves per SIMD */                      \
+    p.nx = skg_cdiv(p.Nq, 192);                                                                                  \
+    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 3, false, 2 | (3 << 2), VROW_>), dim3((unsigned)p.nx * p.heads * p.batch), dim3(256), 0, st, p); \
+  } else if (ND_ == 4 && attn_var() != 7)                                                                               \
     hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 2 | (3 << 2), VROW_>), grid2, dim3(256), 0, st, p);  \
   else                                                                                                           \
     hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 0, VROW_>), grid2, dim3(256), 0, st, p)

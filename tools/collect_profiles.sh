@@ -13,7 +13,7 @@ EXTRA=${3:-}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out profiles
 OUT=gpurun_out/${TAG}_cfg${CFG}
-BENCH="python bench.py --config $CFG --no-cpu-baseline --no-roofline $EXTRA"
+BENCH="python bench.py --config $CFG --no-cpu-baseline --no-roofline --no-at-tolerance $EXTRA"
 rm -rf ${OUT}_trace
 rocprofv3 --kernel-trace --stats --output-format csv -d ${OUT}_trace -- $BENCH --steps 2 --warmup 1 > ${OUT}_trace.log 2>&1
 STATS=$(find ${OUT}_trace -name "*kernel_stats.csv" | head -1)

@@ -9,6 +9,9 @@
     instances agree to < 1 %) is sum / 8.
   effective clock   = GRBM_GUI_ACTIVE per XCD / dispatch duration (the chip clocks to its power budget: DVFS give-back;
     counter passes serialise the dispatches, so the chip runs cooler and faster here than in the un-profiled bench)
+  Dispatches shorter than 30 us: GRBM_GUI_ACTIVE's window (command-processor set-up + drain) is then a large part of the
+    count, so gui / duration is no clock (it read 2.6 - 4 GHz on a 2.4 GHz part in round 3) and busy / gui under-states the
+    kernel: the clock column prints n/a and the busy fraction is marked `>=` (a lower bound) for those rows.
   HBM MB / launch   = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950: FETCH_SIZE counts half of wide coalesced reads)
 Usage: mfma_report.py mfma_counters.json kernel_stats.csv [hbm_counters.json]"""
 import csv
@@ -43,6 +46,10 @@ for k, v in mf.items():
     if hb and "FETCH_SIZE" in hb and "WRITE_SIZE" in hb:
         mb = (2 * hb["FETCH_SIZE"]["sum"] / hb["FETCH_SIZE"]["launches"] + hb["WRITE_SIZE"]["sum"] / hb["WRITE_SIZE"]["launches"]) * 1024 / 1e6
     rows.append((pct, k, avg_ns, busy / (1024.0 * gui) if gui else 0.0, sqb / gui if gui else 0.0, gui / ns if ns else None, mb))
+SHORT_NS = 30e3
 for pct, k, avg_ns, util, sq, clk, mb in sorted(rows, reverse=True)[:24]:
-    print(f"{k[:58]:58s} {pct:6.2f} {(avg_ns or 0) / 1e3:8.1f} {util:9.3f} "
-          f"{(f'{clk:9.2f}' if clk else '        -')} {(f'{mb:13.1f}' if mb is not None else '            -')}")
+    short = (avg_ns or 0) < SHORT_NS or (clk is not None and clk > 2.45)      # (2.4 GHz is the part's ceiling)
+    us = f"{(avg_ns or 0) / 1e3:8.1f}"
+    ut = f"{'>=' if short else '  '}{util:7.3f}"
+    ck = "      n/a" if short else (f"{clk:9.2f}" if clk else "        -")
+    print(f"{k[:58]:58s} {pct:6.2f} {us} {ut} {ck} {(f'{mb:13.1f}' if mb is not None else '            -')}")
