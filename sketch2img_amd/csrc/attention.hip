@@ -1371,27 +1371,43 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const half_t* __restric
   }
 }
 
-// d = 40 / d = 64 forward.  d = 64 ships with ONE register prefetch set: 152 VGPRs = three waves per SIMD instead of two
-// (+8...15 %); d = 40 already runs four waves per SIMD.  SKG_ATTN_VAR=7 launches the two-set form for A/B runs
-// (tools/attn_var_bench.py; the other variants measured in round 2 - all fragments of a tile requested up front, four
-// query tiles per wave - lost and are not instantiated: profiles/r02_attn_variants.txt).
-#define SKG_ATTN_VARIANTS(KS_, ND_, grid2, VROW_)                                                                \
-  if (attn_var() == 8) {      /* four query tiles per wave, two waves per SIMD */                                \
-    p.nx = skg_cdiv(p.Nq, 256);                                                                                  \
-    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, 2 | (2 << 2), VROW_>), dim3((unsigned)p.nx * p.heads * p.batch), dim3(256), 0, st, p); \
-  } else if (attn_var() == 10) {      /* var 8 with two register prefetch sets */                                \
-    p.nx = skg_cdiv(p.Nq, 256);                                                                                  \
-    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, (2 << 2), VROW_>), dim3((unsigned)p.nx * p.heads * p.batch), dim3(256), 0, st, p); \
-  } else if (attn_var() == 11) {      /* var 8 with every fragment of a tile requested up front */               \
-    p.nx = skg_cdiv(p.Nq, 256);                                                                                  \
-    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 4, false, 3 | (2 << 2), VROW_>), dim3((unsigned)p.nx * p.heads * p.batch), dim3(256), 0, st, p); \
-  } else if (attn_var() == 9) {      /* three query tiles per wave, three waves per SIMD */                      \
-    p.nx = skg_cdiv(p.Nq, 192);                                                                                  \
-    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 3, false, 2 | (3 << 2), VROW_>), dim3((unsigned)p.nx * p.heads * p.batch), dim3(256), 0, st, p); \
-  } else if (ND_ == 4 && attn_var() != 7)                                                                               \
-    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 2 | (3 << 2), VROW_>), grid2, dim3(256), 0, st, p);  \
-  else                                                                                                           \
-    hipLaunchKernelGGL((attn_fwd_kernel<KS_, ND_, 2, false, 0, VROW_>), grid2, dim3(256), 0, st, p)
+// d = 40 / d = 64 forward: how many 16-query tiles a wave carries (QT) against how many waves a SIMD holds.
+// Every K / V fragment a wave reads from LDS feeds QT MFMAs, and at QT = 2 the 16 resident waves of a CU move 56 KB through the
+// LDS per 448 MFMA cycles - half the LDS pipe's time, which the probes of round 4 priced at 135 of 632 us at d = 40.  More tiles
+// per wave trade that traffic for occupancy (the register budget): measured on one box (profiles/r04_attn_qt_variants.txt)
+//   d = 40:  QT 2, 4 waves / SIMD 529 us;  QT 3, 3 waves / SIMD (165 VGPRs) 514-520 us;  QT 4, 2 waves / SIMD 554-562 us
+//   d = 64:  QT 2, 3 waves / SIMD 1053 us at 9 480 tokens;  QT 4, 2 waves / SIMD (256 VGPRs) 1001-1006 us there, but
+//            218 against 209 us at 2 568 tokens and 71 against 57 us at 840 (too few workgroups of 256 queries)
+// End to end (same box, alternating): config 2 + 0.3 % / + 0.1 % with QT 3 at d = 40; config 5 - 0.4 % / + 0.0 % with QT 4 at d = 64.
+// So QT 3 runs d = 40 where the launch has >= 1024 workgroups of 192 queries, d = 64 stays at QT 2 with ONE register prefetch
+// set (152 VGPRs = three waves per SIMD instead of two: + 8...15 %).  SKG_ATTN_VAR: 12 = QT 2 everywhere (round 3's
+// dispatch), 9 / 8 = QT 3 at d = 40 / QT 4 at d = 64 whatever the size, 7 = the two-set form at d = 64 (tools/attn_var_bench.py).
+inline int attn_var();
+template <int KS, int ND, bool VROW>
+static void attn_fwd_launch_qt(AttnParams& p, hipStream_t st) {
+  const int var = attn_var();
+  const long rows = (long)p.heads * p.batch;
+  if constexpr (ND == 3) {
+    if (var == 9 || (var == 0 && skg_cdiv(p.Nq, 192) * rows >= 1024)) {
+      p.nx = skg_cdiv(p.Nq, 192);
+      hipLaunchKernelGGL((attn_fwd_kernel<KS, ND, 3, false, 2 | (3 << 2), VROW>), dim3((unsigned)(p.nx * rows)), dim3(256), 0, st, p);
+      return;
+    }
+  } else if constexpr (VROW) {      // (the transposed-V form of this instantiation spills 5 registers: row-major V only)
+    if (var == 8) {      // (opt-in: + 5 % on the kernel alone at 9 480 tokens, nothing end to end on config 5)
+      p.nx = skg_cdiv(p.Nq, 256);
+      hipLaunchKernelGGL((attn_fwd_kernel<KS, ND, 4, false, 2 | (2 << 2), VROW>), dim3((unsigned)(p.nx * rows)), dim3(256), 0, st, p);
+      return;
+    }
+  }
+  p.nx = skg_cdiv(p.Nq, 128);
+  const dim3 grid((unsigned)(p.nx * rows));
+  if (ND == 4 && var != 7)
+    hipLaunchKernelGGL((attn_fwd_kernel<KS, ND, 2, false, 2 | (3 << 2), VROW>), grid, dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<KS, ND, 2, false, 0, VROW>), grid, dim3(256), 0, st, p);
+}
+#define SKG_ATTN_VARIANTS(KS_, ND_, grid2, VROW_) attn_fwd_launch_qt<KS_, ND_, VROW_>(p, st)
 
 // forward: two query tiles per wave (128 queries per workgroup) except at d = 160 (register budget)
 #define SKG_ATTN_FWD_DISPATCH(grid1, grid2, VROW_)                                                                 \

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One kernel shape, a few launches - the target of `rocprofv3 --pmc ...` passes (tools/pmc_kernels.sh).
-    python tools/pmc_kernel.py attn40 | attn64 | conv | gemm_short | gemm_ff1 | ffblock"""
+    python tools/pmc_kernel.py attn40 | attn64 | conv | gemm_short | gemm_ff1 | ffblock | gemm:M:N:K[:res|:geglu]"""
 import os
 import sys
 
@@ -34,11 +34,20 @@ elif what == "conv":
     x = torch.randn(rows * hw * hw, cin, generator=g).half().to(dev)
     w = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(dev)
     fn = lambda: ops.conv3x3(x, w, rows, hw, hw, 0)
+elif what.startswith("gemm:"):
+    f = what.split(":")
+    M, N, K = int(f[1]), int(f[2]), int(f[3])
+    a = torch.randn(M, K, generator=g).half().to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev)
+    res = torch.randn(M, N, generator=g).half().to(dev) if "res" in f[4:] else None
+    out = torch.empty(M, N // 2 if "geglu" in f[4:] else N, device=dev, dtype=torch.float16)
+    fn = lambda: ops.gemm(a, w, out=out, residual=res, geglu="geglu" in f[4:])
 else:
     M, N, K = (65536, 320, 320) if what == "gemm_short" else (65536, 2560, 320)
     a = torch.randn(M, K, generator=g).half().to(dev)
     w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev)
     fn = lambda: ops.gemm(a, w)
+ops.gemm(torch.zeros(128, 64, device=dev, dtype=torch.float16), torch.zeros(64, 64, device=dev, dtype=torch.float16))      # (workspace set-up outside the counted launches)
 for _ in range(6):
     fn()
 torch.cuda.synchronize()
