@@ -256,8 +256,16 @@ void ws_attach(GemmParams& p, hipStream_t st) {
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> lk(g_ws_mu);
   for (const WsEntry& e : g_ws_tab)
-    if (e.dev == dev && e.st == st) { p.ws = e.ws; p.ws_bytes = e.bytes; return; }
-  p.ws = nullptr; p.ws_bytes = 0;
+    if (e.dev == dev && e.st == st) {
+#ifdef SKG_LAB      // (the withdrawn self-finishing split-K launch keeps its tile tickets at the end of the slab)
+      p.ws = e.ws; p.ws_bytes = e.bytes - SKG_WS_TICKET_BYTES;
+      p.ws_cnt = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(e.ws) + p.ws_bytes);
+#else
+      p.ws = e.ws; p.ws_bytes = e.bytes;
+#endif
+      return;
+    }
+  p.ws = nullptr; p.ws_bytes = 0; p.ws_cnt = nullptr;
 }
 }  // namespace
 
@@ -265,6 +273,14 @@ extern "C" int skg_set_workspace(void* ws, size_t bytes, void* stream) {
   SKG_REQUIRE(ws == nullptr || (skg_aligned(ws, 16) && bytes >= (1u << 20)));
   int dev = 0;
   (void)hipGetDevice(&dev);
+#ifdef SKG_LAB
+  if (ws) {      // the tile tickets of the self-finishing split-K launches start at zero (every launch leaves them there)
+    if (hipMemsetAsync(reinterpret_cast<char*>(ws) + bytes - SKG_WS_TICKET_BYTES, 0, SKG_WS_TICKET_BYTES, (hipStream_t)stream) != hipSuccess) {
+      (void)hipGetLastError();
+      return SKG_E_LAUNCH;
+    }
+  }
+#endif
   std::lock_guard<std::mutex> lk(g_ws_mu);
   for (size_t i = 0; i < g_ws_tab.size(); ++i)
     if (g_ws_tab[i].dev == dev && g_ws_tab[i].st == (hipStream_t)stream) {

@@ -128,11 +128,64 @@ __device__ unsigned long long g_phase[1 << 15][16];
 // for - its 25 extra epilogue registers and code cost the plain launches 0.3 % of a batch when they shared one kernel)
 // HILO: the accuracy-mode instantiation (skg_*_hilo): the fp32-staged epilogue also adds p.res_lo and stores
 // lo = fp16(v - fp16(v)) to p.c_lo, whatever the launch (an own instantiation: the plain kernels stay as tuned)
-template <int BM, int BN, int WGM, int WGN, int MODE, int NS = 2, bool GNS = false, bool HILO = false>
-__global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <= 80 * 1024) ? 2 : 1) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
-                                                                  unsigned a_bytes, unsigned b_bytes,
-                                                                  unsigned a_shift, int kt_per_split,
-                                                                  float* __restrict__ ws) {
+// agent-scope (sc1) 16-byte store / load of a slab element: two relaxed 8-byte atomics each (global_store / load_dwordx2 ... sc1)
+__device__ __forceinline__ void st_agent(float* p, float4_t v) {
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  __hip_atomic_store(q, __builtin_bit_cast(unsigned long long, float2v{v[0], v[1]}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, __builtin_bit_cast(unsigned long long, float2v{v[2], v[3]}), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4_t ld_agent(const float* p) {
+  typedef float float2v __attribute__((ext_vector_type(2)));
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(const_cast<float*>(p));
+  const float2v a = __builtin_bit_cast(float2v, __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const float2v b = __builtin_bit_cast(float2v, __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return float4_t{a[0], a[1], b[0], b[1]};
+}
+
+// the epilogue of a split-K launch on 4 summed outputs (row m, columns n .. n + 3): splitk_reduce_kernel and the self-finishing
+// launch (gemm2_splitk_kernel) share it, bit for bit
+__device__ __forceinline__ void splitk_epilogue(const GemmParams& p, float4_t v, size_t m, int n) {
+  if (p.bias) {
+    const half4_t b = ld_half4(p.bias + n);
+    v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
+  }
+  v *= p.alpha;
+  if (p.res) {
+    const half4_t r = ld_half4(p.res + m * p.ldr + n);
+    v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+  }
+  if (p.res_lo) {      // accuracy mode: pair residual
+    const half4_t r = ld_half4(p.res_lo + m * p.ldr + n);
+    v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
+  }
+  if (p.flags & SKG_EPI_RELU) {
+    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+  }
+  if (p.flags & SKG_EPI_OUT_F32) {
+    *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
+  } else {
+    half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    st_half4(reinterpret_cast<half_t*>(p.C) + m * p.ldc + n, o);
+    if (p.c_lo) {      // accuracy mode: pair output, lo = fp16(v - hi)
+      half4_t l = {(half_t)(v[0] - (float)o[0]), (half_t)(v[1] - (float)o[1]), (half_t)(v[2] - (float)o[2]), (half_t)(v[3] - (float)o[3])};
+      st_half4(p.c_lo + m * p.ldc + n, l);
+    }
+  }
+}
+
+// FIX (gemm2_splitk_kernel, lab build only - measured and withdrawn): the split-K launch finishes itself.  Every workgroup writes its fp32 slab as before, then takes a
+// ticket on its tile's counter (p.ws_cnt, kept zero between launches: the counter wraps at `splits`); the workgroup that draws
+// the LAST ticket of a tile adds the slabs in slab order (0, 1, ...: the order of splitk_reduce_kernel, so the result is the
+// same bit pattern whichever workgroup arrives last) and runs the reduce kernel's epilogue on its 128 x BN tile.  No workgroup
+// waits for another one.  Visibility across the XCDs' L2s (one per XCD, not coherent with each other for ordinary accesses): ONE
+// agent-scope release fence per workgroup behind the slab stores (buffer_wbl2 sc1), agent-scope (sc1) loads of the slabs behind
+// the ticket.  Bit-identical to the two-launch path (tools/lab/splitk_self_check.py) and 13-26 % SLOWER end to end in all three
+// forms tried (EXPERIMENTS.md): the reduction is 320 KB through one CU at memory-side latency where splitk_reduce_kernel has
+// the whole chip; the product keeps the reduce launch.
+template <int BM, int BN, int WGM, int WGN, int MODE, int NS, bool GNS, bool HILO, bool FIX>
+__device__ __forceinline__ void gemm2_body(const GemmParams& p, int tiles_n, int nwg, unsigned a_bytes, unsigned b_bytes,
+                                           unsigned a_shift, int kt_per_split, float* __restrict__ ws) {
   constexpr int NW = WGM * WGN;       // waves
   constexpr int NTHR = NW * 64;
   constexpr int WM = BM / WGM;        // wave tile rows (64 or 128)
@@ -419,6 +472,27 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
 #pragma unroll
       for (int v = 0; v < plan_vmem<MT, NT>(gq, ND); ++v) dma_one(d, ibuf, di++);
     }
+#ifdef SKG_LAB
+    // VERDICT r3 #6 cost probe (lab build, SKG_GLUE_PROBE=1; results are wrong by construction): what GroupNorm + SiLU applied to
+    // the convolution's A operand inside the K loop would cost in its cheapest form - packed fp16 on the fragments as they leave
+    // LDS (y = x * s + t; y * rcp(1 + exp2(-1.4427 y))), per-lane constants instead of the per-(sample, channel) table
+    if (p.flags & 0x2000u) {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const h2 sc = {(_Float16)1.0009765625f, (_Float16)1.0009765625f}, sh = {(_Float16)(lane * 1e-4f), (_Float16)0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) {
+            h2 y = h2{xf[ks][i][e], xf[ks][i][e + 1]} * sc + sh;
+            const h2 ex = {(_Float16)__builtin_amdgcn_exp2f((float)(y[0] * (_Float16)-1.4427f)), (_Float16)__builtin_amdgcn_exp2f((float)(y[1] * (_Float16)-1.4427f))};
+            const h2 den = ex + h2{(_Float16)1.f, (_Float16)1.f};
+            y = y * h2{(_Float16)__builtin_amdgcn_rcpf((float)den[0]), (_Float16)__builtin_amdgcn_rcpf((float)den[1])};
+            xf[ks][i][e] = y[0]; xf[ks][i][e + 1] = y[1];
+          }
+    }
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -426,6 +500,9 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][j], xf[ks][i], acc[i][j], 0, 0, 0);
+#ifdef SKG_LAB
+    if (!(p.flags & 0x2000u))
+#endif
     sched_plan<MT, NT, ND>();
   };
 
@@ -495,7 +572,31 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n = n0 + wn * WN + j * 16 + g * 4;
-        if (n < p.N) *reinterpret_cast<float4_t*>(slab + (size_t)m * p.N + n) = acc[i][j];
+        if (n < p.N) {
+          *reinterpret_cast<float4_t*>(slab + (size_t)m * p.N + n) = acc[i][j];
+        }
+      }
+    }
+    if constexpr (FIX) {
+      __shared__ unsigned s_ticket;
+      const int splits = nwg / ntiles;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's slab stores sit in this XCD's L2
+      __syncthreads();
+      if (tid < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // ONE L2 write-back per workgroup (buffer_wbl2 sc1), no invalidate
+      if (tid == 0) s_ticket = atomicInc(p.ws_cnt + (tile_m * tiles_n + tile_n), (unsigned)(splits - 1));      // wraps to 0 at the last ticket
+      __syncthreads();
+      if (s_ticket == (unsigned)(splits - 1)) {          // workgroup-uniform
+        constexpr int N4 = BN / 4;
+        const size_t slab_sz = (size_t)p.M * p.N;
+        for (int i = tid; i < BM * N4; i += NTHR) {
+          const int r = i / N4;
+          const size_t m = (size_t)(m0 + r);
+          const int n = n0 + (i - r * N4) * 4;
+          if (m >= (size_t)p.M || n >= p.N) continue;
+          float4_t v = ld_agent(ws + m * p.N + n);
+          for (int sp = 1; sp < splits; ++sp) v += ld_agent(ws + sp * slab_sz + m * p.N + n);
+          splitk_epilogue(p, v, m, n);
+        }
       }
     }
     continue;
@@ -865,6 +966,25 @@ __global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <
   }   // persistent tile loop
 }
 
+template <int BM, int BN, int WGM, int WGN, int MODE, int NS = 2, bool GNS = false, bool HILO = false>
+__global__ __launch_bounds__(WGM * WGN * 64, (NS * (BM + BN) * BK * 2 + 8 * BN <= 80 * 1024) ? 2 : 1) void gemm2_kernel(const GemmParams p, int tiles_n, int nwg,
+                                                                  unsigned a_bytes, unsigned b_bytes,
+                                                                  unsigned a_shift, int kt_per_split,
+                                                                  float* __restrict__ ws) {
+  gemm2_body<BM, BN, WGM, WGN, MODE, NS, GNS, HILO, false>(p, tiles_n, nwg, a_bytes, b_bytes, a_shift, kt_per_split, ws);
+}
+#ifdef SKG_LAB
+// the self-finishing split-K launch (see FIX above; WITHDRAWN, lab build only: EXPERIMENTS.md round 4): its own kernel, so that
+// the plain instantiations stay as they were tuned
+template <int BM, int BN, int WGM, int WGN, int MODE>
+__global__ __launch_bounds__(WGM * WGN * 64, (2 * (BM + BN) * BK * 2 + 8 * BN <= 80 * 1024) ? 2 : 1) void gemm2_splitk_kernel(const GemmParams p, int tiles_n, int nwg,
+                                                                  unsigned a_bytes, unsigned b_bytes,
+                                                                  unsigned a_shift, int kt_per_split,
+                                                                  float* __restrict__ ws) {
+  gemm2_body<BM, BN, WGM, WGN, MODE, 2, false, false, true>(p, tiles_n, nwg, a_bytes, b_bytes, a_shift, kt_per_split, ws);
+}
+#endif
+
 // out = epi(sum_s slab[s]) for a split-K launch; 4 outputs per thread
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, const float* __restrict__ ws,
                                                             int splits) {
@@ -876,32 +996,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
     const int n = (int)(i - m * N4) * 4;
     float4_t v = *reinterpret_cast<const float4_t*>(ws + m * p.N + n);
     for (int s = 1; s < splits; ++s) v += *reinterpret_cast<const float4_t*>(ws + s * slab + m * p.N + n);
-    if (p.bias) {
-      const half4_t b = ld_half4(p.bias + n);
-      v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3];
-    }
-    v *= p.alpha;
-    if (p.res) {
-      const half4_t r = ld_half4(p.res + m * p.ldr + n);
-      v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-    }
-    if (p.res_lo) {      // accuracy mode: pair residual
-      const half4_t r = ld_half4(p.res_lo + m * p.ldr + n);
-      v[0] += (float)r[0]; v[1] += (float)r[1]; v[2] += (float)r[2]; v[3] += (float)r[3];
-    }
-    if (p.flags & SKG_EPI_RELU) {
-      v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-    }
-    if (p.flags & SKG_EPI_OUT_F32) {
-      *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(p.C) + m * p.ldc + n) = v;
-    } else {
-      half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-      st_half4(reinterpret_cast<half_t*>(p.C) + m * p.ldc + n, o);
-      if (p.c_lo) {      // accuracy mode: pair output, lo = fp16(v - hi)
-        half4_t l = {(half_t)(v[0] - (float)o[0]), (half_t)(v[1] - (float)o[1]), (half_t)(v[2] - (float)o[2]), (half_t)(v[3] - (float)o[3])};
-        st_half4(p.c_lo + m * p.ldc + n, l);
-      }
-    }
+    splitk_epilogue(p, v, m, n);
   }
 }
 
@@ -1004,6 +1099,9 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   const size_t out_bytes = (size_t)p.M * ((p.flags & SKG_EPI_GEGLU) ? p.N / 2 : p.N) * ((p.flags & SKG_EPI_OUT_F32) ? 4 : 2);
   static const bool tap_major = getenv("SKG_TAP_MAJOR") != nullptr;        // A/B switch for the K order (tools/gemm_bench.py)
   if (MODE != MODE_DIRECT && !tap_major) p.flags |= 0x1000u;
+#ifdef SKG_LAB
+  if (MODE != MODE_DIRECT && getenv("SKG_GLUE_PROBE")) p.flags |= 0x2000u;      // cost probe, wrong results (see the K loop)
+#endif
   static const char* smb = getenv("SKG_STREAM_MB");          // tuning only
   if (out_bytes >= (smb ? (size_t)atoi(smb) << 20 : STREAM_OUT_BYTES)) p.flags |= 0x800u;
   const int tiles_n = skg_cdiv(p.N, BN);
@@ -1029,11 +1127,26 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
       const double c = gn * a_mb + (G / gn) * w_mb;
       if (c < 0.9 * cost) { cost = c; best = gn; }
     }
+    static const char* force_gn = getenv("SKG_XGRID_GN");      // tuning (tools/gemm_fetch.sh): force the column blocks of the XCD arrangement
+    if (force_gn) {
+      const int gn = atoi(force_gn);
+      best = (gn >= 1 && gn <= G && G % gn == 0 && tiles_n % gn == 0 && tiles_m % (G / gn) == 0) ? gn : 1;
+    }
     if (!off && best > 1) p.flags |= ((unsigned)best << 20) | ((unsigned)(G == 8 ? 0 : G) << 24);
   }
   if (splits > 1) {
     const int per = skg_cdiv(KT, splits);
     const int ns = skg_cdiv(KT, per);            // every split non-empty
+#ifdef SKG_LAB
+    if constexpr (BM == 128) {
+      const bool self = getenv("SKG_SPLITK_SELF") != nullptr;      // (read per launch) the withdrawn self-finishing form instead of the reduce launch
+      if (p.ws_cnt && self && (size_t)ntiles * 4 <= SKG_WS_TICKET_BYTES && p.N % 4 == 0) {
+        hipLaunchKernelGGL((gemm2_splitk_kernel<BM, BN, WGM, WGN, MODE>), dim3(ntiles * ns), dim3(NTHR), 0, st, p, tiles_n, ntiles * ns,
+                           (unsigned)a, (unsigned)b, (unsigned)s, per, p.ws);
+        return;
+      }
+    }
+#endif
     hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles * ns, NTHR)), dim3(NTHR),
                        0, st, p, tiles_n, ntiles * ns, (unsigned)a, (unsigned)b, (unsigned)s, per, p.ws);
     size_t blocks = ((size_t)p.M * (p.N / 4) + 255) / 256;

@@ -34,12 +34,16 @@ struct GemmParams {
   // split-K workspace of the launch stream (host side: filled by the entry points from the per-stream registry of
   // skg_set_workspace; the kernels get the slab pointer as an argument)
   float* ws; size_t ws_bytes;
+  // tile tickets of the self-finishing split-K launch (gemm2_splitk_kernel): SKG_WS_TICKET_BYTES at the end of the registered
+  // workspace, zeroed at registration and left zero by every launch (nullptr: the launch is followed by splitk_reduce_kernel)
+  unsigned* ws_cnt;
 };
 constexpr unsigned SKG_FLAG_GN_STATS = 0x8000u;      // internal: set by the launcher when the chosen kernel fuses them
 
 // v2 (gemm2.hip): returns true and launches if the shape is eligible, false otherwise (nothing launched).
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st);
 // column width of the tile v2 would use for an M x N output, or 0 if v2 does not take this shape
+constexpr size_t SKG_WS_TICKET_BYTES = 16 << 10;      // 4096 tiles (a split-K launch has at most 256)
 int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode, size_t ws_bytes);
 // lab build only (tools/lab/gemmws.hip): weight-stationary streaming kernel for N = K = 320 plain GEMMs with M >= 32768
 bool skg_gemmws_eligible(const GemmParams& p, int mode);
