@@ -203,6 +203,8 @@ class LaunchTimer:
                 name = f"attn_fwd_short_kernel<{ATTN_SHORT_NAMES[dh]}>"      # the 77 text tokens: the LDS-resident kernel
             else:
                 name = f"attn_fwd_kernel<{ATTN_NAMES.get(dh, '?')}, false, {14 if dh == 64 else 0}, {vrow}>"
+                if dh == 40 and -(-Nq // 192) * heads * batch >= 1024 and not os.environ.get("SKG_ATTN_VAR"):
+                    name = f"attn_fwd_kernel<2, 3, 3, false, 14, {vrow}>"      # three query tiles per wave (attention.hip attn_fwd_launch_qt)
             self.rec.append((name, fl, e0, e1, nbytes, f"attn B{batch} H{heads} Nq{Nq} Nkv{Nkv} d{dh}"))
             return out
 
