@@ -271,6 +271,15 @@ int skg_ff_block_f16_hilo(const void* X, const void* X_lo, int ldx, void* Y, voi
 int skg_xattn_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int HW, int C, int heads, int Nkv,
                         const void* gamma, const void* beta, float eps, const void* Wpack, const void* KVpack,
                         const void* bias_out, float scale, void* stream);
+/* The stashing launch of a guided evaluation (as skg_ff_block_f16_keep): rows >= keep_from - a multiple of HW, i.e. whole images:
+ * the cond half - ALSO store what the backward of the four replaced launches reads: stats fp32 [M - keep_from][2] = norm2's
+ * (mean, rstd) per row, Q / O fp16 [M - keep_from][ldk] = the attn2.to_q output and the attention output (head h in columns
+ * 40 h .. 40 h + 39), lse fp32 [(M - keep_from) / HW][heads][HW] in skg_attn_fwd's convention.  Feeds skg_attn_bwd_delta /
+ * skg_attn_bwd_dq / skg_layernorm_bwd unchanged. */
+int skg_xattn_block_f16_keep(const void* X, int ldx, void* Y, int ldy, int M, int HW, int C, int heads, int Nkv,
+                             const void* gamma, const void* beta, float eps, const void* Wpack, const void* KVpack,
+                             const void* bias_out, float scale, float* stats, void* Q, void* O, int ldk, float* lse,
+                             int keep_from, void* stream);
 /* Accuracy mode: the same launch on a PAIR input X + X_lo (pitch ldx) with a PAIR output Y + Y_lo (pitch ldy). */
 int skg_xattn_block_f16_hilo(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int M, int HW, int C,
                              int heads, int Nkv, const void* gamma, const void* beta, float eps, const void* Wpack,

@@ -51,6 +51,7 @@ SIGNATURES = {
     "skg_ff_block_f16_keep": ("i", "pipiiiippfpppppiip"),
     "skg_xattn_block_f16": ("i", "pipiiiiiippfpppfp"),
     "skg_xattn_block_f16_hilo": ("i", "ppippiiiiiippfpppfp"),
+    "skg_xattn_block_f16_keep": ("i", "pipiiiiiippfpppfpppipip"),
     "skg_gemm_variant": ("i", "iiiii"),
     "skg_set_workspace": ("i", "pzp"),
     "skg_conv3x3_f16": ("i", "pippiiiiiiippifup"),

@@ -36,6 +36,9 @@ struct XAParams {
   int heads, nkv;
   float sc;                // dh^-0.5 * log2(e)
   unsigned wbytes, kvbytes;
+  // stashing launch (skg_xattn_block_f16_keep): rows >= keep_from (whole images) also store what the backward of the four
+  // replaced launches reads - norm2's (mean, rstd), the to_q output, the attention output and the log-sum-exp, indexed from keep_from
+  float* kstats; half_t* kq; half_t* ko; int ldk; float* klse; int keep_from;
 };
 
 constexpr float XA_NEG = -30000.f;
@@ -68,7 +71,7 @@ __device__ __forceinline__ float4_t mfma32_fresh(half8_t a, half8_t b, float4_t 
 
 // HILO (accuracy mode, skg_xattn_block_f16_hilo): LayerNorm reads hi + lo, the residual sum is formed in fp32 on the pair and stored
 // as hi = fp16(v), lo = fp16(v - hi); everything between is the same kernel
-template <bool HILO>
+template <bool HILO, bool KEEP = false>
 __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
   constexpr int KS = 10, C = 320, NU = 20, PIECE = 512;
   constexpr int WQ = 0, NWQ = 30;                        // pieces
@@ -173,6 +176,12 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     s2 += __shfl_xor(s2, 16, 64);
     s2 += __shfl_xor(s2, 32, 64);
     const float rstd = rsqrtf(s2 * (1.f / C) + p.eps);
+    if constexpr (KEEP) {
+      if (m0 >= p.keep_from && g == 0 && mrow < p.M) {
+        p.kstats[(size_t)(mrow - p.keep_from) * 2] = mean;
+        p.kstats[(size_t)(mrow - p.keep_from) * 2 + 1] = rstd;
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const half8_t gv = ld_half8(p.gamma + 32 * ks + 8 * g), bv = ld_half8(p.beta + 32 * ks + 8 * g);
@@ -220,6 +229,14 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     for (int i = 0; i < 8; ++i) qb32[i] = (half_t)((float)(half_t)q[i >> 2][i & 3] * p.sc);
 #pragma unroll
     for (int i = 0; i < 4; ++i) qb16[i] = (half_t)((float)(half_t)q[2][i] * p.sc);
+    if constexpr (KEEP) {      // the to_q output of head h, fp16 as the replaced GEMM stores it: d = 16 t + 4 g + r of row l16
+      if (m0 >= p.keep_from && mrow < p.M) {
+        half_t* qr = p.kq + (size_t)(mrow - p.keep_from) * p.ldk + h * 40 + 4 * g;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (t < 2 || g < 2) st_half4(qr + 16 * t, half4_t{(half_t)q[t][0], (half_t)q[t][1], (half_t)q[t][2], (half_t)q[t][3]});
+      }
+    }
     const half_t* st = smem + STG + (h & 1) * NST * PIECE;
     // ---- S^T = K_h . Q^T: 5 key tiles
     float4_t s[5];
@@ -281,6 +298,18 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     for (int i = 0; i < 8; ++i) ob32[i] = (half_t)(o[i >> 2][i & 3] * inv);
 #pragma unroll
     for (int i = 0; i < 4; ++i) ob16[i] = (half_t)(o[2][i] * inv);
+    if constexpr (KEEP) {      // the attention output (normalised, fp16) and lse = ln sum_k exp(scale q.k) of (row, head)
+      if (m0 >= p.keep_from && mrow < p.M) {
+        half_t* orow = p.ko + (size_t)(mrow - p.keep_from) * p.ldk + h * 40 + 4 * g;
+        st_half4(orow, half4_t{ob32[0], ob32[1], ob32[2], ob32[3]});
+        st_half4(orow + 16, half4_t{ob32[4], ob32[5], ob32[6], ob32[7]});
+        if (g < 2) st_half4(orow + 32, half4_t{ob16[0], ob16[1], ob16[2], ob16[3]});
+        if (g == 0) {
+          const int mk = mrow - p.keep_from, bk = mk / p.HW;
+          p.klse[((size_t)bk * p.heads + h) * p.HW + (mk - bk * p.HW)] = (log2f(li) + mx) * 0.6931471805599453f;
+        }
+      }
+    }
     // ---- Y^T += Wo[:, head h] . O^T
 #pragma unroll
     for (int u = 0; u < NU; ++u) y[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + WOOFF + u * PIECE + lane * 8), ob32, y[u], 0, 0, 0);
@@ -349,8 +378,11 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
 
 static int xattn_block_impl(const void* X, const void* Xl, int ldx, void* Y, void* Yl, int ldy, int M, int HW, int C, int heads,
                             int Nkv, const void* gamma, const void* beta, float eps, const void* Wpack, const void* KVpack,
-                            const void* bias_out, float scale, void* stream) {
+                            const void* bias_out, float scale, void* stream, float* kstats = nullptr, void* kq = nullptr,
+                            void* ko = nullptr, int ldk = 0, float* klse = nullptr, int keep_from = 0) {
   SKG_REQUIRE(X && Y && gamma && beta && Wpack && KVpack && bias_out && M > 0 && (Xl != nullptr) == (Yl != nullptr));
+  SKG_REQUIRE(!kq || (kstats && ko && klse && !Xl && ldk % 4 == 0 && ldk >= C && keep_from >= 0 && keep_from < M && HW > 0 &&
+                      keep_from % HW == 0 && skg_aligned(kq, 8) && skg_aligned(ko, 8)));
   SKG_REQUIRE(C == 320 && heads == 8 && Nkv > 0 && Nkv <= 80 && HW > 0 && HW % 128 == 0 && M % HW == 0);
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(Xl, 16) && skg_aligned(Yl, 16) && skg_aligned(gamma, 16) &&
@@ -364,7 +396,9 @@ static int xattn_block_impl(const void* X, const void* Xl, int ldx, void* Y, voi
   p.sc = scale * 1.4426950408889634f;
   p.wbytes = (unsigned)heads * 60u * 1024u;
   p.kvbytes = (unsigned)(M / HW) * (unsigned)heads * 16u * 1024u;
-  if (Xl) hipLaunchKernelGGL(xattn_block_kernel<true>, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+  p.kstats = kstats; p.kq = (half_t*)kq; p.ko = (half_t*)ko; p.ldk = ldk; p.klse = klse; p.keep_from = keep_from;
+  if (kq) hipLaunchKernelGGL((xattn_block_kernel<false, true>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+  else if (Xl) hipLaunchKernelGGL(xattn_block_kernel<true>, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(xattn_block_kernel<false>, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
   SKG_CHECK_LAUNCH("skg_xattn_block_f16");
   return SKG_OK;
@@ -382,4 +416,17 @@ extern "C" int skg_xattn_block_f16_hilo(const void* X, const void* X_lo, int ldx
                                         const void* KVpack, const void* bias_out, float scale, void* stream) {
   SKG_REQUIRE(X_lo && Y_lo);
   return xattn_block_impl(X, X_lo, ldx, Y, Y_lo, ldy, M, HW, C, heads, Nkv, gamma, beta, eps, Wpack, KVpack, bias_out, scale, stream);
+}
+
+// the stashing launch of a guided step: rows >= keep_from (a multiple of HW: whole images, the cond half) also store norm2's
+// statistics [M - keep_from][2], the to_q output Q and the attention output O ([M - keep_from][ldk], head h in columns
+// 40 h .. 40 h + 39) and lse [(M - keep_from) / HW][heads][HW] (natural log, skg_attn_fwd's convention) - what
+// skg_attn_bwd_dq / skg_layernorm_bwd of the four replaced launches read
+extern "C" int skg_xattn_block_f16_keep(const void* X, int ldx, void* Y, int ldy, int M, int HW, int C, int heads, int Nkv,
+                                        const void* gamma, const void* beta, float eps, const void* Wpack, const void* KVpack,
+                                        const void* bias_out, float scale, float* stats, void* Q, void* O, int ldk, float* lse,
+                                        int keep_from, void* stream) {
+  SKG_REQUIRE(stats && Q && O && lse);
+  return xattn_block_impl(X, nullptr, ldx, Y, nullptr, ldy, M, HW, C, heads, Nkv, gamma, beta, eps, Wpack, KVpack, bias_out, scale, stream,
+                          stats, Q, O, ldk, lse, keep_from);
 }

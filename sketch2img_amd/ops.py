@@ -245,7 +245,7 @@ def ff_block(X, gamma, beta, eps: float, pack: torch.Tensor, bias1_pack: torch.T
 
 
 def xattn_block(X, HW: int, heads: int, Nkv: int, gamma, beta, eps: float, wpack: torch.Tensor, kvpack: torch.Tensor,
-                bias_out: torch.Tensor, scale: float, out=None):
+                bias_out: torch.Tensor, scale: float, out=None, keep_from: Optional[int] = None):
     """Fused cross-attention sub-block at C = 320, 8 heads: out = X + bo + Wo . Attention(Wq . LayerNorm(X), K, V) over the text
     keys of each row's image, in one launch (skg_xattn_block_f16; packs from unet.pack_xattn_weights / pack_xattn_kv).
     X (and out) may be ops.Pair objects (accuracy mode: skg_xattn_block_f16_hilo)."""
@@ -262,6 +262,16 @@ def xattn_block(X, HW: int, heads: int, Nkv: int, gamma, beta, eps: float, wpack
                                            _p(gamma), _p(beta), eps, _p(wpack), _p(kvpack), _p(bias_out), scale, _stream()),
               "skg_xattn_block_f16_hilo")
         return out
+    if keep_from is not None:      # stashing launch: -> (out, stats, q, o, lse) of the rows >= keep_from (skg_xattn_block_f16_keep)
+        Mk = M - keep_from
+        st = torch.empty(Mk, 2, device=X.device, dtype=torch.float32)
+        q = torch.empty(Mk, C, device=X.device, dtype=torch.float16)
+        o = torch.empty(Mk, C, device=X.device, dtype=torch.float16)
+        lse = torch.empty(Mk // HW, heads, HW, device=X.device, dtype=torch.float32)
+        check(lib.skg_xattn_block_f16_keep(_p(X), _ld(X), _p(out), _ld(out), M, HW, C, heads, Nkv, _p(gamma), _p(beta), eps, _p(wpack),
+                                           _p(kvpack), _p(bias_out), scale, _p(st), _p(q), _p(o), C, _p(lse), keep_from, _stream()),
+              "skg_xattn_block_f16_keep")
+        return out, st, q, o, lse
     check(lib.skg_xattn_block_f16(_p(X), _ld(X), _p(out), _ld(out), M, HW, C, heads, Nkv, _p(gamma), _p(beta), eps, _p(wpack),
                                   _p(kvpack), _p(bias_out), scale, _stream()), "skg_xattn_block_f16")
     return out

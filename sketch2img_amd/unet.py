@@ -35,6 +35,7 @@ _GN_CONCAT = os.environ.get("SKG_GN_CONCAT", "1") != "0"
 _FF_BLOCK = os.environ.get("SKG_FF_BLOCK", "1") != "0"              # fused feed-forward sub-block at C = 320 (csrc/ffblock.hip)
 _XATTN_BLOCK = os.environ.get("SKG_XATTN_BLOCK", "1") != "0"        # fused cross-attention sub-block at C = 320, 8 heads (csrc/xattn.hip)
 _FF_KEEP = os.environ.get("SKG_FF_KEEP", "1") != "0"                # ... also for the cond rows of a guided step (stashing launch)
+_XATTN_KEEP = os.environ.get("SKG_XATTN_KEEP", "1") != "0"          # the fused cross-attention launch also in guided steps (stashing launch)
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -451,16 +452,25 @@ class HipUNet:
                 p1 = self.inject(t, p1, rows, HW, heads)
             p1_c = p1
         cb = self.ctx["blocks"][t + ".attn2"]
-        xab = _XATTN_BLOCK and not keep and "kvpack" in cb and heads == 8 and HW % 128 == 0
+        xab = (_XATTN_BLOCK and (not keep or (_XATTN_KEEP and rows % 2 == 0)) and "kvpack" in cb and heads == 8 and HW % 128 == 0)
+        xk_half = ()
         if xab:
-            # no backward will follow: norm2 -> to_q -> attention over the text keys -> to_out + residual in ONE row-local launch
-            # (skg_xattn_block_f16); the text-dependent part needs both halves, so a shared front ends here
+            # norm2 -> to_q -> attention over the text keys -> to_out + residual in ONE row-local launch (skg_xattn_block_f16); the
+            # text-dependent part needs both halves, so a shared front ends here
             if shared:
                 ops.batch_copy(p1, M1, p1_full, M1, 1, M1)
                 x, p1, shared = x_full, p1_full, False
-            p2 = ops.xattn_block(p1, HW, heads, self.ctx["L"], W[t + ".norm2.weight"], W[t + ".norm2.bias"], 1e-5,
-                                 W[t + ".attn2.xpack"], cb["kvpack"], W[t + ".attn2.to_out.0.bias"], scale)
-            st2 = q2 = q2_c = o2 = lse2 = None                # (only a stash would read them, and there is none)
+            xargs = (HW, heads, self.ctx["L"], W[t + ".norm2.weight"], W[t + ".norm2.bias"], 1e-5, W[t + ".attn2.xpack"], cb["kvpack"],
+                     W[t + ".attn2.to_out.0.bias"], scale)
+            if keep:
+                # guided step: the same launch also stores what the backward of the cond rows (second half) reads - norm2's
+                # statistics, q, the attention output and its lse (skg_xattn_block_f16_keep), for those rows only
+                p2, st2, q2_c, o2, lse2 = ops.xattn_block(p1, *xargs, keep_from=(rows // 2) * HW)
+                q2 = q2_c
+                xk_half = ("st2", "q2", "o2", "lse2")
+            else:
+                p2 = ops.xattn_block(p1, *xargs)
+                st2 = q2 = q2_c = o2 = lse2 = None            # (only a stash would read them, and there is none)
         else:
             a2, st2 = ops.layernorm(p1, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
             q2_full = torch.empty(rows * HW, C, device=x.device, dtype=torch.float16) if shared else None
@@ -540,6 +550,7 @@ class HipUNet:
                 half = tuple(k for k, v in ent.items() if v is not None and v.shape[0] == (r1 if k in ("gst", "lse1") else M1_))
                 if "x" not in half:      # the front diverged before p1 (an injector with differing halves): x is full size
                     ent["x"] = x
+            half = tuple(k for k in half if k not in xk_half) + xk_half      # (the stashing cross-attention launch: cond rows only)
             stash.tr[p] = dict(ent, o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=half + st3h)
         return out, opart
 
@@ -1088,8 +1099,8 @@ class HipUNet:
         do2 = ops.gemm(dp2, W[t + ".attn2.to_out.0.weight:T"])
         cb = self.ctx["blocks"][t + ".attn2"]
         L, Lp = self.ctx["L"], self.ctx["Lp"]
-        delta2 = ops.attn_bwd_delta(c(st["o2"]), do2, S, heads, HW, dh)
-        dq2 = ops.attn_bwd_dq(cc("q2"), cb["K"][S * Lp:], cb["V"][S * Lp:], do2, st["lse2"][S:],
+        delta2 = ops.attn_bwd_delta(cc("o2"), do2, S, heads, HW, dh)
+        dq2 = ops.attn_bwd_dq(cc("q2"), cb["K"][S * Lp:], cb["V"][S * Lp:], do2, cs("lse2"),
                               delta2, S, heads, HW, L, Lp, dh, scale)
         da2 = ops.gemm(dq2, W[t + ".attn2.to_q.weight:T"])
         dp1 = ops.layernorm_bwd(cc("p1"), da2, W[t + ".norm2.weight"], cc("st2"), residual=dp2)
