@@ -106,6 +106,7 @@ class LaunchTimer:
         self.ops, self.rec = ops, []
         self._gemm, self._conv, self._attn, self._keep = ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep
         self._up2, self._c4, self._ffb, self._xab = ops.conv_up2, ops.conv4x4s2, ops.ff_block, ops.xattn_block
+        self._ffp = ops.ff_block_proj
 
     def __enter__(self):
         from sketch2img_amd._lib import lib
@@ -230,6 +231,17 @@ class LaunchTimer:
                              f"ff_block M{M} C{C} F{Fh} (LN + FF1 + gate + FF2 + res)" + "+keep" * (k.get("keep_from") is not None)))
             return out
 
+        def ff_block_proj(X, gamma, beta, eps, pack, *a, **k):  # ... + proj_out + outer residual (five chunks more in the pack)
+            M, C = X.shape
+            Fh = (pack.shape[0] - 5) * 32
+            e0, e1 = ev()
+            e0.record()
+            out = self._ffp(X, gamma, beta, eps, pack, *a, **k)
+            e1.record()
+            self.rec.append(("ff_block_kernel<10, proj>", 2.0 * M * C * (3 * Fh + C), e0, e1, 2.0 * (3 * M * C + 3 * C * Fh + C * C),
+                             f"ff_block M{M} C{C} F{Fh} (LN + FF1 + gate + FF2 + res + proj_out + res)" + "+keep" * (k.get("keep_from") is not None)))
+            return out
+
         def xattn_block(X, HW, heads, Nkv, *a, **k):            # norm2 + to_q + text attention + to_out + residual in one launch
             M, C = X.shape
             e0, e1 = ev()
@@ -244,11 +256,13 @@ class LaunchTimer:
 
         ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep = gemm, conv, attn, gemm_keep
         ops.conv_up2, ops.conv4x4s2, ops.ff_block, ops.xattn_block = conv_up2, conv4x4s2, ff_block, xattn_block
+        ops.ff_block_proj = ff_block_proj
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm, self.ops.conv3x3, self.ops.attn_fwd, self.ops.gemm_geglu_keep = self._gemm, self._conv, self._attn, self._keep
         self.ops.conv_up2, self.ops.conv4x4s2, self.ops.ff_block, self.ops.xattn_block = self._up2, self._c4, self._ffb, self._xab
+        self.ops.ff_block_proj = self._ffp
 
     def summary(self):
         """per kernel: [launches, flops, seconds, algorithmic bytes, roofline seconds, seconds of HBM-bound launches];

@@ -249,6 +249,17 @@ int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, int
 int skg_ff_block_f16_keep(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma,
                           const void* beta, float eps, const void* Wpack, const float* bias1_pack,
                           const void* bias2, float* stats, void* H, int ldh, int keep_from, void* stream);
+/* ... followed by Transformer2DModel.proj_out + the transformer's outer residual in the same launch ([diffusers] attention.py
+ * Transformer2DModel.forward: `hidden_states = self.proj_out(hidden_states); output = hidden_states + residual`):
+ *   Y = R + bias_proj + W_proj . fp16(X + FF(LayerNorm(X)))
+ * Wpack holds five more chunks behind the F / 32 feed-forward ones (sketch2img_amd.unet.pack_ff_block(..., w_proj)); the block
+ * output never reaches memory (its backward does not read it).  stats / H / ldh / keep_from as skg_ff_block_f16_keep (H == NULL:
+ * no stash); gn_partial != NULL: also the GroupNorm partial sums of Y, fp32 [M / HW][HW / 128][groups][2], the layout of
+ * skg_gemm_f16_gn (HW % 128 == 0, groups <= 32).  Y must not alias X; it may alias R. */
+int skg_ff_block_proj_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma, const void* beta,
+                          float eps, const void* Wpack, const float* bias1_pack, const void* bias2, const void* bias_proj,
+                          const void* R, int ldr, float* stats, void* H, int ldh, int keep_from, float* gn_partial, int HW,
+                          int groups, void* stream);
 /* Accuracy mode: the same launch on a PAIR input X + X_lo (pitch ldx) with a PAIR output Y + Y_lo (pitch ldy): LayerNorm reads
  * the sum, the residual sum is formed in fp32 and stored as hi = fp16(v), lo = fp16(v - hi).  H / keep_from as _keep (or NULL). */
 int skg_ff_block_f16_hilo(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int M, int C, int F,

@@ -43,6 +43,12 @@ struct FFParams {
   float* stats;            // optional [M][2]: LayerNorm mean / rstd (what the backward of the norm reads)
   half_t* keep; int ldkeep; int keep_from;     // optional: rows >= keep_from also store the FF1 output fp16(W1 a + b1), interleaved pack
   int nt_out;              // store Y non-temporally (the output stream then does not evict the weight chunks from L2)
+  // PROJ (skg_ff_block_proj_f16): Transformer2DModel.proj_out + the outer residual in the same launch - five more weight chunks
+  // behind the nch feed-forward ones (their 40 W1-slot pieces = 4 output tiles x 10 k-steps of W_proj, k order permuted to the
+  // accumulator layout), Y = R + bp + W_proj . fp16(X + FF(X)); optionally the GroupNorm partial sums of Y
+  const half_t* bp; const half_t* R; int ldr;
+  float* gn_partial; int gn_hw, gn_groups;
+  int nch_w1;              // W1-slot chunks the weight pack holds: nch, or nch + 5 with PROJ
 };
 
 constexpr int MAXCH = 40;
@@ -53,8 +59,9 @@ constexpr int MAXCH = 40;
 // two waves of a SIMD in alternate k-steps, 2 = the pair's arithmetic in four stages spread over the MFMAs of two k-steps
 // HILO (accuracy mode, skg_ff_block_f16_hilo): LayerNorm reads hi + lo, the residual sum is formed in fp32 on the pair and
 // stored as hi = fp16(v), lo = fp16(v - hi); everything between is the same kernel
-template <int KS, int PROBE = 0, int SCHED = 0, bool HILO = false>
+template <int KS, int PROBE = 0, int SCHED = 0, bool HILO = false, bool PROJ = false>
 __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
+  static_assert(!PROJ || (!HILO && PROBE == 0 && KS == 10), "the proj_out phase exists for the plain C = 320 kernel");
   constexpr int C = 32 * KS, NU = C / 16, N1 = 4 * KS, NP = N1 + NU, PIECE = 512;
   constexpr int W1ST = N1 * PIECE, W2ST = NU * PIECE;      // halves per ring stage
   constexpr int W2OFF = 2 * W1ST, DUMP = W2OFF + 2 * W2ST, RING = DUMP + (64 - NP) * PIECE;
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
     if constexpr (PROBE == 1 || PROBE == 4) return;
     const int q = wave + 8 * j;
     const int cs = q < N1 ? c + 2 : c + 1;                                   // source chunk
-    const bool live = q < NP && cs < p.nch;
+    const bool live = q < NP && cs < (PROJ && q < N1 ? p.nch_w1 : p.nch);      // (PROJ: W1(nch) is the first proj_out chunk)
     const int dst = q < N1 ? (c & 1) * W1ST + q * PIECE
                            : (q < NP ? W2OFF + ((c + 1) & 1) * W2ST + (q - N1) * PIECE : DUMP + (q - NP) * PIECE);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + dst), 16, live ? (unsigned)lane * 16u : 0x80000000u,
@@ -318,10 +325,20 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
     ff1(hout, c + 1, c, hin, gb, true);
     ff2(gb, c);
   };
+  // PROJ: W1-slot piece q = wave + 8 s (five per wave) of proj chunk j -> ring region `dst` (halves)
+  auto dma_proj = [&](int j, int dst, int s5) {
+    const int q = wave + 8 * s5;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + dst + q * PIECE), 16, (unsigned)lane * 16u,
+                                             (unsigned)((p.nch + j) * NP + q) * 1024u, 0, 0);
+  };
   auto last = [&](const float4_t (&hin)[4], int c) {
     if (keepw) store_f(hin, c);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
+    if constexpr (PROJ) {      // proj chunk 1 -> the W1 stage whose last reader was H(nch - 1), one iteration ago
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5) dma_proj(1, ((p.nch + 1) & 1) * W1ST, s5);
+    }
     half8_t gb;
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) gate2(hin, pr, gb);
@@ -345,6 +362,51 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
     last(hn, c + 1);
   } else {
     last(hc, c);
+  }
+
+  if constexpr (PROJ) {
+    // ---- proj_out on the block's output without leaving the registers: p3 = fp16(X + FF) (the rounding of the unfused launch's
+    // store) becomes the B operand - accumulator tiles 2 ks, 2 ks + 1 are k-slots 8 g + i <-> channel 32 ks + 16 (i >> 2) + 4 g + (i & 3),
+    // the order the proj chunks of the pack are written in - and y restarts from the proj bias.  Chunk nch + j = output tiles
+    // 4 j .. 4 j + 3.
+    half8_t yb[KS];
+    {
+      const half_t* xr = p.X + (size_t)mload * p.ldx + 4 * g;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const half4_t r4 = ld_half4(xr + 16 * u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yb[u >> 1][4 * (u & 1) + r] = (half_t)(y[u][r] + (float)r4[r]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const half4_t b = ld_half4(p.bp + 16 * u + 4 * g);
+      y[u] = float4_t{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+    }
+    // three regions take the five chunks: A = W1 stage nch & 1 (chunk 0, fetched by iteration nch - 2; chunk 3), B = the other W1 stage
+    // (chunk 1, fetched inside last(); chunk 4), and the two idle W2 stages together (chunk 2) - chunk j + 2 is issued during step j,
+    // so a step waits for a chunk issued two steps earlier (counted vmcnt: every wave issues exactly five pieces per chunk)
+    const int regA = (p.nch & 1) * W1ST, regB = ((p.nch + 1) & 1) * W1ST;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      if (j == 0 || j == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // chunk j landed; chunk j + 1 (the five youngest) may still be in flight
+      lds_barrier();
+      const int reg = (j == 2) ? W2OFF : ((j == 0 || j == 3) ? regA : regB);
+      const int regn = (j == 0) ? W2OFF : ((j & 1) ? regA : regB);      // where chunk j + 2 goes: chunk 2 -> W2, 3 -> A, 4 -> B
+      const half_t* fr = smem + reg + lane * 8;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        half8_t wf[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wf[t] = ld_half8(fr + (t * KS + ks) * PIECE);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) y[4 * j + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], yb[ks], y[4 * j + t], 0, 0, 0);
+        if (ks < 5 && j < 3) dma_proj(j + 2, regn, ks);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
   }
 
   // ---- epilogue: the wave's Y^T tile through its own slice of the (now idle) ring, then whole-row 16-byte pieces:
@@ -384,7 +446,8 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
   } else {
   half_t* const stg = smem + wave * (16 * OP);
   {   // the residual is added in fp32 BEFORE staging (lane-local 8-byte reads of X, L2 hits): one fp16 rounding
-    const half_t* xr = p.X + (size_t)mload * p.ldx + 4 * g;
+    // (PROJ: the OUTER residual - the transformer's input - joins here; X + FF went into the proj_out operand above)
+    const half_t* xr = PROJ ? p.R + (size_t)mload * p.ldr + 4 * g : p.X + (size_t)mload * p.ldx + 4 * g;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const half4_t r4 = ld_half4(xr + 16 * u);
@@ -405,6 +468,33 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
       if (p.nt_out) __builtin_nontemporal_store(v, dst); else *dst = v;
     }
   }
+  if constexpr (PROJ) {
+    // GroupNorm partial sums of the 128 x 320 output tile (layout of gemm2.hip's epilogue: [sample][128-row chunk][group][2]): lane j < 32
+    // of every wave sums its group's 10 channels over the wave's 16 staged rows (fp16 values, fp32 sums), the eight waves' figures
+    // meet in the dead FF1-bias area and wave 0 adds them in wave order - fixed order, no atomics
+    if (p.gn_partial) {
+      const int cpg = C / p.gn_groups;
+      float s1 = 0.f, s2 = 0.f;
+      if (lane < p.gn_groups) {
+        for (int row = 0; row < 16; ++row) {
+          if (m0 + row >= p.M) break;
+          const half_t* q = stg + row * OP + lane * cpg;
+          for (int i = 0; i < cpg; ++i) { const float v = (float)q[i]; s1 += v; s2 += v * v; }
+        }
+        bs[(wave * 32 + lane) * 2] = s1;
+        bs[(wave * 32 + lane) * 2 + 1] = s2;
+      }
+      lds_barrier();
+      if (wave == 0 && lane < p.gn_groups) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { t1 += bs[(w * 32 + lane) * 2]; t2 += bs[(w * 32 + lane) * 2 + 1]; }
+        const int mb = blockIdx.x * 128, b = mb / p.gn_hw, chunk = (mb - b * p.gn_hw) >> 7, nchk = p.gn_hw >> 7;
+        float* dst = p.gn_partial + (((size_t)b * nchk + chunk) * p.gn_groups + lane) * 2;
+        dst[0] = t1; dst[1] = t2;
+      }
+    }
+  }
   }
 }
 
@@ -412,8 +502,11 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
 
 static int ff_block_impl(const void* X, const void* Xl, int ldx, void* Y, void* Yl, int ldy, int M, int C, int F, const void* gamma,
                          const void* beta, float eps, const void* Wpack, const float* bias1_pack, const void* bias2,
-                         float* stats, void* H, int ldh, int keep_from, void* stream) {
+                         float* stats, void* H, int ldh, int keep_from, void* stream, const void* bias_proj = nullptr,
+                         const void* R = nullptr, int ldr = 0, float* gn_partial = nullptr, int gn_hw = 0, int gn_groups = 0) {
   SKG_REQUIRE(X && Y && gamma && beta && Wpack && bias1_pack && bias2 && M > 0 && (Xl != nullptr) == (Yl != nullptr));
+  SKG_REQUIRE(!bias_proj || (!Xl && R && ldr % 4 == 0 && ldr >= C && skg_aligned(bias_proj, 8) && skg_aligned(R, 8) && X != Y));
+  SKG_REQUIRE(!gn_partial || (bias_proj && gn_groups > 0 && gn_groups <= 32 && C % gn_groups == 0 && gn_hw % 128 == 0 && M % gn_hw == 0));
   SKG_REQUIRE(!H || (ldh % 8 == 0 && ldh >= 2 * F && keep_from >= 0 && keep_from % 16 == 0 && keep_from < M && skg_aligned(H, 16)));
   SKG_REQUIRE(C == 320 && F % 32 == 0 && F / 32 <= MAXCH && F >= 64);
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
@@ -425,7 +518,10 @@ static int ff_block_impl(const void* X, const void* Xl, int ldx, void* Y, void* 
   p.gamma = (const half_t*)gamma; p.beta = (const half_t*)beta; p.eps = eps;
   p.Wp = (const half_t*)Wpack; p.b1p = bias1_pack; p.b2 = (const half_t*)bias2;
   p.nch = F / 32;
-  p.wbytes = (unsigned)p.nch * 60u * 1024u;
+  p.nch_w1 = p.nch + (bias_proj ? 5 : 0);
+  p.wbytes = (unsigned)p.nch_w1 * 60u * 1024u;
+  p.bp = (const half_t*)bias_proj; p.R = (const half_t*)R; p.ldr = ldr;
+  p.gn_partial = gn_partial; p.gn_hw = gn_hw; p.gn_groups = gn_groups;
   p.stats = stats;
   p.keep = (half_t*)H; p.ldkeep = ldh; p.keep_from = keep_from;
   // Y stored non-temporally: alone the kernel is 0.9 % slower (212.3 against 210.5 us), the batch 0.27 % faster (6.723 / 6.725
@@ -448,7 +544,8 @@ static int ff_block_impl(const void* X, const void* Xl, int ldx, void* Y, void* 
     return SKG_OK;
   }
 #endif
-  if (Xl) hipLaunchKernelGGL((ff_block_kernel<10, 0, 0, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  if (bias_proj) hipLaunchKernelGGL((ff_block_kernel<10, 0, 0, false, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else if (Xl) hipLaunchKernelGGL((ff_block_kernel<10, 0, 0, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((ff_block_kernel<10>), grid, dim3(512), 0, (hipStream_t)stream, p);
   SKG_CHECK_LAUNCH("skg_ff_block_f16");
   return SKG_OK;
@@ -464,6 +561,19 @@ extern "C" int skg_ff_block_f16(const void* X, int ldx, void* Y, int ldy, int M,
                                 const void* beta, float eps, const void* Wpack, const float* bias1_pack,
                                 const void* bias2, float* stats, void* stream) {
   return ff_block_impl(X, nullptr, ldx, Y, nullptr, ldy, M, C, F, gamma, beta, eps, Wpack, bias1_pack, bias2, stats, nullptr, 0, 0, stream);
+}
+
+// ... followed by Transformer2DModel.proj_out + the outer residual in the same launch:
+//   Y = R + bias_proj + W_proj . fp16(X + FF(LayerNorm(X)))        (Y must not alias X; it may alias R)
+// Wpack holds five more chunks behind the F / 32 feed-forward ones (unet.pack_ff_block(..., w_proj)); stats / H / keep_from as _keep
+// (H == NULL: no stash); gn_partial != NULL: also the GroupNorm partial sums of Y, [M / HW][HW / 128][groups][2] as skg_gemm_f16_gn
+extern "C" int skg_ff_block_proj_f16(const void* X, int ldx, void* Y, int ldy, int M, int C, int F, const void* gamma, const void* beta,
+                                     float eps, const void* Wpack, const float* bias1_pack, const void* bias2, const void* bias_proj,
+                                     const void* R, int ldr, float* stats, void* H, int ldh, int keep_from, float* gn_partial, int HW,
+                                     int groups, void* stream) {
+  SKG_REQUIRE(bias_proj && R);
+  return ff_block_impl(X, nullptr, ldx, Y, nullptr, ldy, M, C, F, gamma, beta, eps, Wpack, bias1_pack, bias2, stats, H, ldh, keep_from, stream,
+                       bias_proj, R, ldr, gn_partial, HW, groups);
 }
 
 // accuracy mode: the same launch on a pair input X + X_lo (pitch ldx) with a pair output Y + Y_lo (pitch ldy); H / keep_from as _keep

@@ -244,6 +244,29 @@ def ff_block(X, gamma, beta, eps: float, pack: torch.Tensor, bias1_pack: torch.T
     return (out, stats, pre) if want_stats else (out, pre)
 
 
+def ff_block_proj(X, gamma, beta, eps: float, pack: torch.Tensor, bias1_pack: torch.Tensor, bias2: torch.Tensor, bias_proj: torch.Tensor,
+                  R: torch.Tensor, out=None, want_stats: bool = False, keep_from: Optional[int] = None, gn: Optional[Tuple[int, int]] = None):
+    """ff_block followed by Transformer2DModel.proj_out and the outer residual in the same launch (skg_ff_block_proj_f16):
+    out = R + bias_proj + W_proj . fp16(X + FF(LayerNorm(X))); pack = unet.pack_ff_block(..., w_proj) (five chunks more).
+    gn = (HW, groups): also the GroupNorm partial sums of out.  Returns (out, stats | None, pre | None, GNPartial | None);
+    out must not be X (it may be R)."""
+    _f16(X, gamma, beta, pack, bias2, bias_proj, R)
+    M, C = X.shape
+    assert pack.is_contiguous() and pack.dim() == 3 and pack.shape[1:] == (60, 512) and bias1_pack.dtype == torch.float32
+    F = (pack.shape[0] - 5) * 32
+    assert bias1_pack.shape[0] * 32 == F
+    if out is None:
+        out = torch.empty(M, C, device=X.device, dtype=torch.float16)
+    stats = torch.empty(M, 2, device=X.device, dtype=torch.float32) if want_stats else None
+    pre = None if keep_from is None else torch.empty(M - keep_from, 2 * F, device=X.device, dtype=torch.float16)
+    part = GNPartial(M // gn[0], gn[0], gn[1], X.device) if gn is not None else None
+    check(lib.skg_ff_block_proj_f16(_p(X), _ld(X), _p(out), _ld(out), M, C, F, _p(gamma), _p(beta), eps, _p(pack), _p(bias1_pack), _p(bias2),
+                                    _p(bias_proj), _p(R), _ld(R), _p(stats), _p(pre), _ld(pre) if pre is not None else 0, keep_from or 0,
+                                    _p(part.buf) if part is not None else None, gn[0] if gn else 0, gn[1] if gn else 0, _stream()),
+          "skg_ff_block_proj_f16")
+    return out, stats, pre, part
+
+
 def xattn_block(X, HW: int, heads: int, Nkv: int, gamma, beta, eps: float, wpack: torch.Tensor, kvpack: torch.Tensor,
                 bias_out: torch.Tensor, scale: float, out=None, keep_from: Optional[int] = None):
     """Fused cross-attention sub-block at C = 320, 8 heads: out = X + bo + Wo . Attention(Wq . LayerNorm(X), K, V) over the text

@@ -36,6 +36,7 @@ _FF_BLOCK = os.environ.get("SKG_FF_BLOCK", "1") != "0"              # fused feed
 _XATTN_BLOCK = os.environ.get("SKG_XATTN_BLOCK", "1") != "0"        # fused cross-attention sub-block at C = 320, 8 heads (csrc/xattn.hip)
 _FF_KEEP = os.environ.get("SKG_FF_KEEP", "1") != "0"                # ... also for the cond rows of a guided step (stashing launch)
 _XATTN_KEEP = os.environ.get("SKG_XATTN_KEEP", "1") != "0"          # the fused cross-attention launch also in guided steps (stashing launch)
+_FF_PROJ = os.environ.get("SKG_FF_PROJ", "1") != "0"                # proj_out + outer residual inside the fused feed-forward launch
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -127,7 +128,7 @@ UP2_SMALL_MAPS = os.environ.get("SKG_UP2_SMALL", "1") != "0"    # A/B: polyphase
 UP2_DGRAD = os.environ.get("SKG_UP2_DGRAD", "1") != "0"         # A/B: the upsampler's backward as one 4 x 4 stride-2 convolution
 
 
-def pack_ff_block(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, dev):
+def pack_ff_block(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, dev, w_proj: Optional[torch.Tensor] = None):
     """Fragment-major pack of a GEGLU feed-forward (diffusers FeedForward: net.0.proj [2F, C] = value rows then gate rows,
     net.2 [C, F]) for skg_ff_block_f16 (csrc/ffblock.hip): every 512-half piece is one MFMA A operand in lane order, so
     the kernel fetches it with one LDS-DMA instruction and reads it with one conflict-free ds_read_b128.
@@ -135,7 +136,10 @@ def pack_ff_block(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, dev):
       40 W1 pieces (t, ks): t = value 0-15, value 16-31, gate 0-15, gate 16-31; [lane = 16 g + l][i] = W1[row(t, l)][32 ks + 8 g + i]
       20 W2 pieces u:       [lane = 16 g + l][i] = W2[16 u + l][32 c + 16 (i >> 2) + 4 g + (i & 3)]
     (the hidden-unit order of the second product is the accumulator layout of the first).
-    Returns (pack fp16 [F/32, 60, 512], bias1 fp32 [F/32, 4, 16])."""
+    w_proj [C, C] (Transformer2DModel.proj_out, skg_ff_block_proj_f16): five more chunks j behind them whose first 40 pieces are
+      (t, ks): [lane = 16 g + l][i] = Wp[16 (4 j + t) + l][32 ks + 16 (i >> 2) + 4 g + (i & 3)]   (the block output's accumulator order)
+    and whose last 20 pieces are zeros.
+    Returns (pack fp16 [F/32 (+ 5), 60, 512], bias1 fp32 [F/32, 4, 16])."""
     F2, C = w1.shape
     F = F2 // 2
     assert w2.shape == (C, F) and C % 32 == 0 and F % 32 == 0
@@ -147,7 +151,13 @@ def pack_ff_block(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, dev):
     p1 = rows.permute(0, 1, 3, 4, 2, 5).reshape(nch, 4 * KS, 512)                                 # [c, (t, ks), (g, l, i)]
     w2r = w2h.reshape(NU, 16, nch, 2, 4, 4)                                                       # [u, l, c, i_hi, g, i_lo]
     p2 = w2r.permute(2, 0, 4, 1, 3, 5).reshape(nch, NU, 512)                                      # [c, u, (g, l, i_hi, i_lo)]
-    pack = torch.cat([p1, p2], 1).contiguous().to(dev)
+    pack = torch.cat([p1, p2], 1)
+    if w_proj is not None:
+        assert w_proj.shape == (C, C) and NU % 4 == 0
+        wp = w_proj.detach().to("cpu", torch.float16).reshape(NU, 16, KS, 2, 4, 4)             # [u, l, ks, i_hi, g, i_lo]
+        pp = wp.permute(0, 2, 4, 1, 3, 5).reshape(NU // 4, 4 * KS, 512)                        # [j, (t, ks), (g, l, i_hi, i_lo)]
+        pack = torch.cat([pack, torch.cat([pp, torch.zeros(NU // 4, NU, 512, dtype=torch.float16)], 1)], 0)
+    pack = pack.contiguous().to(dev)
     b1h = b1.to(torch.float16).float()
     bias1 = torch.stack([b1h[:F].reshape(nch, 2, 16), b1h[F:].reshape(nch, 2, 16)], 1).reshape(nch, 4, 16).contiguous().to(dev)
     return pack, bias1
@@ -296,8 +306,16 @@ class HipUNet:
         for k in list(sd.keys()):
             if k.endswith(".ff.net.0.proj.weight") and sd[k].shape[1] == 320 and sd[k].shape[0] // 2 <= 1280:
                 t = k[: -len(".ff.net.0.proj.weight")]
-                W[t + ".ff.pack"], W[t + ".ff.bias1"] = pack_ff_block(sd[k], sd[t + ".ff.net.0.proj.bias"],
-                                                                      sd[t + ".ff.net.2.weight"], dev)
+                # (with Transformer2DModel.proj_out behind it when the block has one of the same width: skg_ff_block_proj_f16;
+                # the plain launch reads the leading chunks of the same tensor)
+                tp = t[: -len(".transformer_blocks.0")] if t.endswith(".transformer_blocks.0") else None
+                wpj = sd.get(tp + ".proj_out.weight") if tp else None
+                wpj = wpj.reshape(wpj.shape[0], -1) if wpj is not None and wpj.numel() == 320 * 320 else None
+                packp, W[t + ".ff.bias1"] = pack_ff_block(sd[k], sd[t + ".ff.net.0.proj.bias"], sd[t + ".ff.net.2.weight"], dev, w_proj=wpj)
+                nchf = sd[k].shape[0] // 64
+                W[t + ".ff.pack"] = packp[:nchf]
+                if wpj is not None:
+                    W[t + ".ff.packp"] = packp
         for k in list(sd.keys()):
             if k.endswith(".attn1.to_q.weight"):
                 p = k[: -len(".to_q.weight")]
@@ -485,7 +503,18 @@ class HipUNet:
             p2 = ops.gemm(o2, W[t + ".attn2.to_out.0.weight"], bias=W[t + ".attn2.to_out.0.bias"], residual=p1)
         ffb = _FF_BLOCK and (t + ".ff.pack") in W and (not keep or rows % 2 == 0)
         st3_half = False
-        if ffb:
+        ffp = ffb and _FF_PROJ and (t + ".ff.packp") in W and (not keep or _FF_KEEP) and HW % 128 == 0
+        opart = None
+        if ffp:
+            # ... and proj_out + the outer residual behind it in the same launch (skg_ff_block_proj_f16): the block output p3 never
+            # reaches memory (no backward reads it); GroupNorm partial sums of the result when the consumer folds them
+            gn = (HW, cfg.norm_groups) if want_part and self._gn_from_producer(rows, HW, C) else None
+            if out is None:
+                out = torch.empty(rows * HW, C, device=x.device, dtype=torch.float16)
+            _, st3, f, opart = ops.ff_block_proj(p2, W[t + ".norm3.weight"], W[t + ".norm3.bias"], 1e-5, W[t + ".ff.packp"], W[t + ".ff.bias1"],
+                                                 W[t + ".ff.net.2.bias"], W[p + ".proj_out.bias"], x, out=out, want_stats=keep,
+                                                 keep_from=(rows // 2) * HW if keep else None, gn=gn)
+        elif ffb:
             # C = 320: norm3 -> FF1 -> gate -> FF2 + residual in ONE row-local launch (skg_ff_block_f16: the row panel and the
             # output accumulators stay in registers, only weights stream).  In a guided step the same launch also stores what
             # the backward of the cond rows reads: the FF1 output (interleaved pack) and norm3's statistics
@@ -532,8 +561,9 @@ class HipUNet:
             f = f[(rows // 2) * HW:]
         if not ffb:
             p3 = ops.gemm(gg, W[t + ".ff.net.2.weight"], bias=W[t + ".ff.net.2.bias"], residual=p2)
-        opart = None
-        if want_part and self._gn_from_producer(rows, HW, C):
+        if ffp:
+            pass
+        elif want_part and self._gn_from_producer(rows, HW, C):
             out, opart = ops.gemm(p3, W[p + ".proj_out.weight"], out, bias=W[p + ".proj_out.bias"], residual=x,
                                   gn_stats=(HW, cfg.norm_groups))
         else:

@@ -1228,6 +1228,53 @@ def test_ff_block_fused(ops, M, Fh):
     assert torch.equal(outw[:, 8:8 + C], y) and float(outw[:, :8].abs().max()) == 0 and float(outw[:, 8 + C:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("rows,HW", [(2, 1024), (16, 4096), (3, 256)])
+def test_ff_block_with_proj_out(ops, rows, HW):
+    """skg_ff_block_proj_f16: the fused feed-forward launch followed by Transformer2DModel.proj_out + the outer residual without the
+    block output leaving the registers, against the two launches it replaces (skg_ff_block_f16, then skg_gemm_f16 + residual with
+    GroupNorm partial sums - same rounding points: rel <= 3e-4, >= 97 % bit-equal) and against the fp32 definition; the stashing
+    form (statistics, FF1 pre-activation of the rows >= keep_from) equals skg_ff_block_f16_keep's; GroupNorm from the partial sums
+    equals GroupNorm of the tensor; output into a strided view, R as the output buffer."""
+    from sketch2img_amd.unet import pack_ff_block
+    d = dev()
+    C, Fh, M, G = 320, 1280, rows * HW, 32
+    x, R = rnd(M, C, seed=71).to(d), rnd(M, C, seed=72).to(d)
+    gam, bet = (1 + 0.2 * rnd(C, seed=73).float()).half().to(d), (0.1 * rnd(C, seed=74).float()).half().to(d)
+    w1, b1 = rnd(2 * Fh, C, seed=75, scale=C ** -0.5), rnd(2 * Fh, seed=76, scale=0.1)
+    w2, b2 = rnd(C, Fh, seed=77, scale=Fh ** -0.5), rnd(C, seed=78, scale=0.1).to(d)
+    wp, bp = rnd(C, C, seed=79, scale=C ** -0.5), rnd(C, seed=80, scale=0.1).to(d)
+    pack, bias1 = pack_ff_block(w1, b1, w2, d)
+    packp, bias1p = pack_ff_block(w1, b1, w2, d, w_proj=wp)
+    assert torch.equal(packp[:Fh // 32], pack) and torch.equal(bias1p, bias1)
+    kf = (rows // 2) * HW
+    p3, st0, pre0 = ops.ff_block(x, gam, bet, 1e-5, pack, bias1, b2, want_stats=True, keep_from=kf)
+    y2, part2 = ops.gemm(p3, wp.to(d), bias=bp, residual=R, gn_stats=(HW, G))
+    buf = torch.full((M, C + 16), 7.0, device=d, dtype=torch.float16)
+    y, st, pre, part = ops.ff_block_proj(x, gam, bet, 1e-5, packp, bias1, b2, bp, R, out=buf[:, 8:8 + C], want_stats=True, keep_from=kf,
+                                         gn=(HW, G))
+    e2 = rel_err(y, y2)
+    same = float((y == y2).float().mean())
+    stray = float((buf[:, :8] - 7).abs().max() + (buf[:, 8 + C:] - 7).abs().max())
+    sel = slice(0, min(M, 8192))
+    a = F.layer_norm(x.float()[sel], (C,), gam.float(), bet.float(), 1e-5)
+    hid = a @ w1.float().to(d).t() + b1.float().to(d)
+    p3f = x.float()[sel] + (hid[:, :Fh] * F.gelu(hid[:, Fh:])) @ w2.float().to(d).t() + b2.float()
+    ref = R.float()[sel] + p3f @ wp.float().to(d).t() + bp.float()
+    e = rel_err(y[sel], ref)
+    print(f"[parity] ff_block_proj rows{rows} HW{HW}: rel {e:.2e} vs fp32, {e2:.2e} vs ff_block + gemm (bit-equal {same:.4f}), stray {stray}")
+    assert e < 2 * FP16_RND and e2 < 3e-4 and same > 0.97 and stray == 0
+    assert torch.equal(st, st0) and torch.equal(pre, pre0)
+    gnw, gnb = (1 + 0.1 * rnd(C, seed=81).float()).half().to(d), (0.1 * rnd(C, seed=82).float()).half().to(d)
+    ga, _ = ops.groupnorm(y.contiguous(), rows, HW, G, 1e-6, gnw, gnb, False, partial=part)
+    gb, _ = ops.groupnorm(y.contiguous(), rows, HW, G, 1e-6, gnw, gnb, False)
+    gc, _ = ops.groupnorm(y2, rows, HW, G, 1e-6, gnw, gnb, False, partial=part2)
+    print(f"[parity] GroupNorm from the launch's partial sums vs from the tensor: rel {rel_err(ga, gb):.2e}; vs the gemm's partials {rel_err(ga, gc):.2e}")
+    assert rel_err(ga, gb) < 1e-3 and rel_err(ga, gc) < 1e-3
+    again = R.clone()      # R as the output buffer (the caller's residual slot), no stash, no statistics
+    ops.ff_block_proj(x, gam, bet, 1e-5, packp, bias1, b2, bp, again, out=again)
+    assert torch.equal(again, y)
+
+
 def test_ff_block_keep_stores_the_pre_activation(ops):
     """skg_ff_block_f16_keep: the cond rows of a guided step (rows >= keep_from) also get the FF1 output in the interleaved pack
     order - what skg_gemm_f16_geglu_keep writes and skg_geglu_bwd reads.  Same MFMA products and the same fp16 rounding as the
