@@ -448,6 +448,42 @@ def test_ff_block_pack_reproduces_the_geglu_feed_forward():
     assert torch.allclose(y.t(), ref, atol=2e-4, rtol=1e-5), float((y.t() - ref).abs().max())
 
 
+def test_ff_pack_proj_chunks_reproduce_proj_out():
+    """unet.pack_ff_block(..., w_proj=) (what skg_ff_block_proj_f16 streams behind the feed-forward chunks), emulated on the CPU with
+    the kernel's own index arithmetic (csrc/ffblock.hip, PROJ): the block output sits in accumulator tiles [16 channels, rows] with
+    lane (l, g) holding rows 4 g + r; tiles 2 ks, 2 ks + 1 become the B operand of k-step ks with k-slot 8 g + i <-> (tile i >> 2,
+    row 4 g + (i & 3)); chunk j's piece (t, ks) is the A operand [16 x 32] of output tile 4 j + t.  Against W_proj @ p3 exactly
+    (inputs on coarse grids); the feed-forward chunks in front are untouched and the 20 W2 slots of the proj chunks are zero."""
+    from sketch2img_amd.unet import pack_ff_block
+    g = torch.Generator().manual_seed(10)
+    C, Fh, M = 320, 1280, 16
+    w1 = torch.randint(-8, 9, (2 * Fh, C), generator=g).float() / 64
+    b1 = torch.randint(-8, 9, (2 * Fh,), generator=g).float() / 64
+    w2 = torch.randint(-8, 9, (C, Fh), generator=g).float() / 64
+    wp = torch.randint(-8, 9, (C, C), generator=g).float() / 64
+    p3 = torch.randint(-16, 17, (M, C), generator=g).float() / 16
+    pack0, bias0 = pack_ff_block(w1, b1, w2, "cpu")
+    pack, bias = pack_ff_block(w1, b1, w2, "cpu", w_proj=wp)
+    nch = Fh // 32
+    assert pack.shape == (nch + 5, 60, 512) and torch.equal(pack[:nch], pack0) and torch.equal(bias, bias0)
+    assert float(pack[nch:, 40:].abs().max()) == 0
+
+    def a32(piece):      # lane 16 g + l holds A[l][8 g + i]
+        return piece.float().reshape(4, 16, 8).permute(1, 0, 2).reshape(16, 32)
+
+    tiles = [p3[:, 16 * u:16 * u + 16].t() for u in range(C // 16)]      # accumulator tiles [16 channels, M rows]
+    out = torch.zeros(C, M)
+    for j in range(5):
+        for t in range(4):
+            for ks in range(10):
+                b = torch.zeros(32, M)
+                for gg in range(4):
+                    for i in range(8):
+                        b[8 * gg + i] = tiles[2 * ks + (i >> 2)][4 * gg + (i & 3)]
+                out[16 * (4 * j + t):16 * (4 * j + t) + 16] += a32(pack[nch + j, t * 10 + ks]) @ b
+    assert torch.equal(out.t(), p3 @ wp.t())
+
+
 def test_xattn_packs_reproduce_cross_attention():
     """unet.pack_xattn_weights / pack_xattn_kv (what skg_xattn_block_f16 consumes), emulated on the CPU with the kernel's own
     index arithmetic (csrc/xattn.hip): K = 32 pieces are A operands [16 x 32] with lane 16 g + l holding A[l][8 g + i], K = 16
