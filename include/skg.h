@@ -30,7 +30,7 @@ extern "C" {
 #define SKG_E_UNSUPPORTED (-2)
 #define SKG_E_LAUNCH (-3)    /* hipGetLastError() != hipSuccess after the launch */
 
-#define SKG_ABI_VERSION 3
+#define SKG_ABI_VERSION 4
 int skg_abi_version(void);
 /* Human-readable text of the last SKG_E_LAUNCH on this thread ("" if none). */
 const char* skg_last_error(void);
@@ -460,10 +460,12 @@ int skg_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
  *   eps = eps_u + g*(eps_c - eps_u);  x0 = (x - c1*eps)/c0;  x_prev = c2*x0 + c3*eps
  * eps_u / eps_c are fp16 NHWC [HW][ld] rows of the UNet output (first 4 channels); lo_off != 0 (accuracy mode): eps is a
  * (hi, lo) pair whose lo part sits lo_off columns to the right in the same rows (0 = plain fp16).
+ * vpred = 1 (scheduler config prediction_type "v_prediction", the public SD2.1-768 checkpoint): the UNet output is v;
+ *   v = v_u + g*(v_c - v_u);  eps = c0*v + c1*x;  x0 = c0*x - c1*v;  x_prev as above (eps_out receives the derived eps).
  * Replaces modules/pipeline.py:99-104 (CFG + scheduler.step). */
 int skg_cfg_ddim_step(const void* eps_u, const void* eps_c, int ld, int lo_off, const float* x, float* x_prev,
                       float* eps_out, int samples, int HW, float g, float c0, float c1, float c2,
-                      float c3, void* stream);
+                      float c3, int vpred, void* stream);
 /* ---- VAE decoder helpers (modules/pipeline.py:118 decode_latents; third-party AutoencoderKL.decode) -------------
  * Row softmax y[m][:] = softmax(x[m][:]) of fp16 scores, fp32 arithmetic: the decoder's single-head mid attention
  * (AttentionBlock: softmax(q k^T / sqrt(C)) v over HW tokens) is GEMM -> this -> GEMM.  N % 8 == 0. */
@@ -489,10 +491,11 @@ int skg_gaussian_sample(const void* moments, int ld, const float* noise, float* 
  *   eps = eps_u + g*(eps_c - eps_u);  x0 = (x - sigma_s*eps)/alpha_s;  x_prev = a*x + b*x0 + c*x0_before
  * x0_io [samples][4][HW] float: the previous step's x0 on entry (not read when c == 0: first-order step), this
  * step's x0 on exit.  The five scalars are host-side fp32 table arithmetic (sketch2img_amd/sampler.py DPMTables).
+ * vpred = 1: the UNet output is v: x0 = alpha_s*x - sigma_s*v (eps_out: alpha_s*v + sigma_s*x).
  * Replaces modules/pipeline.py:99-104 when the pipeline was built with DPMSolverMultistepScheduler. */
 int skg_cfg_dpmpp2m_step(const void* eps_u, const void* eps_c, int ld, int lo_off, const float* x, float* x0_io,
                          float* x_prev, float* eps_out, int samples, int HW, float g, float alpha_s,
-                         float sigma_s, float a, float b, float c, void* stream);
+                         float sigma_s, float a, float b, float c, int vpred, void* stream);
 /* guidance update, modules/pipeline.py:159-161, per sample s:
  *   g = -grad[s] (fp16 NHWC [HW][ld], first 4 ch);  alpha = sqrt(2)*||x_in - x_prev|| / ||g|| * beta
  *   x_prev += alpha * g.   aux float [samples][4] receives (alpha, ||g||, ||x_in-x_prev||*sqrt2, 0). */

@@ -45,11 +45,19 @@ def step_coeffs(tab: DDIMTables, t: int):
     return (float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_p ** 0.5), float((1 - a_p) ** 0.5))
 
 
-def ddim_step(tab: DDIMTables, eps: torch.Tensor, t: int, x: torch.Tensor) -> torch.Tensor:
-    """x_{t-1} for eta = 0, epsilon prediction, no clipping."""
+def ddim_step(tab: DDIMTables, eps: torch.Tensor, t: int, x: torch.Tensor, v_prediction: bool = False) -> torch.Tensor:
+    """x_{t-1} for eta = 0, no clipping.  `eps` is the model output: epsilon, or - v_prediction (the SD2.1-768 checkpoint's
+    scheduler config; published parameterisation of Salimans & Ho, "Progressive distillation", as DDIMScheduler.step
+    applies it) - v = sqrt(abar) eps - sqrt(1 - abar) x0, i.e. x0 = sqrt(abar) x - sqrt(1 - abar) v and
+    eps = sqrt(abar) v + sqrt(1 - abar) x."""
     prev = t - tab.ratio
     a_t = tab.alphas_cumprod[t].to(x.dtype)
     a_p = (tab.alphas_cumprod[prev] if prev >= 0 else torch.tensor(tab.final_alpha_cumprod)).to(x.dtype)
+    if v_prediction:
+        v = eps
+        x0 = a_t ** 0.5 * x - (1 - a_t) ** 0.5 * v
+        eps = a_t ** 0.5 * v + (1 - a_t) ** 0.5 * x
+        return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
     x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
     direction = (1 - a_p) ** 0.5 * eps
     return a_p ** 0.5 * x0 + direction

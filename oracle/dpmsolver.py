@@ -86,11 +86,13 @@ class DPMState:
     history: List[int] = field(default_factory=list)      # order used at each step (for tests)
 
 
-def dpm_step(tab: DPMTables, state: DPMState, eps: torch.Tensor, i: int, x: torch.Tensor) -> torch.Tensor:
-    """prev_sample of step i (index into tab.timesteps); updates `state`."""
+def dpm_step(tab: DPMTables, state: DPMState, eps: torch.Tensor, i: int, x: torch.Tensor,
+             v_prediction: bool = False) -> torch.Tensor:
+    """prev_sample of step i (index into tab.timesteps); updates `state`.  v_prediction: the model output `eps` is v and the
+    data prediction is x0 = alpha_s x - sigma_s v (convert_model_output of the dpmsolver++ algorithm type)."""
     order = step_order(tab, i, state.lower_order_nums)
     alpha_s, sigma_s, a, b, c = step_coeffs(tab, i, order)
-    x0 = (x - sigma_s * eps) / alpha_s
+    x0 = alpha_s * x - sigma_s * eps if v_prediction else (x - sigma_s * eps) / alpha_s
     out = a * x + b * x0
     if order == 2:
         out = out + c * state.x0_before

@@ -24,7 +24,7 @@ LIB_PATH = os.environ.get("SKG_LIB") or os.path.join(_HERE, "libskg.so")
 # statistics - skg_*_hilo_gn, skg_groupnorm_fwd_hilo / _from_partial_hilo, skg_ff_block_f16_hilo - and the pair offset of
 # skg_cfg_ddim_step / skg_cfg_dpmpp2m_step), so that a stale build selected through
 # SKG_LIB fails at load instead of receiving shifted arguments
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # spec letters: p = device/host pointer, i = int, f = float, u = unsigned, z = size_t (return only)
 SIGNATURES = {
@@ -97,12 +97,12 @@ SIGNATURES = {
     "skg_lgp_mse_train": ("i", "pippipiifp"),
     "skg_adamw_step": ("i", "pppppzfffffifp"),
     "skg_lgp_mse_seed": ("i", "pippipiifp"),
-    "skg_cfg_ddim_step": ("i", "ppiipppiifffffp"),
+    "skg_cfg_ddim_step": ("i", "ppiipppiifffffip"),
     "skg_softmax_rows_f16": ("i", "pipiiip"),
     "skg_image_postprocess": ("i", "pipziffp"),
     "skg_image_to_u8": ("i", "pipziffp"),
     "skg_gaussian_sample": ("i", "pippiiifp"),
-    "skg_cfg_dpmpp2m_step": ("i", "ppiippppiiffffffp"),
+    "skg_cfg_dpmpp2m_step": ("i", "ppiippppiiffffffip"),
     "skg_guidance_update": ("i", "pipppiifp"),
 }
 

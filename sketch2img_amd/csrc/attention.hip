@@ -680,6 +680,7 @@ __global__ __launch_bounds__(256, (KS >= 5 ? 2 : (KS >= 3 ? 3 : 4))) void attn_f
   }
 }
 
+#if defined(SKG_LAB) || defined(SKG_PHASES)      // withdrawn round-4 formulation (+ 2.5 % on the kernel, - 3 % on config 5): lab / probe builds only
 // ---- forward, 8 waves, 32 queries per wave, MFMA and softmax of DIFFERENT tiles in one instruction stream (round 4) --------
 // attn_fwd_kernel above runs QK^T -> softmax -> PV of one tile as one dependency chain per wave and hopes that another wave's
 // MFMAs land under this wave's softmax; the counters say they do not (matrix pipe 0.43 busy at d = 40: 448 MFMA + ~316 VALU
@@ -1087,6 +1088,8 @@ __global__ __launch_bounds__(64 * NW, OCC) void attn_fwd8_kernel(const AttnParam
   }
 }
 
+#endif      // SKG_LAB || SKG_PHASES
+
 // dQ: per 64-query block, loop over key tiles.  dS^T = P^T o (dP^T - delta);  dQ^T += K^T dS^T.
 template <int KS, int ND, int QT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
@@ -1468,9 +1471,10 @@ static int attn_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const v
     SKG_CHECK_LAUNCH("skg_attn_fwd (short keys)");
     return SKG_OK;
   }
-  // self-attention of the 64 x 64 / 32 x 32 levels (and SD2.1's 96 x 96 ... 24 x 24): the 8-wave ping-pong kernel, 256 queries
-  // per workgroup, where that still gives every CU a workgroup (SKG_NO_ATTN8: A/B switch, default is the product)
-  static const bool no8 = getenv("SKG_NO_ATTN8") != nullptr || getenv("SKG_ATTN8") == nullptr;      // (round 4: off until it wins)
+#if defined(SKG_LAB) || defined(SKG_PHASES)
+  // lab / probe builds only: the withdrawn 8-wave formulation (attn_fwd8_kernel) for the self-attention of the 64 x 64 / 32 x 32
+  // levels, on request (SKG_ATTN8 = 1: one 8-wave workgroup per CU, 2: three 4-wave ones; SKG_NO_ATTN8 overrides)
+  static const bool no8 = getenv("SKG_NO_ATTN8") != nullptr || getenv("SKG_ATTN8") == nullptr;
   static const int form8 = getenv("SKG_ATTN8") ? atoi(getenv("SKG_ATTN8")) : 0;      // 1: one 8-wave workgroup per CU, 2: three 4-wave ones
   if (vrow && !causal && !no8 && (dh == 40 || dh == 64) && (long)skg_cdiv(Nq, 256) * heads * batch >= 192) {
     const int qpw = form8 == 2 ? 128 : 256;
@@ -1504,6 +1508,7 @@ static int attn_fwd_impl(const void* Q, int ldq, const void* K, int ldk, const v
     SKG_CHECK_LAUNCH("skg_attn_fwd (8 waves)");
     return SKG_OK;
   }
+#endif
   p.nx = skg_cdiv(Nq, dh == 160 ? 64 : 128);       // query tiles per workgroup: see SKG_ATTN_FWD_DISPATCH
   dim3 grid((unsigned)p.nx * heads * batch);
   if (causal) {

@@ -241,11 +241,12 @@ __global__ __launch_bounds__(256) void nhwc2nchw_kernel(const half_t* __restrict
 
 // CFG combine + DDIM (eta = 0) on float NCHW latents, 4 channels.
 // lo_off != 0 (accuracy mode): eps is a PAIR, the lo part lo_off columns to the right of the hi part in the same rows
+// vpred: the model output is v (prediction_type "v_prediction", SD2.1-768): eps = c0 v + c1 x, x0 = c0 x - c1 v
 __global__ __launch_bounds__(256) void cfg_ddim_kernel(const half_t* __restrict__ eu, const half_t* __restrict__ ec,
                                                        int ld, int lo_off, const float* __restrict__ x,
                                                        float* __restrict__ xp, float* __restrict__ eps_out,
                                                        int samples, int HW, float g, float c0, float c1, float c2,
-                                                       float c3) {
+                                                       float c3, int vpred) {
   const size_t total = (size_t)samples * 4 * HW;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int p = (int)(i % HW);
@@ -255,8 +256,15 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const half_t* __restrict_
     const size_t off = (s * HW + p) * ld + c;
     float u = (float)eu[off], v = (float)ec[off];
     if (lo_off) { u += (float)eu[off + lo_off]; v += (float)ec[off + lo_off]; }
-    const float e = u + g * (v - u);
-    const float x0 = (x[i] - c1 * e) / c0;
+    float e = u + g * (v - u);
+    float x0;
+    if (vpred) {
+      const float xv = x[i], vv = e;
+      e = c0 * vv + c1 * xv;
+      x0 = c0 * xv - c1 * vv;
+    } else {
+      x0 = (x[i] - c1 * e) / c0;
+    }
     xp[i] = c2 * x0 + c3 * e;
     if (eps_out) eps_out[i] = e;
   }
@@ -343,11 +351,12 @@ __global__ __launch_bounds__(256) void gaussian_sample_kernel(const half_t* __re
 
 // CFG combine + one DPM-Solver++ (2M) update: x0 = (x - sigma_s*eps)/alpha_s; x_prev = a*x + b*x0 + c*x0_before.
 // x0_io holds the previous step's x0 on entry (ignored when c == 0) and this step's x0 on exit.
+// vpred: the model output is v: x0 = alpha_s x - sigma_s v (eps_out: alpha_s v + sigma_s x)
 __global__ __launch_bounds__(256) void cfg_dpm_kernel(const half_t* __restrict__ eu, const half_t* __restrict__ ec,
                                                       int ld, int lo_off, const float* __restrict__ x, float* __restrict__ x0_io,
                                                       float* __restrict__ xp, float* __restrict__ eps_out,
                                                       int samples, int HW, float g, float alpha_s, float sigma_s,
-                                                      float a, float b, float c) {
+                                                      float a, float b, float c, int vpred) {
   const size_t total = (size_t)samples * 4 * HW;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const int p = (int)(i % HW);
@@ -357,9 +366,15 @@ __global__ __launch_bounds__(256) void cfg_dpm_kernel(const half_t* __restrict__
     const size_t off = (s * HW + p) * ld + ch;
     float u = (float)eu[off], v = (float)ec[off];
     if (lo_off) { u += (float)eu[off + lo_off]; v += (float)ec[off + lo_off]; }
-    const float e = u + g * (v - u);
+    float e = u + g * (v - u);
     const float xv = x[i];
-    const float x0 = (xv - sigma_s * e) / alpha_s;
+    float x0;
+    if (vpred) {
+      x0 = alpha_s * xv - sigma_s * e;
+      e = alpha_s * e + sigma_s * xv;
+    } else {
+      x0 = (xv - sigma_s * e) / alpha_s;
+    }
     float r = a * xv + b * x0;
     if (c != 0.f) r += c * x0_io[i];
     x0_io[i] = x0;
@@ -518,11 +533,12 @@ extern "C" int skg_nhwc_f16_to_nchw_f32(const void* X, int ldx, float* Y, int ro
 
 extern "C" int skg_cfg_ddim_step(const void* eps_u, const void* eps_c, int ld, int lo_off, const float* x, float* x_prev,
                                  float* eps_out, int samples, int HW, float g, float c0, float c1, float c2,
-                                 float c3, void* stream) {
+                                 float c3, int vpred, void* stream) {
   SKG_REQUIRE(eps_u && eps_c && x && x_prev && samples > 0 && HW > 0 && ld >= 4 && lo_off >= 0 && (lo_off == 0 || ld >= lo_off + 4));
+  SKG_REQUIRE(vpred == 0 || vpred == 1);
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3(ew_grid((size_t)samples * 4 * HW)), dim3(256), 0,
                      (hipStream_t)stream, (const half_t*)eps_u, (const half_t*)eps_c, ld, lo_off, x, x_prev, eps_out,
-                     samples, HW, g, c0, c1, c2, c3);
+                     samples, HW, g, c0, c1, c2, c3, vpred);
   SKG_CHECK_LAUNCH("skg_cfg_ddim_step");
   return SKG_OK;
 }
@@ -565,12 +581,13 @@ extern "C" int skg_gaussian_sample(const void* moments, int ld, const float* noi
 
 extern "C" int skg_cfg_dpmpp2m_step(const void* eps_u, const void* eps_c, int ld, int lo_off, const float* x, float* x0_io,
                                     float* x_prev, float* eps_out, int samples, int HW, float g, float alpha_s,
-                                    float sigma_s, float a, float b, float c, void* stream) {
+                                    float sigma_s, float a, float b, float c, int vpred, void* stream) {
   SKG_REQUIRE(eps_u && eps_c && x && x0_io && x_prev && samples > 0 && HW > 0 && ld >= 4 && alpha_s > 0.f);
+  SKG_REQUIRE(vpred == 0 || vpred == 1);
   SKG_REQUIRE(lo_off >= 0 && (lo_off == 0 || ld >= lo_off + 4));
   hipLaunchKernelGGL(cfg_dpm_kernel, dim3(ew_grid((size_t)samples * 4 * HW)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)eps_u, (const half_t*)eps_c, ld, lo_off, x, x0_io, x_prev, eps_out, samples, HW, g,
-                     alpha_s, sigma_s, a, b, c);
+                     alpha_s, sigma_s, a, b, c, vpred);
   SKG_CHECK_LAUNCH("skg_cfg_dpmpp2m_step");
   return SKG_OK;
 }

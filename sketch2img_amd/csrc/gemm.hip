@@ -188,7 +188,12 @@ int launch_plain(const GemmParams& p, hipStream_t st);
 template <int MODE>
 int launch(const GemmParams& p, hipStream_t st) {
   if (!p.gn_partial) return launch_plain<MODE>(p, st);
-  const bool fused = skg_gemm8_eligible(p, MODE) ? skg_gemm8_fuses_gn(p, MODE) : skg_gemm2_fuses_gn(p, MODE);      // (the k-pair kernel declines launches that ask for statistics)
+#ifdef SKG_LAB
+  const bool v9 = skg_gemm9_eligible(p, MODE);      // (no statistics epilogue: the stand-alone pass follows)
+#else
+  constexpr bool v9 = false;
+#endif
+  const bool fused = v9 ? false : skg_gemm8_eligible(p, MODE) ? skg_gemm8_fuses_gn(p, MODE) : skg_gemm2_fuses_gn(p, MODE);      // (the k-pair kernel declines launches that ask for statistics)
   const int rc = launch_plain<MODE>(p, st);
   if (rc != SKG_OK || fused) return rc;
   skg_gn_partial_launch((const half_t*)p.C, p.ldc, p.M / p.gn_hw, p.gn_hw, p.N, p.gn_groups, p.gn_hw / 128, p.gn_partial, st);
@@ -201,6 +206,12 @@ int launch_plain(const GemmParams& p, hipStream_t st) {
 #ifdef SKG_LAB      // withdrawn round-3 experiment (tools/lab/gemmws.hip, EXPERIMENTS.md): lab build only, SKG_GEMMWS=1
   if (skg_gemmws_try_launch(p, MODE, st)) {
     SKG_CHECK_LAUNCH("skg_gemm (ws)");
+    return SKG_OK;
+  }
+#endif
+#ifdef SKG_LAB      // round-5 experiment (tools/lab/gemm9.hip, EXPERIMENTS.md "the hand-placed K loop"): lab build only, SKG_GEMM9=<geometry><variant>
+  if (skg_gemm9_try_launch(p, MODE, st)) {
+    SKG_CHECK_LAUNCH("skg_gemm (v9)");
     return SKG_OK;
   }
 #endif
@@ -302,6 +313,11 @@ extern "C" int skg_gemm_variant(int M, int N, int K, int Cin, int mode) {
 #ifdef SKG_LAB
     if (skg_gemmws_eligible(q, mode)) return 7320;      // (plain epilogue only: launches with statistics / GEGLU / fp32 out take v2)
 #endif
+#ifdef SKG_LAB
+    q.C = (void*)16;      // (alignment checks only)
+    if (skg_gemm9_eligible(q, mode)) return 9320;
+    q.C = nullptr;
+#endif
     if (const int bn8 = skg_gemm8_tile_n(q, mode)) return 8000 + bn8;
 #ifdef SKG_LAB
     q.C = (void*)16;      // (alignment checks only)
@@ -343,6 +359,9 @@ extern "C" int skg_gemm_gn_fused(int M, int N, int K, int Cin, int mode, int HW,
   q.gn_partial = &dummy; q.gn_hw = HW; q.gn_groups = groups;
   const size_t wsb = ws_query_bytes();
   q.ws = wsb ? (float*)&dummy : nullptr; q.ws_bytes = wsb;
+#ifdef SKG_LAB
+  if (skg_gemm9_eligible(q, mode)) return 0;
+#endif
   return (skg_gemm8_eligible(q, mode) ? skg_gemm8_fuses_gn(q, mode) : skg_gemm2_fuses_gn(q, mode)) ? 1 : 0;
 }
 

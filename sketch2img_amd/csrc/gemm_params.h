@@ -52,6 +52,10 @@ bool skg_gemmws_try_launch(const GemmParams& p, int mode, hipStream_t st);
 bool skg_gemm8_eligible(const GemmParams& p, int mode);
 int skg_gemm8_tile_n(const GemmParams& p, int mode);      // 160 / 320, or 0 when v8 does not take the launch
 bool skg_gemm8_try_launch(const GemmParams& p, int mode, hipStream_t st);
+// lab build only (tools/lab/gemm9.hip, round 5): hand-placed K loop - self-pipelined waves on 32x32x16 MFMAs, fragment register
+// double buffer, one barrier per K tile, LDS-DMA spread evenly over the MFMA slots (SKG_GEMM9 selects geometry and schedule variant)
+bool skg_gemm9_eligible(const GemmParams& p, int mode);
+bool skg_gemm9_try_launch(const GemmParams& p, int mode, hipStream_t st);
 // k-pair kernel (gemmk.hip): 128 x 160 tiles, one 8-wave workgroup per CU whose two wave groups take alternate K tiles -
 // the launches with at most one tile per CU (DIRECT / S1, plain epilogue, optional split-K across workgroups on top).
 bool skg_gemmk_eligible(const GemmParams& p, int mode);

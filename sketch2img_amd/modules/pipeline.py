@@ -380,9 +380,15 @@ class AntiGradientPipeline:
         get = lambda k, d: (cfg.get(k, d) if isinstance(cfg, dict) else getattr(cfg, k, d))
         name = type(sch).__name__
         # options that change the arithmetic are rejected, never ignored (a diffusers scheduler object carries them)
-        if get("prediction_type", "epsilon") != "epsilon":
-            raise NotImplementedError(f"prediction_type={get('prediction_type', None)!r}: epsilon prediction only "
-                                      "(SD2.1-768 checkpoints are v-prediction)")
+        # prediction_type "v_prediction" (the public SD2.1-768 checkpoint's scheduler_config.json): the UNet output is v; the
+        # latent update kernels derive eps / x0 from it (skg_cfg_ddim_step / skg_cfg_dpmpp2m_step, vpred = 1).  The reference
+        # itself always builds its schedulers for epsilon prediction (modules/clip_guided_inf.py:14-26)
+        ptype = get("prediction_type", None)
+        if ptype is None:
+            ptype = "epsilon" if get("predict_epsilon", True) else "sample"
+        if ptype not in ("epsilon", "v_prediction"):
+            raise NotImplementedError(f"prediction_type={ptype!r}: 'epsilon' and 'v_prediction' are implemented")
+        vpred = ptype == "v_prediction"
         if get("beta_schedule", "scaled_linear") != "scaled_linear" or get("trained_betas", None) is not None:
             raise NotImplementedError("scaled_linear betas (Stable Diffusion) only")
         if "DDIM" in name and get("clip_sample", False):
@@ -391,14 +397,14 @@ class AntiGradientPipeline:
         if "DPMSolverMultistep" in name or get("algorithm_type", None) is not None:
             if get("algorithm_type", "dpmsolver++") != "dpmsolver++" or get("solver_type", "midpoint") != "midpoint":
                 raise NotImplementedError("DPM-Solver: only algorithm_type='dpmsolver++', solver_type='midpoint'")
-            if get("thresholding", False) or not get("predict_epsilon", True):
-                raise NotImplementedError("DPM-Solver++: epsilon prediction without thresholding only")
+            if get("thresholding", False):
+                raise NotImplementedError("DPM-Solver++ without thresholding only")
             return DPMTables.make(num_inference_steps, get("num_train_timesteps", 1000), get("beta_start", 0.00085),
-                                  get("beta_end", 0.012), get("lower_order_final", True), get("solver_order", 2))
+                                  get("beta_end", 0.012), get("lower_order_final", True), get("solver_order", 2), vpred)
         if "DDIM" not in name and not isinstance(sch, (dict, SimpleNamespace)):
             raise NotImplementedError(f"{name}: DDIMScheduler and DPMSolverMultistepScheduler are implemented")
         return DDIMTables.make(num_inference_steps, get("num_train_timesteps", 1000), get("beta_start", 0.00085),
-                               get("beta_end", 0.012), get("steps_offset", 1), get("set_alpha_to_one", False))
+                               get("beta_end", 0.012), get("steps_offset", 1), get("set_alpha_to_one", False), vpred)
 
     # ------------------------------------------------------------------ modules/pipeline.py:132-161
     def get_noise_level(self, noise, timesteps):

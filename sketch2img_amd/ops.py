@@ -885,26 +885,27 @@ def eps_halves(eps, samples, HW):
 
 
 def cfg_ddim_step(eps_u, eps_c, x, samples, HW, g, coeffs: Tuple[float, float, float, float],
-                  want_eps=False, lo_off: int = 0):
-    """lo_off != 0: eps_u / eps_c are the hi parts of pairs whose lo parts sit lo_off columns to the right (eps_halves)."""
+                  want_eps=False, lo_off: int = 0, v_prediction: bool = False):
+    """lo_off != 0: eps_u / eps_c are the hi parts of pairs whose lo parts sit lo_off columns to the right (eps_halves).
+    v_prediction: the model output is v (eps = c0 v + c1 x, x0 = c0 x - c1 v); the returned eps is the derived one."""
     _f16(eps_u, eps_c)
     x_prev = torch.empty_like(x)
     eps_out = torch.empty_like(x) if want_eps else None
     c0, c1, c2, c3 = coeffs
     check(lib.skg_cfg_ddim_step(_p(eps_u), _p(eps_c), _ld(eps_u), lo_off, _p(x), _p(x_prev), _p(eps_out), samples, HW,
-                                g, c0, c1, c2, c3, _stream()), "skg_cfg_ddim_step")
+                                g, c0, c1, c2, c3, int(bool(v_prediction)), _stream()), "skg_cfg_ddim_step")
     return (x_prev, eps_out) if want_eps else x_prev
 
 
 def cfg_dpmpp2m_step(eps_u, eps_c, x, x0_io, samples, HW, g, coeffs: Tuple[float, float, float, float, float],
-                     want_eps=False, lo_off: int = 0):
+                     want_eps=False, lo_off: int = 0, v_prediction: bool = False):
     """coeffs = (alpha_s, sigma_s, a, b, c); x0_io is updated in place (previous x0 in, this step's x0 out)."""
     _f16(eps_u, eps_c)
     x_prev = torch.empty_like(x)
     eps_out = torch.empty_like(x) if want_eps else None
     al, sg, a, b, c = coeffs
     check(lib.skg_cfg_dpmpp2m_step(_p(eps_u), _p(eps_c), _ld(eps_u), lo_off, _p(x), _p(x0_io), _p(x_prev), _p(eps_out),
-                                   samples, HW, g, al, sg, a, b, c, _stream()), "skg_cfg_dpmpp2m_step")
+                                   samples, HW, g, al, sg, a, b, c, int(bool(v_prediction)), _stream()), "skg_cfg_dpmpp2m_step")
     return (x_prev, eps_out) if want_eps else x_prev
 
 

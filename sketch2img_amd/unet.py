@@ -574,15 +574,21 @@ class HipUNet:
             # a backward through an injected block could never slice an M1-row tensor a second time: ADVICE r3)
             st3h = ("st3",) if st3_half else ()      # fused FF block: norm3's statistics exist for the cond rows only
             ent = dict(x=x_c, gst=gst, pin=pin, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1_c, st2=st2, q2=q2_c)
-            half = ()
-            if r1 != rows:
-                M1_ = r1 * HW
-                half = tuple(k for k, v in ent.items() if v is not None and v.shape[0] == (r1 if k in ("gst", "lse1") else M1_))
-                if "x" not in half:      # the front diverged before p1 (an injector with differing halves): x is full size
-                    ent["x"] = x
+            half = self._stash_half(ent, r1, rows, HW)
+            if r1 != rows and "x" not in half:      # the front diverged before p1 (an injector with differing halves): x is full size
+                ent["x"] = x
             half = tuple(k for k in half if k not in xk_half) + xk_half      # (the stashing cross-attention launch: cond rows only)
             stash.tr[p] = dict(ent, o2=o2, lse2=lse2, p2=p2, st3=st3, f=f, H=H, heads=heads, half=half + st3h)
         return out, opart
+
+    @staticmethod
+    def _stash_half(ent: dict, r1: int, rows: int, HW: int) -> tuple:
+        """Keys of a transformer stash entry whose tensors hold the cond rows only (r1 = rows // 2 of them), derived from what each
+        tensor actually holds - never from how the forward believes it got there - so that the backward can not slice a cond-only
+        tensor a second time.  Per-row tensors have r1 * HW rows; gst / lse1 are per image."""
+        if r1 == rows:
+            return ()
+        return tuple(k for k, v in ent.items() if v is not None and v.shape[0] == (r1 if k in ("gst", "lse1") else r1 * HW))
 
     @staticmethod
     def _dup_partial(part):
@@ -905,14 +911,12 @@ class HipUNet:
             gg = ops.geglu(ff, interleaved=True)
             f = ff[(rows // 2) * HW:]
         if keep:
-            # half: the tensors of the text-independent part hold the cond rows only (as _tr_fwd stashes them)
-            half = ("x", "gst", "pin", "st1", "qkv", "o1", "lse1", "p1", "st2", "q2") if r1 != rows else ()
-            if r1 != rows and self.inject is None:
-                stash.tr[p] = dict(x=x_c.hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1_c.hi, st2=st2, q2=q2_c,
-                                   o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=half)
-            else:
-                stash.tr[p] = dict(x=x.hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=p1.hi, st2=st2, q2=q2,
-                                   o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=())
+            # half: which tensors of the text-independent part hold the cond rows only - derived from their shapes, as _tr_fwd does
+            # (with an injector the shared front ends earlier: x / p1 / q2 are full size while gst .. lse1 are not)
+            own = r1 != rows and self.inject is None
+            ent = dict(x=(x_c if own else x).hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=(p1_c if own else p1).hi,
+                       st2=st2, q2=q2_c if own else q2)
+            stash.tr[p] = dict(ent, o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=self._stash_half(ent, r1, rows, HW))
         if not ffb:
             p3 = self._pair(M, C)
             ops.gemm(gg, W[t + ".ff.net.2.weight"], out=p3.hi, out_lo=p3.lo, bias=W[t + ".ff.net.2.bias"],

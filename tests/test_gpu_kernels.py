@@ -855,15 +855,9 @@ def test_attention_forward(ops, dh, heads, Nq, Nkv):
         assert report("attn lse short-key kernel", lse2.cpu(), rl)[1] < 2e-3
         o3, lse3 = ops.attn_fwd(Q, K, V, B, heads, Nq, Nkv, kvs, dh, scale, want_lse=True, v_rows=True)
         assert torch.equal(o2, o3) and torch.equal(lse2, lse3)
-    elif dh in (40, 64) and ((Nq + 255) // 256) * heads * B >= 192:
-        # large self-attentions with row-major V take the 8-wave ping-pong kernel (attn_fwd8_kernel: 32 x 32 x 16 QK^T tiles,
-        # v_permlane16_swap relayout of P, ragged last key tile / ragged last query block here): another kernel, checked against
-        # the reference like the first one, and bit-repeatable
-        assert report(f"attn fwd 8-wave kernel dh{dh} {Nq}x{Nkv}", o2.float().cpu().view(B, Nq, C), ro)[0] < 2e-3
-        assert report("attn lse 8-wave kernel", lse2.cpu(), rl)[1] < 2e-3
-        o3, lse3 = ops.attn_fwd(Q, K, V, B, heads, Nq, Nkv, kvs, dh, scale, want_lse=True, v_rows=True)
-        assert torch.equal(o2, o3) and torch.equal(lse2, lse3)
     else:
+        # every other shape: the same 4-wave flash kernel as the transposed-copy path (QT 3 at d = 40 on large maps), fed through
+        # ds_read_b64_tr_b16.  (The 8-wave formulation of round 4, attn_fwd8_kernel, left the product: lab build + SKG_ATTN8 only.)
         assert torch.equal(o2, o) and torch.equal(lse2, lse)
 
 
@@ -905,9 +899,9 @@ def test_attention_forward_strided_qkv_and_online_rescale(ops):
     assert torch.equal(o2, o)                        # V as the third column block of the fused buffer, no transpose
 
 
-def test_attention_forward_8wave_online_rescale_and_structure(ops):
-    """attn_fwd8_kernel: (a) spiked keys in late tiles force the reference maximum to move (the rescale branch: alpha crosses
-    from the score layout, query = lane & 31, to the output layout, query = lane & 15 of two tiles); (b) structured probes with
+def test_attention_forward_large_map_online_rescale_and_structure(ops):
+    """The self-attention kernel of the large maps (attn_fwd_kernel<2, 3, 3>: three query tiles per wave at d = 40; row-major V):
+    (a) spiked keys in late tiles force the reference maximum to move (the rescale branch); (b) structured probes with
     exact answers: K = 0 makes the softmax uniform, V = one-hot on single keys / single head columns, so every output
     is an exactly known value - a lost k-step, a wrong key <-> k-slot map or a wrong V row permutation shows as an O(1) error."""
     B, heads, dh, N = 2, 8, 40, 3072
@@ -920,7 +914,7 @@ def test_attention_forward_8wave_online_rescale_and_structure(ops):
     o = ops.attn_fwd(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], B, heads, N, N, N, dh, dh ** -0.5, v_rows=True)
     q, k, v = (qkv[:, i * C:(i + 1) * C].float().view(B, N, C) for i in range(3))
     ro, _ = ref_attention(q, k, v, heads, dh ** -0.5)
-    assert report("attn fwd 8-wave strided + spike", o.float().cpu().view(B, N, C), ro)[0] < 2e-3
+    assert report("attn fwd large map strided + spike", o.float().cpu().view(B, N, C), ro)[0] < 2e-3
     # (b) K = 0: uniform softmax, O[q][c] = mean over keys of V[:, c]
     Q = rnd(B * N, C, seed=2).to(d)
     K0 = torch.zeros(B * N, C, device=d, dtype=torch.float16)
@@ -938,6 +932,79 @@ def test_attention_forward_8wave_online_rescale_and_structure(ops):
         o = ops.attn_fwd(Q, K0, V, B, heads, N, N, N, dh, dh ** -0.5, v_rows=True).float().view(B, N, heads, dh)
         want = float(code.float().mean())
         assert float((o[..., col] - want).abs().max()) < 2e-2 * want / 31 and float(o[..., [c for c in range(dh) if c != col]].abs().max()) == 0.0, col
+
+
+@pytest.mark.parametrize("dh,heads", [(40, 8), (64, 5), (160, 8)])
+def test_attention_short_keys_structured_probes(ops, dh, heads):
+    """ADVICE r3 / VERDICT r4: exact-answer probes for the 77-key cross-attention kernel (attn_fwd_short_kernel) - K = 0 makes the
+    softmax uniform over the 77 valid keys (the three padding keys of the 80-row buffer must not count), V = one-hot on single
+    keys / a key code in single head columns: a lost key, a padding key that leaks, a wrong key <-> k-slot map or a wrong V
+    column shows as an O(1) error."""
+    B, Nq, L, Lp = 2, 1024, 77, 80
+    C = heads * dh
+    d = dev()
+    Q = rnd(B * Nq, C, seed=3).to(d)
+    K0 = torch.zeros(B * Lp, C, device=d, dtype=torch.float16)
+    K0.view(B, Lp, C)[:, L:] = 30.0          # padding rows hold garbage that would win the softmax if a padding key leaked
+    for key in (0, 15, 16, 31, 47, 63, 64, 76):
+        V = torch.zeros(B * Lp, C, device=d, dtype=torch.float16)
+        V.view(B, Lp, C)[:, L:] = 7.0
+        V[key] = 1.0
+        V[Lp + key] = 2.0
+        o = ops.attn_fwd(Q, K0, V, B, heads, Nq, L, Lp, dh, dh ** -0.5, v_rows=True).float().view(B, Nq, C)
+        assert float((o[0] - 1.0 / L).abs().max()) < 2e-3 / L and float((o[1] - 2.0 / L).abs().max()) < 4e-3 / L, key
+    code = (torch.arange(L) % 13 + 1).half()
+    for col in sorted({0, 7, 16, 33, dh - 1}):
+        V = torch.zeros(B * Lp, C, device=d, dtype=torch.float16)
+        V.view(B, Lp, heads, dh)[:, :L, :, col] = code.to(d)[None, :, None]
+        o = ops.attn_fwd(Q, K0, V, B, heads, Nq, L, Lp, dh, dh ** -0.5, v_rows=True).float().view(B, Nq, heads, dh)
+        want = float(code.float().mean())
+        assert float((o[..., col] - want).abs().max()) < 2e-3 * want, col
+        assert float(o[..., [c for c in range(dh) if c != col]].abs().max()) == 0.0, col
+
+
+@pytest.mark.parametrize("keep", [False, True])
+def test_xattn_block_structured_probes(ops, keep):
+    """The same probes through the fused cross-attention launch (skg_xattn_block_f16 / _keep): K = 0 -> uniform softmax over the
+    77 keys whatever q is; V one-hot or coded; to_out = a cyclic column shift, so that a wrong head <-> column map, a lost
+    K = 16 tail step (head columns 32..39) or a wrong Wo fragment shows as an O(1) error at a known place.  x = 0: the
+    output IS the attention term."""
+    from sketch2img_amd.unet import pack_xattn_kv, pack_xattn_weights
+    d = dev()
+    C, heads, dh, Lp, L, rows, HW = 320, 8, 40, 80, 77, 2, 1024
+    M = rows * HW
+    x = torch.zeros(M, C, dtype=torch.float16, device=d)
+    gam, bet = torch.ones(C).half().to(d), (0.1 * rnd(C, seed=41).float()).half().to(d)
+    wq = rnd(C, C, seed=42, scale=C ** -0.5)
+    shift = 3
+    wo = torch.zeros(C, C, dtype=torch.float16)
+    wo[(torch.arange(C) + shift) % C, torch.arange(C)] = 1.0          # y[:, (c + shift) % C] = o[:, c]
+    bo = torch.zeros(C, dtype=torch.float16).to(d)
+    wp = pack_xattn_weights(wq, wo, heads, d)
+    K0 = torch.zeros(rows * Lp, C, device=d, dtype=torch.float16)
+
+    def run(V):
+        kvp = pack_xattn_kv(K0, V, rows, Lp, L, heads)
+        if keep:
+            return ops.xattn_block(x, HW, heads, L, gam, bet, 1e-5, wp, kvp, bo, dh ** -0.5, keep_from=HW)[0].float().view(rows, HW, C)
+        return ops.xattn_block(x, HW, heads, L, gam, bet, 1e-5, wp, kvp, bo, dh ** -0.5).float().view(rows, HW, C)
+
+    for key in (0, 15, 16, 31, 47, 63, 64, 76):
+        V = torch.zeros(rows * Lp, C, device=d, dtype=torch.float16)
+        V[key] = 1.0
+        V[Lp + key] = 2.0
+        y = run(V)
+        assert float((y[0] - 1.0 / L).abs().max()) < 3e-3 / L and float((y[1] - 2.0 / L).abs().max()) < 6e-3 / L, key
+    code = (torch.arange(L) % 13 + 1).half()
+    want = float(code.float().mean())
+    for col in (0, 7, 16, 31, 32, 39):
+        V = torch.zeros(rows * Lp, C, device=d, dtype=torch.float16)
+        V.view(rows, Lp, heads, dh)[:, :L, :, col] = code.to(d)[None, :, None]
+        y = run(V)
+        hot = [(h * dh + col + shift) % C for h in range(heads)]
+        cold = [c for c in range(C) if c not in hot]
+        assert float((y[..., hot] - want).abs().max()) < 3e-3 * want, col
+        assert float(y[..., cold].abs().max()) == 0.0, col
 
 
 @pytest.mark.parametrize("dh,heads,Nq,Nkv,cross", [(40, 8, 256, 256, False), (80, 8, 64, 64, False),
@@ -1079,6 +1146,12 @@ def test_cfg_ddim_and_guidance_update(ops):
     er = eu + 7.5 * (ec - eu)
     assert report("cfg eps", e.cpu(), er)[1] < 1e-5
     assert report("ddim step", xp.cpu(), oddim.ddim_step(otab, er, t, x))[1] < 2e-5
+    # v-prediction (SD2.1-768): the same CFG-combined tensor read as v; eps_out is the derived epsilon
+    c0, c1 = tab.coeffs(t)[:2]
+    xpv, ev = ops.cfg_ddim_step(eps.to(d)[:S * hw], eps.to(d)[S * hw:], x.to(d), S, hw, 7.5, tab.coeffs(t), want_eps=True,
+                                v_prediction=True)
+    assert report("ddim step, v-prediction", xpv.cpu(), oddim.ddim_step(otab, er, t, x, v_prediction=True))[1] < 2e-5
+    assert report("derived eps, v-prediction", ev.cpu(), c0 * er + c1 * x)[1] < 1e-5
     grad = rnd(S * hw, 8, seed=2, scale=3.0)
     xprev = xp.clone()
     aux = ops.guidance_update(grad.to(d), x.to(d), xprev, S, hw, 1.6)
@@ -1115,6 +1188,23 @@ def test_cfg_dpmpp2m_step_vs_oracle(ops):
         assert report(f"dpm++ step {i} (order {order}) eps", e.cpu(), er)[1] < 1e-5
         assert report(f"dpm++ step {i} (order {order}) x_prev", xp.cpu(), ref)[1] < 2e-5
         assert report(f"dpm++ step {i} x0 history", x0_io.cpu(), st.x0_before)[0] < 1e-6      # |x0| ~ 450 at t = 999
+        x, xg = ref, ref.to(d)
+    # v-prediction: two steps (first order, then second order with the x0 history) against the oracle
+    st = odpm.DPMState()
+    x = torch.randn(S, 4, h, h, generator=torch.Generator().manual_seed(2))
+    x0_io = torch.zeros(S, 4, h, h, device=d)
+    xg, seen = x.to(d), 0
+    for i in range(2):
+        eps = rnd(2 * S * hw, ld, seed=20 + i)
+        eu, ec = eps[:S * hw, :4].float(), eps[S * hw:, :4].float()
+        vr = (eu + 7.5 * (ec - eu)).reshape(S, hw, 4).permute(0, 2, 1).reshape(S, 4, h, h)
+        order = tab.order(i, seen)
+        xp = ops.cfg_dpmpp2m_step(eps.to(d)[:S * hw], eps.to(d)[S * hw:], xg, x0_io, S, hw, 7.5, tab.coeffs(i, order),
+                                  v_prediction=True)
+        seen = min(seen + 1, 2)
+        ref = odpm.dpm_step(otab, st, vr, i, x, v_prediction=True)
+        assert report(f"dpm++ v-prediction step {i} x_prev", xp.cpu(), ref)[1] < 2e-5
+        assert report(f"dpm++ v-prediction step {i} x0 history", x0_io.cpu(), st.x0_before)[1] < 2e-5
         x, xg = ref, ref.to(d)
 
 

@@ -51,7 +51,7 @@ def test_library_exports_every_declared_symbol_with_matching_signature():
     for name, sig in decl.items():
         assert _lib.SIGNATURES[name] == sig, (name, _lib.SIGNATURES[name], sig)
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.skg_abi_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib.skg_abi_version() == _lib.ABI_VERSION == 4
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (skg_\w+)", nm))
     assert set(decl) <= exported
@@ -323,7 +323,7 @@ def test_scheduler_options_that_change_the_maths_are_rejected():
     from sketch2img_amd.modules.pipeline import AntiGradientPipeline
     p = AntiGradientPipeline.__new__(AntiGradientPipeline)
     DDIM = type("DDIMScheduler", (), {})
-    for bad in (dict(prediction_type="v_prediction"), dict(clip_sample=True), dict(beta_schedule="linear"),
+    for bad in (dict(prediction_type="sample"), dict(predict_epsilon=False), dict(clip_sample=True), dict(beta_schedule="linear"),
                 dict(trained_betas=[0.1, 0.2])):
         s = DDIM()
         s.config = SimpleNamespace(**bad)
@@ -333,7 +333,15 @@ def test_scheduler_options_that_change_the_maths_are_rejected():
     s = DDIM()
     s.config = SimpleNamespace(prediction_type="epsilon", clip_sample=False, steps_offset=1)
     p.scheduler = s
-    assert p._tables(50).timesteps[0] == 981
+    assert p._tables(50).timesteps[0] == 981 and not p._tables(50).v_prediction
+    # the public SD2.1-768 scheduler_config.json: v-prediction is carried into the tables (the step kernels take it as a flag)
+    s.config = SimpleNamespace(prediction_type="v_prediction", clip_sample=False, steps_offset=1)
+    assert p._tables(50).v_prediction and p._tables(50).timesteps[0] == 981
+    DPM = type("DPMSolverMultistepScheduler", (), {})
+    s = DPM()
+    s.config = SimpleNamespace(prediction_type="v_prediction", algorithm_type="dpmsolver++", solver_type="midpoint")
+    p.scheduler = s
+    assert p._tables(25).v_prediction and len(p._tables(25).timesteps) == 25
 
 
 def test_vae_attention_keys_both_diffusers_spellings():

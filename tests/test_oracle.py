@@ -409,3 +409,35 @@ def test_clip_text_oracle_vs_live_transformers():
         with torch.no_grad():
             ref = model(ids)[0]
         assert (ot.last_hidden_state(cfg, W, ids) - ref).abs().max() < 5e-6
+
+
+def test_v_prediction_known_answers():
+    """v-prediction (the SD2.1-768 scheduler config): with v = sqrt(abar) eps - sqrt(1 - abar) x0 built from a known
+    (x0, eps) pair, the DDIM / DPM-Solver++ steps must land exactly where the epsilon-prediction steps land from the same
+    pair - the two parameterisations describe one trajectory."""
+    from oracle import ddim as oddim
+    from oracle import dpmsolver as odpm
+    g = torch.Generator().manual_seed(4)
+    x0 = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    eps = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    tab = oddim.make_tables(50)
+    for t in (981, 501, 21, 1):
+        a = tab.alphas_cumprod[t].double()
+        x = a ** 0.5 * x0 + (1 - a) ** 0.5 * eps
+        v = a ** 0.5 * eps - (1 - a) ** 0.5 * x0
+        ref = oddim.ddim_step(tab, eps, t, x)
+        got = oddim.ddim_step(tab, v, t, x, v_prediction=True)
+        assert float((got - ref).abs().max()) < 1e-12
+    dt = odpm.make_tables(25)
+    st_e, st_v = odpm.DPMState(), odpm.DPMState()
+    xe = xv = None
+    for i in range(3):
+        s0 = int(dt.timesteps[i])
+        al, sg = dt.alpha_t[s0].double(), dt.sigma_t[s0].double()
+        x = al * x0 + sg * eps if xe is None else xe
+        e_i = (x - al * x0) / sg                       # the eps consistent with (x, x0)
+        v_i = al * e_i - sg * x0
+        xe = odpm.dpm_step(dt, st_e, e_i, i, x)
+        xv = odpm.dpm_step(dt, st_v, v_i, i, x, v_prediction=True)
+        # (alpha_t, sigma_t are fp32 table entries: alpha^2 + sigma^2 = 1 only to ~1e-8, which is all that separates the two)
+        assert float((xe - xv).abs().max()) < 1e-7 * float(xe.abs().max())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One kernel shape, a few launches - the target of `rocprofv3 --pmc ...` passes (tools/pmc_kernels.sh).
-    python tools/pmc_kernel.py attn40 | attn64 | conv | gemm_short | gemm_ff1 | ffblock | gemm:M:N:K[:res|:geglu]"""
+    python tools/pmc_kernel.py attn40 | attn64 | conv | conv64 | gemm_short | gemm_ff1 | ffblock | gemm:M:N:K[:res|:geglu]"""
 import os
 import sys
 
@@ -29,8 +29,8 @@ elif what == "ffblock":
     gam, bet, b2 = torch.ones(C).half().to(dev), torch.zeros(C).half().to(dev), torch.zeros(C).half().to(dev)
     out = torch.empty_like(x)
     fn = lambda: ops.ff_block(x, gam, bet, 1e-5, pack, bias1, b2, out=out)
-elif what == "conv":
-    rows, hw, cin, cout = 16, 32, 1920, 640
+elif what in ("conv", "conv64"):
+    rows, hw, cin, cout = (16, 32, 1920, 640) if what == "conv" else (16, 64, 960, 320)
     x = torch.randn(rows * hw * hw, cin, generator=g).half().to(dev)
     w = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(dev)
     fn = lambda: ops.conv3x3(x, w, rows, hw, hw, 0)
