@@ -152,6 +152,11 @@ int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void* Y, int ld
  * (sketch2img_amd.unet.pack_conv_up2_hilo).  C % 64 == 0. */
 int skg_conv3x3_up2_f16_hilo(const void* X2, int ldx, const void* Wpp3, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW,
                              int C, int Cout, const void* bias, void* stream);
+/* Accuracy mode, cheaper form (round 5): skg_conv3x3_up2_f16 on the hi part of the stream (X [rows*IH*IW][ldx >= Cin], Wpp the
+ * default polyphase pack [4][Cout][4*Cin]) with the output written as the pair Y + Y_lo.  Drops the x_lo and W_lo correction
+ * thirds of skg_conv3x3_up2_f16_hilo (each ~1 % of the mode's eps distance, together two thirds of its time). */
+int skg_conv3x3_up2_f16_pairout(const void* X, int ldx, const void* Wpp, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW,
+                                int Cin, int Cout, const void* bias, void* stream);
 /* Data gradient of the polyphase upsample + convolution above (the autograd backward of diffusers Upsample2D inside
  * torch.autograd.grad at modules/pipeline.py:159): ONE 4 x 4 stride-2 convolution, padding 1, over the gradient at the upsampled
  * size.  X [rows*IH*IW, Cin] (ldx; IH, IW even), Y [rows*(IH/2)*(IW/2), Cout] (ldy), W16 [Cout][16 taps ky*4+kx][Cin]

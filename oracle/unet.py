@@ -203,7 +203,8 @@ def init_weights(cfg: UNetConfig, seed: int = 20260929, dtype=torch.float32,
 # time ("which stored tensors cost the accuracy"): "res" = the residual stream (ResnetBlock / attention / FF sums,
 # conv_in / resampling outputs), "norm" = GroupNorm(+SiLU) / LayerNorm outputs, "lin" = conv / Linear outputs that
 # feed a norm or an activation, "attn" = q / k / v and attention outputs, "temb" = the time-embedding path, "rop" = the residual stream where it is
-# itself a matmul OPERAND (conv_shortcut, the resampling convolutions; idempotent when "res" is rounded anyway).
+# itself a matmul OPERAND (rop_sc: conv_shortcut, rop_dn / rop_up: the resampling convolutions, rop_po: proj_out; skip=("rop",) covers all; idempotent when
+# "res" is rounded anyway).
 _FP16_STORAGE = False
 _FP16_SKIP: frozenset = frozenset()
 
@@ -251,7 +252,7 @@ def resnet_forward(cfg, W, p, x, temb_act):
     h = _r(F.silu(_gn(h, W, p + ".norm2", cfg.norm_groups, 1e-5)), "norm")
     h = F.conv2d(h, W[p + ".conv2.weight"], W[p + ".conv2.bias"], padding=1)
     if (p + ".conv_shortcut.weight") in W:
-        x = _r(F.conv2d(_r(x, "rop"), W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"]), "lin_n")
+        x = _r(F.conv2d(_r(x, "rop_sc"), W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"]), "lin_n")
     return _r(x + h, "res")
 
 
@@ -313,7 +314,7 @@ def transformer2d_forward(cfg, W, p, x, ehs, heads, inject=None):
     else:
         h = _r(F.conv2d(h, W[p + ".proj_in.weight"], W[p + ".proj_in.bias"]), "res")
         h = h.permute(0, 2, 3, 1).reshape(B, H * Wd, C)
-    h = transformer_block_forward(W, p + ".transformer_blocks.0", h, ehs, heads, inject)
+    h = _r(transformer_block_forward(W, p + ".transformer_blocks.0", h, ehs, heads, inject), "rop_po")
     if cfg.use_linear_projection:
         h = F.linear(h, W[p + ".proj_out.weight"], W[p + ".proj_out.bias"])
         h = h.reshape(B, H, Wd, C).permute(0, 3, 1, 2)
@@ -369,7 +370,7 @@ def unet_forward(cfg: UNetConfig, W: Dict[str, torch.Tensor], x: torch.Tensor, t
             blk_res.append(h)
         if i < nb - 1:
             p = f"down_blocks.{i}.downsamplers.0.conv"
-            h = _r(F.conv2d(_r(h, "rop"), W[p + ".weight"], W[p + ".bias"], stride=2, padding=1), "res")
+            h = _r(F.conv2d(_r(h, "rop_dn"), W[p + ".weight"], W[p + ".bias"], stride=2, padding=1), "res")
             skips.append(h)
             blk_res.append(h)
         per_block.append(tuple(blk_res))
@@ -397,7 +398,7 @@ def unet_forward(cfg: UNetConfig, W: Dict[str, torch.Tensor], x: torch.Tensor, t
         if i < nb - 1:
             p = f"up_blocks.{i}.upsamplers.0.conv"
             h = F.interpolate(h, scale_factor=2.0, mode="nearest")
-            h = _r(F.conv2d(_r(h, "rop"), W[p + ".weight"], W[p + ".bias"], padding=1), "res")
+            h = _r(F.conv2d(_r(h, "rop_up"), W[p + ".weight"], W[p + ".bias"], padding=1), "res")
         if i < 3:
             taps_up.append(h)
     h = _r(F.silu(_gn(h, W, "conv_norm_out", cfg.norm_groups, 1e-5)), "norm")

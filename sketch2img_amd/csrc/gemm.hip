@@ -478,6 +478,15 @@ extern "C" int skg_conv3x3_up2_f16_hilo(const void* X2, int ldx, const void* Wpp
   return conv_up2_impl(X2, ldx, Wpp3, Y, Y_lo, ldy, rows, IH, IW, 3 * C, Cout, 2 * C, bias, stream);
 }
 
+// Accuracy mode, round 5: the polyphase launch of skg_conv3x3_up2_f16 on the hi part of the stream with a PAIR output.  Of the three
+// K-thirds of the form above, x_lo W_hi and x_hi W_lo each move eps by ~1 % of the mode's distance from fp32 (tools/eps_decompose_up.py:
+// rel 5.00e-4 -> 5.18e-4 with both dropped) and cost two thirds of the upsamplers' time, the largest single item of the mode's price.
+extern "C" int skg_conv3x3_up2_f16_pairout(const void* X, int ldx, const void* Wpp, void* Y, void* Y_lo, int ldy, int rows, int IH,
+                                           int IW, int Cin, int Cout, const void* bias, void* stream) {
+  SKG_REQUIRE(Y_lo);
+  return conv_up2_impl(X, ldx, Wpp, Y, Y_lo, ldy, rows, IH, IW, Cin, Cout, 0, bias, stream);
+}
+
 // dX of the polyphase upsample + conv above = ONE 4 x 4 stride-2 convolution (padding 1) over dY at the upsampled size with
 // the transposed pre-summed weights: dX[i, j] = sum_{ky, kx < 4} W16[ky, kx]^T dY[2 i - 1 + ky, 2 j - 1 + kx] - 16 tap-products
 // per low-res pixel where the 9-tap dgrad at the upsampled size + 2 x 2 sum-pool spends 36.

@@ -601,6 +601,72 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, int tiles_n, int
     }
     continue;
   }
+#ifdef SKG_LAB      // measured and withdrawn (EXPERIMENTS.md round 5: bit-equal outputs, 10-20 % SLOWER on every shape): lab build, SKG_DIRECT_EPI=1|2
+  // ---- register-direct epilogue (round 5; flag 0x10000 from the launcher: fp16 output, N % BN == 0, 16-byte aligned rows, no
+  // GEGLU / pair / statistics / row map).  v_permlane16_swap between the accumulator tiles (j, j + 1) of a 16-row fragment
+  // gives every lane 8 CONSECUTIVE columns of its row - lane group g holds columns 16 (g & 1) + 8 (g >> 1) .. + 7 of the
+  // 32-column pair - so the residual is one 16-byte load and the output one 16-byte store per lane, 64-byte runs per row and
+  // instruction (the rate of whole rows, EXPERIMENTS.md "store-instruction shape"), with NO LDS staging and NO barrier: a wave
+  // that has finished its K loop stores and leaves (or starts its next tile) without waiting for the other three, and the
+  // co-resident workgroup's K loop runs under it.  An odd last tile column pairs the fragments (i, i + 1) instead (32-byte runs).
+  if (!HILO && !GNS && (p.flags & 0x10000u)) {
+    const int cb = (g & 1) * 16 + (g >> 1) * 8;
+    auto emit = [&](float (&v)[8], int m, int n) {
+      if (m >= p.M) return;
+      half8_t bz = zero_half8();
+      if (p.bias) bz = ld_half8(p.bias + n);
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = (v[e] + (float)bz[e]) * p.alpha;
+      if (p.res) {
+        const half8_t r = ld_half8(p.res + (size_t)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] += (float)r[e];
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fmaxf(x[e], 0.f);
+      }
+      half8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)x[e];
+      half8_t* dst = reinterpret_cast<half8_t*>(reinterpret_cast<half_t*>(p.C) + (size_t)m * p.ldc + n);
+      if (stream_out) __builtin_nontemporal_store(o, dst);
+      else *dst = o;
+    };
+    auto swap8 = [&](const float4_t& a, const float4_t& b, float (&v)[8]) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float fa = a[e], fb = b[e];      // (scalar copies: __builtin_bit_cast on a vector element reads element 0)
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, fa), __builtin_bit_cast(unsigned, fb), false, false);
+        const unsigned s0 = sw[0], s1 = sw[1];
+        v[e] = __builtin_bit_cast(float, s0);
+        v[4 + e] = __builtin_bit_cast(float, s1);
+      }
+    };
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * WM + i * 16 + l16;
+#pragma unroll
+      for (int j = 0; j + 1 < NT; j += 2) {
+        float v[8];
+        swap8(acc[i][j], acc[i][j + 1], v);
+        emit(v, m, n0 + wn * WN + j * 16 + cb);
+      }
+    }
+    if constexpr (NT & 1) {
+      static_assert(MT % 2 == 0, "odd tile column: fragments pair up over rows");
+#pragma unroll
+      for (int i = 0; i < MT; i += 2) {
+        float v[8];
+        swap8(acc[i][NT - 1], acc[i + 1][NT - 1], v);
+        emit(v, m0 + wm * WM + (i + (g & 1)) * 16 + l16, n0 + wn * WN + (NT - 1) * 16 + (g >> 1) * 8);
+      }
+    }
+    SKG_PH(3); SKG_PH(4);
+    continue;
+  }
+#endif
   const bool staged = HILO ||      // (launcher-checked alignment)
                       (!f32out && (p.ldc % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                        (!p.res || ((p.ldr % 8 == 0) && (reinterpret_cast<uintptr_t>(p.res) & 15) == 0)));
@@ -1104,6 +1170,17 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
 #endif
   static const char* smb = getenv("SKG_STREAM_MB");          // tuning only
   if (out_bytes >= (smb ? (size_t)atoi(smb) << 20 : STREAM_OUT_BYTES)) p.flags |= 0x800u;
+#ifdef SKG_LAB
+  // register-direct epilogue (no LDS staging, no barriers): A/B switch SKG_DIRECT_EPI (1 = every eligible launch, 2 = only
+  // K <= 640: the launches whose epilogue weighs as much as their K loop)
+  static const int direct_epi = getenv("SKG_DIRECT_EPI") ? atoi(getenv("SKG_DIRECT_EPI")) : 0;
+  const bool direct_ok = direct_epi && !(p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) && !p.c_lo && !p.res_lo && !p.gn_partial && !p.up2 &&
+                         !p.seg_rows && !p.ntaps && p.N % BN == 0 && p.ldc % 8 == 0 && skg_aligned(p.C, 16) &&
+                         (!p.res || (p.ldr % 8 == 0 && skg_aligned(p.res, 16))) && (!p.bias || skg_aligned(p.bias, 16)) &&
+                         (direct_epi == 1 || p.K <= 640);
+#else
+  constexpr bool direct_ok = false;
+#endif
   const int tiles_n = skg_cdiv(p.N, BN);
   const int ntiles = skg_cdiv(p.M, BM) * tiles_n * (p.up2 == 5 ? 4 : 1);      // (5: the four polyphase launches in one grid)
   unsigned long long a, b, s;
@@ -1113,6 +1190,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU) && !p.up2 && !p.seg_rows) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4, p.ws, p.ws_bytes) : 1;
   constexpr int NTHR = WGM * WGN * 64;
   if (BM == 128 && BN == 160 && splits == 1 && gn_fusable(p, MODE)) p.flags |= SKG_FLAG_GN_STATS;
+  if (direct_ok && splits == 1) p.flags |= 0x10000u;
   // XCDs per K slice: all 8 without split-K; 8 / ns when the slices line up with XCD boundaries
   const int ns_eff = splits > 1 ? skg_cdiv(KT, skg_cdiv(KT, splits)) : 1;
   const int G = (8 % ns_eff == 0) ? 8 / ns_eff : 0;
@@ -1166,6 +1244,17 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   // 128 x 64 tile always (74 KB: two workgroups per CU still fit)
   if constexpr (BM == 128 && (BN == 160 || BN == 64) && (MODE == MODE_DIRECT || MODE == MODE_S1)) {
     static const bool off = getenv("SKG_NO_NS3") != nullptr;        // A/B switch (tools/gemm_bench.py)
+#ifdef SKG_LAB      // round-5 probe (tools/smallm_bench.py --stages): deeper rings for the launches with one workgroup per CU anyway -
+    // SKG_NS (read per launch) = 4 (128 x 160: 148 KB of LDS; 128 x 64: 98 KB) or 6 (128 x 64 only: 148 KB)
+    if (!off && !gns && !hilo && ntiles <= 256) {
+      const char* e = getenv("SKG_NS");
+      const int ns = e ? atoi(e) : 0;
+      if (ns == 4 && KT >= 5) { G2_LAUNCH(4, false, false); return; }
+      if constexpr (BN == 64) {
+        if (ns == 6 && KT >= 7) { G2_LAUNCH(6, false, false); return; }
+      }
+    }
+#endif
     if (!off && KT >= 4 && (BN == 64 || ntiles <= 256)) {
       if constexpr (BN == 160) {
         if (gns) {

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import hashlib
 import json
+import logging
 import os
 from types import SimpleNamespace
 from typing import Callable, List, Optional, Union
@@ -31,6 +32,8 @@ import torch
 from ..config import SD15, SD21, UNetConfig, tap_channels
 from ..sampler import DDIMTables, DPMTables, HipSampler
 from .latent_predictor import LatentEdgePredictor, hook_unet
+
+logger = logging.getLogger(__name__)      # (the reference: diffusers.utils.logging.get_logger(__name__), modules/pipeline.py:11)
 
 
 class UNetFacade:
@@ -207,6 +210,12 @@ class AntiGradientPipeline:
         convolution outputs that feed a norm as (hi, lo) fp16 pairs - max eps deviation from the fp32 reference <= 1e-3
         (north_star's bound; the all-fp16 default, like the reference's own fp16 GPU path, is ~1.7e-3 away).  Works with
         ``setup_lgp`` guidance and with both SatMixin injections."""
+        if torch_dtype == torch.float32 and not residual_fp32:
+            # NOT fp32 compute: the reference's torch_dtype=float32 means an fp32 model; here it selects the (hi, lo) fp16-pair mode
+            # (~12 % slower than fp16, eps within 1e-3 of the fp32 reference) - say so once instead of mapping silently (ADVICE r4)
+            logger.warning("AntiGradientPipeline.from_pretrained(torch_dtype=torch.float32): mapped to residual_fp32=True (the accuracy "
+                           "mode: fp16 MFMA compute with a (hi, lo) fp16-pair residual stream, eps within 1e-3 of the fp32 reference); "
+                           "there is no fp32 compute path")
         residual_fp32 = bool(residual_fp32) or torch_dtype == torch.float32
         root = pretrained_model_name_or_path
         synthetic = synthetic or root is None

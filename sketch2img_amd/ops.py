@@ -48,7 +48,9 @@ def release_stream(stream: "torch.cuda.Stream"):
     with _workspace_lock:
         if _workspace.pop(key, None) is not None:
             check(lib.skg_set_workspace(None, 0, stream.cuda_stream), "skg_set_workspace")
-    for k in [k for k in _scratch if isinstance(k, tuple) and len(k) > 1 and isinstance(k[1], tuple) and k[1][1] == stream.cuda_stream]:
+    # (scratch keys carry (str(device), stream handle): the same handle value - 0, the default stream - exists on every device)
+    for k in [k for k in _scratch if isinstance(k, tuple) and len(k) > 1 and isinstance(k[1], tuple) and k[1][1] == stream.cuda_stream
+              and str(k[1][0]) == str(stream.device)]:
         _scratch.pop(k, None)
 
 
@@ -71,20 +73,22 @@ class private_buffers:
         st = torch.cuda.current_stream()
         self.key = (st.device.index, st.cuda_stream)
         self.prev_owner, _capture_owner = _capture_owner, self.owner
-        self.prev_ws = _workspace.get(self.key)
-        _workspace[self.key] = self.owner["ws"]
-        check(lib.skg_set_workspace(self.owner["ws"].data_ptr(), WORKSPACE_BYTES, st.cuda_stream), "skg_set_workspace")
+        with _workspace_lock:
+            self.prev_ws = _workspace.get(self.key)
+            _workspace[self.key] = self.owner["ws"]
+            check(lib.skg_set_workspace(self.owner["ws"].data_ptr(), WORKSPACE_BYTES, st.cuda_stream), "skg_set_workspace")
         return self
 
     def __exit__(self, *exc):
         global _capture_owner
         _capture_owner = self.prev_owner
-        if self.prev_ws is None:
-            del _workspace[self.key]
-            check(lib.skg_set_workspace(None, 0, self.key[1]), "skg_set_workspace")
-        else:
-            _workspace[self.key] = self.prev_ws
-            check(lib.skg_set_workspace(self.prev_ws.data_ptr(), WORKSPACE_BYTES, self.key[1]), "skg_set_workspace")
+        with _workspace_lock:
+            if self.prev_ws is None:
+                del _workspace[self.key]
+                check(lib.skg_set_workspace(None, 0, self.key[1]), "skg_set_workspace")
+            else:
+                _workspace[self.key] = self.prev_ws
+                check(lib.skg_set_workspace(self.prev_ws.data_ptr(), WORKSPACE_BYTES, self.key[1]), "skg_set_workspace")
 
 
 def _skey(dev):
@@ -365,14 +369,32 @@ def conv_up2(X: torch.Tensor, Wpp: torch.Tensor, rows: int, IH: int, IW: int, ou
     return out
 
 
-def conv_up2_hilo(X2: torch.Tensor, Wpp3: torch.Tensor, rows: int, IH: int, IW: int, out: Pair, *, bias=None):
+def conv_up2_hilo(X2: torch.Tensor, Wpp3: torch.Tensor, rows: int, IH: int, IW: int, out: Pair, *, bias=None, W9x2=None):
     """Accuracy mode: conv_up2 on the pair buffer X2 = [x_hi | x_lo] ([rows*IH*IW, 2C]) with (hi, lo) pre-summed weights
-    Wpp3 [4, Cout, 4 * 3C] (unet.pack_conv_up2_hilo); the output is the pair `out`."""
+    Wpp3 [4, Cout, 4 * 3C] (unet.pack_conv_up2_hilo); the output is the pair `out`.  W9x2 (a callable returning the layer's 9-tap
+    [W | W] pack, built on first use): the fall-back when the polyphase launch is declined (an operand >= 2 GiB - the pair
+    buffer is twice as wide, so the limit comes at half the batch size of conv_up2's): ADVICE r4."""
     _f16(X2, Wpp3, bias, out.hi, out.lo)
     C, Cout = X2.shape[1] // 2, Wpp3.shape[1]
     assert Wpp3.shape == (4, Cout, 12 * C) and Wpp3.is_contiguous() and X2.shape[0] == rows * IH * IW and _ld(out.hi) == _ld(out.lo)
-    check(lib.skg_conv3x3_up2_f16_hilo(_p(X2), _ld(X2), _p(Wpp3), _p(out.hi), _p(out.lo), _ld(out.hi), rows, IH, IW, C, Cout, _p(bias),
-                                       _stream()), "skg_conv3x3_up2_f16_hilo")
+    try:
+        check(lib.skg_conv3x3_up2_f16_hilo(_p(X2), _ld(X2), _p(Wpp3), _p(out.hi), _p(out.lo), _ld(out.hi), rows, IH, IW, C, Cout, _p(bias),
+                                           _stream()), "skg_conv3x3_up2_f16_hilo")
+    except SkgError as e:
+        if e.rc != -2 or W9x2 is None:
+            raise
+        conv3x3(X2, W9x2(), rows, IH, IW, CONV_UP2, out=out.hi, bias=bias, out_lo=out.lo)
+    return out
+
+
+def conv_up2_pairout(X: torch.Tensor, Wpp: torch.Tensor, rows: int, IH: int, IW: int, out: Pair, *, bias=None):
+    """Accuracy mode, cheaper upsampler (round 5): the default polyphase launch on the hi part X [rows*IH*IW, C] (a view of the
+    pair buffer) with the default pack Wpp [4, Cout, 4*C]; only the OUTPUT is a pair.  Raises SkgError(rc = -2) when declined."""
+    _f16(X, Wpp, bias, out.hi, out.lo)
+    Cin, Cout = X.shape[1], Wpp.shape[1]
+    assert Wpp.shape == (4, Cout, 4 * Cin) and Wpp.is_contiguous() and X.shape[0] == rows * IH * IW and _ld(out.hi) == _ld(out.lo)
+    check(lib.skg_conv3x3_up2_f16_pairout(_p(X), _ld(X), _p(Wpp), _p(out.hi), _p(out.lo), _ld(out.hi), rows, IH, IW, Cin, Cout, _p(bias),
+                                          _stream()), "skg_conv3x3_up2_f16_pairout")
     return out
 
 

@@ -124,6 +124,10 @@ def pack_conv_up2_dgrad(w: torch.Tensor, dev) -> torch.Tensor:
 
 
 UP2_POLYPHASE = os.environ.get("SKG_UP2_POLY", "1") != "0"      # A/B switch (bench.py on one box)
+# accuracy mode: 1 = the upsamplers' K-tripled form ([x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo]), 0 (default, round 5) = the default
+# polyphase launch on x_hi with a pair output: both correction thirds together move eps by 3.6 % of the mode's distance from fp32
+# (tools/eps_decompose_up.py) and cost two thirds of the upsamplers' time - the largest single item of the mode's price
+HP_UP_TRIPLE = os.environ.get("SKG_HP_UP_TRIPLE", "0") != "0"
 UP2_SMALL_MAPS = os.environ.get("SKG_UP2_SMALL", "1") != "0"    # A/B: polyphase also where one phase does not fill the chip
 UP2_DGRAD = os.environ.get("SKG_UP2_DGRAD", "1") != "0"         # A/B: the upsampler's backward as one 4 x 4 stride-2 convolution
 
@@ -334,11 +338,25 @@ class HipUNet:
                 W[k + ":2"] = _h(torch.cat([w, w], 1), dev)
             elif ".downsamplers." in k and k.endswith(".weight") or ".upsamplers." in k and k.endswith(".weight"):
                 if ".upsamplers." in k and UP2_POLYPHASE and v.shape[1] % 64 == 0:
-                    W[k + ":pp3"] = pack_conv_up2_hilo(v, dev)      # polyphase with (hi, lo) pre-summed weights
+                    if getattr(self, "_sd_cpu", None) is None:
+                        self._sd_cpu = {}
+                    self._sd_cpu[k] = v.detach().to("cpu", torch.float16)      # (source of the 9-tap fall-back pack: _w9x2)
+                    if HP_UP_TRIPLE or (k + ":pp") not in W:
+                        W[k + ":pp3"] = pack_conv_up2_hilo(v, dev)  # polyphase with (hi, lo) pre-summed weights, K tripled
+                    # (else: the default polyphase pack W[k + ":pp"] on x_hi, pair output only)
                 else:
                     W[k + ":2"] = pack_conv(torch.cat([v, v], 1), dev)
             elif k == "conv_out.weight":      # its operand - the last normalised activation - reaches eps one to one: a pair too
                 W[k + ":2"] = pack_conv(torch.cat([v, v], 1), dev, cout_pad=COUT_PAD)
+
+    def _w9x2(self, k: str) -> torch.Tensor:
+        """The 9-tap [W | W] pack of an upsampler (accuracy mode), built on first use: only a declined polyphase launch needs it."""
+        if k + ":2" not in self.W:
+            v = self._sd_cpu[k] if getattr(self, "_sd_cpu", None) is not None else None
+            if v is None:
+                raise RuntimeError(f"{k}: the polyphase launch was declined and the layer's 9-tap pack is not available")
+            self.W[k + ":2"] = pack_conv(torch.cat([v, v], 1), self.dev)
+        return self.W[k + ":2"]
 
     # ------------------------------------------------------------------ hoisted precompute
     def prepare_timesteps(self, timesteps: Sequence[int]):
@@ -1064,8 +1082,17 @@ class HipUNet:
                 u = (i + 1) * lpb1
                 ctn = cats[u].shape[1] // 2
                 o = P(cats[u][:, :ch_h[u]], cats[u][:, ctn:ctn + ch_h[u]])
-                if (p + ".weight:pp3") in W:      # polyphase, K axis [x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo]: 12 instead of 18 tap-products
-                    ops.conv_up2_hilo(full_of(h, h.hi.shape[1]), W[p + ".weight:pp3"], rows, cur, cur, o, bias=W[p + ".bias"])
+                if not HP_UP_TRIPLE and (p + ".weight:pp") in W and (p + ".weight:pp3") not in W:
+                    try:
+                        ops.conv_up2_pairout(h.hi, W[p + ".weight:pp"], rows, cur, cur, o, bias=W[p + ".bias"])
+                    except ops.SkgError as e:      # declined (an operand >= 2 GiB): the 9-tap [W | W] form on the pair
+                        if e.rc != -2:
+                            raise
+                        ops.conv3x3(full_of(h, h.hi.shape[1]), self._w9x2(p + ".weight"), rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo,
+                                    bias=W[p + ".bias"])
+                elif (p + ".weight:pp3") in W:      # polyphase, K axis [x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo]: 12 instead of 18 tap-products
+                    ops.conv_up2_hilo(full_of(h, h.hi.shape[1]), W[p + ".weight:pp3"], rows, cur, cur, o, bias=W[p + ".bias"],
+                                      W9x2=lambda p=p: self._w9x2(p + ".weight"))
                 else:
                     ops.conv3x3(full_of(h, h.hi.shape[1]), W[p + ".weight:2"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo,
                                 bias=W[p + ".bias"])

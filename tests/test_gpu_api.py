@@ -166,6 +166,80 @@ def test_unet_facade_call_and_hooks(pipe):
     pipe.setup_lgp(pipe.lgp_model)
 
 
+def test_pipeline_accuracy_mode_through_from_pretrained():
+    """the accuracy mode through the API a user of the reference touches.
+    AntiGradientPipeline.from_pretrained(..., residual_fp32=True) and its torch_dtype=torch.float32 spelling
+    (modules/pipeline.py: from_pretrained -> UNetFacade -> HipUNet) must run EXACTLY what a directly built
+    HipUNet(residual_fp32=True) sampler runs - bit-identical latents - unguided, with setup_lgp guidance and with a SatMixin
+    injection; the mode must really be on (another result than the default's) and closer to the fp32 oracle."""
+    import dataclasses
+    from modules.latent_predictor import LatentEdgePredictor
+    from modules.pipeline import AntiGradientPipeline
+    from modules.sketch_guided_attn import SatMixin
+    from oracle import attn_inject, guidance as og, unet as ounet
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import TINY, tap_channels
+    from sketch2img_amd.lgp import HipLGP
+    from sketch2img_amd.sampler import DDIMTables, HipSampler
+    from sketch2img_amd.unet import HipUNet
+    cfg = dataclasses.replace(TINY, block_out_channels=(64, 128, 128, 128))      # (the pair kernels want channel counts % 64 == 0)
+    ocfg = dataclasses.replace(ounet.TINY, block_out_channels=(64, 128, 128, 128))
+    h, T = 32, 3
+    lat = torch.randn(1, 4, h, h, generator=torch.Generator().manual_seed(11))
+    target = synthetic.sketch_targets(0, 1, h)
+    lgp_sd = synthetic.lgp_state_dict(synthetic.lgp_input_dim(cfg))
+
+    def build(**kw):
+        p = AntiGradientPipeline.from_pretrained(None, unet_config=cfg, **kw).to("cuda")
+        lgp = LatentEdgePredictor(synthetic.lgp_input_dim(cfg), 4, 9)
+        lgp.load_state_dict(lgp_sd)
+        lgp.to(p.unet.device, dtype=p.unet.dtype)
+        p.setup_lgp(lgp)
+        return p
+
+    call = dict(negative_prompt="blurry", height=8 * h, width=8 * h, num_inference_steps=T, latents=lat, output_type="latent")
+    pa, pb, pd = build(residual_fp32=True), build(torch_dtype=torch.float32), build(torch_dtype=torch.float16)
+    assert pa.unet.hip.residual_fp32 and pb.unet.hip.residual_fp32 and not pd.unet.hip.residual_fp32
+    ehs = pa._encode_prompt("a cat", "cpu", 1, True, "blurry")
+    W = pa.unet.state_dict()
+    # the same engine built directly
+    net = HipUNet(cfg, W, DEV, residual_fp32=True)
+    net.prepare_context(ehs)
+    tab = DDIMTables.make(T)
+    direct_u = HipSampler(net, None).sample(lat, None, T, tables=tab).cpu()
+    direct_g = HipSampler(net, HipLGP(lgp_sd, tap_channels(cfg), DEV)).sample(lat, target, T, tables=tab).cpu()
+    out_u = {k: p("a cat", **call).cpu() for k, p in (("a", pa), ("b", pb), ("d", pd))}
+    out_g = {k: p("a cat", sketch_image=target, **call).cpu() for k, p in (("a", pa), ("b", pb), ("d", pd))}
+    assert torch.equal(out_u["a"], direct_u) and torch.equal(out_u["b"], direct_u)
+    assert torch.equal(out_g["a"], direct_g) and torch.equal(out_g["b"], direct_g)
+    assert not torch.equal(out_u["d"], direct_u) and not torch.equal(out_g["d"], direct_g)
+    with torch.no_grad():
+        ref_u = og.sample_one(ocfg, W, None, ehs.half().float(), lat, None, T)
+    ea, ed = report("accuracy mode through from_pretrained, unguided vs oracle", out_u["a"], ref_u)[0], \
+        report("default mode, unguided vs oracle", out_u["d"], ref_u)[0]
+    assert ea < ed and ea < 2e-3
+    # ... and through a SatMixin injection (sketch_guided_attn): pipeline object vs the directly built pair engine + injector
+    sd = attn_inject.init_state_dict(ocfg, "sketch")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 4, h, h, generator=g).half().float()
+    with torch.no_grad():
+        res = ounet.unet_forward(ocfg, W, x, 301, ehs.half().float(), down_only=True)
+    res = [tuple(r.half().float().to(DEV) for r in blk) for blk in res]
+    outs = []
+    for p in (pa, pb):
+        sat = quiet(SatMixin, p.unet)
+        sat.load_state_dict(sd)
+        sat.to(torch.device("cuda"), dtype=p.unet.dtype)
+        sat.set_res_samples(res)
+        sat.set_scale(0.7)
+        outs.append(p("a cat", **call).cpu())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], direct_u)      # injected, and the same through both spellings
+    eps_pipe = pa.unet(x.to(DEV), 301, ehs.half().float()).sample.cpu()
+    with torch.no_grad():
+        ref, _ = ounet.unet_forward(ocfg, W, x, 301, ehs.half().float(), inject=attn_inject.make_sketch_inject(ocfg, sd, [tuple(r.cpu() for r in b) for b in res], 0.7))
+    assert report("accuracy mode + sketch injection through the facade vs oracle", eps_pipe, ref)[0] < 2e-3
+
+
 @pytest.mark.parametrize("variant", ["clip", "sketch"])
 def test_injected_attention_vs_oracle(variant):
     from modules.pipeline import AntiGradientPipeline

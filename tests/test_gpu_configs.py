@@ -10,6 +10,7 @@
   * the N > 1 path of bench.py executed as two ranks on one device == the same samples run by one rank, bit for bit.
 Everything goes through the C ABI (libskg.so)."""
 import json
+import math
 import os
 import subprocess
 import sys
@@ -126,7 +127,64 @@ def test_sd15_accuracy_mode_meets_north_star_eps_bound():
     assert worst <= 1e-3 and worst_rel <= 7e-4
 
 
-# ------------------------------------------------------------------------------------------------------ config 4
+def test_sd15_accuracy_mode_heavy_tailed_weights():
+    """VERDICT r4 next #2, margin evidence: the same bound on weights that are NOT uniform - in every convolution / linear layer 1 %
+    of the output channels (at least one) are scaled by 8, the outlier-channel structure trained diffusion UNets show - and four
+    more latent seeds (3, 5, 13, 17; with the previous test's 7, 11, 23, 101: eight), at the first and the last timestep of the
+    schedule.  The outliers inflate the un-normalised output (|eps| up to 8.7 instead of 1.4: measured, round 5, where the plain
+    bound read 4.96e-3 at rel 5.3e-4), so conv_out - the last, linear layer - is rescaled to the OUTPUT SCALE OF THE UNIFORM MODEL
+    (max |eps| = 1.4, std 0.37: the scale every number of DESIGN.md section 5 is quoted at); then both the absolute north_star bound
+    and the scale-free relative bound are asserted.  (For a unit-variance eps - a trained checkpoint - absolute errors scale by
+    1 / 0.37: DESIGN.md section 5 says so.)"""
+    from oracle import unet as ounet
+    from sketch2img_amd.config import SD15
+    from sketch2img_amd.unet import HipUNet
+    _threads()
+    cfg = ounet.SD15
+    W = dict(ounet.init_weights(cfg))
+    gsel = torch.Generator().manual_seed(77)
+    n_scaled = 0
+    for k in sorted(W):
+        if k.endswith(".weight") and W[k].dim() >= 2 and "norm" not in k:
+            co = W[k].shape[0]
+            idx = torch.randperm(co, generator=gsel)[:max(1, co // 100)]
+            W[k] = W[k].clone()
+            W[k][idx] = (W[k][idx] * 8.0).half().float()
+            n_scaled += len(idx)
+    cases = [(t, seeds) for t in (981, 21) for seeds in ((3, 5), (13, 17))]
+
+    def inputs(t, seeds):
+        g = torch.Generator().manual_seed(seeds[0] * 1000 + t)
+        xx = torch.cat([torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(sd_)) for sd_ in seeds]).half().float()
+        return xx, torch.randn(2, 77, 768, generator=g).half().float()
+
+    xx, ehs = inputs(*cases[0])
+    with torch.no_grad():
+        C0, _ = ounet.unet_forward(cfg, W, xx, cases[0][0], ehs)
+    amax0 = float(C0.abs().max())
+    sc = 2.0 ** round(math.log2(1.4 / amax0))          # a power of two: the rescaled fp16 weights are exact
+    W["conv_out.weight"], W["conv_out.bias"] = W["conv_out.weight"] * sc, W["conv_out.bias"] * sc
+    net = HipUNet(SD15, W, DEV, need_backward=False, residual_fp32=True)
+    worst = worst_rel = amax = 0.0
+    for i, (t, seeds) in enumerate(cases):
+        xx, ehs = inputs(t, seeds)
+        net.prepare_context(ehs)
+        A, _ = _hip_eps(net, xx, t, 2, 64)
+        if i == 0:
+            C = C0 * sc                                  # (conv_out is the last, linear layer: exact)
+        else:
+            with torch.no_grad():
+                C, _ = ounet.unet_forward(cfg, W, xx, t, ehs)
+        assert torch.isfinite(A).all()
+        amax = max(amax, float(C.abs().max()))
+        for row in range(2):
+            rAC, mAC = report(f"sd15 eps, heavy-tailed weights: HIP accuracy mode vs fp32 oracle, t = {t}, seed {seeds[row]}", A[row], C[row])
+            worst, worst_rel = max(worst, mAC), max(worst_rel, rAC)
+    print(f"[parity] accuracy mode, heavy-tailed weights ({n_scaled} output channels x 8; conv_out x {sc:g}: un-normalised max |eps| {amax0:.2f}), "
+          f"2 timesteps x 4 seeds: worst max |eps - eps_fp32| = {worst:.2e} (north_star bound 1e-3), worst rel {worst_rel:.2e}, max |eps| {amax:.2f}")
+    assert worst <= 1e-3 and worst_rel <= 7e-4 and amax < 2.0
+
+
 def test_config4_sd15_full_size_sketch_guided_attn_vs_oracle():
     """BASELINE configs[3] at its real size: one CFG-doubled evaluation of the full SD1.5 UNet at 64x64 latents with
     the injected cross-attention on routed residual samples (K / V length N = 4096 / 1024 / 256 / 64)."""
@@ -302,41 +360,48 @@ def test_sd15_config0_trajectories_vs_oracle():
     out_u = HipSampler(net, None).sample(x0, None, T, tables=tab).cpu()
     ru, mu = report("sd15 config[0] unguided 10-step end latents, free running", out_u, ref_u)
     assert torch.isfinite(out_u).all() and ru < 2.2e-3          # measured 1.41e-3 (round 3), x 1.5
-    # (b) guided, teacher-forced
-    tr = []
-    og.sample_one(cfg, W, dict(sd), ehs, x0, tgt, T, trace=tr)
-    assert [t["aux"] is not None for t in tr] == [i <= 5 for i in range(T)]              # Q6: i <= 0.5 T
+    # (b) guided, teacher-forced - two samples (initial latents 1000 + i, sketch 2000 + i)
     sampler = HipSampler(net, HipLGP(sd, tap_channels(SD15), DEV))
     net.prepare_timesteps(tab.timesteps.tolist())
-    noise = x0.to(DEV)
     worst = dict(eps=0.0, nr=0.0, cos=1.0, loss=0.0)
-    for i in range(T):
-        x_i = x0 if i == 0 else tr[i - 1]["latents"]
-        xp, eps, aux = sampler.step(x_i.to(DEV).contiguous(), noise, tgt.to(DEV), tab, i, 7.5, 1.6, want_eps=True)
-        e, _ = report(f"sd15 config[0] step{i} CFG eps (teacher-forced)", eps.cpu(), tr[i]["eps"])
-        worst["eps"] = max(worst["eps"], e)
-        assert e < 1.4e-2                                # CFG-combined eps: 8.4 x the single-row error
-        if tr[i]["aux"] is None:
-            assert aux is None
-            assert report(f"sd15 config[0] step{i} x_prev", xp.cpu(), tr[i]["latents"])[0] < 2e-3
-            continue
-        upd_ref = float(tr[i]["aux"]["alpha"]) * tr[i]["aux"]["cond_grad"]
-        upd = xp.cpu() - (tr[i]["latents"] - upd_ref)
-        nr = float(upd.norm() / upd_ref.norm())
-        cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm()))
-        dl = abs(float(aux[0, 3]) - float(tr[i]["aux"]["loss"])) / float(tr[i]["aux"]["loss"])
-        print(f"[parity] sd15 config[0] step{i} update: |hip|/|oracle|={nr:.4f} cos={cos:.5f} "
-              f"loss hip={float(aux[0, 3]):.4e} oracle={float(tr[i]['aux']['loss']):.4e}")
-        worst["nr"], worst["cos"], worst["loss"] = max(worst["nr"], abs(nr - 1)), min(worst["cos"], cos), max(worst["loss"], dl)
-        # measured (round 3): |ratio - 1| <= 1.5e-5, cos >= 0.99925, loss rel <= 4.1e-4; bounds = measured x 1.5 and more.
-        # Round 4: with the stashing cross-attention launch the six steps read 0.99935 / 0.99765 / 0.99921 / 0.99954 / 0.99956 /
-        # 0.99938 (per-operator launches: 0.99928 / 0.99916 / 0.99933 / 0.99959 / 0.99945 / 0.99948): another fp16 realisation of
-        # the same evaluation (the two differ by 1.2e-3 rel in eps, the distance of either from the fp32 oracle), better on three
-        # steps, worse on three, one of them - step 1 - by 3 x in 1 - cos; the direction's rounding floor between two fp16
-        # evaluations is profiles/r03_lgp_rounding_floor.txt's.  Bound = the worst measured 1 - cos x 1.5.
-        assert abs(nr - 1) < 1e-3 and cos > 0.9965 and dl < 2e-3
-    print(f"[parity] sd15 config[0] guided, worst over 10 steps: eps rel {worst['eps']:.2e}, | |upd| ratio - 1 | {worst['nr']:.2e}, "
-          f"cos {worst['cos']:.5f}, loss rel {worst['loss']:.2e}")
+    omc = []                                             # 1 - cos of every guided step
+    for si in (0, 1):
+        x0, tgt = synthetic.initial_latents(si, 1, h), synthetic.sketch_targets(si, 1, h)
+        tr = []
+        og.sample_one(cfg, W, dict(sd), ehs, x0, tgt, T, trace=tr)
+        assert [t["aux"] is not None for t in tr] == [i <= 5 for i in range(T)]              # Q6: i <= 0.5 T
+        noise = x0.to(DEV)
+        for i in range(T):
+            x_i = x0 if i == 0 else tr[i - 1]["latents"]
+            xp, eps, aux = sampler.step(x_i.to(DEV).contiguous(), noise, tgt.to(DEV), tab, i, 7.5, 1.6, want_eps=True)
+            e, _ = report(f"sd15 config[0] sample {si} step{i} CFG eps (teacher-forced)", eps.cpu(), tr[i]["eps"])
+            worst["eps"] = max(worst["eps"], e)
+            assert e < 1.4e-2                                # CFG-combined eps: 8.4 x the single-row error
+            if tr[i]["aux"] is None:
+                assert aux is None
+                assert report(f"sd15 config[0] sample {si} step{i} x_prev", xp.cpu(), tr[i]["latents"])[0] < 2e-3
+                continue
+            upd_ref = float(tr[i]["aux"]["alpha"]) * tr[i]["aux"]["cond_grad"]
+            upd = xp.cpu() - (tr[i]["latents"] - upd_ref)
+            nr = float(upd.norm() / upd_ref.norm())
+            cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm()))
+            dl = abs(float(aux[0, 3]) - float(tr[i]["aux"]["loss"])) / float(tr[i]["aux"]["loss"])
+            print(f"[parity] sd15 config[0] sample {si} step{i} update: |hip|/|oracle|={nr:.4f} cos={cos:.5f} "
+                  f"loss hip={float(aux[0, 3]):.4e} oracle={float(tr[i]['aux']['loss']):.4e}")
+            worst["nr"], worst["cos"], worst["loss"] = max(worst["nr"], abs(nr - 1)), min(worst["cos"], cos), max(worst["loss"], dl)
+            omc.append(1.0 - cos)
+            # |ratio - 1| <= 1.5e-5 and loss rel <= 4.1e-4 measured (round 3): bounds = measured x 1.5 and more.  The DIRECTION: round 4
+            # fitted cos > 0.9965 to one step of one sample (0.99765 with the stashing cross-attention launch, 0.99916 without).  Round 5
+            # measured both paths over 8 samples x 6 guided steps (tools/traj_seeds.py, profiles/r05_traj_direction_seeds.txt):
+            # 1 - cos mean 5.98e-4 / max 1.64e-3 with the fused launch, mean 6.75e-4 / max 2.73e-3 with the per-operator launches - the
+            # same distribution (the unfused path holds the worst step of the 96): single steps scatter up to ~3e-3 in either
+            # realisation, which is the LGP's rounding floor (profiles/r03_lgp_rounding_floor.txt), not a property of the launch.
+            # So: every step above the floor 0.9965, and the MEAN over the guided steps at round 3's level (1 - cos < 1.1e-3).
+            assert abs(nr - 1) < 1e-3 and cos > 0.9965 and dl < 2e-3
+    mean_omc = sum(omc) / len(omc)
+    print(f"[parity] sd15 config[0] guided, worst over 2 samples x 10 steps: eps rel {worst['eps']:.2e}, | |upd| ratio - 1 | {worst['nr']:.2e}, "
+          f"cos {worst['cos']:.5f} (mean 1 - cos {mean_omc:.2e} over {len(omc)} guided steps), loss rel {worst['loss']:.2e}")
+    assert mean_omc < 1.1e-3
 
 
 @pytest.mark.parametrize("case", ["dpm", "sketch", "clip"])

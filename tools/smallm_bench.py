@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--probes", action="store_true", help="lab build: + no-DMA / no-store / both probes of the k-pair kernel")
     ap.add_argument("--splits", action="store_true", help="gemm2.hip only: cap the cross-workgroup K slices at 8 (ships) / 4 / 2")
     ap.add_argument("--plain", action="store_true", help="the shipped kernels only (no lab variants)")
+    ap.add_argument("--stages", action="store_true", help="lab build, gemm2.hip only: three LDS stages (ships) against four / six (SKG_NS)")
     ap.add_argument("--pool-mb", type=int, default=640, help="weight pool per shape; 0: two copies only = weights warm in the Infinity Cache")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -74,6 +75,9 @@ def main():
                          "kpair-neither": {"SKG_GEMMK": "1", "SKG_GK_EXP": "3"}})
     if args.plain:
         variants = {"shipped": {}}
+    if args.stages:
+        variants = {"ns3": {"SKG_GEMMK": "0", "SKG_GK_EXP": "0", "SKG_NS": "0"}, "ns4": {"SKG_GEMMK": "0", "SKG_GK_EXP": "0", "SKG_NS": "4"},
+                    "ns6": {"SKG_GEMMK": "0", "SKG_GK_EXP": "0", "SKG_NS": "6"}}
     if args.splits:
         variants = {f"max{n}": {"SKG_GEMMK": "0", "SKG_GK_EXP": "0", "SKG_MAX_SPLITS": str(n)} for n in (8, 4, 2)}
     g = torch.Generator().manual_seed(1)
@@ -83,7 +87,7 @@ def main():
     lines.append(hdr)
     for M, N, K, res, n in GEMMS:
         os.environ["SKG_GEMMK"] = "1"
-        assert args.splits or args.plain or lib.skg_gemm_variant(M, N, K, 0, 0) == 9160, (M, N, K)
+        assert args.splits or args.plain or args.stages or lib.skg_gemm_variant(M, N, K, 0, 0) == 9160, (M, N, K)
         copies = max(2, min(64, POOL_BYTES // (N * K * 2)))
         W = [(torch.randn(N, K, generator=g) * K ** -0.5).half().to(DEV) for _ in range(2)]
         W = W + [W[i % 2].clone() for i in range(copies - 2)]
@@ -103,7 +107,7 @@ def main():
     for rows, hw, cin, cout, res, n in CONVS:
         M = rows * hw * hw
         os.environ["SKG_GEMMK"] = "1"
-        assert args.splits or args.plain or lib.skg_gemm_variant(M, cout, 9 * cin, cin, 1) == 9160, (rows, hw, cin, cout)
+        assert args.splits or args.plain or args.stages or lib.skg_gemm_variant(M, cout, 9 * cin, cin, 1) == 9160, (rows, hw, cin, cout)
         copies = max(2, min(64, POOL_BYTES // (cout * 9 * cin * 2)))
         W = [(torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(DEV) for _ in range(2)]
         W = W + [W[i % 2].clone() for i in range(copies - 2)]
