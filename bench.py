@@ -109,6 +109,7 @@ class LaunchTimer:
         self._gemm, self._conv, self._attn, self._keep = ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep
         self._up2, self._c4, self._ffb, self._xab = ops.conv_up2, ops.conv4x4s2, ops.ff_block, ops.xattn_block
         self._ffp = ops.ff_block_proj
+        self._csc = ops.conv3x3_sc
 
     def __enter__(self):
         from sketch2img_amd._lib import lib
@@ -161,6 +162,19 @@ class LaunchTimer:
             gn = gg is not None and bool(lib.skg_gemm_gn_fused(M, Cout, 9 * Cin, Cin, 1 + mode, OH * OH, gg))
             self.rec.append((kname(lib.skg_gemm_variant(M, Cout, 9 * Cin, Cin, 1 + mode), name, gn), 2.0 * M * Cout * 9 * Cin, e0, e1, nbytes,
                              f"conv {name} M{M} Cin{Cin} Cout{Cout}" + "+res" * (k.get("residual") is not None)))
+            return out
+
+        def conv_sc(X, X2, Wcat, rows, IH, IW, *a, **k):     # conv2 + the 1x1 shortcut of a ResnetBlock as one implicit GEMM
+            Cin, K2, Cout = X.shape[1], X2.shape[1], Wcat.shape[0]
+            M, K = rows * IH * IW, 9 * Cin + K2
+            e0, e1 = ev()
+            e0.record()
+            out = self._csc(X, X2, Wcat, rows, IH, IW, *a, **k)
+            e1.record()
+            gg = k.get("gn_groups")
+            gn = gg is not None and bool(lib.skg_gemm_gn_fused(M, Cout, K, Cin, 1, IH * IW, gg))
+            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, K, Cin, 1), "S1", gn), 2.0 * M * Cout * K, e0, e1,
+                             2.0 * (M * Cin + M * K2 + Cout * K + M * Cout), f"conv S1 + shortcut M{M} Cin{Cin} K2 {K2} Cout{Cout}"))
             return out
 
         def v2name(M, N, K, Cin, mode, label, phases=1):
@@ -259,12 +273,14 @@ class LaunchTimer:
         ops.gemm, ops.conv3x3, ops.attn_fwd, ops.gemm_geglu_keep = gemm, conv, attn, gemm_keep
         ops.conv_up2, ops.conv4x4s2, ops.ff_block, ops.xattn_block = conv_up2, conv4x4s2, ff_block, xattn_block
         ops.ff_block_proj = ff_block_proj
+        ops.conv3x3_sc = conv_sc
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm, self.ops.conv3x3, self.ops.attn_fwd, self.ops.gemm_geglu_keep = self._gemm, self._conv, self._attn, self._keep
         self.ops.conv_up2, self.ops.conv4x4s2, self.ops.ff_block, self.ops.xattn_block = self._up2, self._c4, self._ffb, self._xab
         self.ops.ff_block_proj = self._ffp
+        self.ops.conv3x3_sc = self._csc
 
     def summary(self):
         """per kernel: [launches, flops, seconds, algorithmic bytes, roofline seconds, seconds of HBM-bound launches];

@@ -157,6 +157,18 @@ int skg_conv3x3_up2_f16_hilo(const void* X2, int ldx, const void* Wpp3, void* Y,
  * thirds of skg_conv3x3_up2_f16_hilo (each ~1 % of the mode's eps distance, together two thirds of its time). */
 int skg_conv3x3_up2_f16_pairout(const void* X, int ldx, const void* Wpp, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW,
                                 int Cin, int Cout, const void* bias, void* stream);
+
+/* conv2 + conv_shortcut of a ResnetBlock whose channel count changes, as ONE implicit GEMM (round 5; diffusers ResnetBlock2D:
+ * output = conv2(.) + conv_shortcut(x), under modules/pipeline.py:96): the 1x1 shortcut is a tenth "tap" without halo -
+ *   Y[m][n] = sum_{tap, c} X[pixel(m) + tap][c] * Wcat[n][tap * Cin + c] + sum_{c2 < K2} X2[m][c2] * Wcat[n][9 * Cin + c2] + bias[n]
+ * X [rows*IH*IW][ldx >= Cin] the 3x3 input (stride 1), X2 [rows*IH*IW][ldx2 >= K2] the block's input x, Wcat [Cout][9*Cin + K2]
+ * (conv2's tap-major pack followed by the shortcut weight; bias = conv2.bias + conv_shortcut.bias).  Y_lo != NULL (accuracy mode):
+ * pair output, and X2 / K2 are the pair buffer [x_hi | x_lo] / 2 * Cin_x against [W_sc | W_sc].  gn_partial != NULL: the GroupNorm
+ * partial sums of the output as skg_conv3x3_f16_gn writes them.  Removes one GEMM launch, its M x Cout output write and the
+ * residual read of conv2's epilogue per such block (14 per SD1.5 evaluation).  Cin % 64 == 0, K2 % 64 == 0. */
+int skg_conv3x3_sc_f16(const void* X, int ldx, const void* X2, int ldx2, int K2, const void* Wcat, void* Y, void* Y_lo, int ldy,
+                       int rows, int IH, int IW, int Cin, int Cout, const void* bias, unsigned flags, float* gn_partial, int groups,
+                       void* stream);
 /* Data gradient of the polyphase upsample + convolution above (the autograd backward of diffusers Upsample2D inside
  * torch.autograd.grad at modules/pipeline.py:159): ONE 4 x 4 stride-2 convolution, padding 1, over the gradient at the upsampled
  * size.  X [rows*IH*IW, Cin] (ldx; IH, IW even), Y [rows*(IH/2)*(IW/2), Cout] (ldy), W16 [Cout][16 taps ky*4+kx][Cin]

@@ -34,6 +34,7 @@ SIGNATURES = {
     "skg_conv3x3_up2_f16": ("i", "pippiiiiiipp"),
     "skg_conv3x3_up2_f16_hilo": ("i", "pipppiiiiiipp"),
     "skg_conv3x3_up2_f16_pairout": ("i", "pipppiiiiiipp"),
+    "skg_conv3x3_sc_f16": ("i", "pipiipppiiiiiipupip"),
     "skg_conv4x4s2_f16": ("i", "pippiiiiiipp"),
     "skg_gemm_f16_rows": ("i", "pipipiiiipiip"),
     "skg_gemm_f16_hilo": ("i", "pipippiiiipppifup".replace(" ", "")),

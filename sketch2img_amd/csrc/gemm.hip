@@ -231,7 +231,7 @@ int launch_plain(const GemmParams& p, hipStream_t st) {
   }
   if (p.flags & SKG_EPI_GEGLU) return SKG_E_UNSUPPORTED;     // fused GEGLU exists in the LDS-DMA kernel only
   if (p.c_lo || p.res_lo) return SKG_E_UNSUPPORTED;          // so does the hi / lo epilogue
-  if (p.ntaps || p.up2 || p.seg_rows) return SKG_E_UNSUPPORTED;      // and the polyphase tap walk / the output row maps
+  if (p.ntaps || p.up2 || p.seg_rows || p.K2) return SKG_E_UNSUPPORTED;      // and the polyphase tap walk / the output row maps / the second operand
   const int tm = skg_cdiv(p.M, BM);
   if (use_wide(p.M, p.N)) {
     dim3 grid(p.N / 128, tm);
@@ -427,6 +427,30 @@ extern "C" int skg_conv3x3_f16_gn(const void* X, int ldx, const void* Wp, void* 
   SKG_REQUIRE(gn_args_ok(gn_partial, rows * OH * OW, Cout, OH * OW, groups, ldy, flags) && skg_aligned(Y, 16));
   return conv_impl(X, ldx, Wp, Y, ldy, rows, IH, IW, Cin, Cout, mode, bias, residual, ldr, alpha, flags, gn_partial,
                    groups, stream);
+}
+
+// ---- conv2 + conv_shortcut of a ResnetBlock as ONE implicit GEMM (include/skg.h) -------------------------------------------
+extern "C" int skg_conv3x3_sc_f16(const void* X, int ldx, const void* X2, int ldx2, int K2, const void* Wcat, void* Y, void* Y_lo,
+                                  int ldy, int rows, int IH, int IW, int Cin, int Cout, const void* bias, unsigned flags,
+                                  float* gn_partial, int groups, void* stream) {
+  SKG_REQUIRE(X && X2 && Wcat && Y && rows > 0 && IH > 0 && IW > 0 && K2 > 0 && K2 % 64 == 0 && Cin % 64 == 0 && Cout % 8 == 0);
+  SKG_REQUIRE(ldx % 8 == 0 && ldx >= Cin && ldx2 % 8 == 0 && ldx2 >= K2 && ldy % 8 == 0 && ldy >= Cout);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(X2, 16) && skg_aligned(Wcat, 16) && skg_aligned(Y, 16) && (!Y_lo || skg_aligned(Y_lo, 16)) &&
+              (!bias || skg_aligned(bias, 8)) && !(flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)));
+  SKG_REQUIRE((unsigned long long)rows * IH * IW * ldx2 * 2ull < 0x7fffffffull);
+  GemmParams p{};
+  p.A = (const half_t*)X; p.lda = ldx; p.B = (const half_t*)Wcat; p.ldb = 9 * Cin + K2; p.C = Y; p.ldc = ldy;
+  p.bias = (const half_t*)bias; p.c_lo = (half_t*)Y_lo;
+  p.N = Cout; p.K = 9 * Cin + K2; p.alpha = 1.f; p.flags = flags;
+  p.IH = IH; p.IW = IW; p.Cin = Cin; p.OH = IH; p.OW = IW; p.M = rows * IH * IW; p.gn_hw = IH * IW;
+  p.A2 = (const half_t*)X2; p.lda2 = ldx2; p.K2 = K2;
+  if (gn_partial) {
+    SKG_REQUIRE(gn_args_ok(gn_partial, p.M, Cout, IH * IW, groups, ldy, flags));
+    p.gn_partial = gn_partial; p.gn_groups = groups;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  ws_attach(p, st);
+  return launch<MODE_S1>(p, st);
 }
 
 // ---- nearest-2x upsample + 3x3 conv, polyphase (include/skg.h) -----------------------------------------------------------

@@ -209,6 +209,10 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, int tiles_n, int
   const __amdgpu_buffer_rsrc_t rA =
       __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - a_shift), 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, b_bytes, 0x00020000);
+  // second A operand (the folded 1x1 shortcut, MODE_S1 only): plain row-major rows, no halo
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A2 ? p.A2 : p.A), 0, p.A2 ? ((unsigned)(p.M - 1) * (unsigned)p.lda2 + (unsigned)p.K2) * 2u : 0u, 0x00020000);
+  const int KT1 = (MODE == MODE_S1 && p.K2) ? (p.K - p.K2) / BK : (1 << 30);      // first K tile of the second operand
 
   // Persistent workgroups: the grid holds at most one resident wave of workgroups; each walks tiles
   // vb = blockIdx.x, blockIdx.x + gridDim.x, ...  A workgroup's s_endpgm waits for all of its stores to be
@@ -326,9 +330,24 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, int tiles_n, int
   // selects) and the individual instructions (`dma_one`, d = 0 .. ACH+BCH-1) so that the main loop can place each
   // instruction between MFMAs.  !live: every lane out of range -> zero fill, no memory traffic.
   const bool tap_minor = (p.flags & 0x1000u) != 0;
-  struct DmaStep { unsigned va[ACH]; unsigned vb[BCH]; unsigned soa, sob; };
+  struct DmaStep { unsigned va[ACH]; unsigned vb[BCH]; unsigned soa, sob; bool second; };
   auto dma_prepare = [&](int kt, bool live) {
     DmaStep d;
+    d.second = false;
+    if (MODE == MODE_S1 && kt >= KT1) {      // (wave-uniform) the shortcut operand: row m of A2, channels (kt - KT1) * 64 ..
+      d.second = true;
+#pragma unroll
+      for (int j = 0; j < ACH; ++j) {
+        const int r = (j * NW + wave) * 8 + lr;
+        const unsigned pk = (unsigned)(lq ^ ((r >> 1) & 7)) * 16u;
+        d.va[j] = (live && m0 + r < p.M) ? (unsigned)(m0 + r) * (unsigned)p.lda2 * 2u + pk : OOB;
+      }
+#pragma unroll
+      for (int j = 0; j < BCH; ++j) d.vb[j] = live ? b_voff[j] : OOB;
+      d.soa = (unsigned)(kt - KT1) * (BK * 2u);
+      d.sob = (unsigned)kt * (BK * 2u);          // the weight row is [9 taps x Cin | K2]: position kt * 64 either way
+      return d;
+    }
     const int k0 = kt * BK;
     unsigned soff = (unsigned)k0 * 2u;
     int tap = 0, ky = 0, kx = 0, c0 = 0;
@@ -394,7 +413,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, int tiles_n, int
     return d;
   };
   auto dma_one = [&](const DmaStep& d, int buf, int i) {     // buf, i: compile-time constants at every call site
-    if (i < ACH) dma16(rA, &smem[buf * STAGE + (i * NW + wave) * 8 * BK], d.va[i], d.soa);
+    if (i < ACH) dma16(d.second ? rA2 : rA, &smem[buf * STAGE + (i * NW + wave) * 8 * BK], d.va[i], d.soa);
     else dma16(rB, &smem[buf * STAGE + BM * BK + ((i - ACH) * NW + wave) * 8 * BK], d.vb[i - ACH], d.sob);
   };
 

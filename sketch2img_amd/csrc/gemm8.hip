@@ -67,6 +67,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
   const __amdgpu_buffer_rsrc_t rA =
       __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A - a_shift), 0, a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, b_bytes, 0x00020000);
+  // second A operand (the ResnetBlock's 1x1 shortcut folded in as K tiles past the 3x3 walk: gemm_params.h): plain rows, no halo
+  const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(p.A2 ? p.A2 : p.A), 0, p.A2 ? ((unsigned)(p.M - 1) * (unsigned)p.lda2 + (unsigned)p.K2) * 2u : 0u, 0x00020000);
+  const int KT1 = (MODE == MODE_S1 && p.K2) ? (p.K - p.K2) / BK : (1 << 30);
 
   // XCD-aware tile assignment (workgroup b -> XCD b % 8): every XCD owns a contiguous tile range, n fastest
   int lid;
@@ -137,6 +141,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
     unsigned soa, sob;
     int tap;
     const bool live = kt < KT;
+    if (MODE == MODE_S1 && live && kt >= KT1) {      // (wave-uniform) the shortcut operand: row m of A2, channels (kt - KT1) * 64 ..
+#pragma unroll
+      for (int j = 0; j < ACH; ++j) {
+        const int r = (j * NW + wave) * 8 + lr;
+        const unsigned pk = (unsigned)(lq ^ ((r >> 1) & 7)) * 16u;
+        dma16(rA2, &smem[buf * STAGE + (j * NW + wave) * 8 * BK], m0 + r < p.M ? (unsigned)(m0 + r) * (unsigned)p.lda2 * 2u + pk : OOB,
+              (unsigned)(kt - KT1) * (BK * 2u));
+      }
+      return;
+    }
     ktile(live ? kt : 0, soa, sob, tap);
 #pragma unroll
     for (int j = 0; j < ACH; ++j) {
@@ -150,6 +164,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm8_kernel(const GemmParams p, int 
     int tap;
     const bool live = kt < KT;
     ktile(live ? kt : 0, soa, sob, tap);
+    if (MODE == MODE_S1 && live && kt >= KT1) sob = (unsigned)kt * (BK * 2u);      // weight row = [9 taps x Cin | K2]
 #pragma unroll
     for (int j = 0; j < BCH; ++j) {
       half_t* dst = (j == BCH - 1 && last_b_idle) ? &smem[NS * STAGE] : &smem[buf * STAGE + BM * BK + (j * NW + wave) * 8 * BK];

@@ -31,6 +31,10 @@ struct GemmParams {
   // segmented output rows (skg_gemm_f16_rows): row m of the product is stored to row (m / seg_rows) * seg_stride + m % seg_rows
   // of C - one launch writes the image tokens of every batch row into its slot of a longer per-row buffer (0 = off)
   int seg_rows, seg_stride;
+  // conv2 + conv_shortcut as ONE implicit GEMM (skg_conv3x3_sc_f16, MODE_S1 only, round 5): K tiles past the 9 * Cin of the 3x3
+  // walk read a SECOND row-major operand A2 [M][lda2 >= K2] (the ResnetBlock's input x: the 1x1 shortcut as a tenth "tap"
+  // without halo) against columns [9 * Cin, 9 * Cin + K2) of the weight rows; K = 9 * Cin + K2 (0 = off)
+  const half_t* A2; int lda2, K2;
   // split-K workspace of the launch stream (host side: filled by the entry points from the per-stream registry of
   // skg_set_workspace; the kernels get the slab pointer as an argument)
   float* ws; size_t ws_bytes;

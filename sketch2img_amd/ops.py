@@ -350,6 +350,24 @@ def conv3x3(X: torch.Tensor, Wp: torch.Tensor, rows: int, IH: int, IW: int, mode
     return out
 
 
+def conv3x3_sc(X: torch.Tensor, X2: torch.Tensor, Wcat: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *,
+               bias=None, relu: bool = False, gn_groups: Optional[int] = None, out_lo=None):
+    """conv2 + conv_shortcut of a ResnetBlock as ONE implicit GEMM (skg_conv3x3_sc_f16): X [rows*IH*IW, Cin] the 3x3 input,
+    X2 [rows*IH*IW, K2] the block's input (accuracy mode: the pair buffer [x_hi | x_lo]), Wcat [Cout, 9*Cin + K2], bias =
+    conv2.bias + conv_shortcut.bias.  Returns out, or (out, GNPartial) with gn_groups.  Raises SkgError(rc = -2) when declined."""
+    _f16(X, X2, Wcat, bias, out_lo)
+    Cin, K2, Cout = X.shape[1], X2.shape[1], Wcat.shape[0]
+    assert Wcat.shape[1] == 9 * Cin + K2 and Wcat.is_contiguous() and X.shape[0] == X2.shape[0] == rows * IH * IW
+    if out is None:
+        out = torch.empty(rows * IH * IW, Cout, device=X.device, dtype=torch.float16)
+    assert out_lo is None or _ld(out_lo) == _ld(out)
+    part = GNPartial(rows, IH * IW, gn_groups, X.device) if gn_groups is not None else None
+    check(lib.skg_conv3x3_sc_f16(_p(X), _ld(X), _p(X2), _ld(X2), K2, _p(Wcat), _p(out), _p(out_lo), _ld(out), rows, IH, IW, Cin, Cout,
+                                 _p(bias), EPI_RELU if relu else 0, _p(part.buf) if part is not None else None,
+                                 gn_groups or 0, _stream()), "skg_conv3x3_sc_f16")
+    return (out, part) if part is not None else out
+
+
 def conv_up2(X: torch.Tensor, Wpp: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None, W9=None):
     """Nearest-2x upsample + 3x3 conv, polyphase (four 4-tap convs over the low-res input).  X [rows*IH*IW, Cin] (view),
     Wpp [4, Cout, 4*Cin] (unet.pack_conv_up2).  Returns [rows*2IH*2IW, Cout].  W9: the layer's ordinary 9-tap pack - the

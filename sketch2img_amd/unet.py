@@ -37,6 +37,7 @@ _XATTN_BLOCK = os.environ.get("SKG_XATTN_BLOCK", "1") != "0"        # fused cros
 _FF_KEEP = os.environ.get("SKG_FF_KEEP", "1") != "0"                # ... also for the cond rows of a guided step (stashing launch)
 _XATTN_KEEP = os.environ.get("SKG_XATTN_KEEP", "1") != "0"          # the fused cross-attention launch also in guided steps (stashing launch)
 _FF_PROJ = os.environ.get("SKG_FF_PROJ", "1") != "0"                # proj_out + outer residual inside the fused feed-forward launch
+_RES_SC = os.environ.get("SKG_RES_SC", "1") != "0"                  # conv2 + conv_shortcut of a ResnetBlock as one implicit GEMM (round 5)
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -290,6 +291,19 @@ class HipUNet:
                     W[k + ":T"] = _h(v.t(), dev)
             else:
                 W[k] = _h(_pad_vec(v, COUT_PAD) if k == "conv_out.bias" else v, dev)
+        # conv2 + conv_shortcut as ONE implicit GEMM (ops.conv3x3_sc): [conv2 tap-major pack | W_sc] along K, biases summed
+        if _RES_SC:
+            for k in list(sd.keys()):
+                if k.endswith(".conv_shortcut.weight"):
+                    r = k[: -len(".conv_shortcut.weight")]
+                    w2, wsc = sd[r + ".conv2.weight"], sd[k].reshape(sd[k].shape[0], sd[k].shape[1])
+                    if w2.shape[1] % 64 or wsc.shape[1] % 64:
+                        continue
+                    w2p = w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1)                   # [Cout][ky][kx][Cin] (pack_conv's order)
+                    W[r + ".conv2.weight:sc"] = _h(torch.cat([w2p, wsc], 1), dev)
+                    if self.residual_fp32:
+                        W[r + ".conv2.weight:sc2"] = _h(torch.cat([w2p, wsc, wsc], 1), dev)  # the pair operand [x_hi | x_lo] . [W | W]
+                    W[r + ".conv2.bias:sc"] = _h(sd[r + ".conv2.bias"].float() + sd[r + ".conv_shortcut.bias"].float(), dev)
         # FF1 (GEGLU projection): rows interleaved [a a g g] so the GEMM epilogue can gate in registers
         for k in list(sd.keys()):
             if k.endswith(".ff.net.0.proj.weight"):
@@ -434,16 +448,29 @@ class HipUNet:
         else:
             h1, part1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, bias=tb[p]), None
         n2, st2 = ops.groupnorm(h1, rows, HW, G, 1e-5, W[p + ".norm2.weight"], W[p + ".norm2.bias"], True, partial=part1)
-        if (p + ".conv_shortcut.weight") in W:
-            sc = ops.gemm(x, W[p + ".conv_shortcut.weight"], bias=W[p + ".conv_shortcut.bias"])
-        else:
-            sc = x
         opart = None
-        if want_part and fuse:
-            out, opart = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out, bias=W[p + ".conv2.bias"],
-                                     residual=sc, gn_groups=G)
-        else:
-            out = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out, bias=W[p + ".conv2.bias"], residual=sc)
+        done = False
+        if (p + ".conv2.weight:sc") in W:
+            # the 1x1 shortcut as K tiles behind conv2's 3x3 walk: one launch, no [M, Cout] round trip of the shortcut output
+            try:
+                if want_part and fuse:
+                    out, opart = ops.conv3x3_sc(n2, x, W[p + ".conv2.weight:sc"], rows, H, H, out=out, bias=W[p + ".conv2.bias:sc"], gn_groups=G)
+                else:
+                    out = ops.conv3x3_sc(n2, x, W[p + ".conv2.weight:sc"], rows, H, H, out=out, bias=W[p + ".conv2.bias:sc"])
+                done = True
+            except ops.SkgError as e:      # declined (an operand >= 2 GiB): the two launches
+                if e.rc != -2:
+                    raise
+        if not done:
+            if (p + ".conv_shortcut.weight") in W:
+                sc = ops.gemm(x, W[p + ".conv_shortcut.weight"], bias=W[p + ".conv_shortcut.bias"])
+            else:
+                sc = x
+            if want_part and fuse:
+                out, opart = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out, bias=W[p + ".conv2.bias"],
+                                         residual=sc, gn_groups=G)
+            else:
+                out = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out, bias=W[p + ".conv2.bias"], residual=sc)
         if stash is not None:
             stash.res[p] = dict(x=x, st1=st1, h1=h1, st2=st2, H=H, half=half)
         return out, opart
@@ -827,14 +854,27 @@ class HipUNet:
         n2, st2 = self._gn_hp(h1, rows, HW, 1e-5, p + ".norm2", True, partial=part1)
         if stash is not None:      # the backward differentiates the fp16 (hi) values, as in the default mode
             stash.res[p] = dict(x=x.hi, st1=st1, h1=h1.hi, st2=st2, H=H, half=half)
+        out = out or self._pair(M, Cout)
+        opart = None
+        if (p + ".conv2.weight:sc2") in W:
+            # conv2 + the K-doubled shortcut [x_hi | x_lo] . [W_sc | W_sc] in one launch, pair output
+            xf = x.full if x.full is not None else full_of(x, x.hi.shape[1])
+            try:
+                if want_part and fuse:
+                    _, opart = ops.conv3x3_sc(n2, xf, W[p + ".conv2.weight:sc2"], rows, H, H, out=out.hi, out_lo=out.lo,
+                                              bias=W[p + ".conv2.bias:sc"], gn_groups=G)
+                else:
+                    ops.conv3x3_sc(n2, xf, W[p + ".conv2.weight:sc2"], rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias:sc"])
+                return out, opart
+            except ops.SkgError as e:
+                if e.rc != -2:
+                    raise
         if (p + ".conv_shortcut.weight") in W:
             sc = self._pair(M, Cout)                                 # the stream as a matmul operand: [hi | lo] . [W | W]
             xf = x.full if x.full is not None else full_of(x, x.hi.shape[1])
             ops.gemm(xf, W[p + ".conv_shortcut.weight:2"], out=sc.hi, out_lo=sc.lo, bias=W[p + ".conv_shortcut.bias"])
         else:
             sc = x
-        out = out or self._pair(M, Cout)
-        opart = None
         if want_part and fuse:
             _, opart = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
                                    residual=sc.hi, residual_lo=sc.lo, gn_groups=G)

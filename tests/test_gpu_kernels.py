@@ -1127,6 +1127,55 @@ def test_mse_seed(ops):
     assert dO[:S * hw].abs().max() == 0 and dO[:, 4:].abs().max() == 0
 
 
+# ------------------------------------------------------------------------- conv2 + conv_shortcut as one implicit GEMM
+@pytest.mark.parametrize("rows,hw,cin,cout,cx,gn", [(16, 64, 320, 320, 640, True), (16, 64, 320, 320, 960, False), (8, 32, 640, 640, 1920, True),
+                                                    (8, 32, 640, 640, 320, False), (8, 16, 1280, 1280, 2560, False), (16, 8, 1280, 1280, 2560, False),
+                                                    (3, 32, 64, 160, 128, False)])
+def test_conv3x3_with_folded_shortcut(ops, rows, hw, cin, cout, cx, gn):
+    """skg_conv3x3_sc_f16 (round 5): Y = conv3x3(X) + X2 W_sc^T + bias with the 1x1 shortcut as K tiles behind the 3x3 walk - on the
+    256 x 320 ping-pong tile (64 x 64 level), the 128 x 160 tiles, split-K (the small maps) alike - against (a) fp32 torch,
+    (b) the two launches it replaces (the shortcut output is no longer rounded to fp16 on the way: rel <= 3e-4), and the GroupNorm
+    partial sums of the output against the stand-alone statistics of what was written; bit-repeatable."""
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(rows, cin, hw, hw, generator=g).half()
+    x2 = torch.randn(rows * hw * hw, cx, generator=g).half()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
+    wsc = (torch.randn(cout, cx, generator=g) * cx ** -0.5).half()
+    b = (torch.randn(cout, generator=g) * 0.1).half()
+    xn = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(d)
+    wp = w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous()
+    wcat = torch.cat([wp, wsc], 1).contiguous().to(d)
+    G = 32 if cout % 32 == 0 else 8
+    if gn:
+        y, part = ops.conv3x3_sc(xn, x2.to(d), wcat, rows, hw, hw, bias=b.to(d), gn_groups=G)
+    else:
+        y = ops.conv3x3_sc(xn, x2.to(d), wcat, rows, hw, hw, bias=b.to(d))
+    torch.cuda.synchronize()
+    nr = min(rows, 2)
+    ref = F.conv2d(x[:nr].float().to(d), w.float().to(d), b.float().to(d), padding=1).permute(0, 2, 3, 1).reshape(-1, cout) \
+        + x2[:nr * hw * hw].float().to(d) @ wsc.float().to(d).t()
+    r, _ = report(f"conv3x3 + shortcut rows{rows} {cin}->{cout} (+{cx}) @{hw} vs fp32", y[:nr * hw * hw].float().cpu(), ref.cpu())
+    assert r < 4e-4
+    sc = ops.gemm(x2.to(d), wsc.to(d))
+    y2 = ops.conv3x3(xn, wp.to(d), rows, hw, hw, 0, bias=b.to(d), residual=sc)
+    assert report("conv3x3 + shortcut vs the two launches", y.float().cpu(), y2.float().cpu())[0] < 4e-4
+    y3 = ops.conv3x3_sc(xn, x2.to(d), wcat, rows, hw, hw, bias=b.to(d))
+    assert torch.equal(y3, y)
+    if gn:
+        st = ops.groupnorm_stats(y, rows, hw * hw, G, 1e-5)
+        gam, bet = torch.ones(cout).half().to(d), torch.zeros(cout).half().to(d)
+        n_ref = ops.groupnorm_apply(y, rows, hw * hw, G, st, gam, bet, False)
+        n_par, _ = ops.groupnorm(y, rows, hw * hw, G, 1e-5, gam, bet, False, partial=part)
+        assert report("GroupNorm from the fused launch's partial sums", n_par.float().cpu(), n_ref.float().cpu())[0] < 2e-4
+    # pair output (accuracy mode): hi + lo carries the fp32 result
+    lo = torch.empty_like(y)
+    hi = torch.empty_like(y)
+    ops.conv3x3_sc(xn, x2.to(d), wcat, rows, hw, hw, out=hi, out_lo=lo, bias=b.to(d))
+    rp, _ = report("conv3x3 + shortcut, pair output vs fp32", (hi[:nr * hw * hw].float() + lo[:nr * hw * hw].float()).cpu(), ref.cpu())
+    assert rp < 1e-4 and torch.equal(hi, y)
+
+
 # ---------------------------------------------------------------------------------------------- sampler pointwise
 def test_cfg_ddim_and_guidance_update(ops):
     from sketch2img_amd.sampler import DDIMTables

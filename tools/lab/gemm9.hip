@@ -341,7 +341,7 @@ int gemm9_tile(const GemmParams& p, int mode) {
   if (mode == MODE_S1 && p.Cin % BK != 0) return 0;
   if (p.flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)) return 0;
   if (p.c_lo || p.res_lo) return 0;
-  if (p.ntaps || p.up2 || p.seg_rows) return 0;
+  if (p.ntaps || p.up2 || p.seg_rows || p.K2) return 0;
   if (p.ldc % 8 != 0 || (p.res && p.ldr % 8 != 0)) return 0;
   if (!skg_aligned(p.C, 16) || (p.res && !skg_aligned(p.res, 16)) || (p.bias && !skg_aligned(p.bias, 16))) return 0;
   unsigned long long a, b, s;

@@ -181,7 +181,7 @@ bool ws_enabled() {
 
 bool skg_gemmws_eligible(const GemmParams& p, int mode) {
   if (!ws_enabled() || mode != MODE_DIRECT || p.N != WN || p.K != WK || p.M < 32768) return false;
-  if (p.flags || p.gn_partial || p.aux || p.c_lo || p.res_lo || p.ntaps || p.up2) return false;
+  if (p.flags || p.gn_partial || p.aux || p.c_lo || p.res_lo || p.ntaps || p.up2 || p.K2) return false;
   if (p.lda % 8 || p.ldb % 8 || p.ldc % 8 || (p.res && p.ldr % 8)) return false;
   if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C) |
        reinterpret_cast<uintptr_t>(p.res)) & 15)
