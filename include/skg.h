@@ -277,6 +277,15 @@ int skg_ff_block_proj_f16(const void* X, int ldx, void* Y, int ldy, int M, int C
                           float eps, const void* Wpack, const float* bias1_pack, const void* bias2, const void* bias_proj,
                           const void* R, int ldr, float* stats, void* H, int ldh, int keep_from, float* gn_partial, int HW,
                           int groups, void* stream);
+
+/* Accuracy mode (round 5): skg_ff_block_proj_f16 on pairs - X + X_lo in (pitch ldx), Y + Y_lo out (pitch ldy), outer residual
+ * R + R_lo (pitch ldr).  proj_out takes the block output as the pair it is, W_proj . hi + W_proj . lo on the same weight
+ * fragments (the K-doubled [p3_hi | p3_lo] . [W | W] GEMM of the unfused accuracy-mode path, without its second weight read and
+ * without the [M, 2C] round trip of p3); gn_partial: the GroupNorm partial sums of Y's hi part.  Y must not alias X. */
+int skg_ff_block_proj_f16_hilo(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int M, int C, int F,
+                               const void* gamma, const void* beta, float eps, const void* Wpack, const float* bias1_pack,
+                               const void* bias2, const void* bias_proj, const void* R, const void* R_lo, int ldr, float* stats,
+                               void* H, int ldh, int keep_from, float* gn_partial, int HW, int groups, void* stream);
 /* Accuracy mode: the same launch on a PAIR input X + X_lo (pitch ldx) with a PAIR output Y + Y_lo (pitch ldy): LayerNorm reads
  * the sum, the residual sum is formed in fp32 and stored as hi = fp16(v), lo = fp16(v - hi).  H / keep_from as _keep (or NULL). */
 int skg_ff_block_f16_hilo(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int M, int C, int F,

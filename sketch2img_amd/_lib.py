@@ -52,6 +52,7 @@ SIGNATURES = {
     "skg_ff_block_f16": ("i", "pipiiiippfppppp"),
     "skg_ff_block_f16_keep": ("i", "pipiiiippfpppppiip"),
     "skg_ff_block_proj_f16": ("i", "pipiiiippfpppppippiipiip"),
+    "skg_ff_block_proj_f16_hilo": ("i", "ppippiiiippfppppppippiipiip"),
     "skg_xattn_block_f16": ("i", "pipiiiiiippfpppfp"),
     "skg_xattn_block_f16_hilo": ("i", "ppippiiiiiippfpppfp"),
     "skg_xattn_block_f16_keep": ("i", "pipiiiiiippfpppfpppipip"),

@@ -47,6 +47,7 @@ struct FFParams {
   // behind the nch feed-forward ones (their 40 W1-slot pieces = 4 output tiles x 10 k-steps of W_proj, k order permuted to the
   // accumulator layout), Y = R + bp + W_proj . fp16(X + FF(X)); optionally the GroupNorm partial sums of Y
   const half_t* bp; const half_t* R; int ldr;
+  const half_t* Rl;        // HILO + PROJ (skg_ff_block_proj_f16_hilo): the outer residual is the pair R + Rl (pitch ldr)
   float* gn_partial; int gn_hw, gn_groups;
   int nch_w1;              // W1-slot chunks the weight pack holds: nch, or nch + 5 with PROJ
 };
@@ -61,7 +62,7 @@ constexpr int MAXCH = 40;
 // stored as hi = fp16(v), lo = fp16(v - hi); everything between is the same kernel
 template <int KS, int PROBE = 0, int SCHED = 0, bool HILO = false, bool PROJ = false>
 __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
-  static_assert(!PROJ || (!HILO && PROBE == 0 && KS == 10), "the proj_out phase exists for the plain C = 320 kernel");
+  static_assert(!PROJ || (PROBE == 0 && KS == 10), "the proj_out phase exists for the C = 320 kernel");
   constexpr int C = 32 * KS, NU = C / 16, N1 = 4 * KS, NP = N1 + NU, PIECE = 512;
   constexpr int W1ST = N1 * PIECE, W2ST = NU * PIECE;      // halves per ring stage
   constexpr int W2OFF = 2 * W1ST, DUMP = W2OFF + 2 * W2ST, RING = DUMP + (64 - NP) * PIECE;
@@ -369,14 +370,24 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
     // store) becomes the B operand - accumulator tiles 2 ks, 2 ks + 1 are k-slots 8 g + i <-> channel 32 ks + 16 (i >> 2) + 4 g + (i & 3),
     // the order the proj chunks of the pack are written in - and y restarts from the proj bias.  Chunk nch + j = output tiles
     // 4 j .. 4 j + 3.
-    half8_t yb[KS];
+    // (HILO: the block output is the pair p3 = hi + lo and proj_out takes both - W . hi + W . lo on the SAME weight fragments: the
+    // K-doubled GEMM of the unfused accuracy-mode path at the price of 40 more MFMAs per chunk and no second weight read)
+    half8_t yb[KS], ybl[HILO ? KS : 1];
     {
       const half_t* xr = p.X + (size_t)mload * p.ldx + 4 * g;
+      const half_t* xlr = HILO ? p.Xl + (size_t)mload * p.ldx + 4 * g : nullptr;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
         const half4_t r4 = ld_half4(xr + 16 * u);
+        half4_t l4 = {0, 0, 0, 0};
+        if constexpr (HILO) l4 = ld_half4(xlr + 16 * u);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) yb[u >> 1][4 * (u & 1) + r] = (half_t)(y[u][r] + (float)r4[r]);
+        for (int r = 0; r < 4; ++r) {
+          const float v = y[u][r] + (float)r4[r] + (HILO ? (float)l4[r] : 0.f);
+          const half_t hi = (half_t)v;
+          yb[u >> 1][4 * (u & 1) + r] = hi;
+          if constexpr (HILO) ybl[u >> 1][4 * (u & 1) + r] = (half_t)(v - (float)hi);
+        }
       }
     }
 #pragma unroll
@@ -403,6 +414,10 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
         for (int t = 0; t < 4; ++t) wf[t] = ld_half8(fr + (t * KS + ks) * PIECE);
 #pragma unroll
         for (int t = 0; t < 4; ++t) y[4 * j + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], yb[ks], y[4 * j + t], 0, 0, 0);
+        if constexpr (HILO) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) y[4 * j + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t], ybl[ks], y[4 * j + t], 0, 0, 0);
+        }
         if (ks < 5 && j < 3) dma_proj(j + 2, regn, ks);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -412,13 +427,39 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
   // ---- epilogue: the wave's Y^T tile through its own slice of the (now idle) ring, then whole-row 16-byte pieces:
   // residual read + store are 10 KB contiguous per wave when the rows are dense
   lds_barrier();
+  // PROJ: GroupNorm partial sums of the 128 x 320 output tile (layout of gemm2.hip's epilogue: [sample][128-row chunk][group][2]): lane
+  // j < 32 of every wave sums its group's 10 channels over the wave's 16 staged rows (fp16 values - HILO: of the hi part -, fp32 sums),
+  // the eight waves' figures meet in the dead FF1-bias area and wave 0 adds them in wave order - fixed order, no atomics
+  auto gn_from_stage = [&](const half_t* stg) {
+    const int cpg = C / p.gn_groups;
+    float s1 = 0.f, s2 = 0.f;
+    if (lane < p.gn_groups) {
+      for (int row = 0; row < 16; ++row) {
+        if (m0 + row >= p.M) break;
+        const half_t* q = stg + row * OP + lane * cpg;
+        for (int i = 0; i < cpg; ++i) { const float v = (float)q[i]; s1 += v; s2 += v * v; }
+      }
+      bs[(wave * 32 + lane) * 2] = s1;
+      bs[(wave * 32 + lane) * 2 + 1] = s2;
+    }
+    lds_barrier();
+    if (wave == 0 && lane < p.gn_groups) {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { t1 += bs[(w * 32 + lane) * 2]; t2 += bs[(w * 32 + lane) * 2 + 1]; }
+      const int mb = blockIdx.x * 128, b = mb / p.gn_hw, chunk = (mb - b * p.gn_hw) >> 7, nchk = p.gn_hw >> 7;
+      float* dst = p.gn_partial + (((size_t)b * nchk + chunk) * p.gn_groups + lane) * 2;
+      dst[0] = t1; dst[1] = t2;
+    }
+  };
   if constexpr (HILO) {
   half_t* const stg = smem + wave * (16 * OP);
   constexpr int PPR = C / 8;                              // 16-byte pieces per row
   {   // the pair residual joins the accumulators first (ONE read of X: Y may alias X), then hi and lo are staged and stored in
       // two passes through the same wave-private slice (LDS operations of a wave execute in order)
-    const half_t* xr = p.X + (size_t)mload * p.ldx + 4 * g;
-    const half_t* xlr = p.Xl + (size_t)mload * p.ldx + 4 * g;
+      // (PROJ: the OUTER residual pair - the transformer's input - joins here; X + FF went into the proj_out operand above)
+    const half_t* xr = PROJ ? p.R + (size_t)mload * p.ldr + 4 * g : p.X + (size_t)mload * p.ldx + 4 * g;
+    const half_t* xlr = PROJ ? p.Rl + (size_t)mload * p.ldr + 4 * g : p.Xl + (size_t)mload * p.ldx + 4 * g;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const half4_t r4 = ld_half4(xr + 16 * u), l4 = ld_half4(xlr + 16 * u);
@@ -441,6 +482,12 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
       const int pi = lane + 64 * j;
       const int row = pi / PPR, pc = pi - row * PPR;
       if (m0 + row < p.M) st_half8(dst + (size_t)(m0 + row) * p.ldy + pc * 8, ld_half8(stg + row * OP + pc * 8));
+    }
+    if constexpr (PROJ) {
+      if (part == 0 && p.gn_partial) {      // (workgroup-uniform) statistics of the hi part, before the lo pass reuses the slice
+        gn_from_stage(stg);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     }
   }
   } else {
@@ -469,31 +516,7 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
     }
   }
   if constexpr (PROJ) {
-    // GroupNorm partial sums of the 128 x 320 output tile (layout of gemm2.hip's epilogue: [sample][128-row chunk][group][2]): lane j < 32
-    // of every wave sums its group's 10 channels over the wave's 16 staged rows (fp16 values, fp32 sums), the eight waves' figures
-    // meet in the dead FF1-bias area and wave 0 adds them in wave order - fixed order, no atomics
-    if (p.gn_partial) {
-      const int cpg = C / p.gn_groups;
-      float s1 = 0.f, s2 = 0.f;
-      if (lane < p.gn_groups) {
-        for (int row = 0; row < 16; ++row) {
-          if (m0 + row >= p.M) break;
-          const half_t* q = stg + row * OP + lane * cpg;
-          for (int i = 0; i < cpg; ++i) { const float v = (float)q[i]; s1 += v; s2 += v * v; }
-        }
-        bs[(wave * 32 + lane) * 2] = s1;
-        bs[(wave * 32 + lane) * 2 + 1] = s2;
-      }
-      lds_barrier();
-      if (wave == 0 && lane < p.gn_groups) {
-        float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) { t1 += bs[(w * 32 + lane) * 2]; t2 += bs[(w * 32 + lane) * 2 + 1]; }
-        const int mb = blockIdx.x * 128, b = mb / p.gn_hw, chunk = (mb - b * p.gn_hw) >> 7, nchk = p.gn_hw >> 7;
-        float* dst = p.gn_partial + (((size_t)b * nchk + chunk) * p.gn_groups + lane) * 2;
-        dst[0] = t1; dst[1] = t2;
-      }
-    }
+    if (p.gn_partial) gn_from_stage(stg);
   }
   }
 }
@@ -503,9 +526,11 @@ __global__ __launch_bounds__(512, 1) void ff_block_kernel(const FFParams p) {
 static int ff_block_impl(const void* X, const void* Xl, int ldx, void* Y, void* Yl, int ldy, int M, int C, int F, const void* gamma,
                          const void* beta, float eps, const void* Wpack, const float* bias1_pack, const void* bias2,
                          float* stats, void* H, int ldh, int keep_from, void* stream, const void* bias_proj = nullptr,
-                         const void* R = nullptr, int ldr = 0, float* gn_partial = nullptr, int gn_hw = 0, int gn_groups = 0) {
+                         const void* R = nullptr, int ldr = 0, float* gn_partial = nullptr, int gn_hw = 0, int gn_groups = 0,
+                         const void* Rl = nullptr) {
   SKG_REQUIRE(X && Y && gamma && beta && Wpack && bias1_pack && bias2 && M > 0 && (Xl != nullptr) == (Yl != nullptr));
-  SKG_REQUIRE(!bias_proj || (!Xl && R && ldr % 4 == 0 && ldr >= C && skg_aligned(bias_proj, 8) && skg_aligned(R, 8) && X != Y));
+  SKG_REQUIRE(!bias_proj || (R && (Rl != nullptr) == (Xl != nullptr) && ldr % 4 == 0 && ldr >= C && skg_aligned(bias_proj, 8) && skg_aligned(R, 8) &&
+                             skg_aligned(Rl, 8) && X != Y));
   SKG_REQUIRE(!gn_partial || (bias_proj && gn_groups > 0 && gn_groups <= 32 && C % gn_groups == 0 && gn_hw % 128 == 0 && M % gn_hw == 0));
   SKG_REQUIRE(!H || (ldh % 8 == 0 && ldh >= 2 * F && keep_from >= 0 && keep_from % 16 == 0 && keep_from < M && skg_aligned(H, 16)));
   SKG_REQUIRE(C == 320 && F % 32 == 0 && F / 32 <= MAXCH && F >= 64);
@@ -520,7 +545,7 @@ static int ff_block_impl(const void* X, const void* Xl, int ldx, void* Y, void* 
   p.nch = F / 32;
   p.nch_w1 = p.nch + (bias_proj ? 5 : 0);
   p.wbytes = (unsigned)p.nch_w1 * 60u * 1024u;
-  p.bp = (const half_t*)bias_proj; p.R = (const half_t*)R; p.ldr = ldr;
+  p.bp = (const half_t*)bias_proj; p.R = (const half_t*)R; p.ldr = ldr; p.Rl = (const half_t*)Rl;
   p.gn_partial = gn_partial; p.gn_hw = gn_hw; p.gn_groups = gn_groups;
   p.stats = stats;
   p.keep = (half_t*)H; p.ldkeep = ldh; p.keep_from = keep_from;
@@ -544,7 +569,8 @@ static int ff_block_impl(const void* X, const void* Xl, int ldx, void* Y, void* 
     return SKG_OK;
   }
 #endif
-  if (bias_proj) hipLaunchKernelGGL((ff_block_kernel<10, 0, 0, false, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  if (bias_proj && Xl) hipLaunchKernelGGL((ff_block_kernel<10, 0, 0, true, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else if (bias_proj) hipLaunchKernelGGL((ff_block_kernel<10, 0, 0, false, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
   else if (Xl) hipLaunchKernelGGL((ff_block_kernel<10, 0, 0, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((ff_block_kernel<10>), grid, dim3(512), 0, (hipStream_t)stream, p);
   SKG_CHECK_LAUNCH("skg_ff_block_f16");
@@ -574,6 +600,17 @@ extern "C" int skg_ff_block_proj_f16(const void* X, int ldx, void* Y, int ldy, i
   SKG_REQUIRE(bias_proj && R);
   return ff_block_impl(X, nullptr, ldx, Y, nullptr, ldy, M, C, F, gamma, beta, eps, Wpack, bias1_pack, bias2, stats, H, ldh, keep_from, stream,
                        bias_proj, R, ldr, gn_partial, HW, groups);
+}
+
+// accuracy mode, round 5: skg_ff_block_proj_f16 on pairs - X + X_lo in, Y + Y_lo out, outer residual R + R_lo (pitch ldr); proj_out takes
+// the block output as the pair it is (W . hi + W . lo on the same weight fragments); gn_partial: statistics of Y's hi part
+extern "C" int skg_ff_block_proj_f16_hilo(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int M, int C, int F,
+                                          const void* gamma, const void* beta, float eps, const void* Wpack, const float* bias1_pack,
+                                          const void* bias2, const void* bias_proj, const void* R, const void* R_lo, int ldr, float* stats,
+                                          void* H, int ldh, int keep_from, float* gn_partial, int HW, int groups, void* stream) {
+  SKG_REQUIRE(X_lo && Y_lo && bias_proj && R && R_lo);
+  return ff_block_impl(X, X_lo, ldx, Y, Y_lo, ldy, M, C, F, gamma, beta, eps, Wpack, bias1_pack, bias2, stats, H, ldh, keep_from, stream,
+                       bias_proj, R, ldr, gn_partial, HW, groups, R_lo);
 }
 
 // accuracy mode: the same launch on a pair input X + X_lo (pitch ldx) with a pair output Y + Y_lo (pitch ldy); H / keep_from as _keep

@@ -254,6 +254,22 @@ def ff_block_proj(X, gamma, beta, eps: float, pack: torch.Tensor, bias1_pack: to
     out = R + bias_proj + W_proj . fp16(X + FF(LayerNorm(X))); pack = unet.pack_ff_block(..., w_proj) (five chunks more).
     gn = (HW, groups): also the GroupNorm partial sums of out.  Returns (out, stats | None, pre | None, GNPartial | None);
     out must not be X (it may be R)."""
+    pair = isinstance(X, Pair)
+    if pair:      # accuracy mode: X, R and out are pairs (skg_ff_block_proj_f16_hilo)
+        _f16(X.hi, X.lo, gamma, beta, pack, bias2, bias_proj, R.hi, R.lo)
+        M, C = X.hi.shape
+        F = (pack.shape[0] - 5) * 32
+        assert pack.is_contiguous() and pack.shape[1:] == (60, 512) and bias1_pack.shape[0] * 32 == F and out is not None
+        assert _ld(X.lo) == _ld(X.hi) and _ld(out.lo) == _ld(out.hi) and _ld(R.lo) == _ld(R.hi)
+        dev = X.hi.device
+        stats = torch.empty(M, 2, device=dev, dtype=torch.float32) if want_stats else None
+        pre = None if keep_from is None else torch.empty(M - keep_from, 2 * F, device=dev, dtype=torch.float16)
+        part = GNPartial(M // gn[0], gn[0], gn[1], dev) if gn is not None else None
+        check(lib.skg_ff_block_proj_f16_hilo(_p(X.hi), _p(X.lo), _ld(X.hi), _p(out.hi), _p(out.lo), _ld(out.hi), M, C, F, _p(gamma), _p(beta), eps,
+                                             _p(pack), _p(bias1_pack), _p(bias2), _p(bias_proj), _p(R.hi), _p(R.lo), _ld(R.hi), _p(stats), _p(pre),
+                                             _ld(pre) if pre is not None else 0, keep_from or 0, _p(part.buf) if part is not None else None,
+                                             gn[0] if gn else 0, gn[1] if gn else 0, _stream()), "skg_ff_block_proj_f16_hilo")
+        return out, stats, pre, part
     _f16(X, gamma, beta, pack, bias2, bias_proj, R)
     M, C = X.shape
     assert pack.is_contiguous() and pack.dim() == 3 and pack.shape[1:] == (60, 512) and bias1_pack.dtype == torch.float32

@@ -37,6 +37,7 @@ _XATTN_BLOCK = os.environ.get("SKG_XATTN_BLOCK", "1") != "0"        # fused cros
 _FF_KEEP = os.environ.get("SKG_FF_KEEP", "1") != "0"                # ... also for the cond rows of a guided step (stashing launch)
 _XATTN_KEEP = os.environ.get("SKG_XATTN_KEEP", "1") != "0"          # the fused cross-attention launch also in guided steps (stashing launch)
 _FF_PROJ = os.environ.get("SKG_FF_PROJ", "1") != "0"                # proj_out + outer residual inside the fused feed-forward launch
+_FF_PROJ_HP = os.environ.get("SKG_FF_PROJ_HP", "1") != "0"          # ... in the accuracy mode too (skg_ff_block_proj_f16_hilo, round 5)
 _RES_SC = os.environ.get("SKG_RES_SC", "1") != "0"                  # conv2 + conv_shortcut of a ResnetBlock as one implicit GEMM (round 5)
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
@@ -944,6 +945,21 @@ class HipUNet:
                      residual=p1.hi, residual_lo=p1.lo)
         ffb = _FF_BLOCK and (t + ".ff.pack") in W and (not keep or (rows % 2 == 0 and _FF_KEEP))
         f = None
+        ffp = ffb and _FF_PROJ and _FF_PROJ_HP and (t + ".ff.packp") in W and HW % 128 == 0
+        if ffp:
+            # ... with proj_out (on the pair p3 = hi + lo: W . hi + W . lo on the same fragments) and the outer residual pair in the
+            # same launch (skg_ff_block_proj_f16_hilo): the K-doubled proj_out GEMM and the [M, 2C] round trip of p3 disappear
+            out = out or self._pair(M, C)
+            gn = (HW, self.cfg.norm_groups) if want_part and self._gn_from_producer(rows, HW, C) else None
+            _, st3, f, opart = ops.ff_block_proj(p2, W[t + ".norm3.weight"], W[t + ".norm3.bias"], 1e-5, W[t + ".ff.packp"], W[t + ".ff.bias1"],
+                                                 W[t + ".ff.net.2.bias"], W[p + ".proj_out.bias"], x, out=out, want_stats=keep,
+                                                 keep_from=(rows // 2) * HW if keep else None, gn=gn)
+            if keep:
+                own = r1 != rows and self.inject is None
+                ent = dict(x=(x_c if own else x).hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=(p1_c if own else p1).hi,
+                           st2=st2, q2=q2_c if own else q2)
+                stash.tr[p] = dict(ent, o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=self._stash_half(ent, r1, rows, HW))
+            return out, opart
         if ffb:
             # C = 320: norm3 -> FF1 -> gate -> FF2 + residual in ONE row-local launch on the pair (guided steps: the same launch
             # stores the cond rows' FF1 output and norm3's statistics for the backward)

@@ -1414,6 +1414,58 @@ def test_ff_block_with_proj_out(ops, rows, HW):
     assert torch.equal(again, y)
 
 
+@pytest.mark.parametrize("rows,HW", [(2, 1024), (4, 4096)])
+def test_ff_block_with_proj_out_pairs(ops, rows, HW):
+    """skg_ff_block_proj_f16_hilo (accuracy mode, round 5): pair in, pair out, pair outer residual; proj_out takes the block output as
+    the pair it is.  Against the fp32 definition on the fp32 value of the input pairs (hi + lo of the output: rel <= 3e-4 - the
+    roundings left are the fp16 MFMA operands inside), against the two launches it replaces (skg_ff_block_f16_hilo, then the
+    K-doubled skg_gemm_f16_hilo_gn), the stash against skg_ff_block_f16_hilo's, GroupNorm from the partial sums."""
+    from sketch2img_amd.ops import Pair
+    from sketch2img_amd.unet import pack_ff_block
+    d = dev()
+    C, Fh, M, G = 320, 1280, rows * HW, 32
+
+    def pair_of(t32):
+        pr = Pair.empty(M, C, d)
+        hi = t32.half()
+        pr.hi.copy_(hi.to(d)); pr.lo.copy_((t32 - hi.float()).half().to(d))
+        return pr
+
+    x32, r32 = rnd(M, C, seed=71).float() * 1.0003, rnd(M, C, seed=72).float() * 0.9997      # (values that need their lo parts)
+    X, R = pair_of(x32), pair_of(r32)
+    xv, rv = (X.hi.float() + X.lo.float()), (R.hi.float() + R.lo.float())
+    gam, bet = (1 + 0.2 * rnd(C, seed=73).float()).half().to(d), (0.1 * rnd(C, seed=74).float()).half().to(d)
+    w1, b1 = rnd(2 * Fh, C, seed=75, scale=C ** -0.5), rnd(2 * Fh, seed=76, scale=0.1)
+    w2, b2 = rnd(C, Fh, seed=77, scale=Fh ** -0.5), rnd(C, seed=78, scale=0.1).to(d)
+    wp, bp = rnd(C, C, seed=79, scale=C ** -0.5), rnd(C, seed=80, scale=0.1).to(d)
+    pack, bias1 = pack_ff_block(w1, b1, w2, d)
+    packp, _ = pack_ff_block(w1, b1, w2, d, w_proj=wp)
+    kf = (rows // 2) * HW
+    p3, st0, pre0 = ops.ff_block(X, gam, bet, 1e-5, pack, bias1, b2, want_stats=True, keep_from=kf)
+    y2 = Pair.empty(M, C, d)
+    w2x = torch.cat([wp, wp], 1).contiguous().to(d)
+    _, part2 = ops.gemm(p3.full, w2x, out=y2.hi, out_lo=y2.lo, bias=bp, residual=R.hi, residual_lo=R.lo, gn_stats=(HW, G))
+    out = Pair.empty(M, C, d)
+    y, st, pre, part = ops.ff_block_proj(X, gam, bet, 1e-5, packp, bias1, b2, bp, R, out=out, want_stats=True, keep_from=kf, gn=(HW, G))
+    sel = slice(0, min(M, 8192))
+    a = F.layer_norm(xv[sel], (C,), gam.float(), bet.float(), 1e-5)
+    hid = a @ w1.float().to(d).t() + b1.float().to(d)
+    p3f = xv[sel] + (hid[:, :Fh] * F.gelu(hid[:, Fh:])) @ w2.float().to(d).t() + b2.float()
+    ref = rv[sel] + p3f @ wp.float().to(d).t() + bp.float()
+    yv, y2v = y.hi.float() + y.lo.float(), y2.hi.float() + y2.lo.float()
+    e, e2 = rel_err(yv[sel], ref), rel_err(yv, y2v)
+    print(f"[parity] ff_block_proj on pairs rows{rows} HW{HW}: hi + lo rel {e:.2e} vs fp32 (hi alone {rel_err(y.hi[sel], ref):.2e}), "
+          f"{e2:.2e} vs ff_block_hilo + K-doubled gemm")
+    assert e < 3e-4 and e2 < 2e-4
+    assert torch.equal(st, st0) and torch.equal(pre, pre0)
+    gnw, gnb = (1 + 0.1 * rnd(C, seed=81).float()).half().to(d), (0.1 * rnd(C, seed=82).float()).half().to(d)
+    ga, _ = ops.groupnorm(y.hi.contiguous(), rows, HW, G, 1e-6, gnw, gnb, False, partial=part)
+    gb, _ = ops.groupnorm(y.hi.contiguous(), rows, HW, G, 1e-6, gnw, gnb, False)
+    assert rel_err(ga, gb) < 1e-3
+    y3 = ops.ff_block_proj(X, gam, bet, 1e-5, packp, bias1, b2, bp, R, out=Pair.empty(M, C, d))[0]
+    assert torch.equal(y3.hi, y.hi) and torch.equal(y3.lo, y.lo)
+
+
 def test_ff_block_keep_stores_the_pre_activation(ops):
     """skg_ff_block_f16_keep: the cond rows of a guided step (rows >= keep_from) also get the FF1 output in the interleaved pack
     order - what skg_gemm_f16_geglu_keep writes and skg_geglu_bwd reads.  Same MFMA products and the same fp16 rounding as the
