@@ -317,6 +317,12 @@ int skg_xattn_block_f16_keep(const void* X, int ldx, void* Y, int ldy, int M, in
                              const void* gamma, const void* beta, float eps, const void* Wpack, const void* KVpack,
                              const void* bias_out, float scale, float* stats, void* Q, void* O, int ldk, float* lse,
                              int keep_from, void* stream);
+/* ... on pairs (accuracy mode, round 5): skg_xattn_block_f16_hilo that also stores, for the rows >= keep_from, what the backward of
+ * the replaced launches reads (stats, Q, O, lse as skg_xattn_block_f16_keep). */
+int skg_xattn_block_f16_hilo_keep(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int M, int HW, int C,
+                                  int heads, int Nkv, const void* gamma, const void* beta, float eps, const void* Wpack,
+                                  const void* KVpack, const void* bias_out, float scale, float* stats, void* Q, void* O, int ldk,
+                                  float* lse, int keep_from, void* stream);
 /* Accuracy mode: the same launch on a PAIR input X + X_lo (pitch ldx) with a PAIR output Y + Y_lo (pitch ldy). */
 int skg_xattn_block_f16_hilo(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int M, int HW, int C,
                              int heads, int Nkv, const void* gamma, const void* beta, float eps, const void* Wpack,
@@ -367,6 +373,12 @@ int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, const void* 
                     const void* dO, int lddo, const float* lse,
                     const float* delta, void* dQ, int lddq, int batch, int heads, int Nq, int Nkv,
                     int kv_stride, int dh, float scale, void* stream);
+/* skg_attn_bwd_dq with skg_attn_bwd_delta in its prologue (round 5): O [batch*Nq][ldo] is the forward's output; delta is formed from
+ * the dO fragments the launch loads anyway, used, and stored to delta_out [batch][heads][Nq] for the skg_attn_bwd_dkv launch
+ * that follows (summation order differs from skg_attn_bwd_delta's: equal to fp32 rounding, not bit for bit). */
+int skg_attn_bwd_dq_delta(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int lddo,
+                          const void* O, int ldo, const float* lse, float* delta_out, void* dQ, int lddq, int batch, int heads,
+                          int Nq, int Nkv, int kv_stride, int dh, float scale, void* stream);
 int skg_attn_bwd_dkv(const void* Q, int ldq, const void* K, int ldk,
                      const void* V, int ldv, const void* dO, int lddo,
                      const float* lse, const float* delta, void* dK, int lddk, void* dV, int lddv,

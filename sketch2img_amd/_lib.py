@@ -55,6 +55,7 @@ SIGNATURES = {
     "skg_ff_block_proj_f16_hilo": ("i", "ppippiiiippfppppppippiipiip"),
     "skg_xattn_block_f16": ("i", "pipiiiiiippfpppfp"),
     "skg_xattn_block_f16_hilo": ("i", "ppippiiiiiippfpppfp"),
+    "skg_xattn_block_f16_hilo_keep": ("i", "ppippiiiiiippfpppfpppipip"),
     "skg_xattn_block_f16_keep": ("i", "pipiiiiiippfpppfpppipip"),
     "skg_gemm_variant": ("i", "iiiii"),
     "skg_set_workspace": ("i", "pzp"),
@@ -76,6 +77,7 @@ SIGNATURES = {
     "skg_attn_fwd_rowv": ("i", "pipipipipiiiiiifp"),
     "skg_attn_bwd_delta": ("i", "pipipiiiip"),
     "skg_attn_bwd_dq": ("i", "pipipipipppiiiiiiifp"),
+    "skg_attn_bwd_dq_delta": ("i", "pipipipipipppiiiiiiifp"),
     "skg_attn_bwd_dkv": ("i", "pipipipipppipiiiiiifp"),
     "skg_transpose_f16": ("i", "pipiiip"),
     "skg_axpby_f16": ("i", "pipipiiiffp"),

@@ -36,6 +36,8 @@ struct AttnParams {
   half_t* O2; int ldo2;           // dkv: dV
   float* lse;                     // [batch][heads][Nq]
   const float* delta;             // [batch][heads][Nq]
+  const half_t* Of; int ldof;     // dq with the delta prologue (skg_attn_bwd_dq_delta): the forward's O, and where delta is also stored
+  float* delta_out;
   int batch, heads, Nq, Nkv, kv_stride, dh;
   float scale;
   int nx;                         // workgroups per (batch row, head): launches are 1-D, nx * heads * batch
@@ -1120,7 +1122,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     }
     const size_t sidx = ((size_t)b * p.heads + h) * p.Nq + (qok[i] ? q[i] : 0);
     // minus lse (log2 domain) and minus delta ride in as the C operands of the S and dP MFMAs (see the forward)
-    const float nl = qok[i] ? -p.lse[sidx] * LOG2E : NEG_BIG, nd = qok[i] ? -p.delta[sidx] : 0.f;
+    float dl;
+    if (p.Of) {      // (launch-uniform) delta = sum_c O dO of this query from the dO fragments already in registers: the four lanes of a
+                     // query hold 8 channels of every 32 each; the sum also goes to delta_out for the dK / dV launch
+      float sm = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c = 32 * ks + 8 * g;
+        if (qok[i] && c < dh) {
+          const half8_t of = ld_half8(p.Of + (size_t)(b * p.Nq + q[i]) * p.ldof + h * dh + c);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sm += (float)of[j] * (float)dof[i][ks][j];
+        }
+      }
+      sm += __shfl_xor(sm, 16, 64);
+      sm += __shfl_xor(sm, 32, 64);
+      if (g == 0 && qok[i]) p.delta_out[sidx] = sm;
+      dl = sm;
+    } else {
+      dl = qok[i] ? p.delta[sidx] : 0.f;
+    }
+    const float nl = qok[i] ? -p.lse[sidx] * LOG2E : NEG_BIG, nd = qok[i] ? -dl : 0.f;
     nlse[i] = float4_t{nl, nl, nl, nl};
     ndl[i] = float4_t{nd, nd, nd, nd};
 #pragma unroll
@@ -1554,17 +1576,18 @@ extern "C" int skg_attn_bwd_delta(const void* O, int ldo, const void* dO, int ld
   return SKG_OK;
 }
 
-extern "C" int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
-                               const void* dO, int lddo, const float* lse,
-                               const float* delta, void* dQ, int lddq, int batch, int heads, int Nq, int Nkv,
-                               int kv_stride, int dh, float scale, void* stream) {
-  SKG_REQUIRE(Q && K && V && dO && lse && delta && dQ && common_ok(batch, heads, Nq, Nkv, kv_stride, dh));
+static int attn_bwd_dq_impl(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int lddo,
+                            const float* lse, const float* delta, void* dQ, int lddq, int batch, int heads, int Nq, int Nkv,
+                            int kv_stride, int dh, float scale, void* stream, const void* O, int ldo, float* delta_out) {
+  SKG_REQUIRE(Q && K && V && dO && lse && (delta || (O && delta_out)) && dQ && common_ok(batch, heads, Nq, Nkv, kv_stride, dh));
+  SKG_REQUIRE(!O || (ldo % 8 == 0 && skg_aligned(O, 16)));
   SKG_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 && lddq % 4 == 0);
   SKG_REQUIRE(skg_aligned(Q, 16) && skg_aligned(K, 16) && skg_aligned(V, 16) && skg_aligned(dO, 16) && skg_aligned(dQ, 8));
   AttnParams p{};
   p.Q = (const half_t*)Q; p.ldq = ldq; p.K = (const half_t*)K; p.ldk = ldk; p.V = (const half_t*)V; p.ldv = ldv;
   p.dO = (const half_t*)dO; p.lddo = lddo;
   p.lse = const_cast<float*>(lse); p.delta = delta; p.O = (half_t*)dQ; p.ldo = lddq;
+  p.Of = (const half_t*)O; p.ldof = ldo; p.delta_out = delta_out;
   p.batch = batch; p.heads = heads; p.Nq = Nq; p.Nkv = Nkv; p.kv_stride = kv_stride; p.dh = dh; p.scale = scale;
   hipStream_t st = (hipStream_t)stream;
   p.nx = skg_cdiv(Nq, dh <= 40 ? 128 : 64);         // query tiles per wave: 2 up to d = 40, 1 beyond
@@ -1580,6 +1603,25 @@ extern "C" int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, c
   }
   SKG_CHECK_LAUNCH("skg_attn_bwd_dq");
   return SKG_OK;
+}
+
+extern "C" int skg_attn_bwd_dq(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv,
+                               const void* dO, int lddo, const float* lse,
+                               const float* delta, void* dQ, int lddq, int batch, int heads, int Nq, int Nkv,
+                               int kv_stride, int dh, float scale, void* stream) {
+  SKG_REQUIRE(delta);
+  return attn_bwd_dq_impl(Q, ldq, K, ldk, V, ldv, dO, lddo, lse, delta, dQ, lddq, batch, heads, Nq, Nkv, kv_stride, dh, scale, stream,
+                          nullptr, 0, nullptr);
+}
+
+// ... with skg_attn_bwd_delta in its prologue (round 5): delta[b][h][q] = sum_d dO O is formed from the dO fragments the launch loads
+// anyway, used, and stored to delta_out for the dK / dV launch that follows - one launch and one read of dO fewer per attention
+extern "C" int skg_attn_bwd_dq_delta(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int lddo,
+                                     const void* O, int ldo, const float* lse, float* delta_out, void* dQ, int lddq, int batch,
+                                     int heads, int Nq, int Nkv, int kv_stride, int dh, float scale, void* stream) {
+  SKG_REQUIRE(O && delta_out);
+  return attn_bwd_dq_impl(Q, ldq, K, ldk, V, ldv, dO, lddo, lse, nullptr, dQ, lddq, batch, heads, Nq, Nkv, kv_stride, dh, scale, stream,
+                          O, ldo, delta_out);
 }
 
 extern "C" int skg_attn_bwd_dkv(const void* Q, int ldq, const void* K, int ldk,

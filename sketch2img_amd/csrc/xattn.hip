@@ -146,6 +146,12 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     s2 += __shfl_xor(s2, 16, 64);
     s2 += __shfl_xor(s2, 32, 64);
     const float rstd = rsqrtf(s2 * (1.f / C) + p.eps);
+    if constexpr (KEEP) {
+      if (m0 >= p.keep_from && g == 0 && mrow < p.M) {
+        p.kstats[(size_t)(mrow - p.keep_from) * 2] = mean;
+        p.kstats[(size_t)(mrow - p.keep_from) * 2 + 1] = rstd;
+      }
+    }
     asm volatile("" : "+v"(xlr));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -381,7 +387,7 @@ static int xattn_block_impl(const void* X, const void* Xl, int ldx, void* Y, voi
                             const void* bias_out, float scale, void* stream, float* kstats = nullptr, void* kq = nullptr,
                             void* ko = nullptr, int ldk = 0, float* klse = nullptr, int keep_from = 0) {
   SKG_REQUIRE(X && Y && gamma && beta && Wpack && KVpack && bias_out && M > 0 && (Xl != nullptr) == (Yl != nullptr));
-  SKG_REQUIRE(!kq || (kstats && ko && klse && !Xl && ldk % 4 == 0 && ldk >= C && keep_from >= 0 && keep_from < M && HW > 0 &&
+  SKG_REQUIRE(!kq || (kstats && ko && klse && ldk % 4 == 0 && ldk >= C && keep_from >= 0 && keep_from < M && HW > 0 &&
                       keep_from % HW == 0 && skg_aligned(kq, 8) && skg_aligned(ko, 8)));
   SKG_REQUIRE(C == 320 && heads == 8 && Nkv > 0 && Nkv <= 80 && HW > 0 && HW % 128 == 0 && M % HW == 0);
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
@@ -397,7 +403,8 @@ static int xattn_block_impl(const void* X, const void* Xl, int ldx, void* Y, voi
   p.wbytes = (unsigned)heads * 60u * 1024u;
   p.kvbytes = (unsigned)(M / HW) * (unsigned)heads * 16u * 1024u;
   p.kstats = kstats; p.kq = (half_t*)kq; p.ko = (half_t*)ko; p.ldk = ldk; p.klse = klse; p.keep_from = keep_from;
-  if (kq) hipLaunchKernelGGL((xattn_block_kernel<false, true>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+  if (kq && Xl) hipLaunchKernelGGL((xattn_block_kernel<true, true>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+  else if (kq) hipLaunchKernelGGL((xattn_block_kernel<false, true>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
   else if (Xl) hipLaunchKernelGGL(xattn_block_kernel<true>, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(xattn_block_kernel<false>, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
   SKG_CHECK_LAUNCH("skg_xattn_block_f16");
@@ -428,5 +435,15 @@ extern "C" int skg_xattn_block_f16_keep(const void* X, int ldx, void* Y, int ldy
                                         int keep_from, void* stream) {
   SKG_REQUIRE(stats && Q && O && lse);
   return xattn_block_impl(X, nullptr, ldx, Y, nullptr, ldy, M, HW, C, heads, Nkv, gamma, beta, eps, Wpack, KVpack, bias_out, scale, stream,
+                          stats, Q, O, ldk, lse, keep_from);
+}
+
+// ... on pairs (accuracy mode, round 5): skg_xattn_block_f16_hilo that also stashes what the backward of the cond rows reads
+extern "C" int skg_xattn_block_f16_hilo_keep(const void* X, const void* X_lo, int ldx, void* Y, void* Y_lo, int ldy, int M, int HW, int C,
+                                             int heads, int Nkv, const void* gamma, const void* beta, float eps, const void* Wpack,
+                                             const void* KVpack, const void* bias_out, float scale, float* stats, void* Q, void* O, int ldk,
+                                             float* lse, int keep_from, void* stream) {
+  SKG_REQUIRE(X_lo && Y_lo && stats && Q && O && lse);
+  return xattn_block_impl(X, X_lo, ldx, Y, Y_lo, ldy, M, HW, C, heads, Nkv, gamma, beta, eps, Wpack, KVpack, bias_out, scale, stream,
                           stats, Q, O, ldk, lse, keep_from);
 }

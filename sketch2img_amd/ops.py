@@ -299,6 +299,18 @@ def xattn_block(X, HW: int, heads: int, Nkv: int, gamma, beta, eps: float, wpack
     assert wpack.is_contiguous() and wpack.shape == (heads, 60, 512) and kvpack.is_contiguous() and kvpack.shape == (M // HW, heads, 16, 512)
     if out is None:
         out = Pair.empty(M, C, Xh.device) if pair else torch.empty(M, C, device=Xh.device, dtype=torch.float16)
+    if pair and keep_from is not None:      # accuracy mode, guided step: the stashing launch on pairs (skg_xattn_block_f16_hilo_keep)
+        assert _ld(X.lo) == _ld(X.hi) and _ld(out.lo) == _ld(out.hi)
+        Mk = M - keep_from
+        dev = Xh.device
+        st = torch.empty(Mk, 2, device=dev, dtype=torch.float32)
+        q = torch.empty(Mk, C, device=dev, dtype=torch.float16)
+        o = torch.empty(Mk, C, device=dev, dtype=torch.float16)
+        lse = torch.empty(Mk // HW, heads, HW, device=dev, dtype=torch.float32)
+        check(lib.skg_xattn_block_f16_hilo_keep(_p(X.hi), _p(X.lo), _ld(X.hi), _p(out.hi), _p(out.lo), _ld(out.hi), M, HW, C, heads, Nkv,
+                                                _p(gamma), _p(beta), eps, _p(wpack), _p(kvpack), _p(bias_out), scale, _p(st), _p(q), _p(o), C,
+                                                _p(lse), keep_from, _stream()), "skg_xattn_block_f16_hilo_keep")
+        return out, st, q, o, lse
     if pair:
         assert _ld(X.lo) == _ld(X.hi) and _ld(out.lo) == _ld(out.hi)
         check(lib.skg_xattn_block_f16_hilo(_p(X.hi), _p(X.lo), _ld(X.hi), _p(out.hi), _p(out.lo), _ld(out.hi), M, HW, C, heads, Nkv,
@@ -754,6 +766,17 @@ def attn_bwd_dq(Q, K, V, dO, lse, delta, batch, heads, Nq, Nkv, kv_stride, dh, s
                               _p(lse), _p(delta), _p(out), _ld(out), batch, heads, Nq, Nkv, kv_stride, dh,
                               scale, _stream()), "skg_attn_bwd_dq")
     return out
+
+
+def attn_bwd_dq_delta(Q, K, V, dO, O, lse, batch, heads, Nq, Nkv, kv_stride, dh, scale, out=None):
+    """attn_bwd_delta + attn_bwd_dq in one launch (skg_attn_bwd_dq_delta) -> (dQ, delta)."""
+    _f16(Q, K, V, dO, O)
+    if out is None:
+        out = torch.empty(batch * Nq, heads * dh, device=Q.device, dtype=torch.float16)
+    delta = torch.empty(batch, heads, Nq, device=Q.device, dtype=torch.float32)
+    check(lib.skg_attn_bwd_dq_delta(_p(Q), _ld(Q), _p(K), _ld(K), _p(V), _ld(V), _p(dO), _ld(dO), _p(O), _ld(O), _p(lse), _p(delta),
+                                    _p(out), _ld(out), batch, heads, Nq, Nkv, kv_stride, dh, scale, _stream()), "skg_attn_bwd_dq_delta")
+    return out, delta
 
 
 def attn_bwd_dkv(Q, K, V, dO, lse, delta, batch, heads, Nq, Nkv, dh, scale, dK=None, dV=None):

@@ -36,8 +36,10 @@ _FF_BLOCK = os.environ.get("SKG_FF_BLOCK", "1") != "0"              # fused feed
 _XATTN_BLOCK = os.environ.get("SKG_XATTN_BLOCK", "1") != "0"        # fused cross-attention sub-block at C = 320, 8 heads (csrc/xattn.hip)
 _FF_KEEP = os.environ.get("SKG_FF_KEEP", "1") != "0"                # ... also for the cond rows of a guided step (stashing launch)
 _XATTN_KEEP = os.environ.get("SKG_XATTN_KEEP", "1") != "0"          # the fused cross-attention launch also in guided steps (stashing launch)
+_XATTN_KEEP_HP = os.environ.get("SKG_XATTN_KEEP_HP", "1") != "0"    # ... and in the accuracy mode's guided steps (pairs)
 _FF_PROJ = os.environ.get("SKG_FF_PROJ", "1") != "0"                # proj_out + outer residual inside the fused feed-forward launch
 _FF_PROJ_HP = os.environ.get("SKG_FF_PROJ_HP", "1") != "0"          # ... in the accuracy mode too (skg_ff_block_proj_f16_hilo, round 5)
+_ATTN_DQ_DELTA = os.environ.get("SKG_ATTN_DQ_DELTA", "1") != "0"    # attention backward: delta inside the dQ launch (round 5)
 _RES_SC = os.environ.get("SKG_RES_SC", "1") != "0"                  # conv2 + conv_shortcut of a ResnetBlock as one implicit GEMM (round 5)
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
@@ -920,15 +922,23 @@ class HipUNet:
                 p1 = self.inject(t, p1, rows, HW, heads)
             p1_c = p1
         cb = self.ctx["blocks"][t + ".attn2"]
-        xab = _XATTN_BLOCK and not keep and "kvpack" in cb and heads == 8 and HW % 128 == 0
+        xab = (_XATTN_BLOCK and (not keep or (_XATTN_KEEP_HP and rows % 2 == 0)) and "kvpack" in cb and heads == 8 and HW % 128 == 0)
+        xk_half = ()
         if xab:
-            # no backward will follow: norm2 -> to_q -> text attention -> to_out + residual in ONE row-local launch on the pair
+            # norm2 -> to_q -> text attention -> to_out + residual in ONE row-local launch on the pair; in a guided step the same
+            # launch stores what the backward of the cond rows reads (skg_xattn_block_f16_hilo_keep), as _tr_fwd does
             if shared:
                 ops.batch_copy(p1.full, M1, p1_full.full, M1, 1, M1)
                 x, p1, shared = x_full, p1_full, False
-            p2 = ops.xattn_block(p1, HW, heads, self.ctx["L"], W[t + ".norm2.weight"], W[t + ".norm2.bias"], 1e-5,
-                                 W[t + ".attn2.xpack"], cb["kvpack"], W[t + ".attn2.to_out.0.bias"], scale)
-            st2 = q2 = q2_c = o2 = lse2 = None
+            xargs = (HW, heads, self.ctx["L"], W[t + ".norm2.weight"], W[t + ".norm2.bias"], 1e-5, W[t + ".attn2.xpack"], cb["kvpack"],
+                     W[t + ".attn2.to_out.0.bias"], scale)
+            if keep:
+                p2, st2, q2_c, o2, lse2 = ops.xattn_block(p1, *xargs, keep_from=(rows // 2) * HW)
+                q2 = q2_c
+                xk_half = ("st2", "q2", "o2", "lse2")
+            else:
+                p2 = ops.xattn_block(p1, *xargs)
+                st2 = q2 = q2_c = o2 = lse2 = None
         else:
             a2, st2 = ops.layernorm_hilo(p1.hi, p1.lo, W[t + ".norm2.weight"], W[t + ".norm2.bias"], want_stats=True)
             q2_full = torch.empty(M, C, device=self.dev, dtype=torch.float16) if shared else None
@@ -958,7 +968,9 @@ class HipUNet:
                 own = r1 != rows and self.inject is None
                 ent = dict(x=(x_c if own else x).hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=(p1_c if own else p1).hi,
                            st2=st2, q2=q2_c if own else q2)
-                stash.tr[p] = dict(ent, o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=self._stash_half(ent, r1, rows, HW))
+                half = self._stash_half(ent, r1, rows, HW)
+                half = tuple(k for k in half if k not in xk_half) + xk_half
+                stash.tr[p] = dict(ent, o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=half)
             return out, opart
         if ffb:
             # C = 320: norm3 -> FF1 -> gate -> FF2 + residual in ONE row-local launch on the pair (guided steps: the same launch
@@ -990,7 +1002,9 @@ class HipUNet:
             own = r1 != rows and self.inject is None
             ent = dict(x=(x_c if own else x).hi, gst=gst, pin=pin.hi, st1=st1, qkv=qkv, o1=o1, lse1=lse1, p1=(p1_c if own else p1).hi,
                        st2=st2, q2=q2_c if own else q2)
-            stash.tr[p] = dict(ent, o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=self._stash_half(ent, r1, rows, HW))
+            half = self._stash_half(ent, r1, rows, HW)
+            half = tuple(k for k in half if k not in xk_half) + xk_half
+            stash.tr[p] = dict(ent, o2=o2, lse2=lse2, p2=p2.hi, st3=st3, f=f, H=H, heads=heads, half=half)
         if not ffb:
             p3 = self._pair(M, C)
             ops.gemm(gg, W[t + ".ff.net.2.weight"], out=p3.hi, out_lo=p3.lo, bias=W[t + ".ff.net.2.bias"],
@@ -1216,19 +1230,25 @@ class HipUNet:
         do2 = ops.gemm(dp2, W[t + ".attn2.to_out.0.weight:T"])
         cb = self.ctx["blocks"][t + ".attn2"]
         L, Lp = self.ctx["L"], self.ctx["Lp"]
-        delta2 = ops.attn_bwd_delta(cc("o2"), do2, S, heads, HW, dh)
-        dq2 = ops.attn_bwd_dq(cc("q2"), cb["K"][S * Lp:], cb["V"][S * Lp:], do2, cs("lse2"),
-                              delta2, S, heads, HW, L, Lp, dh, scale)
+        if _ATTN_DQ_DELTA:      # delta = sum_d dO O in the prologue of the dQ launch (one launch and one read of dO fewer)
+            dq2, _ = ops.attn_bwd_dq_delta(cc("q2"), cb["K"][S * Lp:], cb["V"][S * Lp:], do2, cc("o2"), cs("lse2"), S, heads, HW, L, Lp, dh, scale)
+        else:
+            delta2 = ops.attn_bwd_delta(cc("o2"), do2, S, heads, HW, dh)
+            dq2 = ops.attn_bwd_dq(cc("q2"), cb["K"][S * Lp:], cb["V"][S * Lp:], do2, cs("lse2"),
+                                  delta2, S, heads, HW, L, Lp, dh, scale)
         da2 = ops.gemm(dq2, W[t + ".attn2.to_q.weight:T"])
         dp1 = ops.layernorm_bwd(cc("p1"), da2, W[t + ".norm2.weight"], cc("st2"), residual=dp2)
         # self-attention
         do1 = ops.gemm(dp1, W[t + ".attn1.to_out.0.weight:T"])
         qkv = cc("qkv")
         Q, K, V = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-        delta1 = ops.attn_bwd_delta(cc("o1"), do1, S, heads, HW, dh)
         lse1 = cs("lse1")
         dqkv = torch.empty(M0, 3 * C, device=self.dev, dtype=torch.float16)
-        ops.attn_bwd_dq(Q, K, V, do1, lse1, delta1, S, heads, HW, HW, HW, dh, scale, out=dqkv[:, :C])
+        if _ATTN_DQ_DELTA:
+            _, delta1 = ops.attn_bwd_dq_delta(Q, K, V, do1, cc("o1"), lse1, S, heads, HW, HW, HW, dh, scale, out=dqkv[:, :C])
+        else:
+            delta1 = ops.attn_bwd_delta(cc("o1"), do1, S, heads, HW, dh)
+            ops.attn_bwd_dq(Q, K, V, do1, lse1, delta1, S, heads, HW, HW, HW, dh, scale, out=dqkv[:, :C])
         ops.attn_bwd_dkv(Q, K, V, do1, lse1, delta1, S, heads, HW, HW, dh, scale, dK=dqkv[:, C:2 * C], dV=dqkv[:, 2 * C:])
         da1 = ops.gemm(dqkv, W[t + ".attn1.qkv:T"])
         dpin = ops.layernorm_bwd(cc("pin"), da1, W[t + ".norm1.weight"], cc("st1"), residual=dp1)

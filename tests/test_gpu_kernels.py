@@ -465,6 +465,24 @@ def test_fused_blocks_on_pairs(ops):
     r = float((s - s4).norm() / s4.norm())
     print(f"[parity] xattn_block on a pair vs the unfused pair launches: rel {r:.2e}")
     assert r < 1e-4 and float((y.hi.float() - s.float()).abs().max()) <= 2.0 ** -10 * float(s.abs().max())
+    # ... and its stashing form (skg_xattn_block_f16_hilo_keep, guided steps of the accuracy mode): the same pair (to 1 ulp of lo on
+    # a few outputs: another instantiation of the same source), and for the rows from keep_from on norm2's statistics, q, the
+    # attention output and lse of the unfused pair launches
+    kf = 2 * HW
+    yk, stk, qk, ok, lsek = ops.xattn_block(xp, HW, heads, L, gam, bet, 1e-5, wp, kvp, bo.to(d), dh ** -0.5, keep_from=kf)
+    sk = yk.hi.double() + yk.lo.double()
+    rk = float((sk - s).norm() / s.norm())
+    a2k, st_ref = ops.layernorm_hilo(xp.hi[kf:], xp.lo[kf:], gam, bet, 1e-5, want_stats=True)
+    q_ref = ops.gemm(a2k, wq.to(d))
+    o_ref, lse_ref = ops.attn_fwd(q_ref, K[2 * Lp:], V[2 * Lp:], 1, heads, HW, L, Lp, dh, dh ** -0.5, want_lse=True, v_rows=True)
+    e_st = float((stk - st_ref.reshape(-1, 2)).abs().max() / st_ref.abs().max())
+    e_q, e_o = rel_err(qk, q_ref), rel_err(ok, o_ref)
+    e_l = float((lsek.reshape(-1) - lse_ref.reshape(-1)).abs().max())
+    print(f"[parity] xattn_block_hilo_keep vs plain pair launch rel {rk:.2e}; stats {e_st:.1e}  q rel {e_q:.1e}  o rel {e_o:.1e}  lse max abs {e_l:.1e}")
+    assert rk < 1e-6 and float((yk.hi != y.hi).float().mean()) < 1e-3
+    assert e_st < 1e-5 and e_q < 3e-4 and e_o < 6e-4 and e_l < 2e-3
+    yk2 = ops.xattn_block(xp, HW, heads, L, gam, bet, 1e-5, wp, kvp, bo.to(d), dh ** -0.5, keep_from=kf)
+    assert torch.equal(yk2[0].full, yk.full) and torch.equal(yk2[2], qk)
 
 
 @pytest.mark.parametrize("rows,ih,cin,cout", [(2, 16, 128, 320), (4, 32, 640, 640), (2, 8, 1280, 1280)])
@@ -1030,6 +1048,11 @@ def test_attention_backward(ops, dh, heads, Nq, Nkv, cross):
     dq = ops.attn_bwd_dq(Q, K, V, dO, lse, delta, B, heads, Nq, Nkv, kvs, dh, scale)
     # tolerance: P and dS are rounded to fp16 before their MFMA products, delta uses the fp16 O
     assert report(f"attn dq dh{dh}", dq.float().cpu().view(B, Nq, C), qf.grad)[0] < 4e-3
+    # the same with delta formed in the launch's prologue (skg_attn_bwd_dq_delta): delta to fp32 rounding, dq to its own rounding
+    dq_f, delta_f = ops.attn_bwd_dq_delta(Q, K, V, dO, o, lse, B, heads, Nq, Nkv, kvs, dh, scale)
+    assert float((delta_f - delta).abs().max()) <= 2e-5 * max(1.0, float(delta.abs().max()))
+    assert report(f"attn dq with the delta prologue dh{dh}", dq_f.float().cpu().view(B, Nq, C), qf.grad)[0] < 4e-3
+    assert rel_err(dq_f, dq) < 5e-4
     if not cross:
         dk, dv = ops.attn_bwd_dkv(Q, K, V, dO, lse, delta, B, heads, Nq, Nkv, dh, scale)
         assert report(f"attn dk dh{dh}", dk.float().cpu().view(B, Nkv, C), kf.grad)[0] < 4e-3
