@@ -1092,7 +1092,9 @@ inline int pick_splits(long nwg, int KT, size_t slab_bytes, const float* ws, siz
   // K >= 8192: 720 -> 990 TFLOP/s) beat the three-stage single workgroup (870) there; below that the fp32 slabs +
   // reduce pass cost more than they hide and the launch takes the three-stage kernel instead
   if (!ws || nwg > 256 || KT < (nwg == 256 ? 128 : 16)) return 1;
-  int s = (int)((512 + nwg - 1) / nwg);
+  const char* tgt = getenv("SKG_SPLIT_TARGET");        // tuning (tools/smallm_bench.py --split-stages): workgroups a split launch aims at
+  const int target = tgt ? atoi(tgt) : 512;
+  int s = (int)((target + nwg - 1) / nwg);
   const char* cap = getenv("SKG_MAX_SPLITS");          // tuning (tools/smallm_bench.py --splits): read per launch
   const int smax = cap ? atoi(cap) : 8;
   if (s > smax) s = smax < 1 ? 1 : smax;
@@ -1159,6 +1161,7 @@ inline int persistent_grid(int nwg, int nthr) {
 }
 
 constexpr size_t STREAM_OUT_BYTES = (size_t)32 << 20;      // the aggregate L2 (8 x 4 MB)
+constexpr int SPLIT_NS_DEFAULT = 2;                        // LDS stages of a split-K launch with <= 256 workgroups (see launch_cfg)
 
 // GroupNorm statistics in the epilogue: the plain 128 x 160 instantiations (two or three stages, no split-K) with the
 // staged epilogue, whole tiles, 128-row chunks that stay inside one sample and groups that stay inside one tile
@@ -1244,8 +1247,25 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
       }
     }
 #endif
-    hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles * ns, NTHR)), dim3(NTHR),
-                       0, st, p, tiles_n, ntiles * ns, (unsigned)a, (unsigned)b, (unsigned)s, per, p.ws);
+    // at most one workgroup per CU anyway: a deeper LDS ring (three / four stages, 110 / 147 KB) keeps two / three operand tiles of
+    // its K slice in flight where the two-stage kernel waits out one DMA latency per step (SKG_SPLIT_NS, read per launch: tuning)
+    bool deep = false;
+    if constexpr (BM == 128 && BN == 160 && (MODE == MODE_DIRECT || MODE == MODE_S1)) {
+      const char* e = getenv("SKG_SPLIT_NS");
+      const int sns = e ? atoi(e) : SPLIT_NS_DEFAULT;
+      if (ntiles * ns <= 256 && per >= 4 && sns >= 3) {
+        deep = true;
+        if (sns >= 4)
+          hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 4, false, false>), dim3(ntiles * ns), dim3(NTHR), 0, st, p, tiles_n, ntiles * ns,
+                             (unsigned)a, (unsigned)b, (unsigned)s, per, p.ws);
+        else
+          hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE, 3, false, false>), dim3(ntiles * ns), dim3(NTHR), 0, st, p, tiles_n, ntiles * ns,
+                             (unsigned)a, (unsigned)b, (unsigned)s, per, p.ws);
+      }
+    }
+    if (!deep)
+      hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles * ns, NTHR)), dim3(NTHR),
+                         0, st, p, tiles_n, ntiles * ns, (unsigned)a, (unsigned)b, (unsigned)s, per, p.ws);
     size_t blocks = ((size_t)p.M * (p.N / 4) + 255) / 256;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p,
                        (const float*)p.ws, ns);

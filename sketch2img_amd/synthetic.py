@@ -7,7 +7,9 @@ All values are rounded through fp16 so that an fp32 checker sees bit-identical p
 """
 from __future__ import annotations
 
+import hashlib
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, Tuple
 
@@ -78,9 +80,32 @@ def unet_param_shapes(cfg: UNetConfig) -> "OrderedDict[str, tuple]":
     return s
 
 
+def _disk_cached(name: str, make):
+    """SKG_SYNTH_CACHE_DIR=<dir> (the test suite sets it: a dozen bench.py subprocesses each draw the same 860 M values, 10-13 s a
+    time): the tensors are stored as fp16 - every value is fp16-representable by construction, so the round trip is exact."""
+    d = os.environ.get("SKG_SYNTH_CACHE_DIR")
+    if not d:
+        return make()
+    path = os.path.join(d, name + ".pt")
+    if os.path.exists(path):
+        return {k: v.float() for k, v in torch.load(path, mmap=True).items()}
+    sd = make()
+    tmp = f"{path}.{os.getpid()}.tmp"
+    torch.save({k: v.half() for k, v in sd.items()}, tmp)
+    os.replace(tmp, path)
+    return sd
+
+
 def unet_state_dict(cfg: UNetConfig, seed: int = WEIGHT_SEED) -> Dict[str, torch.Tensor]:
-    g = torch.Generator().manual_seed(seed)
     shapes = unet_param_shapes(cfg)
+    if sum(math.prod(s) for s in shapes.values()) > 100_000_000:      # (full-size architectures only: the tiny test configs take milliseconds)
+        tag = hashlib.sha256(repr((cfg, seed, sorted(shapes.items()))).encode()).hexdigest()[:16]
+        return _disk_cached(f"unet_{tag}", lambda: _unet_state_dict(cfg, seed, shapes))
+    return _unet_state_dict(cfg, seed, shapes)
+
+
+def _unet_state_dict(cfg: UNetConfig, seed: int, shapes) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
     for k, shp in shapes.items():
         leaf = k.split(".")[-2]

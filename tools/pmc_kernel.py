@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One kernel shape, a few launches - the target of `rocprofv3 --pmc ...` passes (tools/pmc_kernels.sh).
-    python tools/pmc_kernel.py attn40 | attn64 | conv | conv64 | gemm_short | gemm_ff1 | ffblock | gemm:M:N:K[:res|:geglu]"""
+    python tools/pmc_kernel.py attn40 | attn64 | conv | conv64 | gemm_short | gemm_ff1 | ffblock | gemm:M:N:K[:res|:geglu] | conv:rows:hw:cin:cout[:res]"""
 import os
 import sys
 
@@ -34,6 +34,14 @@ elif what in ("conv", "conv64"):
     x = torch.randn(rows * hw * hw, cin, generator=g).half().to(dev)
     w = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(dev)
     fn = lambda: ops.conv3x3(x, w, rows, hw, hw, 0)
+elif what.startswith("conv:"):
+    f = what.split(":")
+    rows, hw, cin, cout = int(f[1]), int(f[2]), int(f[3]), int(f[4])
+    x = torch.randn(rows * hw * hw, cin, generator=g).half().to(dev)
+    w = (torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(dev)
+    res = torch.randn(rows * hw * hw, cout, generator=g).half().to(dev) if "res" in f[5:] else None
+    out = torch.empty(rows * hw * hw, cout, device=dev, dtype=torch.float16)
+    fn = lambda: ops.conv3x3(x, w, rows, hw, hw, 0, out=out, residual=res)
 elif what.startswith("gemm:"):
     f = what.split(":")
     M, N, K = int(f[1]), int(f[2]), int(f[3])

@@ -64,6 +64,8 @@ def main():
     ap.add_argument("--splits", action="store_true", help="gemm2.hip only: cap the cross-workgroup K slices at 8 (ships) / 4 / 2")
     ap.add_argument("--plain", action="store_true", help="the shipped kernels only (no lab variants)")
     ap.add_argument("--stages", action="store_true", help="lab build, gemm2.hip only: three LDS stages (ships) against four / six (SKG_NS)")
+    ap.add_argument("--split-stages", action="store_true", help="gemm2.hip only: split-K launches on 2 stages x 512 workgroups (ships before round 5) "
+                    "against 3 / 4 stages x 256 workgroups (SKG_SPLIT_NS / SKG_SPLIT_TARGET)")
     ap.add_argument("--pool-mb", type=int, default=640, help="weight pool per shape; 0: two copies only = weights warm in the Infinity Cache")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
@@ -80,6 +82,11 @@ def main():
                     "ns6": {"SKG_GEMMK": "0", "SKG_GK_EXP": "0", "SKG_NS": "6"}}
     if args.splits:
         variants = {f"max{n}": {"SKG_GEMMK": "0", "SKG_GK_EXP": "0", "SKG_MAX_SPLITS": str(n)} for n in (8, 4, 2)}
+    if args.split_stages:
+        base = {"SKG_GEMMK": "0", "SKG_GK_EXP": "0"}
+        variants = {"ns2x512": dict(base, SKG_SPLIT_NS="2", SKG_SPLIT_TARGET="512"), "ns3x512": dict(base, SKG_SPLIT_NS="3", SKG_SPLIT_TARGET="512"),
+                    "ns3x256": dict(base, SKG_SPLIT_NS="3", SKG_SPLIT_TARGET="256"), "ns4x256": dict(base, SKG_SPLIT_NS="4", SKG_SPLIT_TARGET="256"),
+                    "ns4x512": dict(base, SKG_SPLIT_NS="4", SKG_SPLIT_TARGET="512")}
     g = torch.Generator().manual_seed(1)
     lines, tot = [], {v: {"gemm": 0.0, "conv": 0.0} for v in variants}
     flops = {"gemm": 0.0, "conv": 0.0}
@@ -87,7 +94,7 @@ def main():
     lines.append(hdr)
     for M, N, K, res, n in GEMMS:
         os.environ["SKG_GEMMK"] = "1"
-        assert args.splits or args.plain or args.stages or lib.skg_gemm_variant(M, N, K, 0, 0) == 9160, (M, N, K)
+        assert args.splits or args.plain or args.stages or args.split_stages or lib.skg_gemm_variant(M, N, K, 0, 0) == 9160, (M, N, K)
         copies = max(2, min(64, POOL_BYTES // (N * K * 2)))
         W = [(torch.randn(N, K, generator=g) * K ** -0.5).half().to(DEV) for _ in range(2)]
         W = W + [W[i % 2].clone() for i in range(copies - 2)]
@@ -107,7 +114,7 @@ def main():
     for rows, hw, cin, cout, res, n in CONVS:
         M = rows * hw * hw
         os.environ["SKG_GEMMK"] = "1"
-        assert args.splits or args.plain or args.stages or lib.skg_gemm_variant(M, cout, 9 * cin, cin, 1) == 9160, (rows, hw, cin, cout)
+        assert args.splits or args.plain or args.stages or args.split_stages or lib.skg_gemm_variant(M, cout, 9 * cin, cin, 1) == 9160, (rows, hw, cin, cout)
         copies = max(2, min(64, POOL_BYTES // (cout * 9 * cin * 2)))
         W = [(torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5).half().to(DEV) for _ in range(2)]
         W = W + [W[i % 2].clone() for i in range(copies - 2)]
