@@ -1161,7 +1161,7 @@ inline int persistent_grid(int nwg, int nthr) {
 }
 
 constexpr size_t STREAM_OUT_BYTES = (size_t)32 << 20;      // the aggregate L2 (8 x 4 MB)
-constexpr int SPLIT_NS_DEFAULT = 2;                        // LDS stages of a split-K launch with <= 256 workgroups (see launch_cfg)
+constexpr int SPLIT_NS_DEFAULT = 3;                        // LDS stages of a split-K launch with <= 256 workgroups (see launch_cfg)
 
 // GroupNorm statistics in the epilogue: the plain 128 x 160 instantiations (two or three stages, no split-K) with the
 // staged epilogue, whole tiles, 128-row chunks that stay inside one sample and groups that stay inside one tile

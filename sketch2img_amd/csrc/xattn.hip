@@ -71,14 +71,23 @@ __device__ __forceinline__ float4_t mfma32_fresh(half8_t a, half8_t b, float4_t 
 
 // HILO (accuracy mode, skg_xattn_block_f16_hilo): LayerNorm reads hi + lo, the residual sum is formed in fp32 on the pair and stored
 // as hi = fp16(v), lo = fp16(v - hi); everything between is the same kernel
-template <bool HILO, bool KEEP = false>
+// DH = 64 (round 5: the 5 x 64 heads of SD2.1's C = 320 blocks): no K = 16 tails on the head width - Q^T is 4 tiles, S^T and the
+// out-projection take two K = 32 steps over d, O^T is 4 tiles; only the key axis (80 = 2 x 32 + 16) keeps its K = 16 step.  The LDS image is
+// 40 Wq pieces + two stages of [K 10 | V 10 | Wo 40] = 160 KB exactly: dead DMA slots are skipped (wave-uniform branch) instead of dumped.
+template <bool HILO, bool KEEP = false, int DH = 40>
 __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
   constexpr int KS = 10, C = 320, NU = 20, PIECE = 512;
-  constexpr int WQ = 0, NWQ = 30;                        // pieces
-  constexpr int STG = NWQ * PIECE, NST = 46;             // stage = [K 8 | V 8 | Wo 30] pieces
-  constexpr int KOFF = 0, VOFF = 8 * PIECE, WOOFF = 16 * PIECE;
-  constexpr int DUMP = STG + 2 * NST * PIECE;            // 2 pieces for dead DMA slots
-  constexpr int LDSH = DUMP + 2 * PIECE;
+  constexpr bool D64 = DH == 64;
+  static_assert(DH == 40 || DH == 64, "head width");
+  constexpr int NTQ = D64 ? 4 : 3;                       // 16-row tiles of Q^T / O^T
+  constexpr int WQ = 0, NWQ = NTQ * KS;                  // pieces
+  constexpr int NKP = D64 ? 10 : 8, NVP = D64 ? 10 : 8;  // K / V image pieces per (image, head)
+  constexpr int NWO = D64 ? 40 : 30, WPH = NWQ + NWO;    // Wo image pieces; pack pieces per head
+  constexpr int STG = NWQ * PIECE, NST = NKP + NVP + NWO;      // stage = [K | V | Wo]: 46 / 60 pieces
+  constexpr int KOFF = 0, VOFF = NKP * PIECE, WOOFF = (NKP + NVP) * PIECE;
+  constexpr int DUMP = STG + 2 * NST * PIECE;            // (DH = 40) 2 pieces for dead DMA slots
+  constexpr int LDSH = DUMP + (D64 ? 0 : 2 * PIECE);
+  constexpr int NSTS = (NST + 7) / 8, NWQS = (NWQ + 7) / 8;    // DMA slots per wave: stage 6 / 8, Wq 4 / 5
   constexpr int OP = C + 8;
   static_assert(8 * 16 * OP <= LDSH, "epilogue staging fits");
   __shared__ __attribute__((aligned(16))) half_t smem[LDSH];        // ONE object (LDS-DMA + ds_read: see gemm2.hip)
@@ -93,26 +102,32 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
   auto dma_stage = [&](int h, int j) {
     const int q = wave + 8 * j;
     const bool live = q < NST && h < p.heads;
+    if constexpr (D64) {
+      if (!live) return;
+    }
     const int dst = q < NST ? STG + (h & 1) * NST * PIECE + q * PIECE : DUMP + (q - NST) * PIECE;
     const unsigned voff = live ? (unsigned)lane * 16u : 0x80000000u;
-    if (q < 16)
+    if (q < NKP + NVP)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rKV, (lds_ptr_t)(smem + dst), 16, voff,
-                                               (unsigned)(((img * p.heads + h) * 16 + q) * 1024), 0, 0);
+                                               (unsigned)(((img * p.heads + h) * (NKP + NVP) + q) * 1024), 0, 0);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + dst), 16, voff, (unsigned)((h * 60 + 30 + (q - 16)) * 1024), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + dst), 16, voff, (unsigned)((h * WPH + NWQ + (q - (NKP + NVP))) * 1024), 0, 0);
   };
   // slot j (0..3) of the Wq fetch of head h: piece q = wave + 8 j
   auto dma_wq = [&](int h, int j) {
     const int q = wave + 8 * j;
     const bool live = q < NWQ && h < p.heads;
+    if constexpr (D64) {
+      if (!live) return;
+    }
     const int dst = q < NWQ ? WQ + q * PIECE : DUMP + (q - NWQ) * PIECE;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + dst), 16, live ? (unsigned)lane * 16u : 0x80000000u,
-                                             (unsigned)((h * 60 + q) * 1024), 0, 0);
+                                             (unsigned)((h * WPH + q) * 1024), 0, 0);
   };
 #pragma unroll
-  for (int j = 0; j < 4; ++j) dma_wq(0, j);
+  for (int j = 0; j < NWQS; ++j) dma_wq(0, j);
 #pragma unroll
-  for (int j = 0; j < 6; ++j) dma_stage(0, j);
+  for (int j = 0; j < NSTS; ++j) dma_stage(0, j);
 
   // ---- the wave's 16 rows: load, LayerNorm (as norms.hip), keep as B operands
   const int m0 = blockIdx.x * 128 + wave * 16;
@@ -215,32 +230,39 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();                                           // A: Wq_h and stage h landed; every wave is done with head h - 1
     // ---- Q^T = Wq_h . A^T; the next head's [K | V | Wo] is fetched under it (its stage was head h - 1's)
-    float4_t q[3] = {fresh(), fresh(), fresh()};
+    float4_t q[NTQ];
+#pragma unroll
+    for (int t = 0; t < NTQ; ++t) q[t] = fresh();
     {
       const half_t* fr = smem + WQ + lane * 8;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < NTQ; ++t)
           q[t] = ks == 0 ? mfma32_fresh(ld_half8(fr + (t * KS + ks) * PIECE), xb[ks], q[t])
                          : __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(fr + (t * KS + ks) * PIECE), xb[ks], q[t], 0, 0, 0);
-        if (ks < 6) dma_stage(h + 1, ks);
+        if (ks < NSTS) dma_stage(h + 1, ks);
       }
     }
     lds_barrier();                                           // B: every wave has read Wq_h - its region takes Wq_{h+1}
     // q: fp16 (the rounding of the stored to_q output), then scaled and rounded again (attn_fwd_short_kernel's qf)
-    half8_t qb32;
+    half8_t qb32, qb32b;      // (qb32b: d 32..63 of a 64-wide head)
     half4v qb16;
 #pragma unroll
     for (int i = 0; i < 8; ++i) qb32[i] = (half_t)((float)(half_t)q[i >> 2][i & 3] * p.sc);
+    if constexpr (D64) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qb16[i] = (half_t)((float)(half_t)q[2][i] * p.sc);
+      for (int i = 0; i < 8; ++i) qb32b[i] = (half_t)((float)(half_t)q[2 + (i >> 2)][i & 3] * p.sc);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) qb16[i] = (half_t)((float)(half_t)q[2][i] * p.sc);
+    }
     if constexpr (KEEP) {      // the to_q output of head h, fp16 as the replaced GEMM stores it: d = 16 t + 4 g + r of row l16
       if (m0 >= p.keep_from && mrow < p.M) {
-        half_t* qr = p.kq + (size_t)(mrow - p.keep_from) * p.ldk + h * 40 + 4 * g;
+        half_t* qr = p.kq + (size_t)(mrow - p.keep_from) * p.ldk + h * DH + 4 * g;
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
-          if (t < 2 || g < 2) st_half4(qr + 16 * t, half4_t{(half_t)q[t][0], (half_t)q[t][1], (half_t)q[t][2], (half_t)q[t][3]});
+        for (int t = 0; t < NTQ; ++t)
+          if (D64 || t < 2 || g < 2) st_half4(qr + 16 * t, half4_t{(half_t)q[t][0], (half_t)q[t][1], (half_t)q[t][2], (half_t)q[t][3]});
       }
     }
     const half_t* st = smem + STG + (h & 1) * NST * PIECE;
@@ -248,9 +270,15 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     float4_t s[5];
 #pragma unroll
     for (int kt = 0; kt < 5; ++kt) s[kt] = mfma32_fresh(ld_half8(st + KOFF + kt * PIECE + lane * 8), qb32, fresh());
+    if constexpr (D64) {
 #pragma unroll
-    for (int kt = 0; kt < 5; ++kt)
-      s[kt] = mfma_k16(*reinterpret_cast<const half4v*>(st + KOFF + 5 * PIECE + kt * 256 + lane * 4), qb16, s[kt]);
+      for (int kt = 0; kt < 5; ++kt)
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + KOFF + (5 + kt) * PIECE + lane * 8), qb32b, s[kt], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 5; ++kt)
+        s[kt] = mfma_k16(*reinterpret_cast<const half4v*>(st + KOFF + 5 * PIECE + kt * 256 + lane * 4), qb16, s[kt]);
+    }
     dma_wq(h + 1, 0);
     dma_wq(h + 1, 1);
     // keys behind nkv are masked (lane holds keys 16 kt + 4 g + r)
@@ -287,29 +315,38 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     for (int i = 0; i < 4; ++i) pb16[i] = (half_t)s[4][i];
     dma_wq(h + 1, 2);
     dma_wq(h + 1, 3);
-    // ---- O^T = V_h^T . P^T: 3 tiles of d
-    float4_t o[3];
+    if constexpr (NWQS > 4) dma_wq(h + 1, 4);
+    // ---- O^T = V_h^T . P^T: 3 / 4 tiles of d
+    float4_t o[NTQ];
 #pragma unroll
-    for (int dt = 0; dt < 3; ++dt) o[dt] = mfma32_fresh(ld_half8(st + VOFF + (dt * 2) * PIECE + lane * 8), pb32[0], fresh());
+    for (int dt = 0; dt < NTQ; ++dt) o[dt] = mfma32_fresh(ld_half8(st + VOFF + (dt * 2) * PIECE + lane * 8), pb32[0], fresh());
 #pragma unroll
-    for (int dt = 0; dt < 3; ++dt)
+    for (int dt = 0; dt < NTQ; ++dt)
       o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + VOFF + (dt * 2 + 1) * PIECE + lane * 8), pb32[1], o[dt], 0, 0, 0);
 #pragma unroll
-    for (int dt = 0; dt < 3; ++dt)
-      o[dt] = mfma_k16(*reinterpret_cast<const half4v*>(st + VOFF + 6 * PIECE + dt * 256 + lane * 4), pb16, o[dt]);
+    for (int dt = 0; dt < NTQ; ++dt)
+      o[dt] = mfma_k16(*reinterpret_cast<const half4v*>(st + VOFF + 2 * NTQ * PIECE + dt * 256 + lane * 4), pb16, o[dt]);
     const float inv = 1.f / li;
-    half8_t ob32;
+    half8_t ob32, ob32b;
     half4v ob16;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ob32[i] = (half_t)(o[i >> 2][i & 3] * inv);
+    if constexpr (D64) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ob16[i] = (half_t)(o[2][i] * inv);
+      for (int i = 0; i < 8; ++i) ob32b[i] = (half_t)(o[2 + (i >> 2)][i & 3] * inv);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ob16[i] = (half_t)(o[2][i] * inv);
+    }
     if constexpr (KEEP) {      // the attention output (normalised, fp16) and lse = ln sum_k exp(scale q.k) of (row, head)
       if (m0 >= p.keep_from && mrow < p.M) {
-        half_t* orow = p.ko + (size_t)(mrow - p.keep_from) * p.ldk + h * 40 + 4 * g;
+        half_t* orow = p.ko + (size_t)(mrow - p.keep_from) * p.ldk + h * DH + 4 * g;
         st_half4(orow, half4_t{ob32[0], ob32[1], ob32[2], ob32[3]});
         st_half4(orow + 16, half4_t{ob32[4], ob32[5], ob32[6], ob32[7]});
-        if (g < 2) st_half4(orow + 32, half4_t{ob16[0], ob16[1], ob16[2], ob16[3]});
+        if constexpr (D64) {
+          st_half4(orow + 32, half4_t{ob32b[0], ob32b[1], ob32b[2], ob32b[3]});
+          st_half4(orow + 48, half4_t{ob32b[4], ob32b[5], ob32b[6], ob32b[7]});
+        } else if (g < 2) st_half4(orow + 32, half4_t{ob16[0], ob16[1], ob16[2], ob16[3]});
         if (g == 0) {
           const int mk = mrow - p.keep_from, bk = mk / p.HW;
           p.klse[((size_t)bk * p.heads + h) * p.HW + (mk - bk * p.HW)] = (log2f(li) + mx) * 0.6931471805599453f;
@@ -319,9 +356,15 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAParams p) {
     // ---- Y^T += Wo[:, head h] . O^T
 #pragma unroll
     for (int u = 0; u < NU; ++u) y[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + WOOFF + u * PIECE + lane * 8), ob32, y[u], 0, 0, 0);
+    if constexpr (D64) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
-      y[u] = mfma_k16(*reinterpret_cast<const half4v*>(st + WOOFF + 20 * PIECE + u * 256 + lane * 4), ob16, y[u]);
+      for (int u = 0; u < NU; ++u)
+        y[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ld_half8(st + WOOFF + (NU + u) * PIECE + lane * 8), ob32b, y[u], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+        y[u] = mfma_k16(*reinterpret_cast<const half4v*>(st + WOOFF + 20 * PIECE + u * 256 + lane * 4), ob16, y[u]);
+    }
   }
 
   // ---- epilogue (as ffblock.hip): residual added in fp32, the tile through the wave's own slice of the idle LDS, whole-row stores
@@ -389,7 +432,8 @@ static int xattn_block_impl(const void* X, const void* Xl, int ldx, void* Y, voi
   SKG_REQUIRE(X && Y && gamma && beta && Wpack && KVpack && bias_out && M > 0 && (Xl != nullptr) == (Yl != nullptr));
   SKG_REQUIRE(!kq || (kstats && ko && klse && ldk % 4 == 0 && ldk >= C && keep_from >= 0 && keep_from < M && HW > 0 &&
                       keep_from % HW == 0 && skg_aligned(kq, 8) && skg_aligned(ko, 8)));
-  SKG_REQUIRE(C == 320 && heads == 8 && Nkv > 0 && Nkv <= 80 && HW > 0 && HW % 128 == 0 && M % HW == 0);
+  SKG_REQUIRE(C == 320 && (heads == 8 || heads == 5) && Nkv > 0 && Nkv <= 80 && HW > 0 && HW % 128 == 0 && M % HW == 0);
+  const bool d64 = heads == 5;      // SD2.1: 5 heads of 64 (pack_xattn_weights / pack_xattn_kv lay the images out per head width)
   SKG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C);
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(Y, 16) && skg_aligned(Xl, 16) && skg_aligned(Yl, 16) && skg_aligned(gamma, 16) &&
               skg_aligned(beta, 16) && skg_aligned(Wpack, 16) && skg_aligned(KVpack, 16) && skg_aligned(bias_out, 8));
@@ -400,10 +444,15 @@ static int xattn_block_impl(const void* X, const void* Xl, int ldx, void* Y, voi
   p.Wp = (const half_t*)Wpack; p.KVp = (const half_t*)KVpack; p.bo = (const half_t*)bias_out;
   p.heads = heads; p.nkv = Nkv;
   p.sc = scale * 1.4426950408889634f;
-  p.wbytes = (unsigned)heads * 60u * 1024u;
-  p.kvbytes = (unsigned)(M / HW) * (unsigned)heads * 16u * 1024u;
+  p.wbytes = (unsigned)heads * (d64 ? 80u : 60u) * 1024u;
+  p.kvbytes = (unsigned)(M / HW) * (unsigned)heads * (d64 ? 20u : 16u) * 1024u;
   p.kstats = kstats; p.kq = (half_t*)kq; p.ko = (half_t*)ko; p.ldk = ldk; p.klse = klse; p.keep_from = keep_from;
-  if (kq && Xl) hipLaunchKernelGGL((xattn_block_kernel<true, true>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+  if (d64) {
+    if (kq && Xl) hipLaunchKernelGGL((xattn_block_kernel<true, true, 64>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+    else if (kq) hipLaunchKernelGGL((xattn_block_kernel<false, true, 64>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+    else if (Xl) hipLaunchKernelGGL((xattn_block_kernel<true, false, 64>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((xattn_block_kernel<false, false, 64>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
+  } else if (kq && Xl) hipLaunchKernelGGL((xattn_block_kernel<true, true>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
   else if (kq) hipLaunchKernelGGL((xattn_block_kernel<false, true>), dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
   else if (Xl) hipLaunchKernelGGL(xattn_block_kernel<true>, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(xattn_block_kernel<false>, dim3(M / 128), dim3(512), 0, (hipStream_t)stream, p);

@@ -296,7 +296,8 @@ def xattn_block(X, HW: int, heads: int, Nkv: int, gamma, beta, eps: float, wpack
     Xh = X.hi if pair else X
     _f16(Xh, gamma, beta, wpack, kvpack, bias_out)
     M, C = Xh.shape
-    assert wpack.is_contiguous() and wpack.shape == (heads, 60, 512) and kvpack.is_contiguous() and kvpack.shape == (M // HW, heads, 16, 512)
+    wp, kp = (60, 16) if heads == 8 else (80, 20)      # pieces per head: 8 x 40 (padded to 48) or 5 x 64
+    assert wpack.is_contiguous() and wpack.shape == (heads, wp, 512) and kvpack.is_contiguous() and kvpack.shape == (M // HW, heads, kp, 512)
     if out is None:
         out = Pair.empty(M, C, Xh.device) if pair else torch.empty(M, C, device=Xh.device, dtype=torch.float16)
     if pair and keep_from is not None:      # accuracy mode, guided step: the stashing launch on pairs (skg_xattn_block_f16_hilo_keep)

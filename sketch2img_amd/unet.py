@@ -35,6 +35,7 @@ _GN_CONCAT = os.environ.get("SKG_GN_CONCAT", "1") != "0"
 _FF_BLOCK = os.environ.get("SKG_FF_BLOCK", "1") != "0"              # fused feed-forward sub-block at C = 320 (csrc/ffblock.hip)
 _XATTN_BLOCK = os.environ.get("SKG_XATTN_BLOCK", "1") != "0"        # fused cross-attention sub-block at C = 320, 8 heads (csrc/xattn.hip)
 _FF_KEEP = os.environ.get("SKG_FF_KEEP", "1") != "0"                # ... also for the cond rows of a guided step (stashing launch)
+_XATTN_HEADS = (8,) if os.environ.get("SKG_XATTN_D64", "1") == "0" else (8, 5)     # head counts of the fused cross-attention launch at C = 320 (5 x 64: round 5)
 _XATTN_KEEP = os.environ.get("SKG_XATTN_KEEP", "1") != "0"          # the fused cross-attention launch also in guided steps (stashing launch)
 _XATTN_KEEP_HP = os.environ.get("SKG_XATTN_KEEP_HP", "1") != "0"    # ... and in the accuracy mode's guided steps (pairs)
 _FF_PROJ = os.environ.get("SKG_FF_PROJ", "1") != "0"                # proj_out + outer residual inside the fused feed-forward launch
@@ -172,52 +173,68 @@ def pack_ff_block(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, dev, w_p
 
 
 def pack_xattn_weights(wq: torch.Tensor, wo: torch.Tensor, heads: int, dev):
-    """Fragment-major pack of attn2.to_q [C, C] and attn2.to_out.0 [C, C] for skg_xattn_block_f16 (csrc/xattn.hip), C = 320,
-    head width 40 padded to 48: per head h 60 pieces of 512 halves = the kernel's LDS image:
+    """Fragment-major pack of attn2.to_q [C, C] and attn2.to_out.0 [C, C] for skg_xattn_block_f16 (csrc/xattn.hip), C = 320; per head h
+    the kernel's LDS image in pieces of 512 halves.
+    8 heads of 40 (SD1.5; head width padded to 48), 60 pieces:
       30 Wq pieces (t, ks):  [lane = 16 g + l][i] = Wq[40 h + 16 t + l][32 ks + 8 g + i]         (rows 40..47 of the head: zeros)
       Wo image (30 pieces):  20 K = 32 fragments  [lane][i] = Wo[16 u + l][40 h + 16 (i >> 2) + 4 g + (i & 3)]
                              20 K = 16 fragments  [lane][i < 4] = Wo[16 u + l][40 h + 32 + 4 g + i]   (d >= 40: zeros)
-    Returns fp16 [heads, 60, 512]."""
+    5 heads of 64 (SD2.1), 80 pieces: 40 Wq pieces (t < 4, ks) as above, then 2 x 20 K = 32 fragments
+      [s][u]: [lane][i] = Wo[16 u + l][64 h + 32 s + 16 (i >> 2) + 4 g + (i & 3)].
+    Returns fp16 [heads, 60 | 80, 512]."""
     C = wq.shape[0]
     dh = C // heads
-    assert wq.shape == (C, C) and wo.shape == (C, C) and C == 320 and dh == 40
+    assert wq.shape == (C, C) and wo.shape == (C, C) and C == 320 and dh in (40, 64)
     KS, NU = C // 32, C // 16
+    DP = 48 if dh == 40 else 64
+    NT = DP // 16
     wqh, woh = wq.detach().to("cpu", torch.float16), wo.detach().to("cpu", torch.float16)      # host-side packing
     out = []
     for h in range(heads):
-        q = torch.zeros(48, C, dtype=torch.float16)
+        q = torch.zeros(DP, C, dtype=torch.float16)
         q[:dh] = wqh[h * dh:(h + 1) * dh]
-        pq = q.reshape(3, 16, KS, 4, 8).permute(0, 2, 3, 1, 4).reshape(3 * KS, 512)          # [t, ks][g, l, i]
-        o = torch.zeros(C, 48, dtype=torch.float16)
+        pq = q.reshape(NT, 16, KS, 4, 8).permute(0, 2, 3, 1, 4).reshape(NT * KS, 512)          # [t, ks][g, l, i]
+        o = torch.zeros(C, DP, dtype=torch.float16)
         o[:, :dh] = woh[:, h * dh:(h + 1) * dh]
         o32 = o[:, :32].reshape(NU, 16, 2, 4, 4).permute(0, 3, 1, 2, 4).reshape(-1)             # [u][g, l, i_hi, i_lo]
-        o16 = o[:, 32:].reshape(NU, 16, 4, 4).permute(0, 2, 1, 3).reshape(-1)                   # [u][g, l, i]
-        out.append(torch.cat([pq.reshape(-1), o32, o16]).reshape(60, 512))
+        if dh == 40:
+            tail = o[:, 32:].reshape(NU, 16, 4, 4).permute(0, 2, 1, 3).reshape(-1)              # [u][g, l, i]
+        else:
+            tail = o[:, 32:].reshape(NU, 16, 2, 4, 4).permute(0, 3, 1, 2, 4).reshape(-1)        # the second K = 32 step: d 32..63
+        out.append(torch.cat([pq.reshape(-1), o32, tail]).reshape(-1, 512))
     return torch.stack(out).contiguous().to(dev)
 
 
 def pack_xattn_kv(K: torch.Tensor, V: torch.Tensor, rows: int, Lp: int, L: int, heads: int) -> torch.Tensor:
     """Fragment-major pack of the text keys / values of every batch row for skg_xattn_block_f16: K, V [rows * Lp, C] (what
-    prepare_context hoists per prompt), L <= 80 valid keys per row.  Per (row, head) 16 pieces of 512 halves:
+    prepare_context hoists per prompt), L <= 80 valid keys per row.  Per (row, head), pieces of 512 halves.
+    Head width 40 (16 pieces):
       K image: 5 K = 32 fragments [lane = 16 g + l][i] = K[key 16 kt + l][40 h + 16 (i >> 2) + 4 g + (i & 3)], then 5 K = 16
                fragments [lane][i < 4] = K[key 16 kt + l][40 h + 32 + 4 g + i]                                   (8 pieces)
       V image: (dt, s) K = 32 fragments [lane][i] = V[key 32 s + 16 (i >> 2) + 4 g + (i & 3)][40 h + 16 dt + l], then 3 K = 16
                fragments [lane][i < 4] = V[key 64 + 4 g + i][40 h + 16 dt + l]                                   (8 pieces)
-    Keys >= L and head columns >= 40 are zeros.  Returns fp16 [rows, heads, 16, 512] on K's device."""
+    Head width 64 (20 pieces): K image [s][kt] 2 x 5 K = 32 fragments (d = 64 h + 32 s + ...), V image (dt < 4, s) 8 K = 32 fragments
+    then 4 K = 16 fragments (2 pieces); no padding.
+    Keys >= L and head columns >= the head width are zeros.  Returns fp16 [rows, heads, 16 | 20, 512] on K's device."""
     C = K.shape[1]
     dh = C // heads
-    assert dh == 40 and L <= 80 and K.shape == V.shape == (rows * Lp, C)
+    assert dh in (40, 64) and L <= 80 and K.shape == V.shape == (rows * Lp, C)
     dev = K.device
-    k = torch.zeros(rows, heads, 80, 48, device=dev, dtype=torch.float16)
-    v = torch.zeros(rows, heads, 80, 48, device=dev, dtype=torch.float16)
+    DP = 48 if dh == 40 else 64
+    NT = DP // 16
+    k = torch.zeros(rows, heads, 80, DP, device=dev, dtype=torch.float16)
+    v = torch.zeros(rows, heads, 80, DP, device=dev, dtype=torch.float16)
     k[:, :, :L, :dh] = K.reshape(rows, Lp, heads, dh)[:, :L].permute(0, 2, 1, 3)
     v[:, :, :L, :dh] = V.reshape(rows, Lp, heads, dh)[:, :L].permute(0, 2, 1, 3)
     R = rows * heads
-    k, v = k.reshape(R, 80, 48), v.reshape(R, 80, 48)
+    k, v = k.reshape(R, 80, DP), v.reshape(R, 80, DP)
     k32 = k[:, :, :32].reshape(R, 5, 16, 2, 4, 4).permute(0, 1, 4, 2, 3, 5).reshape(R, 5 * 512)      # [kt][g, l, i_hi, i_lo]
+    v32 = v[:, :64].reshape(R, 2, 2, 4, 4, NT, 16).permute(0, 5, 1, 3, 6, 2, 4).reshape(R, 2 * NT * 512)   # [dt, s][g, l, i_hi, i_lo]
+    v16 = v[:, 64:].reshape(R, 4, 4, NT, 16).permute(0, 3, 1, 4, 2).reshape(R, NT * 256)             # [dt][g, l, i]
+    if dh == 64:
+        k32b = k[:, :, 32:].reshape(R, 5, 16, 2, 4, 4).permute(0, 1, 4, 2, 3, 5).reshape(R, 5 * 512)
+        return torch.cat([k32, k32b, v32, v16], 1).reshape(rows, heads, 20, 512).contiguous()
     k16 = k[:, :, 32:].reshape(R, 5, 16, 4, 4).permute(0, 1, 3, 2, 4).reshape(R, 5 * 256)            # [kt][g, l, i]
-    v32 = v[:, :64].reshape(R, 2, 2, 4, 4, 3, 16).permute(0, 5, 1, 3, 6, 2, 4).reshape(R, 6 * 512)   # [dt, s][g, l, i_hi, i_lo]
-    v16 = v[:, 64:].reshape(R, 4, 4, 3, 16).permute(0, 3, 1, 4, 2).reshape(R, 3 * 256)               # [dt][g, l, i]
     pad_k = torch.zeros(R, 4096 - 5 * 768, device=dev, dtype=torch.float16)
     pad_v = torch.zeros(R, 4096 - 6 * 512 - 3 * 256, device=dev, dtype=torch.float16)
     return torch.cat([k32, k16, pad_k, v32, v16, pad_v], 1).reshape(rows, heads, 16, 512).contiguous()
@@ -315,14 +332,14 @@ class HipUNet:
                 W[k[:-len("weight")] + "bias"] = _h(sd[k[:-len("weight")] + "bias"][idx], dev)
                 if bw:
                     W[k + ":T"] = _h(sd[k][idx].t(), dev)
-        # 64 x 64 level of SD1.5 (C = 320, 8 heads of 40): norm2 -> to_q -> text attention -> to_out + residual as ONE row-local
-        # launch for the rows nobody differentiates (csrc/xattn.hip); the per-prompt K / V packs are made in prepare_context
+        # first level (C = 320; SD1.5: 8 heads of 40, SD2.1: 5 heads of 64): norm2 -> to_q -> text attention -> to_out + residual as
+        # ONE row-local launch (csrc/xattn.hip); the per-prompt K / V packs are made in prepare_context
         cfg = self.cfg
         heads320 = cfg.num_heads[list(cfg.block_out_channels).index(320)] if 320 in cfg.block_out_channels else None
         for k in list(sd.keys()):
-            if k.endswith(".attn2.to_q.weight") and sd[k].shape == (320, 320) and heads320 == 8:
+            if k.endswith(".attn2.to_q.weight") and sd[k].shape == (320, 320) and heads320 in _XATTN_HEADS:
                 t = k[: -len(".to_q.weight")]
-                W[t + ".xpack"] = pack_xattn_weights(sd[k], sd[t + ".to_out.0.weight"], 8, dev)
+                W[t + ".xpack"] = pack_xattn_weights(sd[k], sd[t + ".to_out.0.weight"], heads320, dev)
         # 64 x 64 level (C = 320): the whole feed-forward sub-block as ONE row-local launch (csrc/ffblock.hip)
         for k in list(sd.keys()):
             if k.endswith(".ff.net.0.proj.weight") and sd[k].shape[1] == 320 and sd[k].shape[0] // 2 <= 1280:
@@ -427,7 +444,7 @@ class HipUNet:
                 Vc = ops.gemm(x, wv)
                 ctx["blocks"][p] = dict(K=Kc, V=Vc)
                 if (p + ".xpack") in W and L <= 80:
-                    ctx["blocks"][p]["kvpack"] = pack_xattn_kv(Kc, Vc, rows, Lp, L, 8)
+                    ctx["blocks"][p]["kvpack"] = pack_xattn_kv(Kc, Vc, rows, Lp, L, W[p + ".xpack"].shape[0])
         self.ctx = ctx
 
     # ------------------------------------------------------------------ modules, forward
@@ -518,7 +535,7 @@ class HipUNet:
                 p1 = self.inject(t, p1, rows, HW, heads)
             p1_c = p1
         cb = self.ctx["blocks"][t + ".attn2"]
-        xab = (_XATTN_BLOCK and (not keep or (_XATTN_KEEP and rows % 2 == 0)) and "kvpack" in cb and heads == 8 and HW % 128 == 0)
+        xab = (_XATTN_BLOCK and (not keep or (_XATTN_KEEP and rows % 2 == 0)) and "kvpack" in cb and heads in _XATTN_HEADS and HW % 128 == 0)
         xk_half = ()
         if xab:
             # norm2 -> to_q -> attention over the text keys -> to_out + residual in ONE row-local launch (skg_xattn_block_f16); the
@@ -922,7 +939,7 @@ class HipUNet:
                 p1 = self.inject(t, p1, rows, HW, heads)
             p1_c = p1
         cb = self.ctx["blocks"][t + ".attn2"]
-        xab = (_XATTN_BLOCK and (not keep or (_XATTN_KEEP_HP and rows % 2 == 0)) and "kvpack" in cb and heads == 8 and HW % 128 == 0)
+        xab = (_XATTN_BLOCK and (not keep or (_XATTN_KEEP_HP and rows % 2 == 0)) and "kvpack" in cb and heads in _XATTN_HEADS and HW % 128 == 0)
         xk_half = ()
         if xab:
             # norm2 -> to_q -> text attention -> to_out + residual in ONE row-local launch on the pair; in a guided step the same

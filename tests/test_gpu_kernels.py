@@ -114,6 +114,40 @@ def test_three_stage_pipeline_bitwise_equals_two_stage_under_stress():
     assert not diff, f"three-stage output differs from two-stage: {diff[:5]}"
 
 
+def test_split_k_deep_ring_bitwise_equals_two_stage(ops):
+    """Round 5: split-K launches with at most one workgroup per CU run on the three-stage LDS ring (SPLIT_NS_DEFAULT; SKG_SPLIT_NS is
+    read per launch).  Same K slices, same order inside a slice: the fp32 slabs - and so the reduced outputs - must equal the
+    two-stage launch's bit for bit (also the four-stage ring the tuning switch reaches), on GEMM and implicit-GEMM shapes of the
+    8 x 8 / 16 x 16 levels incl. a ragged last slice; and be right."""
+    import os
+    d = dev()
+    old = os.environ.get("SKG_SPLIT_NS")
+    try:
+        for (M, N, K, cin) in ((512, 1280, 10240, 0), (1024, 1280, 5120, 0), (512, 1280, 11520, 1280), (1024, 1280, 23040, 2560), (384, 640, 2880 + 64 * 9, 384)):
+            conv = cin > 0
+            if conv:
+                hw = 8
+                rows = M // (hw * hw)
+                x, w = rnd(M, cin, seed=5).to(d), rnd(N, 9 * cin, seed=6, scale=(9 * cin) ** -0.5).to(d)
+            else:
+                x, w = rnd(M, K, seed=5).to(d), rnd(N, K, seed=6, scale=K ** -0.5).to(d)
+            b, r = rnd(N, seed=7).to(d), rnd(M, N, seed=8).to(d)
+            outs = {}
+            for ns in ("2", "3", "4"):
+                os.environ["SKG_SPLIT_NS"] = ns
+                outs[ns] = (ops.conv3x3(x, w, rows, hw, hw, 0, bias=b, residual=r) if conv else ops.gemm(x, w, bias=b, residual=r)).clone()
+            torch.cuda.synchronize()
+            assert torch.equal(outs["3"], outs["2"]) and torch.equal(outs["4"], outs["2"]), (M, N, K, cin)
+            if not conv:
+                ref = x.float() @ w.float().t() + b.float() + r.float()
+                assert rel_err(outs["3"], ref) < 1.5 * FP16_RND
+    finally:
+        if old is None:
+            os.environ.pop("SKG_SPLIT_NS", None)
+        else:
+            os.environ["SKG_SPLIT_NS"] = old
+
+
 def test_gemm_rejects_bad_args(ops):
     from sketch2img_amd._lib import SkgError
     A, B = rnd(16, 24).to(dev()), rnd(8, 24).to(dev())        # K % 32 != 0
@@ -450,7 +484,15 @@ def test_fused_blocks_on_pairs(ops):
     y0 = ops.ff_block(xp, gam, bet, 1e-5, pack, bias1, b2.to(d))
     assert torch.equal(xin.full, y0.full) and torch.equal(y0.full, y.full)
     # cross-attention block
-    rows, HW, L, heads, dh, Lp = 3, 512, 77, 8, 40, 80
+    for heads in (8, 5):
+        _xattn_pair_checks(ops, heads, g, gam, bet)
+
+
+def _xattn_pair_checks(ops, heads, g, gam, bet):
+    from sketch2img_amd.unet import pack_xattn_kv, pack_xattn_weights
+    d = dev()
+    C = 320
+    rows, HW, L, dh, Lp = 3, 512, 77, C // heads, 80
     M = rows * HW
     xp = _as_pair(ops, (torch.randn(M, C, generator=g) * 1.5 - 0.2).to(d))
     wq, wo, bo = rnd(C, C, seed=64, scale=C ** -0.5), rnd(C, C, seed=65, scale=C ** -0.5), rnd(C, seed=66, scale=0.1)
@@ -463,7 +505,7 @@ def test_fused_blocks_on_pairs(ops):
     ops.gemm(o2, wo.to(d), out=y4.hi, out_lo=y4.lo, bias=bo.to(d), residual=xp.hi, residual_lo=xp.lo)
     s, s4 = y.hi.double() + y.lo.double(), y4.hi.double() + y4.lo.double()
     r = float((s - s4).norm() / s4.norm())
-    print(f"[parity] xattn_block on a pair vs the unfused pair launches: rel {r:.2e}")
+    print(f"[parity] xattn_block ({heads} heads) on a pair vs the unfused pair launches: rel {r:.2e}")
     assert r < 1e-4 and float((y.hi.float() - s.float()).abs().max()) <= 2.0 ** -10 * float(s.abs().max())
     # ... and its stashing form (skg_xattn_block_f16_hilo_keep, guided steps of the accuracy mode): the same pair (to 1 ulp of lo on
     # a few outputs: another instantiation of the same source), and for the rows from keep_from on norm2's statistics, q, the
@@ -1518,16 +1560,17 @@ def test_ff_block_keep_stores_the_pre_activation(ops):
 
 
 # ---------------------------------------------------------------------------------------------- fused cross-attention sub-block
-@pytest.mark.parametrize("rows,HW,L", [(2, 1024, 77), (16, 4096, 77), (3, 128, 40)])
-def test_xattn_block_fused(ops, rows, HW, L):
+@pytest.mark.parametrize("rows,HW,L,heads", [(2, 1024, 77, 8), (16, 4096, 77, 8), (3, 128, 40, 8), (2, 1024, 77, 5), (4, 9216, 77, 5), (3, 128, 33, 5)])
+def test_xattn_block_fused(ops, rows, HW, L, heads):
     """skg_xattn_block_f16 (norm2 -> attn2.to_q -> attention over the text keys -> attn2.to_out + residual in ONE launch,
     C = 320, 8 heads of 40) against (a) the fp32 definition on the same fp16 inputs: the output rounding plus the internal fp16
     roundings the unfused path has too (LayerNorm output, q, scaled q, probabilities, attention output) - rel <= 2 x FP16_RND
-    on an O(1) residual stream; (b) the four launches it replaces (skg_layernorm_fwd, skg_gemm_f16, skg_attn_fwd_rowv,
+    on an O(1) residual stream (heads = 5: the 5 x 64 instantiation of SD2.1's first level, round 5); (b) the four launches it replaces (skg_layernorm_fwd, skg_gemm_f16, skg_attn_fwd_rowv,
     skg_gemm_f16 + residual), which round at the same points: rel <= 3e-4, >= 95 % of the outputs bit-equal; in place == out of place."""
     from sketch2img_amd.unet import pack_xattn_kv, pack_xattn_weights
     d = dev()
-    C, heads, dh, Lp = 320, 8, 40, 80
+    C, Lp = 320, 80
+    dh = C // heads
     M = rows * HW
     scale = dh ** -0.5
     x = rnd(M, C, seed=31)
