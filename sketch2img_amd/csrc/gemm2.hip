@@ -1351,9 +1351,14 @@ int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode, size_t ws_bytes) {
   const TileCfg t = pick_tile(M, N, K);
   const int KT = K / BK;
   const long ntiles = (long)skg_cdiv(M, t.bm) * skg_cdiv(N, t.bn);
-  const bool three = t.bm == 128 && (t.bn == 160 || t.bn == 64) && (mode == MODE_DIRECT || mode == MODE_S1) &&
-                     !getenv("SKG_NO_NS3") && KT >= 4 && (t.bn == 64 || ntiles <= 256) &&
-                     pick_splits(ntiles, KT, (size_t)M * N * 4, ws_bytes ? (const float*)1 : nullptr, ws_bytes) == 1;
+  const int splits = t.bm == 128 ? pick_splits(ntiles, KT, (size_t)M * N * 4, ws_bytes ? (const float*)1 : nullptr, ws_bytes) : 1;
+  bool three = t.bm == 128 && (t.bn == 160 || t.bn == 64) && (mode == MODE_DIRECT || mode == MODE_S1) &&
+               !getenv("SKG_NO_NS3") && KT >= 4 && (t.bn == 64 || ntiles <= 256) && splits == 1;
+  if (splits > 1 && t.bm == 128 && t.bn == 160 && (mode == MODE_DIRECT || mode == MODE_S1)) {      // split launch on the deep ring (launch_cfg)
+    const int per = skg_cdiv(KT, splits), ns = skg_cdiv(KT, per);
+    const char* e = getenv("SKG_SPLIT_NS");
+    three = ntiles * ns <= 256 && per >= 4 && (e ? atoi(e) : SPLIT_NS_DEFAULT) >= 3;      // (a tuning value of 4 is reported as three stages too)
+  }
   return t.bn + (three ? 10000 : 0);
 }
 
