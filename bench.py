@@ -10,11 +10,19 @@ then - N > 1 - the gather of the decoded images on rank 0).  ``--config`` picks 
     4            configs[3]: SD1.5, 8 samples per GPU, 512x512, sketch_guided_attn injection, no LGP gradient
     5            configs[4]: SD2.1 architecture, 4 samples per GPU, 768x768, clip_guided_attn injection
 
+``value`` is timed in the ACCURACY mode of the UNet (``residual_fp32``: the mode that meets north_star's
+"<= 1e-3 max latent-eps deviation vs reference"; round 6 - VERDICT r5 next #1); the all-fp16 mode (the reference's own
+GPU configuration, app.py:34) is timed beside it on three batches and reported as ``config.fast_fp16_value``
+(``--fast-fp16`` swaps the two).  Everything a reader needs to judge the line is a FLAT scalar: ``config.mode``,
+``config.eps_max`` / ``eps_bound`` / ``eps_rel`` / ``eps_max_unit_var``, ``config.fast_fp16_value``, the box calibration
+``config.box_mfma_tflops`` / ``box_sclk_mhz`` / ``box_power_w`` / ``box_power_cap_w`` and ``roofline.*_frac``.
+
 Weights, text embeddings, sketch inputs and initial latents are synthetic (seeded) and resident in HBM before
 the timed region.  N > 1: one process per GPU (torch.distributed / RCCL), rank 0's weights are broadcast
 once, every rank samples its own images (weak scaling, no per-step collective).
 
     python bench.py --gpus 1 --steps 2 --warmup 1
+    python bench.py --gpus 8                       (launches itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 ... bench.py --gpus 8
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant contraction kernel,
@@ -28,7 +36,10 @@ import glob
 import json
 import os
 import re
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -54,7 +65,12 @@ def f_img_tflop(config: int, T: int) -> float:
     return T * 2 * (GF_C4_ROW if config == 4 else GF_C5_ROW) / 1e3
 
 
-WORKLOADS = {
+WORKLOADS = {      # (<= 120 characters: parsers of the contract line cut longer strings; the long form is `workload_detail`)
+    2: "BASELINE configs[1]: SD1.5 fp16, {S} samples/GPU, 512x512, {T} {sched} steps, CFG 7.5, LGP guidance steps 0..{G}",
+    4: "BASELINE configs[3]: SD1.5 fp16, {S} samples/GPU, 512x512, {T} {sched} steps, CFG 7.5, sketch_guided_attn",
+    5: "BASELINE configs[4]: SD2.1 fp16, {S} samples/GPU, 768x768, {T} {sched} steps, CFG 7.5, clip_guided_attn",
+}
+WORKLOAD_DETAILS = {
     2: "BASELINE.json configs[1]: SD1.5 architecture (synthetic seeded weights), {S} independent samples per GPU, "
        "512x512 (64x64 latents), {T} {sched} steps, CFG 7.5, LGP sketch guidance on steps 0..{G} (beta 1.6)",
     4: "BASELINE.json configs[3]: SD1.5 architecture (synthetic seeded weights), {S} independent samples per GPU, "
@@ -64,6 +80,7 @@ WORKLOADS = {
        "independent samples per GPU, 768x768 (96x96 latents), {T} {sched} steps, CFG 7.5, clip_guided_attn injection on "
        "[zeros; 257 CLIP tokens] (scale 1.0)",
 }
+EPS_BOUND = 1e-3      # north_star: "<= 1e-3 max latent-eps deviation vs reference"
 
 
 def parse():
@@ -80,14 +97,20 @@ def parse():
                     help="images (default): VAE decode on-rank + gather of uint8 images inside the timed region, as "
                          "north_star states; latents: gather the fp32 latents, no decode (round-1 behaviour)")
     ap.add_argument("--no-guidance", action="store_true", help="informational: config 2 without the LGP guidance (no backward)")
-    ap.add_argument("--residual-fp32", action="store_true",
-                    help="informational: HipUNet's opt-in accuracy mode (hi / lo residual stream; config 2, with or without guidance) - "
-                         "prices the mode that meets north_star's 1e-3 eps bound")
-    ap.add_argument("--no-at-tolerance", action="store_true",
-                    help="skip the second timed region: the same workload in HipUNet's accuracy mode (the `at_tolerance` object)")
-    ap.add_argument("--at-tolerance-steps", type=int, default=3, help="timed batches of the accuracy-mode region (after 1 warm-up)")
-    ap.add_argument("--at-tolerance-multi", action="store_true",
-                    help="run the accuracy-mode region at --gpus > 1 too (default: N = 1 only - it builds a second full workload on every rank)")
+    ap.add_argument("--mode", default="tolerance", choices=("tolerance", "fast"),
+                    help="what `value` is timed in: tolerance (default) = HipUNet(residual_fp32=True), the mode that meets north_star's "
+                         "1e-3 eps bound; fast = every stored tensor fp16 (the reference's own GPU configuration)")
+    ap.add_argument("--residual-fp32", dest="mode", action="store_const", const="tolerance", help="= --mode tolerance")
+    ap.add_argument("--fast-fp16", dest="mode", action="store_const", const="fast", help="= --mode fast")
+    ap.add_argument("--no-second-mode", "--no-at-tolerance", dest="no_second_mode", action="store_true",
+                    help="skip the second timed region (the same workload in the OTHER mode: `config.fast_fp16_value`)")
+    ap.add_argument("--second-mode-steps", "--at-tolerance-steps", dest="second_mode_steps", type=int, default=3,
+                    help="timed batches of the second region (after 1 warm-up)")
+    ap.add_argument("--second-mode-multi", "--at-tolerance-multi", dest="second_mode_multi", action="store_true",
+                    help="run the second region at --gpus > 1 too (default: N = 1 only - it builds a second full workload on every rank)")
+    ap.add_argument("--no-box-probe", action="store_true", help="skip the box calibration (MFMA probe + rocm-smi sample)")
+    ap.add_argument("--plumbing-check", action="store_true",
+                    help="tests only: launcher / rendezvous / barrier / JSON relay without the hot path (runs without a GPU)")
     ap.add_argument("--graph", action="store_true", help="replay the two step variants from captured hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -110,6 +133,7 @@ class LaunchTimer:
         self._up2, self._c4, self._ffb, self._xab = ops.conv_up2, ops.conv4x4s2, ops.ff_block, ops.xattn_block
         self._ffp = ops.ff_block_proj
         self._csc = ops.conv3x3_sc
+        self._up2p = ops.conv_up2_pairout
 
     def __enter__(self):
         from sketch2img_amd._lib import lib
@@ -117,18 +141,20 @@ class LaunchTimer:
 
         MODES = {"DIRECT": 0, "S1": 1, "S2": 2, "UP2": 3, "S2T": 4}
 
-        def kname(variant, mode, gn=False):
+        def kname(variant, mode, gn=False, hilo=False):
             """The name rocprofv3 prints for the instantiation that ran (template arguments spelled out); gn: the one
-            whose epilogue also writes the GroupNorm partial sums of the output."""
+            whose epilogue also writes the GroupNorm partial sums of the output; hilo: the accuracy mode's pair epilogue."""
             bn = variant % 1000
-            g = "true" if gn else "false"
+            g, h = "true" if gn else "false", "true" if hilo else "false"
             if variant in (8160, 8320):
-                return f"gemm8_kernel<{variant - 8000}, {MODES[mode]}, 0, {g}>"
+                return f"gemm8_kernel<{variant - 8000}, {MODES[mode]}, 0, {g}, {h}>"
             if variant >= 2000:
                 stages = 3 if variant >= 10000 else 2
-                # (..., GNS, HILO): the accuracy-mode instantiation is never part of a bench batch
-                return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}, {stages}, {g}, false>"
+                return f"gemm2_kernel<{256 if bn == 320 else 128}, {bn}, 2, {4 if bn == 320 else 2}, {MODES[mode]}, {stages}, {g}, {h}>"
             return f"gemm_kernel<{bn}, {MODES[mode]}>"
+
+        def is_pair(k):
+            return k.get("out_lo") is not None
 
         def ev():
             return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -144,7 +170,9 @@ class LaunchTimer:
             tag = "+res" * (k.get("residual") is not None) + "+geglu" * bool(k.get("geglu")) + "+f32" * bool(k.get("out_f32"))
             gs = k.get("gn_stats")
             gn = gs is not None and bool(lib.skg_gemm_gn_fused(M, N, K, 0, 0, gs[0], gs[1]))
-            self.rec.append((kname(lib.skg_gemm_variant(M, N, K, 0, 0), "DIRECT", gn), 2.0 * M * N * K, e0, e1, nbytes,
+            nbytes += 2.0 * M * N * (is_pair(k) + (k.get("residual_lo") is not None))
+            tag += "+pair" * is_pair(k)
+            self.rec.append((kname(lib.skg_gemm_variant(M, N, K, 0, 0), "DIRECT", gn, is_pair(k)), 2.0 * M * N * K, e0, e1, nbytes,
                              f"gemm M{M} N{N} K{K}{tag}"))
             return out
 
@@ -160,8 +188,9 @@ class LaunchTimer:
             nbytes = 2.0 * (X.shape[0] * Cin + Cout * 9 * Cin + M * Cout + (M * Cout if k.get("residual") is not None else 0))
             gg = k.get("gn_groups")
             gn = gg is not None and bool(lib.skg_gemm_gn_fused(M, Cout, 9 * Cin, Cin, 1 + mode, OH * OH, gg))
-            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, 9 * Cin, Cin, 1 + mode), name, gn), 2.0 * M * Cout * 9 * Cin, e0, e1, nbytes,
-                             f"conv {name} M{M} Cin{Cin} Cout{Cout}" + "+res" * (k.get("residual") is not None)))
+            nbytes += 2.0 * M * Cout * (is_pair(k) + (k.get("residual_lo") is not None))
+            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, 9 * Cin, Cin, 1 + mode), name, gn, is_pair(k)), 2.0 * M * Cout * 9 * Cin, e0, e1, nbytes,
+                             f"conv {name} M{M} Cin{Cin} Cout{Cout}" + "+res" * (k.get("residual") is not None) + "+pair" * is_pair(k)))
             return out
 
         def conv_sc(X, X2, Wcat, rows, IH, IW, *a, **k):     # conv2 + the 1x1 shortcut of a ResnetBlock as one implicit GEMM
@@ -173,8 +202,9 @@ class LaunchTimer:
             e1.record()
             gg = k.get("gn_groups")
             gn = gg is not None and bool(lib.skg_gemm_gn_fused(M, Cout, K, Cin, 1, IH * IW, gg))
-            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, K, Cin, 1), "S1", gn), 2.0 * M * Cout * K, e0, e1,
-                             2.0 * (M * Cin + M * K2 + Cout * K + M * Cout), f"conv S1 + shortcut M{M} Cin{Cin} K2 {K2} Cout{Cout}"))
+            self.rec.append((kname(lib.skg_gemm_variant(M, Cout, K, Cin, 1), "S1", gn, is_pair(k)), 2.0 * M * Cout * K, e0, e1,
+                             2.0 * (M * Cin + M * K2 + Cout * K + M * Cout * (1 + is_pair(k))),
+                             f"conv S1 + shortcut M{M} Cin{Cin} K2 {K2} Cout{Cout}" + "+pair" * is_pair(k)))
             return out
 
         def v2name(M, N, K, Cin, mode, label, phases=1):
@@ -195,6 +225,18 @@ class LaunchTimer:
             one = ((M + 127) // 128) * ((Cout + 159) // 160) < 200            # the four phases as one grid (gemm.hip)
             self.rec.append((v2name(M, Cout, 4 * Cin, Cin, 0, "S1", 4 if one else 1), 2.0 * M * Cout * 16 * Cin, e0, e1,
                              2.0 * (M * Cin + 16 * Cout * Cin + 4 * M * Cout), f"conv UP2 polyphase M{4 * M} Cin{Cin} Cout{Cout}", 1 if one else 4))
+            return out
+
+        def conv_up2_pairout(X, Wpp, rows, IH, IW, *a, **k):      # accuracy mode: the same polyphase launches with a pair output
+            Cin, Cout = X.shape[1], Wpp.shape[1]
+            M = rows * IH * IW
+            e0, e1 = ev()
+            e0.record()
+            out = self._up2p(X, Wpp, rows, IH, IW, *a, **k)
+            e1.record()
+            one = ((M + 127) // 128) * ((Cout + 159) // 160) < 200
+            self.rec.append((v2name(M, Cout, 4 * Cin, Cin, 0, "S1", 4 if one else 1).replace("false>", "true>"), 2.0 * M * Cout * 16 * Cin, e0, e1,
+                             2.0 * (M * Cin + 16 * Cout * Cin + 8 * M * Cout), f"conv UP2 polyphase M{4 * M} Cin{Cin} Cout{Cout}+pair", 1 if one else 4))
             return out
 
         def conv4x4s2(X, W16, rows, IH, IW, *a, **k):
@@ -236,8 +278,11 @@ class LaunchTimer:
                              2.0 * (M * K + N * K + M * N + M * N // 2), f"gemm M{M} N{N} K{K}+geglu+keep"))
             return out
 
+        def hi(X):
+            return X.hi if isinstance(X, ops.Pair) else X
+
         def ff_block(X, gamma, beta, eps, pack, *a, **k):       # norm3 + FF1 + gate + FF2 + residual in one launch
-            M, C = X.shape
+            M, C = hi(X).shape
             Fh = pack.shape[0] * 32
             e0, e1 = ev()
             e0.record()
@@ -248,7 +293,7 @@ class LaunchTimer:
             return out
 
         def ff_block_proj(X, gamma, beta, eps, pack, *a, **k):  # ... + proj_out + outer residual (five chunks more in the pack)
-            M, C = X.shape
+            M, C = hi(X).shape
             Fh = (pack.shape[0] - 5) * 32
             e0, e1 = ev()
             e0.record()
@@ -259,7 +304,7 @@ class LaunchTimer:
             return out
 
         def xattn_block(X, HW, heads, Nkv, *a, **k):            # norm2 + to_q + text attention + to_out + residual in one launch
-            M, C = X.shape
+            M, C = hi(X).shape
             e0, e1 = ev()
             e0.record()
             out = self._xab(X, HW, heads, Nkv, *a, **k)
@@ -274,6 +319,7 @@ class LaunchTimer:
         ops.conv_up2, ops.conv4x4s2, ops.ff_block, ops.xattn_block = conv_up2, conv4x4s2, ff_block, xattn_block
         ops.ff_block_proj = ff_block_proj
         ops.conv3x3_sc = conv_sc
+        ops.conv_up2_pairout = conv_up2_pairout
         return self
 
     def __exit__(self, *exc):
@@ -281,6 +327,7 @@ class LaunchTimer:
         self.ops.conv_up2, self.ops.conv4x4s2, self.ops.ff_block, self.ops.xattn_block = self._up2, self._c4, self._ffb, self._xab
         self.ops.ff_block_proj = self._ffp
         self.ops.conv3x3_sc = self._csc
+        self.ops.conv_up2_pairout = self._up2p
 
     def summary(self):
         """per kernel: [launches, flops, seconds, algorithmic bytes, roofline seconds, seconds of HBM-bound launches];
@@ -421,10 +468,14 @@ def cpu_baseline(extrapolate_c2: bool = True):
         x, tgt = synthetic.initial_latents(0, 1, h), synthetic.sketch_targets(0, 1, h)
         tab = oddim.make_tables(50)
         t = int(tab.timesteps[0])
+        # the fp32 references of `config.eps_max`: full SD1.5, 2 CFG rows, 64 x 64 latents, at the first / middle / last timestep of the
+        # schedule, the latents of samples 0 / 1 / 2 (the first evaluation doubles as the warm-up: first touch of the 64x64 buffers)
+        eps_cases = []
         with torch.no_grad():
-            # warm-up (first touch of the 64x64 buffers) - and the fp32 reference of `eps_max`: full SD1.5, 2 CFG rows, 64 x 64, t = 981
-            eps_ref, _ = ounet.unet_forward(cfg, W, torch.cat([x] * 2), t, ehs)
-        res["_parity"].update(eps_ref=eps_ref, eps_x=x, eps_t=t, eps_ehs=ehs)
+            for i, tt in enumerate((int(tab.timesteps[0]), int(tab.timesteps[len(tab.timesteps) // 2]), int(tab.timesteps[-1]))):
+                xi = synthetic.initial_latents(i, 1, h)
+                eps_cases.append(dict(x=xi, t=tt, ref=ounet.unet_forward(cfg, W, torch.cat([xi] * 2), tt, ehs)[0]))
+        res["_parity"].update(eps_cases=eps_cases, eps_ehs=ehs)
         times = {}
         for guided in (True, False):
             t0 = time.time()
@@ -450,8 +501,8 @@ _SD_CACHE: dict = {}      # the (broadcast) synthetic state dicts: the accuracy-
 
 def build_workload(args, rank, world, dev, dist, residual_fp32=None):
     """Everything resident in HBM: engines, inputs, tables.  Returns a dict with `one_batch()`.
-    residual_fp32: override of args.residual_fp32 (the `at_tolerance` region builds the accuracy-mode twin of the workload)."""
-    residual_fp32 = args.residual_fp32 if residual_fp32 is None else residual_fp32
+    residual_fp32: override of the headline mode (the second timed region builds the other mode's twin of the workload)."""
+    residual_fp32 = (args.mode == "tolerance") if residual_fp32 is None else residual_fp32
     from sketch2img_amd import synthetic
     from sketch2img_amd.config import SD15, SD21, SD_VAE, tap_channels
     from sketch2img_amd.dist import broadcast_state_dict, gather_images, gather_latents
@@ -524,16 +575,137 @@ def build_workload(args, rank, world, dev, dist, residual_fp32=None):
     return dict(one_batch=one_batch, sampler=sampler, net=net, decode_events=decode_events, vae=vae, S=S, h=h, T=T, tab=tab, lat0=lat0, target=target)
 
 
+def _free_port() -> int:
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` (N > 1) outside a launcher: re-exec under torch.distributed.run, one rank per GPU, relay rank 0's
+    JSON line and the exit code (VERDICT r5 next #6: the driver's scaling command must not die on a WORLD_SIZE assert)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SKG_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # (stderr passes through)
+    lines = r.stdout.splitlines()
+    js = [l for l in lines if l.startswith('{"metric"')]
+    for l in lines:
+        if l not in js[-1:]:
+            print(l, file=sys.stderr)
+    if js:
+        print(js[-1], flush=True)
+    sys.exit(r.returncode if (r.returncode or js) else 1)
+
+
+# ------------------------------------------------------------------------------------------------ box calibration
+def _smi_sample():
+    """One `rocm-smi` reading: (sclk MHz, package power W, power cap W) - each None when the tool or the field is missing."""
+    def run(*a):
+        try:
+            return subprocess.run(["rocm-smi", *a], capture_output=True, text=True, timeout=20).stdout
+        except Exception:
+            return ""
+    dev = os.environ.get("SKG_BENCH_SMI_DEVICE")          # (HIP_VISIBLE_DEVICES may renumber: default = the first card rocm-smi lists)
+    sel = ["-d", dev] if dev else []
+    out = run(*sel, "--showpower", "--showclocks")
+    cap = run(*sel, "--showmaxpower")
+    ck = re.search(r"sclk[^(\n]*\((\d+)Mhz\)", out)
+    pw = re.search(r"Power[^:\n]*\(W\)\s*:\s*([0-9.]+)", out) or re.search(r"Power[^:\n]*:\s*([0-9.]+)", out)
+    cp = re.search(r"Max[^:\n]*Power[^:\n]*:\s*([0-9.]+)", cap) or re.search(r"Power[^:\n]*:\s*([0-9.]+)", cap)
+    return (int(ck.group(1)) if ck else None, float(pw.group(1)) if pw else None, float(cp.group(1)) if cp else None)
+
+
+def box_probe(dev, seconds: float = 1.6):
+    """What THIS box sustains (VERDICT r5 next #5: the same kernels read 11-12 % apart on two driver boxes): the in-library bare
+    MFMA stream (skg_box_probe_mfma: register-resident 16x16x32 fp16 MFMAs on pseudo-random operands, 512 workgroups x 8 waves)
+    runs for `seconds`; the LAST third is timed with HIP events (the clock has settled under the power limit by then) while
+    one rocm-smi reading is taken beside it.  -> flat scalars for the contract line."""
+    from sketch2img_amd._lib import check, lib
+    out = torch.empty(512 * 512, device=dev, dtype=torch.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    iters = 4096
+    flop = 512 * 8 * iters * 40 * 2 * 16 * 16 * 32
+
+    def burst(n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            check(lib.skg_box_probe_mfma(out.data_ptr(), iters, st), "skg_box_probe_mfma")
+        e1.record()
+        return e0, e1
+
+    e0, e1 = burst(4)
+    torch.cuda.synchronize()
+    per = e0.elapsed_time(e1) * 1e-3 / 4                       # seconds per launch (first estimate)
+    n = max(6, int(seconds / max(per, 1e-4)))
+    smi = {}
+    th = threading.Thread(target=lambda: smi.update(v=_smi_sample()))
+    a0, a1 = burst(n - n // 3)                                 # queued asynchronously: the GPU is busy for ~seconds from here
+    b0, b1 = burst(n // 3)
+    th.start()                                                 # ... and the reading is taken while it is
+    th.join()
+    torch.cuda.synchronize()
+    sclk, power, cap = smi.get("v", (None, None, None))
+    t_tail = b0.elapsed_time(b1) * 1e-3
+    return dict(box_mfma_tflops=flop * (n // 3) / t_tail / 1e12, box_sclk_mhz=sclk, box_power_w=power, box_power_cap_w=cap,
+                box_probe_s=(a0.elapsed_time(b1)) * 1e-3)
+
+
+def plumbing_check(args, world, rank):
+    """Tests only (no GPU needed): everything of the N > 1 launch path except the hot path - rendezvous, barrier, max over ranks,
+    rank 0's single JSON line - with the gloo backend."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t0 = time.perf_counter()
+    dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0 + rank], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "-1"))))
+    if rank == 0:
+        print(json.dumps({"metric": "plumbing-check (no hot path)", "value": 0.0, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ranks": ranks, "max_over_ranks": float(tt),
+                          "self_launched": os.environ.get("SKG_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    dist.destroy_process_group()
+
+
+def _timed(one_batch, steps, warmup, barrier, dist, dev):
+    out = None
+    for _ in range(warmup):
+        out = one_batch()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = one_batch()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    return dt, out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (an external launcher started another number of ranks)"
+    if args.plumbing_check:
+        return plumbing_check(args, world, rank)
     # test-only switches: run the N > 1 code path with several ranks on ONE GPU (gloo carries CUDA tensors)
     backend = os.environ.get("SKG_BENCH_BACKEND", "nccl")
     if "SKG_BENCH_DEVICE" in os.environ:
         local = int(os.environ["SKG_BENCH_DEVICE"])
+    assert torch.cuda.is_available() and local < torch.cuda.device_count(), \
+        (f"rank {rank}: no cuda:{local} ({torch.cuda.device_count()} visible device(s)); several ranks on one device is a test "
+         "configuration: SKG_BENCH_DEVICE=0 SKG_BENCH_BACKEND=gloo")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -552,6 +724,11 @@ def main():
 
     from sketch2img_amd import ops
 
+    tol = args.mode == "tolerance"
+    box = {}
+    if rank == 0 and not args.no_box_probe:
+        box = box_probe(dev)
+
     t_setup = time.time()
     wl = build_workload(args, rank, world, dev, dist)
     one_batch, S, T, C = wl["one_batch"], wl["S"], wl["T"], args.config
@@ -566,20 +743,10 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    out = None
     for _ in range(args.warmup):
-        out = one_batch()
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        one_batch()
     wl["decode_events"].clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_batch()
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+    dt, out = _timed(one_batch, args.steps, 0, barrier, dist, dev)
     lat_final = wl["sampler"].last_latents
     finite = bool(torch.isfinite(lat_final).all())
     if dist is not None:
@@ -607,74 +774,78 @@ def main():
         name, (n, fl, sec, nb, _, _) = max(agg.items(), key=lambda kv: kv[1][2])
         tot_sec = sum(v[2] for v in agg.values())
         traffic, traffic_file = pmc_traffic(C, name)
+        byop = by_operator(agg)
         roof = dict(bound="mfma", kernel=name, achieved=fl / sec / 1e12, peak=PEAK_FP16_TFLOPS, unit="TFLOP/s",
                     frac=fl / sec / 1e12 / PEAK_FP16_TFLOPS, traffic=traffic, algorithmic_bytes=nb / n,
-                    traffic_source=(f"from committed profile {traffic_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes "
-                                    "per launch = (2*FETCH + WRITE)*1024), not measured in this run") if traffic_file else None,
+                    traffic_source=(f"committed {traffic_file}: rocprofv3 --pmc passes, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch") if traffic_file else None,
                     launches=n, avg_launch_us=sec / n * 1e6, avg_launch_gflop=fl / n / 1e9,
-                    timing=("HIP events on the launch stream around every launch (includes the launch gap), one instrumented batch after the timed "
-                            "region with the guidance branch in line (the timed region runs it on a second stream beside the last up block)"),
+                    timing="HIP events on the launch stream around every launch of one instrumented batch, guidance branch in line",
                     all_contraction_tflops=sum(v[1] for v in agg.values()) / tot_sec / 1e12,
                     contraction_share_of_step=tot_sec / (dt / args.steps),
                     # every launch against ITS OWN bound, max(flops / 2.5 PFLOP/s, algorithmic bytes / 8 TB/s): the short-K
                     # projections (K = 320: 320 flop per output byte against a machine balance of 312) are HBM-bound launches
                     # of the same instantiation that runs the MFMA-bound ones
-                    all_contraction_frac_of_own_roofline=sum(v[4] for v in agg.values()) / tot_sec,
-                    # the same launches grouped by OPERATOR (an operator may run on several instantiations: the 3x3
-                    # convolution on gemm2_kernel<..., 1, ...> and, for the 64x64 level, on gemm8_kernel<320, 1, 0>)
-                    by_operator=by_operator(agg),
-                    per_kernel={k: dict(launches=v[0], tflops=v[1] / v[2] / 1e12, seconds=v[2],
-                                        frac_of_own_roofline=v[4] / v[2], hbm_bound_share_of_time=v[5] / v[2])
-                                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])})
+                    all_contraction_frac_of_own_roofline=sum(v[4] for v in agg.values()) / tot_sec)
+        # FLAT per-operator fractions of the MFMA peak (an operator may run on several instantiations: the 3x3 convolution on
+        # gemm2_kernel<..., 1, ...> and, for the 64x64 level, on gemm8_kernel<320, 1, ...>)
+        for op_name, key in (("conv3x3", "conv3x3_frac"), ("gemm", "gemm_frac"), ("attention_fwd", "attn_fwd_frac"), ("ff_block", "ff_block_frac"),
+                             ("xattn_block", "xattn_block_frac"), ("conv3x3_resample", "conv_resample_frac")):
+            roof[key] = byop[op_name]["frac"] if op_name in byop else None
         rp = rocprof_duration(C, name)
+        roof["rocprof_frac"] = roof["rocprof_avg_launch_us"] = roof["rocprof_source"] = None
         if rp is not None:
             avg_ns, calls, f = rp
-            roof["rocprof"] = dict(avg_launch_us=avg_ns / 1e3, launches=calls, achieved=fl / n / avg_ns / 1e3,
-                                   frac=fl / n / avg_ns / 1e3 / PEAK_FP16_TFLOPS,
-                                   source=f"committed {f} (rocprofv3 --kernel-trace --stats of this command)")
-    # ---- second timed region: the SAME workload with the UNet in its accuracy mode - the configuration that meets north_star's
-    # "<= 1e-3 max latent-eps deviation vs reference" (DESIGN.md 5); `value` above is the all-fp16 default like the reference's GPU path
-    at_tol, wl2 = None, None
-    want_tol = not args.residual_fp32 and not args.no_at_tolerance and not args.graph and args.scheduler == "ddim" and not args.no_guidance
-    if want_tol and world > 1 and not args.at_tolerance_multi:
+            roof["rocprof_frac"] = fl / n / avg_ns / 1e3 / PEAK_FP16_TFLOPS
+            roof["rocprof_avg_launch_us"] = avg_ns / 1e3
+            roof["rocprof_source"] = f"committed {f} (rocprofv3 --kernel-trace --stats of this command), {calls} launches"
+        # the nested detail (parsers that keep scalars only drop these; everything needed to judge the line is flat above)
+        roof["by_operator"] = byop
+        roof["per_kernel"] = {k: dict(launches=v[0], tflops=v[1] / v[2] / 1e12, seconds=v[2],
+                                      frac_of_own_roofline=v[4] / v[2], hbm_bound_share_of_time=v[5] / v[2])
+                              for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
+    # ---- second timed region: the SAME workload in the OTHER mode (headline = accuracy mode -> the all-fp16 mode here: the reference's
+    # own GPU configuration, app.py:34, which misses north_star's eps bound; --fast-fp16 swaps the two)
+    second, wl2 = None, None
+    want2 = not args.no_second_mode and not args.graph and args.scheduler == "ddim" and not args.no_guidance
+    if want2 and world > 1 and not args.second_mode_multi:
         # (the scaling runs: a second full workload per rank - weights, packs, broadcast - would only lengthen them; the mode's
         # cost is a per-GPU figure and is measured at N = 1)
-        at_tol, want_tol = dict(skipped="n_gpus > 1: measured at N = 1 (pass --at-tolerance-multi to time it here)"), False
-    if want_tol:
-        wl2 = build_workload(args, rank, world, dev, dist, residual_fp32=True)
-        wl2["one_batch"]()
-        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.at_tolerance_steps):
-            wl2["one_batch"]()
-        torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
-        dt2 = time.perf_counter() - t0
+        second, want2 = dict(skipped="n_gpus > 1: measured at N = 1 (pass --second-mode-multi to time it here)"), False
+    if want2:
+        wl2 = build_workload(args, rank, world, dev, dist, residual_fp32=not tol)
+        dt2, _ = _timed(wl2["one_batch"], args.second_mode_steps, 1, barrier, dist, dev)
         fin2 = bool(torch.isfinite(wl2["sampler"].last_latents).all())
         if dist is not None:
-            tt = torch.tensor([dt2, float(not fin2)], device=dev, dtype=torch.float64)
+            tt = torch.tensor([float(not fin2)], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt2, fin2 = float(tt[0]), not bool(tt[1])
-        v2 = world * S * args.at_tolerance_steps / dt2
-        at_tol = dict(value=v2, unit="images/s", ms_per_step=dt2 / args.at_tolerance_steps * 1e3, steps=args.at_tolerance_steps, warmup=1,
-                      cost_vs_default=1.0 - v2 / value, outputs_finite=fin2, eps_max=None, eps_max_default=None,
-                      mode="HipUNet(residual_fp32=True) = AntiGradientPipeline.from_pretrained(..., residual_fp32=True): residual stream and "
-                           "the conv outputs that feed a norm as (hi, lo) fp16 pairs, same workload, same timed-region definition")
+            fin2 = not bool(tt[0])
+        v2 = world * S * args.second_mode_steps / dt2
+        second = dict(value=v2, unit="images/s", ms_per_step=dt2 / args.second_mode_steps * 1e3, steps=args.second_mode_steps, warmup=1,
+                      outputs_finite=fin2, mode="fast_fp16" if tol else "residual_fp32")
         finite = finite and fin2
+    eps = {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
         par = cpu.pop("_parity")
-        if at_tol is not None and C == 2 and "eps_ref" in par:
-            # eps of ONE full-size evaluation (2 CFG rows, 64 x 64 latents, t = 981) of both modes against the fp32 CPU oracle
+        if C == 2 and "eps_cases" in par:
+            # eps of full-size evaluations (2 CFG rows, 64 x 64 latents; first / middle / last timestep, three samples) of the mode(s)
+            # built above against the fp32 CPU oracle
             from sketch2img_amd.unet import CIN_PAD
-            xin = torch.cat([par["eps_x"]] * 2).to(dev, torch.float32).contiguous()
-            for key, net in (("eps_max_default", wl["net"]), ("eps_max", wl2["net"])):
+            nets = {("residual_fp32" if tol else "fast_fp16"): wl["net"]}
+            if wl2 is not None:
+                nets["fast_fp16" if tol else "residual_fp32"] = wl2["net"]
+            for mode_name, net in nets.items():
                 saved_ctx = net.ctx
                 net.prepare_context(par["eps_ehs"])
-                e, _ = net.forward(ops.nchw_to_nhwc(xin, CIN_PAD), par["eps_t"], 2, xin.shape[-1], want_taps=False, shared_input=True)
-                at_tol[key] = float((ops.nhwc_to_nchw(e, 2, 4, xin.shape[-1], xin.shape[-1]).cpu() - par["eps_ref"]).abs().max())
+                mx = rel = std = 0.0
+                for case in par["eps_cases"]:
+                    xin = torch.cat([case["x"]] * 2).to(dev, torch.float32).contiguous()
+                    e, _ = net.forward(ops.nchw_to_nhwc(xin, CIN_PAD), case["t"], 2, xin.shape[-1], want_taps=False, shared_input=True)
+                    d = ops.nhwc_to_nchw(e, 2, 4, xin.shape[-1], xin.shape[-1]).cpu() - case["ref"]
+                    mx, rel = max(mx, float(d.abs().max())), max(rel, float(d.norm() / case["ref"].norm()))
+                    std = max(std, float(case["ref"].std()))
                 net.ctx = saved_ctx
-            at_tol["eps_max_of"] = ("max |eps - eps_fp32_oracle| of one full-size evaluation (SD1.5, 2 CFG rows, 64x64 latents, t = 981, |eps| <= ~1.4); "
-                                    "north_star's bound: 1e-3")
+                eps[mode_name] = dict(eps_max=mx, eps_rel=rel, eps_std=std, evals=len(par["eps_cases"]))
         if C == 2:
             # the HIP path on the oracle's inputs: full SD1.5, 1 sample, 32 x 32 latents, 10 unguided DDIM steps, free running
             from sketch2img_amd.sampler import HipSampler
@@ -695,38 +866,61 @@ def main():
         metric = "sketch-guided images/sec whole-node, SD1.5 512px 50-step DDIM"
         if C == 5:
             metric = "sketch-guided images/sec whole-node, SD2.1 768px 50-step DDIM (clip_guided_attn)"
+        mode_name = "residual_fp32" if tol else "fast_fp16"
+        fmt = dict(S=S, T=T, G=int(0.5 * T), sched=sched)
+        variant = (" - INFORMATIONAL VARIANT: guidance off" if args.no_guidance else "")
+        mine = eps.get(mode_name, {})
+        other = eps.get("fast_fp16" if tol else "residual_fp32", {})
+        config = {
+            "workload": WORKLOADS[C].format(**fmt) + (" (guidance OFF)" if args.no_guidance else ""),
+            "baseline_config": C, "samples_per_gpu": S, "global_batch": world * S, "ddim_steps": T,
+            "scheduler": args.scheduler, "hip_graphs": bool(args.graph),
+            # ---- the mode `value` was timed in, and its accuracy against the fp32 CPU oracle (flat scalars: VERDICT r5 next #1)
+            "mode": mode_name,                       # residual_fp32 = the north_star-compliant accuracy mode
+            "eps_bound": EPS_BOUND,
+            "eps_max": mine.get("eps_max"),         # worst max |eps - eps_fp32 oracle| over `eps_evals` full-size evaluations (this run)
+            "eps_rel": mine.get("eps_rel"),         # worst relative Frobenius distance (scale-free)
+            "eps_evals": mine.get("evals"),
+            # the same absolute error for a UNIT-VARIANCE eps (a trained checkpoint): the synthetic model's eps has std ~0.37 and the
+            # error scales with conv_out (tests/test_gpu_configs.py checks the power-of-two rescale) - reported, not asserted
+            "eps_max_unit_var": (mine["eps_max"] / mine["eps_std"]) if mine else None,
+            "eps_std": mine.get("eps_std"),
+            # ---- the other mode, timed beside it (three batches after one warm-up)
+            ("fast_fp16_value" if tol else "residual_fp32_value"): second.get("value") if second else None,
+            ("fast_fp16_ms_per_step" if tol else "residual_fp32_ms_per_step"): second.get("ms_per_step") if second else None,
+            ("fast_fp16_eps_max" if tol else "residual_fp32_eps_max"): other.get("eps_max"),
+            "mode_cost": (1.0 - (value / second["value"] if tol else second["value"] / value)) if second and "value" in second else None,
+            # ---- box calibration: what a bare MFMA stream sustains on THIS box, and one rocm-smi reading under it
+            "box_mfma_tflops": box.get("box_mfma_tflops"), "box_sclk_mhz": box.get("box_sclk_mhz"),
+            "box_power_w": box.get("box_power_w"), "box_power_cap_w": box.get("box_power_cap_w"),
+            "value_per_box_pflops": (value / world / (box["box_mfma_tflops"] / 1e3)) if box.get("box_mfma_tflops") else None,
+            "hip_streams": (2 if (C == 2 and not args.no_guidance and wl["sampler"].fork_guidance and not args.graph) else 1),
+            "output": ("decoded uint8 images [S, H, W, 3] (VAE decode on-rank, inside the timed region"
+                       + (", gathered on rank 0)" if world > 1 else ")")) if args.gather == "images"
+            else "fp32 latents (no decode)",
+            "parallelism": (f"replicas x{world} (samples sharded, weights broadcast, "
+                            f"{'decoded images' if args.gather == 'images' else 'latents'} gathered"
+                            + (f"; backend {dist.get_backend()}" + (" = RCCL" if dist.get_backend() == "nccl" else "") + ")"
+                               if dist is not None else "; single process, no process group)")),
+        }
         res = {
             "metric": metric,
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
-            "config": {"workload": WORKLOADS[C].format(S=S, T=T, G=int(0.5 * T), sched=sched)
-                       + (" - INFORMATIONAL VARIANT: guidance off" if args.no_guidance else "")
-                       + (", accuracy mode (hi / lo residual stream)" if args.residual_fp32 else ""),
-                       "baseline_config": C, "samples_per_gpu": S, "global_batch": world * S, "ddim_steps": T,
-                       "scheduler": args.scheduler, "hip_graphs": bool(args.graph),
-                       # the north_star-compliant record (eps <= 1e-3 mode, same workload, same timed-region definition; details in
-                       # the top-level `at_tolerance` object): short keys here so that parsers which keep `config` keep it
-                       "at_tol": (None if not at_tol or "value" not in at_tol else
-                                  {"value": at_tol["value"], "ms_per_step": at_tol["ms_per_step"], "eps_max": at_tol["eps_max"],
-                                   "steps": at_tol["steps"]}),
-                       "hip_streams": (2 if (C == 2 and not args.no_guidance and wl["sampler"].fork_guidance and not args.graph) else 1),
-                       "output": ("decoded uint8 images [S, H, W, 3] (VAE decode on-rank, inside the timed region"
-                                  + (", gathered on rank 0)" if world > 1 else ")")) if args.gather == "images"
-                       else "fp32 latents (no decode)",
-                       "parallelism": (f"replicas x{world} (samples sharded, weights broadcast, "
-                                       f"{'decoded images' if args.gather == 'images' else 'latents'} gathered"
-                                       + (f"; torch.distributed backend {dist.get_backend()}"
-                                          + (" = RCCL" if dist.get_backend() == "nccl" else "") + ")" if dist is not None
-                                          else "; single process, no process group)"))},
+            "config": config,
+            "workload_detail": WORKLOAD_DETAILS[C].format(**fmt) + variant
+            + (", UNet in its accuracy mode (residual stream and the conv outputs that feed a norm as (hi, lo) fp16 pairs: "
+               "AntiGradientPipeline.from_pretrained(..., residual_fp32=True))" if tol else ", every stored tensor fp16"),
             "ms_per_image": dt / args.steps / S * 1e3,
             "decode_ms_per_step": decode_s / args.steps * 1e3 if wl["decode_events"] else None,
             "value_excluding_decode": world * S * args.steps / (dt - decode_s) if wl["decode_events"] and world == 1 else None,
             "achieved_tflops_per_gpu": value / world * f_img_tflop(C, T) if args.scheduler == "ddim" and not args.no_guidance else None,
             "tflop_per_image": f_img_tflop(C, T), "outputs_finite": finite, "out_shape": list(out.shape),
-            "setup_s": t_setup, "at_tolerance": at_tol, "roofline": roof, "cpu_baseline": cpu,
+            "setup_s": t_setup, "second_mode": second, "eps_vs_fp32_oracle": eps or None, "box": box or None,
+            "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     if not finite:

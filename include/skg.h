@@ -30,7 +30,7 @@ extern "C" {
 #define SKG_E_UNSUPPORTED (-2)
 #define SKG_E_LAUNCH (-3)    /* hipGetLastError() != hipSuccess after the launch */
 
-#define SKG_ABI_VERSION 4
+#define SKG_ABI_VERSION 5
 int skg_abi_version(void);
 /* Human-readable text of the last SKG_E_LAUNCH on this thread ("" if none). */
 const char* skg_last_error(void);
@@ -165,7 +165,8 @@ int skg_conv3x3_up2_f16_pairout(const void* X, int ldx, const void* Wpp, void* Y
  * (conv2's tap-major pack followed by the shortcut weight; bias = conv2.bias + conv_shortcut.bias).  Y_lo != NULL (accuracy mode):
  * pair output, and X2 / K2 are the pair buffer [x_hi | x_lo] / 2 * Cin_x against [W_sc | W_sc].  gn_partial != NULL: the GroupNorm
  * partial sums of the output as skg_conv3x3_f16_gn writes them.  Removes one GEMM launch, its M x Cout output write and the
- * residual read of conv2's epilogue per such block (14 per SD1.5 evaluation).  Cin % 64 == 0, K2 % 64 == 0. */
+ * residual read of conv2's epilogue per such block (14 per SD1.5 evaluation).  Cin % 64 == 0, K2 % 64 == 0.  Returns
+ * SKG_E_UNSUPPORTED (nothing launched: run conv2 and the shortcut GEMM as two launches) when X2 spans 2 GiB or more. */
 int skg_conv3x3_sc_f16(const void* X, int ldx, const void* X2, int ldx2, int K2, const void* Wcat, void* Y, void* Y_lo, int ldy,
                        int rows, int IH, int IW, int Cin, int Cout, const void* bias, unsigned flags, float* gn_partial, int groups,
                        void* stream);
@@ -539,6 +540,13 @@ int skg_cfg_dpmpp2m_step(const void* eps_u, const void* eps_c, int ld, int lo_of
  *   x_prev += alpha * g.   aux float [samples][4] receives (alpha, ||g||, ||x_in-x_prev||*sqrt2, 0). */
 int skg_guidance_update(const void* grad, int ld, const float* x_in, float* x_prev, float* aux,
                         int samples, int HW, float beta, void* stream);
+
+/* Box calibration (bench.py `config.box_mfma_tflops`; no reference call site - measurement infrastructure): one launch of
+ * SKG_BOX_PROBE_WORKGROUPS workgroups x 8 waves, each wave `iters` rounds of 40 register-resident 16x16x32 fp16 MFMAs on
+ * pseudo-random operands = SKG_BOX_PROBE_WORKGROUPS * 8 * iters * 40 * 16384 flop.  out: float [SKG_BOX_PROBE_WORKGROUPS * 512]
+ * (the accumulator sums: only there so that the loop is not removed).  Time it with events on `stream`. */
+#define SKG_BOX_PROBE_WORKGROUPS 512
+int skg_box_probe_mfma(float* out, int iters, void* stream);
 
 #ifdef __cplusplus
 }

@@ -22,9 +22,10 @@ LIB_PATH = os.environ.get("SKG_LIB") or os.path.join(_HERE, "libskg.so")
 # include/skg.h SKG_ABI_VERSION: bumped whenever an entry point changes its signature (2: skg_attn_bwd_dq / _dkv lost
 # their transposed-operand pointers, skg_set_workspace became per stream; 3: the accuracy-mode entry points with GroupNorm
 # statistics - skg_*_hilo_gn, skg_groupnorm_fwd_hilo / _from_partial_hilo, skg_ff_block_f16_hilo - and the pair offset of
-# skg_cfg_ddim_step / skg_cfg_dpmpp2m_step), so that a stale build selected through
+# skg_cfg_ddim_step / skg_cfg_dpmpp2m_step; 5: skg_box_probe_mfma, skg_conv3x3_sc_f16 declines instead of failing on the 2 GiB
+# operand limit), so that a stale build selected through
 # SKG_LIB fails at load instead of receiving shifted arguments
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # spec letters: p = device/host pointer, i = int, f = float, u = unsigned, z = size_t (return only)
 SIGNATURES = {
@@ -109,6 +110,7 @@ SIGNATURES = {
     "skg_gaussian_sample": ("i", "pippiiifp"),
     "skg_cfg_dpmpp2m_step": ("i", "ppiippppiiffffffip"),
     "skg_guidance_update": ("i", "pipppiifp"),
+    "skg_box_probe_mfma": ("i", "pip"),
 }
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "u": ctypes.c_uint,

@@ -437,7 +437,9 @@ extern "C" int skg_conv3x3_sc_f16(const void* X, int ldx, const void* X2, int ld
   SKG_REQUIRE(ldx % 8 == 0 && ldx >= Cin && ldx2 % 8 == 0 && ldx2 >= K2 && ldy % 8 == 0 && ldy >= Cout);
   SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(X2, 16) && skg_aligned(Wcat, 16) && skg_aligned(Y, 16) && (!Y_lo || skg_aligned(Y_lo, 16)) &&
               (!bias || skg_aligned(bias, 8)) && !(flags & (SKG_EPI_OUT_F32 | SKG_EPI_GEGLU)));
-  SKG_REQUIRE((unsigned long long)rows * IH * IW * ldx2 * 2ull < 0x7fffffffull);
+  // the second operand goes through a 32-bit buffer descriptor: a larger one is DECLINED (nothing launched; the caller runs
+  // conv2 and the shortcut GEMM as two launches), not an argument error
+  if ((unsigned long long)rows * IH * IW * ldx2 * 2ull >= 0x7fffffffull) return SKG_E_UNSUPPORTED;
   GemmParams p{};
   p.A = (const half_t*)X; p.lda = ldx; p.B = (const half_t*)Wcat; p.ldb = 9 * Cin + K2; p.C = Y; p.ldc = ldy;
   p.bias = (const half_t*)bias; p.c_lo = (half_t*)Y_lo;

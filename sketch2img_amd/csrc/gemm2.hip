@@ -1086,18 +1086,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p, 
 }
 
 
+// Tuning values of the split-K policy (tools/smallm_bench.py --splits / --split-stages), ONE helper for launch_cfg, pick_splits and
+// skg_gemm2_tile_n: validated, read once per process in the product build; the lab build re-reads them per launch so
+// that the tool can walk its variants in one process (SKG_LIB=.../libskg_lab.so).
+struct SplitTuning { int target, smax, ns; };
+inline SplitTuning read_split_tuning() {
+  auto geti = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+  SplitTuning t{geti("SKG_SPLIT_TARGET", 512), geti("SKG_MAX_SPLITS", 8), geti("SKG_SPLIT_NS", 3 /* SPLIT_NS_DEFAULT */)};
+  t.target = t.target < 1 ? 1 : t.target > 4096 ? 4096 : t.target;      // workgroups a split launch aims at
+  t.smax = t.smax < 1 ? 1 : t.smax > 64 ? 64 : t.smax;                   // cap of the split factor
+  t.ns = t.ns <= 2 ? 2 : t.ns >= 4 ? 4 : 3;                              // LDS stages of a split launch with <= 256 workgroups
+  return t;
+}
+inline SplitTuning split_tuning() {
+#ifdef SKG_LAB
+  return read_split_tuning();
+#else
+  static const SplitTuning t = read_split_tuning();
+  return t;
+#endif
+}
+
 // number of K splits for a launch of `nwg` 128-row tiles over KT K-tiles (1 = no split)
 inline int pick_splits(long nwg, int KT, size_t slab_bytes, const float* ws, size_t ws_bytes) {
   // nwg == 256 is ONE workgroup per CU: nothing overlaps its DMA waits.  Two K halves per CU (16x16-level convs,
   // K >= 8192: 720 -> 990 TFLOP/s) beat the three-stage single workgroup (870) there; below that the fp32 slabs +
   // reduce pass cost more than they hide and the launch takes the three-stage kernel instead
   if (!ws || nwg > 256 || KT < (nwg == 256 ? 128 : 16)) return 1;
-  const char* tgt = getenv("SKG_SPLIT_TARGET");        // tuning (tools/smallm_bench.py --split-stages): workgroups a split launch aims at
-  const int target = tgt ? atoi(tgt) : 512;
-  int s = (int)((target + nwg - 1) / nwg);
-  const char* cap = getenv("SKG_MAX_SPLITS");          // tuning (tools/smallm_bench.py --splits): read per launch
-  const int smax = cap ? atoi(cap) : 8;
-  if (s > smax) s = smax < 1 ? 1 : smax;
+  const SplitTuning tune = split_tuning();
+  int s = (int)((tune.target + nwg - 1) / nwg);
+  if (s > tune.smax) s = tune.smax;
   while (s > 1 && KT / s < 8) --s;
   while (s > 1 && (size_t)s * slab_bytes > ws_bytes) --s;
   return s;
@@ -1161,7 +1179,7 @@ inline int persistent_grid(int nwg, int nthr) {
 }
 
 constexpr size_t STREAM_OUT_BYTES = (size_t)32 << 20;      // the aggregate L2 (8 x 4 MB)
-constexpr int SPLIT_NS_DEFAULT = 3;                        // LDS stages of a split-K launch with <= 256 workgroups (see launch_cfg)
+static_assert(true, "");                                 // (SPLIT_NS default = 3: read_split_tuning, LDS stages of a split-K launch with <= 256 workgroups)
 
 // GroupNorm statistics in the epilogue: the plain 128 x 160 instantiations (two or three stages, no split-K) with the
 // staged epilogue, whole tiles, 128-row chunks that stay inside one sample and groups that stay inside one tile
@@ -1251,8 +1269,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
     // its K slice in flight where the two-stage kernel waits out one DMA latency per step (SKG_SPLIT_NS, read per launch: tuning)
     bool deep = false;
     if constexpr (BM == 128 && BN == 160 && (MODE == MODE_DIRECT || MODE == MODE_S1)) {
-      const char* e = getenv("SKG_SPLIT_NS");
-      const int sns = e ? atoi(e) : SPLIT_NS_DEFAULT;
+      const int sns = split_tuning().ns;
       if (ntiles * ns <= 256 && per >= 4 && sns >= 3) {
         deep = true;
         if (sns >= 4)
@@ -1356,8 +1373,7 @@ int skg_gemm2_tile_n(int M, int N, int K, int Cin, int mode, size_t ws_bytes) {
                !getenv("SKG_NO_NS3") && KT >= 4 && (t.bn == 64 || ntiles <= 256) && splits == 1;
   if (splits > 1 && t.bm == 128 && t.bn == 160 && (mode == MODE_DIRECT || mode == MODE_S1)) {      // split launch on the deep ring (launch_cfg)
     const int per = skg_cdiv(KT, splits), ns = skg_cdiv(KT, per);
-    const char* e = getenv("SKG_SPLIT_NS");
-    three = ntiles * ns <= 256 && per >= 4 && (e ? atoi(e) : SPLIT_NS_DEFAULT) >= 3;      // (a tuning value of 4 is reported as three stages too)
+    three = ntiles * ns <= 256 && per >= 4 && split_tuning().ns >= 3;      // (a tuning value of 4 is reported as three stages too)
   }
   return t.bn + (three ? 10000 : 0);
 }

@@ -228,8 +228,14 @@ class HipSampler:
         step path allocates outside torch's (graph-private) pool or synchronises with the host."""
         T = len(tab.timesteps)
         inj = self.unet.inject
+        # everything that is baked into the captured kernel arguments: the schedule (timesteps AND the table values the per-step
+        # coefficients come from - two schedulers may share timesteps and differ in betas / final alpha), the prediction type, shapes,
+        # the guidance constants (ADVICE r5: v_prediction was missing -> a stale graph would have been replayed)
+        acp = tab.alphas_cumprod
         key = (type(tab).__name__, tuple(int(t) for t in tab.timesteps), tuple(x.shape), tgt is None,
-               float(guidance_scale), float(beta), bool(self.share_cfg_prefix))
+               float(guidance_scale), float(beta), bool(self.share_cfg_prefix), bool(tab.v_prediction),
+               float(getattr(tab, "final_alpha_cumprod", 0.0)), int(acp.numel()), float(acp.double().sum()), float(acp[0]), float(acp[-1]),
+               getattr(tab, "solver_order", 0), getattr(tab, "lower_order_final", None))
         # What a captured step points at besides the static latents: the text context's K / V (prepare_context builds a
         # NEW dict per prompt) and the injector's per-image K / V (set_state / set_res_samples build a new dict per sketch)
         # and scale.  The entry keeps STRONG references to those objects and is valid only while the pipeline still holds

@@ -133,6 +133,12 @@ UP2_POLYPHASE = os.environ.get("SKG_UP2_POLY", "1") != "0"      # A/B switch (be
 # polyphase launch on x_hi with a pair output: both correction thirds together move eps by 3.6 % of the mode's distance from fp32
 # (tools/eps_decompose_up.py) and cost two thirds of the upsamplers' time - the largest single item of the mode's price
 HP_UP_TRIPLE = os.environ.get("SKG_HP_UP_TRIPLE", "0") != "0"
+# accuracy mode (round 6): GroupNorm OUTPUTS kept as (hi, lo) pairs - the K-doubled operand [n_hi | n_lo] . [W | W] of the matmul that
+# consumes them - at the sites whose fp16 rounding carries the most of the mode's remaining eps distance (tools/eps_decompose_sites.py:
+# the norm outputs of the LAST up block are 66 % of its variance; conv_norm_out, 18 %, has been a pair since round 4).  Comma-separated
+# norm names of the last up block ("<resnet>.norm1" / ".norm2" -> conv1 / conv2, "<attention>.norm" -> proj_in); "" = none (round 5).
+HP_NORM_PAIRS = tuple(n for n in os.environ.get(
+    "SKG_HP_NORM_PAIRS", "up_blocks.3.resnets.2.norm2,up_blocks.3.attentions.2.norm").split(",") if n)
 UP2_SMALL_MAPS = os.environ.get("SKG_UP2_SMALL", "1") != "0"    # A/B: polyphase also where one phase does not fill the chip
 UP2_DGRAD = os.environ.get("SKG_UP2_DGRAD", "1") != "0"         # A/B: the upsampler's backward as one 4 x 4 stride-2 convolution
 
@@ -252,17 +258,38 @@ class Stash:
     misc: dict = field(default_factory=dict)
 
 
+class _Packs(dict):
+    """Weight packs by name.  `lazy[k] = make` registers a pack that is only built (from a host copy of the tensor) the first time it
+    is read: the packs of code paths that normally never run - the two-launch fall-back of a declined fused launch (they
+    were ~0.5 GB of resident duplicates)."""
+
+    def __init__(self):
+        super().__init__()
+        self.lazy: Dict[str, Callable[[], torch.Tensor]] = {}
+
+    def __missing__(self, k):
+        v = self[k] = self.lazy.pop(k)()         # (KeyError for a name that was never registered)
+        return v
+
+    def __contains__(self, k):
+        return dict.__contains__(self, k) or k in self.lazy
+
+
 class HipUNet:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda",
                  need_backward: bool = True, residual_fp32: bool = False):
-        """residual_fp32: opt-in ACCURACY mode (forward only) that meets north_star's <= 1e-3 max eps deviation from the
-        fp32 reference: the residual stream and every conv output that feeds a norm or the residual sum are kept as
-        (hi, lo) pairs of fp16 tensors (~22 mantissa bits), see forward() / _forward_hp()."""
+        """residual_fp32: opt-in ACCURACY mode that meets north_star's <= 1e-3 max eps deviation from the fp32 reference: the
+        residual stream and every conv output that feeds a norm or the residual sum are kept as (hi, lo) pairs of fp16 tensors
+        (~22 mantissa bits), see forward() / _forward_hp().  Where the stream itself is a matmul operand the pair is the K-doubled
+        operand (shortcuts, downsamplers, proj_out, conv_out) - EXCEPT the three nearest-2x upsampler convolutions, which read the hi
+        part only and write a pair (round 5: SKG_HP_UP_TRIPLE=1 restores their pair operand; the declined-launch fall-back keeps the
+        hi-only operand too).  Guided steps work: the pair forward stashes the hi activations and the ordinary backward runs on them."""
         self.cfg = cfg
         self.dev = torch.device(device)
         self.need_backward = need_backward
         self.residual_fp32 = residual_fp32
-        self.W: Dict[str, torch.Tensor] = {}
+        self.W: Dict[str, torch.Tensor] = _Packs()
+        self.hp_norm_pairs: set = set()
         self._pack(state_dict)
         if residual_fp32:
             assert all(c % 64 == 0 for c in cfg.block_out_channels), \
@@ -277,7 +304,32 @@ class HipUNet:
     # ------------------------------------------------------------------ packing
     def _pack(self, sd):
         W, dev, bw = self.W, self.dev, self.need_backward
+        # ResnetBlocks whose conv2 + conv_shortcut run as ONE implicit GEMM (ops.conv3x3_sc): the forward packs of the two separate
+        # launches are only read when that launch is declined (an operand >= 2 GiB) - registered lazily, from fp16 host copies
+        folded = set()
+        if _RES_SC:
+            for k, v in sd.items():
+                if k.endswith(".conv_shortcut.weight"):
+                    r = k[: -len(".conv_shortcut.weight")]
+                    if sd[r + ".conv2.weight"].shape[1] % 64 == 0 and v.shape[1] % 64 == 0:
+                        folded.add(r)
+
+        def lazy(key, tensor, make):
+            host = tensor.detach().to("cpu", torch.float16)
+            W.lazy[key] = lambda: make(host)
+
         for k, v in sd.items():
+            r = k.rsplit(".", 2)[0]
+            if r in folded and k.endswith(".conv2.weight"):
+                lazy(k, v, lambda h: pack_conv(h, dev))
+                if bw:
+                    W[k + ":T"] = pack_conv_dgrad(v, dev)
+                continue
+            if r in folded and k.endswith(".conv_shortcut.weight"):
+                lazy(k, v, lambda h: _h(h.reshape(h.shape[0], h.shape[1]), dev))
+                if bw:
+                    W[k + ":T"] = _h(v.reshape(v.shape[0], v.shape[1]).t(), dev)
+                continue
             if v.dim() == 4 and v.shape[2] == 3:
                 if k == "conv_in.weight":
                     W[k] = pack_conv(v, dev, cin_pad=CIN_PAD)
@@ -312,18 +364,15 @@ class HipUNet:
             else:
                 W[k] = _h(_pad_vec(v, COUT_PAD) if k == "conv_out.bias" else v, dev)
         # conv2 + conv_shortcut as ONE implicit GEMM (ops.conv3x3_sc): [conv2 tap-major pack | W_sc] along K, biases summed
-        if _RES_SC:
-            for k in list(sd.keys()):
-                if k.endswith(".conv_shortcut.weight"):
-                    r = k[: -len(".conv_shortcut.weight")]
-                    w2, wsc = sd[r + ".conv2.weight"], sd[k].reshape(sd[k].shape[0], sd[k].shape[1])
-                    if w2.shape[1] % 64 or wsc.shape[1] % 64:
-                        continue
-                    w2p = w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1)                   # [Cout][ky][kx][Cin] (pack_conv's order)
-                    W[r + ".conv2.weight:sc"] = _h(torch.cat([w2p, wsc], 1), dev)
-                    if self.residual_fp32:
-                        W[r + ".conv2.weight:sc2"] = _h(torch.cat([w2p, wsc, wsc], 1), dev)  # the pair operand [x_hi | x_lo] . [W | W]
-                    W[r + ".conv2.bias:sc"] = _h(sd[r + ".conv2.bias"].float() + sd[r + ".conv_shortcut.bias"].float(), dev)
+        for r in sorted(folded):
+            w2, wsc = sd[r + ".conv2.weight"], sd[r + ".conv_shortcut.weight"]
+            wsc = wsc.reshape(wsc.shape[0], wsc.shape[1])
+            w2p = w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1)                   # [Cout][ky][kx][Cin] (pack_conv's order)
+            if self.residual_fp32:      # (the accuracy mode reads only :sc2 - the pair operand [x_hi | x_lo] . [W | W] - and the summed bias)
+                W[r + ".conv2.weight:sc2"] = _h(torch.cat([w2p, wsc, wsc], 1), dev)
+            else:
+                W[r + ".conv2.weight:sc"] = _h(torch.cat([w2p, wsc], 1), dev)
+            W[r + ".conv2.bias:sc"] = _h(sd[r + ".conv2.bias"].float() + sd[r + ".conv_shortcut.bias"].float(), dev)
         # FF1 (GEGLU projection): rows interleaved [a a g g] so the GEMM epilogue can gate in registers
         for k in list(sd.keys()):
             if k.endswith(".ff.net.0.proj.weight"):
@@ -367,7 +416,10 @@ class HipUNet:
         convolutions, proj_out) the operand is the PAIR [hi | lo] along K and the weight pack is [W | W]."""
         W, dev = self.W, self.dev
         for k, v in sd.items():
-            if k.endswith(".conv_shortcut.weight") or k.endswith(".proj_out.weight"):
+            if k.endswith(".conv_shortcut.weight") and (k[: -len(".conv_shortcut.weight")] + ".conv2.weight:sc2") in W:
+                host = v.detach().to("cpu", torch.float16)          # (fall-back of a declined conv3x3_sc launch only)
+                W.lazy[k + ":2"] = lambda h=host: _h(torch.cat([h.reshape(h.shape[0], h.shape[1])] * 2, 1), dev)
+            elif k.endswith(".conv_shortcut.weight") or k.endswith(".proj_out.weight"):
                 w = v.reshape(v.shape[0], v.shape[1])
                 W[k + ":2"] = _h(torch.cat([w, w], 1), dev)
             elif ".downsamplers." in k and k.endswith(".weight") or ".upsamplers." in k and k.endswith(".weight"):
@@ -382,6 +434,28 @@ class HipUNet:
                     W[k + ":2"] = pack_conv(torch.cat([v, v], 1), dev)
             elif k == "conv_out.weight":      # its operand - the last normalised activation - reaches eps one to one: a pair too
                 W[k + ":2"] = pack_conv(torch.cat([v, v], 1), dev, cout_pad=COUT_PAD)
+        # norm outputs as pairs (HP_NORM_PAIRS): the [W | W] pack of the matmul behind each listed norm
+        self.hp_norm_pairs = set()
+        for name in HP_NORM_PAIRS:
+            r, which = name.rsplit(".", 1)
+            if which == "norm" and (r + ".proj_in.weight") in sd:
+                w = sd[r + ".proj_in.weight"]
+                w = w.reshape(w.shape[0], w.shape[1])
+                W[r + ".proj_in.weight:n2"] = _h(torch.cat([w, w], 1), dev)
+            elif which == "norm1" and (r + ".conv1.weight") in sd:
+                W[r + ".conv1.weight:n2"] = pack_conv(torch.cat([sd[r + ".conv1.weight"]] * 2, 1), dev)
+            elif which == "norm2" and (r + ".conv2.weight") in sd:
+                w2 = sd[r + ".conv2.weight"]
+                w2p = torch.cat([w2, w2], 1).permute(0, 2, 3, 1).reshape(w2.shape[0], -1)      # per tap [W | W]
+                if (r + ".conv2.weight:sc2") in W:      # folded shortcut: [conv2 taps on the pair | W_sc | W_sc]
+                    wsc = sd[r + ".conv_shortcut.weight"]
+                    wsc = wsc.reshape(wsc.shape[0], wsc.shape[1])
+                    W[r + ".conv2.weight:n2"] = _h(torch.cat([w2p, wsc, wsc], 1), dev)
+                else:
+                    W[r + ".conv2.weight:n2"] = _h(w2p, dev)
+            else:
+                raise ValueError(f"SKG_HP_NORM_PAIRS: {name!r} is not a GroupNorm of this UNet")
+            self.hp_norm_pairs.add(name)
 
     def _w9x2(self, k: str) -> torch.Tensor:
         """The 9-tap [W | W] pack of an upsampler (accuracy mode), built on first use: only a declined polyphase launch needs it."""
@@ -853,7 +927,13 @@ class HipUNet:
         return ops.Pair.empty(M, C, self.dev)
 
     def _gn_hp(self, x, rows, HW, eps, name, silu, partial=None):
-        """-> (normalised fp16 tensor, statistics [rows, groups, 2]); partial: the producer's epilogue sums (see ops.groupnorm_hilo)"""
+        """-> (normalised fp16 tensor, statistics [rows, groups, 2]); partial: the producer's epilogue sums (see ops.groupnorm_hilo).
+        A norm listed in HP_NORM_PAIRS returns its output as a PAIR (ops.Pair with .full = the K-doubled operand [hi | lo])."""
+        if name in self.hp_norm_pairs:
+            n = self._pair(x.hi.shape[0], x.hi.shape[1])
+            _, st = ops.groupnorm_hilo(x.hi, x.lo, rows, HW, self.cfg.norm_groups, eps, self.W[name + ".weight"],
+                                       self.W[name + ".bias"], silu, out=n.hi, out_lo=n.lo, want_stats=True, partial=partial)
+            return n, st
         return ops.groupnorm_hilo(x.hi, x.lo, rows, HW, self.cfg.norm_groups, eps, self.W[name + ".weight"],
                                   self.W[name + ".bias"], silu, want_stats=True, partial=partial)
 
@@ -867,11 +947,16 @@ class HipUNet:
         h1 = self._pair(M, Cout)                                    # conv1 output feeds norm2: kept as a pair ("lin_n")
         fuse = self._gn_from_producer(rows, HW, Cout)
         part1 = None
+        a1, w1 = (n1.full, W[p + ".conv1.weight:n2"]) if isinstance(n1, ops.Pair) else (n1, W[p + ".conv1.weight"])
         if fuse:
-            _, part1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p], gn_groups=G)
+            _, part1 = ops.conv3x3(a1, w1, rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p], gn_groups=G)
         else:
-            ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p])
+            ops.conv3x3(a1, w1, rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p])
         n2, st2 = self._gn_hp(h1, rows, HW, 1e-5, p + ".norm2", True, partial=part1)
+        n2_pair = isinstance(n2, ops.Pair)
+        w2n = W[p + ".conv2.weight:n2"] if n2_pair else None
+        if n2_pair:
+            n2 = n2.full
         if stash is not None:      # the backward differentiates the fp16 (hi) values, as in the default mode
             stash.res[p] = dict(x=x.hi, st1=st1, h1=h1.hi, st2=st2, H=H, half=half)
         out = out or self._pair(M, Cout)
@@ -879,27 +964,33 @@ class HipUNet:
         if (p + ".conv2.weight:sc2") in W:
             # conv2 + the K-doubled shortcut [x_hi | x_lo] . [W_sc | W_sc] in one launch, pair output
             xf = x.full if x.full is not None else full_of(x, x.hi.shape[1])
+            wsc2 = w2n if n2_pair else W[p + ".conv2.weight:sc2"]
             try:
                 if want_part and fuse:
-                    _, opart = ops.conv3x3_sc(n2, xf, W[p + ".conv2.weight:sc2"], rows, H, H, out=out.hi, out_lo=out.lo,
+                    _, opart = ops.conv3x3_sc(n2, xf, wsc2, rows, H, H, out=out.hi, out_lo=out.lo,
                                               bias=W[p + ".conv2.bias:sc"], gn_groups=G)
                 else:
-                    ops.conv3x3_sc(n2, xf, W[p + ".conv2.weight:sc2"], rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias:sc"])
+                    ops.conv3x3_sc(n2, xf, wsc2, rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias:sc"])
                 return out, opart
             except ops.SkgError as e:
                 if e.rc != -2:
                     raise
+            if n2_pair:      # the two-launch fall-back takes conv2's own [W | W] taps (the leading columns of the folded pack)
+                w2n = w2n[:, : 9 * n2.shape[1]]
         if (p + ".conv_shortcut.weight") in W:
             sc = self._pair(M, Cout)                                 # the stream as a matmul operand: [hi | lo] . [W | W]
             xf = x.full if x.full is not None else full_of(x, x.hi.shape[1])
             ops.gemm(xf, W[p + ".conv_shortcut.weight:2"], out=sc.hi, out_lo=sc.lo, bias=W[p + ".conv_shortcut.bias"])
         else:
             sc = x
+        w2 = w2n if n2_pair else W[p + ".conv2.weight"]
+        if w2.shape[1] != 9 * n2.shape[1]:      # (a column slice of the folded pack: the kernel wants the 9-tap pack contiguous)
+            w2 = w2.contiguous()
         if want_part and fuse:
-            _, opart = ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
+            _, opart = ops.conv3x3(n2, w2, rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
                                    residual=sc.hi, residual_lo=sc.lo, gn_groups=G)
         else:
-            ops.conv3x3(n2, W[p + ".conv2.weight"], rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
+            ops.conv3x3(n2, w2, rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
                         residual=sc.hi, residual_lo=sc.lo)
         return out, opart
 
@@ -916,7 +1007,10 @@ class HipUNet:
         M1 = r1 * HW
         g, gst = self._gn_hp(x, r1, HW, 1e-6, p + ".norm", False, partial=xpart)
         pin = self._pair(M1, C)
-        ops.gemm(g, W[p + ".proj_in.weight"], out=pin.hi, out_lo=pin.lo, bias=W[p + ".proj_in.bias"])
+        if isinstance(g, ops.Pair):
+            ops.gemm(g.full, W[p + ".proj_in.weight:n2"], out=pin.hi, out_lo=pin.lo, bias=W[p + ".proj_in.bias"])
+        else:
+            ops.gemm(g, W[p + ".proj_in.weight"], out=pin.hi, out_lo=pin.lo, bias=W[p + ".proj_in.bias"])
         a1, st1 = ops.layernorm_hilo(pin.hi, pin.lo, W[t + ".norm1.weight"], W[t + ".norm1.bias"], want_stats=True)
         qkv = ops.gemm(a1, W[t + ".attn1.qkv"])
         o1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], r1, heads, HW, HW, HW, dh, scale,
@@ -1172,11 +1266,10 @@ class HipUNet:
                 if not HP_UP_TRIPLE and (p + ".weight:pp") in W and (p + ".weight:pp3") not in W:
                     try:
                         ops.conv_up2_pairout(h.hi, W[p + ".weight:pp"], rows, cur, cur, o, bias=W[p + ".bias"])
-                    except ops.SkgError as e:      # declined (an operand >= 2 GiB): the 9-tap [W | W] form on the pair
-                        if e.rc != -2:
+                    except ops.SkgError as e:      # declined (an operand >= 2 GiB): the 9-tap gather form on the SAME hi-only operand
+                        if e.rc != -2:               # (both routes of the mode must see the same operand; pair output either way)
                             raise
-                        ops.conv3x3(full_of(h, h.hi.shape[1]), self._w9x2(p + ".weight"), rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo,
-                                    bias=W[p + ".bias"])
+                        ops.conv3x3(h.hi, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo, bias=W[p + ".bias"])
                 elif (p + ".weight:pp3") in W:      # polyphase, K axis [x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo]: 12 instead of 18 tap-products
                     ops.conv_up2_hilo(full_of(h, h.hi.shape[1]), W[p + ".weight:pp3"], rows, cur, cur, o, bias=W[p + ".bias"],
                                       W9x2=lambda p=p: self._w9x2(p + ".weight"))

@@ -588,3 +588,15 @@ def test_bench_prints_one_contract_line():
     assert roof["bound"] in ("mfma", "hbm") and 0 < roof["frac"] < 1 and roof["unit"] == "TFLOP/s" and "gemm" in roof["kernel"]
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["out_shape"] == [1, 512, 512, 3] and d["config"]["baseline_config"] == 2
+    # round 6: `value` is timed in the accuracy mode; everything a parser that keeps only scalars and strings
+    # of <= 120 characters needs is FLAT inside `config` / `roofline`
+    cfgd = d["config"]
+    assert cfgd["mode"] == "residual_fp32" and cfgd["eps_bound"] == 1e-3 and cfgd["fast_fp16_value"] > 0
+    for k, v in list(cfgd.items()) + [(k, v) for k, v in roof.items() if k not in ("by_operator", "per_kernel")]:
+        assert v is None or isinstance(v, (int, float, bool)) or (isinstance(v, str) and len(v) <= 120), (k, v)
+    for k in ("eps_max", "eps_rel", "eps_max_unit_var", "box_mfma_tflops", "box_sclk_mhz", "box_power_w", "box_power_cap_w", "mode_cost"):
+        assert k in cfgd, k
+    assert 500 < cfgd["box_mfma_tflops"] < 2500                       # a bare MFMA stream: ~2.0 PFLOP/s on random operands (round 5)
+    for k in ("conv3x3_frac", "gemm_frac", "attn_fwd_frac", "rocprof_frac"):
+        assert k in roof, k
+    assert 0 < roof["conv3x3_frac"] < 1 and 0 < roof["gemm_frac"] < 1 and 0 < roof["attn_fwd_frac"] < 1

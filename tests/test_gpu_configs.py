@@ -92,10 +92,16 @@ def test_sd15_accuracy_mode_meets_north_star_eps_bound():
     reference's own GPU configuration - no implementation gets there (previous test: 1.5-1.8e-3, 1.0e-3 of it from the
     fp16 residual stream alone, tools/eps_decompose.py).  HipUNet(residual_fp32=True) keeps the residual stream and the conv
     outputs that feed a norm / the residual sum as (hi, lo) fp16 pairs (~22 mantissa bits; the pair is the K-doubled operand
-    where the stream itself enters a matmul).  Full-size SD1.5 evaluations (64 x 64 latents) at the start, the middle and the
-    end of the 50-step schedule, four latent seeds (two independent rows per evaluation, each with its own text row); asserts
-    the north-star number itself on every row; one evaluation is also checked against the oracle's emulation of the mode,
-    fp16_storage(skip=("res", "lin_n", "rop")) (predicted: rel 5.2e-4, max 7.2e-4)."""
+    where the stream itself enters a matmul) and - round 6 - the GroupNorm outputs of the last up block whose rounding carries
+    the most of what is left (unet.HP_NORM_PAIRS, tools/eps_decompose_sites.py).
+    Round 6: 32 rows - four timesteps across the 50-step schedule x four pairs of latent seeds (two
+    independent rows per evaluation, each with its own text row), full-size SD1.5 evaluations (64 x 64 latents).  The maximum
+    of |eps - eps_fp32| over a row is an extreme value of 16 384 nearly Gaussian errors (it sits at ~4.2 sigma, the worst of 32
+    rows at ~4.9 sigma), so the test prints the DISTRIBUTION - per-row maxima, pooled percentiles, sigma - and asserts the
+    north_star number on every row, a margin on the pooled p99.99 and the scale-free relative distance.  One evaluation is
+    also checked against the oracle's emulation of the mode, and one is repeated with conv_out scaled by 2 (exact in fp16):
+    the error scales with the output, so the figure for a UNIT-VARIANCE eps is max / std - printed, with the relative bound
+    asserted (DESIGN.md 5 states the absolute one honestly)."""
     from oracle import unet as ounet
     from sketch2img_amd.config import SD15
     from sketch2img_amd.unet import HipUNet
@@ -103,9 +109,10 @@ def test_sd15_accuracy_mode_meets_north_star_eps_bound():
     cfg = ounet.SD15
     W = ounet.init_weights(cfg)
     net = HipUNet(SD15, W, DEV, need_backward=False, residual_fp32=True)
-    worst = worst_rel = 0.0
-    for t in (981, 501, 21):
-        for seeds in ((7, 11), (23, 101)):
+    row_max, row_rel, pooled, stds = [], [], [], []
+    first = None
+    for t in (981, 661, 341, 21):
+        for seeds in ((7, 11), (23, 101), (3, 5), (13, 17)):
             g = torch.Generator().manual_seed(seeds[0] * 1000 + t)
             xx = torch.cat([torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(sd_)) for sd_ in seeds]).half().float()
             ehs = torch.randn(2, 77, 768, generator=g).half().float()
@@ -115,16 +122,43 @@ def test_sd15_accuracy_mode_meets_north_star_eps_bound():
                 C, _ = ounet.unet_forward(cfg, W, xx, t, ehs)
             for row in range(2):
                 rAC, mAC = report(f"sd15 eps  HIP accuracy mode vs fp32 oracle, t = {t}, seed {seeds[row]}", A[row], C[row])
-                worst, worst_rel = max(worst, mAC), max(worst_rel, rAC)
-            if t == 981 and seeds == (7, 11):
+                row_max.append(mAC); row_rel.append(rAC); stds.append(float(C[row].std()))
+                pooled.append((A[row] - C[row]).abs().flatten())
+            if first is None:
+                first = (xx, ehs, t, A, C)
                 with torch.no_grad(), ounet.fp16_storage(skip=("res", "lin_n", "rop")):
                     B, _ = ounet.unet_forward(cfg, W, xx, t, ehs)
                 rAC, mAC = report("sd15 eps  HIP accuracy mode vs fp32 oracle", A, C)
-                rBC, mBC = report("sd15 eps  oracle emulation of the accuracy mode vs fp32 oracle", B, C)
-                report("sd15 eps  HIP accuracy mode vs its oracle emulation", A, B)
-                assert mAC < 1.35 * mBC and rAC < 1.25 * rBC + 5e-5
-    print(f"[parity] accuracy mode, 3 timesteps x 4 seeds: worst max |eps - eps_fp32| = {worst:.2e} (north_star bound 1e-3), worst rel {worst_rel:.2e}")
-    assert worst <= 1e-3 and worst_rel <= 7e-4
+                rBC, mBC = report("sd15 eps  oracle emulation of round 5's form of the accuracy mode vs fp32 oracle", B, C)
+                report("sd15 eps  HIP accuracy mode vs that emulation", A, B)
+                assert mAC < 1.35 * mBC and rAC < 1.25 * rBC + 5e-5          # (round 6's norm pairs only move the HIP side down)
+    err = torch.cat(pooled)
+    q = lambda f: float(torch.quantile(err[:: max(1, err.numel() // 400000)], f))      # (torch.quantile's input limit)
+    sigma = float(err.pow(2).mean().sqrt())
+    rm = sorted(row_max)
+    worst, worst_rel = rm[-1], max(row_rel)
+    print(f"[parity] accuracy mode, 4 timesteps x 8 seeds = {len(rm)} rows: per-row max |eps - eps_fp32|: min {rm[0]:.2e} median {rm[len(rm) // 2]:.2e} "
+          f"second worst {rm[-2]:.2e} WORST {worst:.2e} (north_star bound 1e-3: margin {100 * (1 - worst / 1e-3):.0f} %); pooled |err|: rms {sigma:.2e} "
+          f"p99 {q(0.99):.2e} p99.9 {q(0.999):.2e} max / rms {worst / sigma:.2f}; rel: worst {worst_rel:.2e} mean {sum(row_rel) / len(row_rel):.2e}; "
+          f"eps std {min(stds):.3f}-{max(stds):.3f}")
+    assert worst <= 1e-3 and worst_rel <= 6.2e-4
+    assert q(0.99) <= 5.5e-4 and rm[len(rm) // 2] <= 8e-4
+    # unit-variance report: conv_out x 2 (a power of two: exact) -> every eps and every error doubles; absolute errors for a
+    # unit-variance eps are therefore max / std of this model's
+    xx, ehs, t, A, C = first
+    saved = {k: net.W[k].clone() for k in ("conv_out.weight:2", "conv_out.bias")}
+    for k in saved:
+        net.W[k].mul_(2.0)
+    net.prepare_context(ehs)
+    A2, _ = _hip_eps(net, xx, t, 2, 64)
+    for k, v in saved.items():
+        net.W[k].copy_(v)
+    lin = float((A2 - 2.0 * A).abs().max())
+    r2, m2 = report("sd15 eps  accuracy mode, conv_out x 2 vs 2 x fp32 oracle (linearity of the error in the output scale)", A2, 2.0 * C)
+    std = float(C.std())
+    print(f"[parity] accuracy mode: conv_out x 2 reproduces 2 x eps to {lin:.1e}; at eps std {2 * std:.2f} the max error reads {m2:.2e}; for a UNIT-VARIANCE "
+          f"eps: worst max {worst / min(stds):.2e}, rms {sigma / (sum(stds) / len(stds)):.2e} (absolute), relative {worst_rel:.2e} (scale-free)")
+    assert lin <= 2e-6 * 2 and abs(m2 / (2.0 * float((A - C).abs().max())) - 1) < 1e-3 and r2 <= 6.2e-4
 
 
 def test_sd15_accuracy_mode_heavy_tailed_weights():
@@ -327,6 +361,84 @@ def test_tiny_50_step_trajectories_unguided_bounded_guided_reported():
     l_ref = float(tr[25]["aux"]["loss"])
     print(f"[parity] tiny 50-step guided: loss at the last guided step hip {l_hip:.4e} oracle {l_ref:.4e}")
     assert abs(l_hip - l_ref) < 0.25 * l_ref
+
+
+# ------------------------------------------------------------------ configs[1] at its REAL batch: 16 rows vs the oracle
+@pytest.mark.parametrize("residual_fp32", [False, True])
+def test_sd15_config1_real_batch_16_rows_vs_oracle(residual_fp32):
+    """every other full-size oracle comparison runs 2 rows (M = 8 192 at the 64 x 64 level); the bench runs
+    configs[1]'s real batch - 8 samples = 16 rows, M = 65 536 - where dispatch picks other instantiations (the 256 x 320 ping-pong
+    tile, no split-K at 64 x 64 / 32 x 32, other split factors below).  Here: full SD1.5 @ 64 x 64, 8 samples, (1) one evaluation
+    at t = 981 and (2) one guided step (i = 0 of 50) through the sampler, both modes; rows {0, 8} and {7, 15} - samples 0 and 7,
+    the first and the last of the batch - against oracle.unet.unet_forward / oracle.guidance.apply_anti_gradient on those
+    two samples ALONE (samples are independent: the reference itself only runs B = 1, modules/pipeline.py:160).  Same bounds
+    as the 2-row tests.  Prints the instantiations the 16-row launches walk beside the 2-row ones."""
+    from oracle import ddim as oddim, guidance as og, unet as ounet
+    from sketch2img_amd import ops, synthetic
+    from sketch2img_amd._lib import lib
+    from sketch2img_amd.config import SD15, tap_channels
+    from sketch2img_amd.lgp import HipLGP
+    from sketch2img_amd.sampler import DDIMTables, HipSampler
+    from sketch2img_amd.unet import CIN_PAD, HipUNet
+    _threads()
+    cfg = ounet.SD15
+    S, h, T = 8, 64, 50
+    W = synthetic.unet_state_dict(SD15)
+    sd = synthetic.lgp_state_dict(synthetic.lgp_input_dim(SD15))
+    x0, tgt = synthetic.initial_latents(0, S, h), synthetic.sketch_targets(0, S, h)
+    net = HipUNet(SD15, W, DEV, residual_fp32=residual_fp32)
+    net.prepare_context(synthetic.text_embeddings(S))
+    tab, otab = DDIMTables.make(T), oddim.make_tables(T)
+    t = int(tab.timesteps[0])
+    net.prepare_timesteps(tab.timesteps.tolist())
+    shapes = [("conv 64x64 320->320", 4096, 320, 2880, 320, 1), ("conv 32x32 640->640", 1024, 640, 5760, 640, 1),
+              ("conv 16x16 1280->1280", 256, 1280, 11520, 1280, 1), ("conv 8x8 1280->1280", 64, 1280, 11520, 1280, 1),
+              ("gemm 64x64 K320 N320", 4096, 320, 320, 0, 0), ("gemm 64x64 QKV", 4096, 960, 320, 0, 0),
+              ("gemm 16x16 K1280 N1280", 256, 1280, 1280, 0, 0), ("gemm 16x16 FF2 K5120", 256, 1280, 5120, 0, 0)]
+    for name, hw, N, K, Cin, mode in shapes:
+        print(f"[parity] instantiation (skg_gemm_variant) {name:24s}: 16 rows -> {lib.skg_gemm_variant(16 * hw, N, K, Cin, mode)}, "
+              f"8 rows (cond-only backward) -> {lib.skg_gemm_variant(8 * hw, N, K, Cin, mode)}, 2 rows -> {lib.skg_gemm_variant(2 * hw, N, K, Cin, mode)}")
+    assert lib.skg_gemm_variant(16 * 4096, 320, 2880, 320, 1) != lib.skg_gemm_variant(2 * 4096, 320, 2880, 320, 1)
+    # (1) one evaluation, 16 rows, the sampler's own call form (shared CFG prefix)
+    x32 = ops.nchw_to_nhwc(torch.cat([x0, x0]).to(DEV), CIN_PAD)
+    eps, taps = net.forward(x32, t, 2 * S, h, shared_input=True)
+    A = ops.nhwc_to_nchw(eps, 2 * S, 4, h, h).cpu()
+    taps_hip = [(tp.float().cpu().reshape(2 * S, s_, s_, -1).permute(0, 3, 1, 2), s_) for tp, s_ in taps]
+    # (2) one guided step of the 8 samples
+    sampler = HipSampler(net, HipLGP(sd, tap_channels(SD15), DEV))
+    xp, eps_cfg, aux = sampler.step(x0.to(DEV), x0.to(DEV), tgt.to(DEV), tab, 0, 7.5, 1.6, want_eps=True)
+    xp, eps_cfg, aux = xp.cpu(), eps_cfg.cpu(), aux.cpu()
+    assert torch.isfinite(xp).all()
+    ehs1 = synthetic.text_embeddings(1)
+    for si in (0, S - 1):
+        xi, ti = x0[si:si + 1], tgt[si:si + 1]
+        x_in = torch.cat([xi] * 2).requires_grad_(True)
+        with torch.enable_grad():
+            eo, to = ounet.unet_forward(cfg, W, x_in, t, ehs1)
+        eu, ec = eo.detach().chunk(2)
+        e_cfg = eu + 7.5 * (ec - eu)
+        nxt = oddim.ddim_step(otab, e_cfg, t, xi)
+        new, ao = og.apply_anti_gradient(to, dict(sd), otab.alphas_cumprod, x_in, nxt, xi, t, ti, 1.6, return_aux=True)
+        for row, orow in ((si, 0), (S + si, 1)):
+            r, m = report(f"sd15 16 rows, residual_fp32={residual_fp32}: eps row {row} (sample {si}) vs fp32 oracle", A[row], eo.detach()[orow])
+            if residual_fp32:
+                assert m <= 1e-3 and r <= 7e-4              # north_star's bound, as the 2-row sweep asserts it
+            else:
+                assert r < 2e-3 and m < 3e-3                # the default mode's 2-row bounds
+            for k, ((th, s_), tor) in enumerate(zip(taps_hip, to)):
+                rt = float((th[row] - tor.detach()[orow]).norm() / tor.detach()[orow].norm())
+                assert rt < (1.5e-3 if residual_fp32 else 2.5e-3), (k, row, rt)
+        rc, _ = report(f"sd15 16 rows, residual_fp32={residual_fp32}: CFG eps of the guided step, sample {si}", eps_cfg[si], e_cfg[0])
+        assert rc < (7e-3 if residual_fp32 else 1.4e-2)
+        upd_ref = float(ao["alpha"]) * ao["cond_grad"]
+        upd = xp[si:si + 1] - (new - upd_ref)
+        nr = float(upd.norm() / upd_ref.norm())
+        cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm()))
+        dl = abs(float(aux[si, 3]) - float(ao["loss"])) / float(ao["loss"])
+        print(f"[parity] sd15 16 rows, residual_fp32={residual_fp32}: guided step, sample {si}: |hip|/|oracle| = {nr:.5f}, cos = {cos:.5f}, "
+              f"loss hip {float(aux[si, 3]):.4e} oracle {float(ao['loss']):.4e}, alpha hip {float(aux[si, 0]):.4f} oracle {float(ao['alpha']):.4f}")
+        # free-running within the step (the HIP update starts from the HIP x_{t-1}): the scheduler step's own eps error enters `upd`
+        assert abs(nr - 1) < 2e-2 and cos > 0.9965 and dl < 2e-3
 
 
 # ------------------------------------------------------------------ full architecture, config[0]'s trajectory shape
@@ -584,10 +696,11 @@ def test_two_ranks_on_one_device_equal_one_rank_bitwise(tmp_path):
     sample -> on-rank VAE decode -> gather of uint8 images.  The gathered images of global samples {0, 1} must equal,
     bit for bit, what a single rank produces for sample 0 and for sample 1 (placement independence)."""
     common = ["--steps", "1", "--warmup", "0", "--ddim-steps", "3", "--samples-per-gpu", "1", "--no-cpu-baseline",
-              "--no-roofline"]
+              "--no-roofline", "--no-box-probe", "--no-second-mode"]
     two = tmp_path / "two.pt"
+    # (round 6: plain `python bench.py --gpus 2` - bench.py launches its own ranks under torch.distributed.run)
     d2 = _bench(common + ["--gpus", "2", "--dump-images", str(two)],
-                env={"SKG_BENCH_BACKEND": "gloo", "SKG_BENCH_DEVICE": "0"}, nproc=2)
+                env={"SKG_BENCH_BACKEND": "gloo", "SKG_BENCH_DEVICE": "0"})
     assert d2["n_gpus"] == 2 and d2["config"]["global_batch"] == 2 and d2["outputs_finite"]
     assert d2["out_shape"] == [2, 512, 512, 3]
     got = torch.load(two)["images"]
@@ -607,10 +720,10 @@ def test_rccl_path_executes_on_one_gpu(tmp_path):
     (broadcast_state_dict: UNet / LGP / VAE buckets, int64 buffers included) and the final gather of the decoded uint8 images
     through real RCCL calls on device tensors; the gathered images must equal the plain single-process run bit for bit."""
     common = ["--steps", "1", "--warmup", "0", "--ddim-steps", "3", "--samples-per-gpu", "2", "--no-cpu-baseline",
-              "--no-roofline", "--gpus", "1"]
+              "--no-roofline", "--gpus", "1", "--no-box-probe", "--no-second-mode"]
     a, b = tmp_path / "rccl.pt", tmp_path / "plain.pt"
     d = _bench(common + ["--dump-images", str(a)], env={"SKG_BENCH_FORCE_DIST": "1"}, launcher=True, port=29633)
-    assert "backend nccl = RCCL" in d["config"]["parallelism"] and d["outputs_finite"] and d["out_shape"] == [2, 512, 512, 3]
+    assert "backend nccl = RCCL" in d["config"]["parallelism"] and len(d["config"]["parallelism"]) <= 120 and d["outputs_finite"] and d["out_shape"] == [2, 512, 512, 3]
     p = _bench(common + ["--dump-images", str(b)])
     assert "no process group" in p["config"]["parallelism"]
     ia, ib = torch.load(a), torch.load(b)
@@ -626,6 +739,7 @@ def test_bench_contract_line_configs_4_and_5(config):
         assert k in d, k
     assert d["value"] > 0 and d["outputs_finite"] and d["config"]["baseline_config"] == config
     assert f"configs[{config - 1}]" in d["config"]["workload"] and "model" not in d["config"]
+    assert d["config"]["mode"] == "residual_fp32" and d["config"]["fast_fp16_value"] > 0 and d["config"]["box_mfma_tflops"] > 0
     assert d["out_shape"] == ([1, 512, 512, 3] if config == 4 else [1, 768, 768, 3])
     roof = d["roofline"]
     assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and roof["unit"] == "TFLOP/s"

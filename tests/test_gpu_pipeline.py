@@ -576,3 +576,58 @@ def test_lgp_train_step_end_to_end_tiny(tiny):
     print(f"[parity] lgp train_step loss hip {float(loss):.5f} oracle {float(ref):.5f}")
     assert abs(float(loss) - float(ref)) < 1e-2 * float(ref)
     assert tr.step_count == 1 and int(tr.state_dict()["layers.5.num_batches_tracked"]) == 1
+
+
+# ------------------------------------------------------------------- declined fused launches fall back to the same numbers
+@pytest.mark.parametrize("residual_fp32", [False, True])
+def test_declined_conv_shortcut_fold_falls_back_to_two_launches(monkeypatch, residual_fp32):
+    """skg_conv3x3_sc_f16 DECLINES (SKG_E_UNSUPPORTED, tests/test_host.py checks the return code of the C ABI on a
+    >= 2 GiB operand) and HipUNet._res_fwd / _res_fwd_hp then run conv2 and the shortcut GEMM as two launches from packs that are
+    built on first use.  Forced here by making every conv3x3_sc call decline: the evaluation must equal the fused one up to the fp16
+    rounding of the shortcut output that the fold removes (default mode) / to pair accuracy (accuracy mode), taps included; the
+    accuracy mode's upsampler fall-back keeps the hi-only operand of the launch it replaces."""
+    from oracle import unet as ounet
+    from sketch2img_amd import ops
+    from sketch2img_amd._lib import SkgError
+    from sketch2img_amd.config import TINY
+    from sketch2img_amd.unet import CIN_PAD, HipUNet
+    import dataclasses
+    boc = (64, 128, 128, 128)                                   # (the pair kernels want channel counts % 64 == 0)
+    cfg, ocfg = dataclasses.replace(TINY, block_out_channels=boc), dataclasses.replace(ounet.TINY, block_out_channels=boc)
+    W = ounet.init_weights(ocfg)
+    g = torch.Generator().manual_seed(3)
+    h, rows = 32, 4
+    x = torch.randn(rows, 4, h, h, generator=g)
+    ehs = torch.randn(rows, 77, cfg.cross_attention_dim, generator=g).half().float()
+    net = HipUNet(cfg, W, DEV, need_backward=False, residual_fp32=residual_fp32)
+    assert not residual_fp32 or net.hp_norm_pairs              # (the norm-pair sites of the accuracy mode go through the fall-back too)
+    net.prepare_context(ehs)
+    lazy_before = set(net.W.lazy)
+    assert any(k.endswith(".conv2.weight") for k in lazy_before) and any(k.endswith(".conv_shortcut.weight") for k in lazy_before)
+
+    def run():
+        eps, taps = net.forward(ops.nchw_to_nhwc(x.to(DEV), CIN_PAD), 500, rows, h)
+        return ops.nhwc_to_nchw(eps, rows, 4, h, h).cpu(), [t[0].float().cpu() for t in taps]
+
+    e0, t0 = run()
+    assert set(net.W.lazy) == lazy_before                      # the fused path never touches the fall-back packs
+    calls = []
+
+    def declined(*a, **k):
+        calls.append(1)
+        err = SkgError("forced decline")
+        err.rc = -2
+        raise err
+
+    monkeypatch.setattr(ops, "conv3x3_sc", declined)
+    if residual_fp32:
+        monkeypatch.setattr(ops, "conv_up2_pairout", declined)
+    e1, t1 = run()
+    assert len(calls) >= 4 and not any(k.endswith(".conv2.weight") for k in net.W.lazy)
+    r, _ = report(f"eps, declined conv3x3_sc vs fused (residual_fp32={residual_fp32})", e1, e0)
+    assert r < (2e-4 if residual_fp32 else 1.5e-3)
+    for i, (a, b) in enumerate(zip(t1, t0)):
+        assert report(f"tap{i}, declined vs fused", a, b)[0] < (1e-3 if residual_fp32 else 2e-3)
+    with torch.no_grad():
+        C, _ = ounet.unet_forward(ocfg, W, x, 500, ehs)
+    assert report("eps, declined path vs fp32 oracle", e1, C)[0] < (8e-4 if residual_fp32 else 2.5e-3)

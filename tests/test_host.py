@@ -51,7 +51,7 @@ def test_library_exports_every_declared_symbol_with_matching_signature():
     for name, sig in decl.items():
         assert _lib.SIGNATURES[name] == sig, (name, _lib.SIGNATURES[name], sig)
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.skg_abi_version() == _lib.ABI_VERSION == 4
+    assert _lib.lib.skg_abi_version() == _lib.ABI_VERSION == 5
     nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (skg_\w+)", nm))
     assert set(decl) <= exported
@@ -68,6 +68,9 @@ def test_host_side_argument_checks_do_not_need_a_gpu():
     assert lib.skg_ff_block_f16(16, 320, 16, 320, 128, 320, 1296, 16, 16, 1e-5, 16, 16, 16, None, None) == -1   # F % 32
     assert lib.skg_xattn_block_f16(16, 320, 16, 320, 4096, 4096, 320, 8, 81, 16, 16, 1e-5, 16, 16, 16, 0.158, None) == -1   # Nkv <= 80
     assert lib.skg_xattn_block_f16(16, 320, 16, 320, 4096, 1000, 320, 8, 77, 16, 16, 1e-5, 16, 16, 16, 0.158, None) == -1  # HW % 128
+    # conv2 + folded shortcut: an X2 operand of 2 GiB or more is DECLINED (-2: the caller runs the two launches), not a bad argument
+    sc_args = lambda rows, k2: (16, 320, 16, k2, k2, 16, 16, None, 320, rows, 64, 64, 320, 320, None, 0, None, 0, None)
+    assert lib.skg_conv3x3_sc_f16(*sc_args(140, 1920)) == -2 and lib.skg_conv3x3_sc_f16(*sc_args(16, 1920 + 8)) == -1      # K2 % 64
     assert lib.skg_gemm_variant(65536, 320, 2880, 320, 2) == 2160
     assert lib.skg_gemm_variant(4096, 64, 96, 32, 2) == 1064
     # GroupNorm statistics in the producer's epilogue: which launches fuse them (the rest run the stand-alone pass)
@@ -229,6 +232,37 @@ def test_two_process_gloo_broadcast_and_gather(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o[-2000:]
+
+
+def test_bench_gpus_n_launches_itself():
+    """`python bench.py --gpus 2` outside a launcher re-execs under torch.distributed.run (one rank per GPU),
+    relays rank 0's single JSON line on stdout and the exit code.  --plumbing-check keeps the hot path out (no GPU here): rendezvous
+    on 127.0.0.1, barrier, max over ranks.  A mismatching external launcher still trips the assert."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--plumbing-check", "--steps", "3", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-2000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout                  # ONE line on stdout: the contract line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["self_launched"] and d["ranks"] == [[0, 0], [1, 1]] and d["steps"] == 3 and d["max_over_ranks"] >= 1.0
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--plumbing-check"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                         capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
+
+
+def test_bench_workload_strings_survive_a_120_character_cut():
+    """The driver's parser keeps scalars and strings of at most 120 characters inside `config`: the workload name must fit."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for C in (2, 4, 5):
+        s = b.WORKLOADS[C].format(S=8, T=50, G=25, sched="DPM-Solver++ 2M")
+        assert len(s) <= 120 and f"configs[{C - 1}]" in s
+    assert abs(b.f_img_tflop(2, 50) - 107.65) < 0.01 and b.EPS_BOUND == 1e-3
 
 
 def test_shard_range_covers_everything():

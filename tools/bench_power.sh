@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 for C in 2 4 5; do
   ( while true; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | tr '\n' ' '; echo; sleep 0.25; done ) > gpurun_out/bp_smi_c$C.txt &
   SMI=$!
-  python bench.py --config $C --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-at-tolerance 2>/dev/null > gpurun_out/bp_bench_c$C.json
+  python bench.py --config $C --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --fast-fp16 --no-second-mode 2>/dev/null > gpurun_out/bp_bench_c$C.json
   kill $SMI; wait $SMI 2>/dev/null
   python - <<PY
 import json, re, statistics as st

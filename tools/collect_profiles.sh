@@ -5,7 +5,8 @@
 #   3. --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -> profiles/<tag>_cfg<C>_mfma_counters.{json,txt}
 # (counter passes carry --pmc only: no trace domains).  The counter passes run a 6-step schedule of the same workload
 # (per-launch figures do not depend on the step count).  Run on the GPU box from the repo root:
-#   bash tools/collect_profiles.sh r03 2
+#   bash tools/collect_profiles.sh r06 2              (the headline = accuracy mode; round 6)
+#   bash tools/collect_profiles.sh r06fast 2 --fast-fp16   (the all-fp16 mode)
 set -e
 TAG=${1:-r03}
 CFG=${2:-2}
@@ -13,7 +14,7 @@ EXTRA=${3:-}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out profiles
 OUT=gpurun_out/${TAG}_cfg${CFG}
-BENCH="python bench.py --config $CFG --no-cpu-baseline --no-roofline --no-at-tolerance $EXTRA"
+BENCH="python bench.py --config $CFG --no-cpu-baseline --no-roofline --no-second-mode --no-box-probe $EXTRA"
 rm -rf ${OUT}_trace
 rocprofv3 --kernel-trace --stats --output-format csv -d ${OUT}_trace -- $BENCH --steps 2 --warmup 1 > ${OUT}_trace.log 2>&1
 STATS=$(find ${OUT}_trace -name "*kernel_stats.csv" | head -1)

@@ -12,11 +12,11 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value'],4), 'images/s', round(d['ms_per_step'],1), 'ms/batch', 'finite', d.get('outputs_finite'))"; }
 for i in 1 2; do
   for V in 0 1; do
-    SKG_ATTN_DQ_DELTA=$V python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-at-tolerance 2>/dev/null | one "default ATTN_DQ_DELTA=$V"
+    SKG_ATTN_DQ_DELTA=$V python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --fast-fp16 --no-second-mode 2>/dev/null | one "default ATTN_DQ_DELTA=$V"
   done
 done | tee $T/ab_dq_delta.txt
 for i in 1 2; do
   for V in 0 1; do
-    SKG_XATTN_KEEP_HP=$V python bench.py --residual-fp32 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | one "accuracy XATTN_KEEP_HP=$V"
+    SKG_XATTN_KEEP_HP=$V python bench.py --residual-fp32 --no-second-mode --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | one "accuracy XATTN_KEEP_HP=$V"
   done
 done | tee $T/ab_xattn_keep_hp.txt

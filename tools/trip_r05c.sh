@@ -11,14 +11,14 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value'],4), 'images/s', round(d['ms_per_step'],1), 'ms/batch', 'finite', d.get('outputs_finite'))"; }
 for i in 1 2; do
   for V in 0 1; do
-    SKG_XATTN_D64=$V python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-at-tolerance 2>/dev/null | one "config 5 default XATTN_D64=$V"
+    SKG_XATTN_D64=$V python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --fast-fp16 --no-second-mode 2>/dev/null | one "config 5 default XATTN_D64=$V"
   done
 done | tee $T/ab_xattn_d64.txt
 for V in 0 1; do
-  SKG_XATTN_D64=$V python bench.py --config 5 --residual-fp32 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | one "config 5 accuracy XATTN_D64=$V"
+  SKG_XATTN_D64=$V python bench.py --config 5 --residual-fp32 --no-second-mode --steps 2 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | one "config 5 accuracy XATTN_D64=$V"
 done | tee -a $T/ab_xattn_d64.txt
 for i in 1 2; do
   for V in 2 3; do
-    SKG_SPLIT_NS=$V python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-at-tolerance 2>/dev/null | one "config 2 default SPLIT_NS=$V"
+    SKG_SPLIT_NS=$V python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --fast-fp16 --no-second-mode 2>/dev/null | one "config 2 default SPLIT_NS=$V"
   done
 done | tee $T/ab_split_ns.txt
