@@ -137,8 +137,17 @@ HP_UP_TRIPLE = os.environ.get("SKG_HP_UP_TRIPLE", "0") != "0"
 # consumes them - at the sites whose fp16 rounding carries the most of the mode's remaining eps distance (tools/eps_decompose_sites.py:
 # the norm outputs of the LAST up block are 66 % of its variance; conv_norm_out, 18 %, has been a pair since round 4).  Comma-separated
 # norm names of the last up block ("<resnet>.norm1" / ".norm2" -> conv1 / conv2, "<attention>.norm" -> proj_in); "" = none (round 5).
+# Default = norm2 of the last two ResnetBlocks, norm1 of the last one and the three attention GroupNorms, chosen together with
+# HP_PLAIN_LEVELS = 2 on one box (profiles/r06_eps_variants.txt, 16 rows, ms per 16-row evaluation): round 5's mode 4.83e-4 rel / 8.7e-4
+# worst max / 19.34 ms; this default 4.11e-4 / 7.2e-4 / 19.42 ms; all nine sites 3.75e-4 / 6.8e-4 / 19.95 ms; the default mode 17.29 ms.
 HP_NORM_PAIRS = tuple(n for n in os.environ.get(
-    "SKG_HP_NORM_PAIRS", "up_blocks.3.resnets.2.norm2,up_blocks.3.attentions.2.norm").split(",") if n)
+    "SKG_HP_NORM_PAIRS", "up_blocks.3.resnets.1.norm2,up_blocks.3.resnets.2.norm1,up_blocks.3.resnets.2.norm2,up_blocks.3.attentions.0.norm,"
+                         "up_blocks.3.attentions.1.norm,up_blocks.3.attentions.2.norm").split(",") if n)
+# accuracy mode (round 6): the DEEPEST resolution levels run the default fp16 kernels - tools/eps_decompose_stream.py: of what the pairs
+# (residual stream, conv outputs that feed a norm, stream-as-operand) buy, 60 % is bought in the last up block, 25 % in the first down block
+# (its skips feed the last up block), 15 % at the 32 x 32 level, ~4 % at the 16 x 16 level and nothing at 8 x 8.  n = number of deepest
+# levels (8 x 8, 16 x 16, ...) whose blocks run plain fp16: down_blocks[nb - n ..], mid_block, up_blocks[.. n - 1]; 0 = pairs everywhere.
+HP_PLAIN_LEVELS = int(os.environ.get("SKG_HP_PLAIN_LEVELS", "2"))
 UP2_SMALL_MAPS = os.environ.get("SKG_UP2_SMALL", "1") != "0"    # A/B: polyphase also where one phase does not fill the chip
 UP2_DGRAD = os.environ.get("SKG_UP2_DGRAD", "1") != "0"         # A/B: the upsampler's backward as one 4 x 4 stride-2 convolution
 
@@ -290,6 +299,8 @@ class HipUNet:
         self.residual_fp32 = residual_fp32
         self.W: Dict[str, torch.Tensor] = _Packs()
         self.hp_norm_pairs: set = set()
+        nb = len(cfg.block_out_channels)
+        self.hp_plain_levels = max(0, min(HP_PLAIN_LEVELS, nb - 1)) if residual_fp32 else 0
         self._pack(state_dict)
         if residual_fp32:
             assert all(c % 64 == 0 for c in cfg.block_out_channels), \
@@ -300,6 +311,19 @@ class HipUNet:
         self.tbias: Dict[int, Dict[str, torch.Tensor]] = {}
         self.ctx: Optional[dict] = None
         self.inject: Optional[Callable] = None      # set by modules.*_guided_attn.SatMixin
+
+    def _hp_plain(self, name: str) -> bool:
+        """Accuracy mode: does this module (state-dict prefix) run the default fp16 kernels (HP_PLAIN_LEVELS)?  Resolution level of
+        down_blocks.i = i, of mid_block = nb - 1, of up_blocks.i = nb - 1 - i; plain iff level >= nb - hp_plain_levels."""
+        if not self.residual_fp32 or self.hp_plain_levels == 0:
+            return not self.residual_fp32
+        nb, pl = len(self.cfg.block_out_channels), self.hp_plain_levels
+        part = name.split(".")
+        if part[0] == "down_blocks":
+            return int(part[1]) >= nb - pl
+        if part[0] == "up_blocks":
+            return int(part[1]) <= pl - 1
+        return part[0] == "mid_block"
 
     # ------------------------------------------------------------------ packing
     def _pack(self, sd):
@@ -368,7 +392,7 @@ class HipUNet:
             w2, wsc = sd[r + ".conv2.weight"], sd[r + ".conv_shortcut.weight"]
             wsc = wsc.reshape(wsc.shape[0], wsc.shape[1])
             w2p = w2.permute(0, 2, 3, 1).reshape(w2.shape[0], -1)                   # [Cout][ky][kx][Cin] (pack_conv's order)
-            if self.residual_fp32:      # (the accuracy mode reads only :sc2 - the pair operand [x_hi | x_lo] . [W | W] - and the summed bias)
+            if not self._hp_plain(r):   # (the accuracy mode's pair blocks read only :sc2 - the pair operand [x_hi | x_lo] . [W | W] - and the summed bias)
                 W[r + ".conv2.weight:sc2"] = _h(torch.cat([w2p, wsc, wsc], 1), dev)
             else:
                 W[r + ".conv2.weight:sc"] = _h(torch.cat([w2p, wsc], 1), dev)
@@ -416,6 +440,8 @@ class HipUNet:
         convolutions, proj_out) the operand is the PAIR [hi | lo] along K and the weight pack is [W | W]."""
         W, dev = self.W, self.dev
         for k, v in sd.items():
+            if self._hp_plain(k):       # (a block of the deepest levels: runs the default kernels, HP_PLAIN_LEVELS)
+                continue
             if k.endswith(".conv_shortcut.weight") and (k[: -len(".conv_shortcut.weight")] + ".conv2.weight:sc2") in W:
                 host = v.detach().to("cpu", torch.float16)          # (fall-back of a declined conv3x3_sc launch only)
                 W.lazy[k + ":2"] = lambda h=host: _h(torch.cat([h.reshape(h.shape[0], h.shape[1])] * 2, 1), dev)
@@ -984,7 +1010,7 @@ class HipUNet:
         else:
             sc = x
         w2 = w2n if n2_pair else W[p + ".conv2.weight"]
-        if w2.shape[1] != 9 * n2.shape[1]:      # (a column slice of the folded pack: the kernel wants the 9-tap pack contiguous)
+        if not w2.is_contiguous():              # (a column slice of the folded pack: the kernel wants the 9-tap pack contiguous)
             w2 = w2.contiguous()
         if want_part and fuse:
             _, opart = ops.conv3x3(n2, w2, rows, H, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
@@ -1134,7 +1160,10 @@ class HipUNet:
         """The forward of forward() with the residual stream as (hi, lo) pairs; the same graph, the same kernels for every
         contraction, pair-aware epilogues / norms (skg_*_hilo), the same GroupNorm statistics from the producers' epilogues and
         the same shared CFG front.  Concatenations [h | skip] are pair buffers [h_hi | skip_hi | h_lo | skip_lo], filled in
-        place by their producers."""
+        place by their producers.  Round 6: the blocks of the `hp_plain_levels` deepest resolution levels run the DEFAULT kernels
+        on plain fp16 tensors (their pairs buy ~4 % of what the mode's pairs buy, tools/eps_decompose_stream.py): the stride-2
+        convolution that enters the zone reads the pair and writes fp16, the upsampler that leaves it reads fp16 and writes a pair;
+        skips produced inside the zone are consumed inside it (the U-Net's skips connect equal resolutions)."""
         cfg, W = self.cfg, self.W
         if stash is not None:
             stash.misc.update(rows=rows, H=H)
@@ -1150,12 +1179,19 @@ class HipUNet:
         P = HipUNet._Pair
         n_made = [0]
         skip_parts: List[Optional[ops.GNPartial]] = []       # partial sums of each skip, when its producer left them
+        pl = self.hp_plain_levels
+        plain_up = lambda i: i <= pl - 1                      # up block i (and concat buffer u with u // lpb1 == i) is in the plain zone
+        plain_down = lambda i: i >= nb - pl                   # down block i
 
         def skip_slot(ch_s: int, size: int):
-            """The pair view inside the concat buffer that will consume the skip produced next."""
+            """The view inside the concat buffer that will consume the skip produced next: a pair view, or - the consumer is a
+            block of the plain zone - the fp16 right-hand columns."""
             u = n_skips - 1 - n_made[0]
             n_made[0] += 1
             ct = ch_h[u] + ch_s
+            if plain_up(u // lpb1):
+                cats[u] = torch.empty(rows * size * size, ct, device=self.dev, dtype=torch.float16)
+                return cats[u][:, ch_h[u]:]
             cats[u] = torch.empty(rows * size * size, 2 * ct, device=self.dev, dtype=torch.float16)
             return P(cats[u][:, ch_h[u]:ct], cats[u][:, ct + ch_h[u]:], None)
 
@@ -1179,6 +1215,15 @@ class HipUNet:
             ops.conv3x3(x, W[wkey], r, size, size, mode, out=o.hi, out_lo=o.lo, bias=W[bkey])
             return None
 
+        def conv_plain(x, wkey, bkey, size, mode, o):
+            """conv with an fp16 output (the plain zone; forward()'s form)"""
+            osz = size // 2 if mode == ops.CONV_S2 else size
+            if self._gn_from_producer(rows, osz * osz, o.shape[1]):
+                return ops.conv3x3(x, W[wkey], rows, size, size, mode, out=o, bias=W[bkey], gn_groups=G)[1]
+            ops.conv3x3(x, W[wkey], rows, size, size, mode, out=o, bias=W[bkey])
+            return None
+
+        hi_of = lambda v: v.hi if isinstance(v, ops.Pair) else v
         shared = shared_input and rows % 2 == 0 and rows >= 2 and nb > 1 and cfg.layers_per_block >= 1
         cur = H
         taps_down = []
@@ -1204,33 +1249,52 @@ class HipUNet:
             for j in range(cfg.layers_per_block):
                 if shared and i == 0 and j == 0:
                     continue
-                if i < nb - 1:
-                    h, hp = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, full_of=full_of, stash=stash,
-                                             xpart=hp, want_part=True)
-                    h, hp = self._tr_fwd_hp(f"down_blocks.{i}.attentions.{j}", h, rows, cur, cfg.num_heads[i],
-                                            out=skip_slot(boc[i], cur), stash=stash, xpart=hp,
+                rp, ap = f"down_blocks.{i}.resnets.{j}", f"down_blocks.{i}.attentions.{j}"
+                if plain_down(i):      # forward()'s form on fp16 tensors
+                    if i < nb - 1:
+                        h, hp = self._res_fwd(rp, h, rows, cur, tb, stash, xpart=hp, want_part=True)
+                        h, hp = self._tr_fwd(ap, h, rows, cur, cfg.num_heads[i], stash, out=skip_slot(boc[i], cur), xpart=hp,
+                                             want_part=j < cfg.layers_per_block - 1)
+                    else:
+                        h, hp = self._res_fwd(rp, h, rows, cur, tb, stash, out=skip_slot(boc[i], cur), xpart=hp, want_part=True)
+                elif i < nb - 1:
+                    h, hp = self._res_fwd_hp(rp, h, rows, cur, tb, full_of=full_of, stash=stash, xpart=hp, want_part=True)
+                    h, hp = self._tr_fwd_hp(ap, h, rows, cur, cfg.num_heads[i], out=skip_slot(boc[i], cur), stash=stash, xpart=hp,
                                             want_part=j < cfg.layers_per_block - 1)
                 else:
-                    h, hp = self._res_fwd_hp(f"down_blocks.{i}.resnets.{j}", h, rows, cur, tb, out=skip_slot(boc[i], cur),
-                                             full_of=full_of, stash=stash, xpart=hp, want_part=True)
+                    h, hp = self._res_fwd_hp(rp, h, rows, cur, tb, out=skip_slot(boc[i], cur), full_of=full_of, stash=stash, xpart=hp,
+                                             want_part=True)
                 skip_parts.append(hp)
             if i < nb - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
-                o = skip_slot(boc[i], cur // 2)
-                hp = conv_pair(full_of(h, boc[i]), p + ".weight:2", p + ".bias", cur, ops.CONV_S2, o, want=True)
+                o = skip_slot(boc[i], cur // 2)               # (a pair, or fp16 when the consumer - the same level of the up path - is plain)
+                if plain_down(i):
+                    hp = conv_plain(h, p + ".weight", p + ".bias", cur, ops.CONV_S2, o)
+                elif isinstance(o, ops.Pair):
+                    hp = conv_pair(full_of(h, boc[i]), p + ".weight:2", p + ".bias", cur, ops.CONV_S2, o, want=True)
+                else:                                         # entering the plain zone: the pair as K-doubled operand, fp16 out
+                    hp = conv_plain(full_of(h, boc[i]), p + ".weight:2", p + ".bias", cur, ops.CONV_S2, o)
                 h = o
                 cur //= 2
                 skip_parts.append(hp)
             if i < 3:
-                taps_down.append((h.hi, cur))
-        h, hp = self._res_fwd_hp("mid_block.resnets.0", h, rows, cur, tb, full_of=full_of, stash=stash, xpart=hp, want_part=True)
-        tap_r0 = (h.hi, cur)
-        h, hp = self._tr_fwd_hp("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash=stash, xpart=hp, want_part=True)
-        tap_at = (h.hi, cur)
-        ct0 = cats[0].shape[1] // 2
-        h, _ = self._res_fwd_hp("mid_block.resnets.1", h, rows, cur, tb, out=P(cats[0][:, :ch_h[0]], cats[0][:, ct0:ct0 + ch_h[0]]),
-                                stash=stash, xpart=hp)
-        tap_r1 = (h.hi, cur)
+                taps_down.append((hi_of(h), cur))
+        if pl > 0:
+            h, hp = self._res_fwd("mid_block.resnets.0", h, rows, cur, tb, stash, xpart=hp, want_part=True)
+            tap_r0 = (h, cur)
+            h, hp = self._tr_fwd("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash, xpart=hp, want_part=True)
+            tap_at = (h, cur)
+            h, _ = self._res_fwd("mid_block.resnets.1", h, rows, cur, tb, stash, out=cats[0][:, :ch_h[0]], xpart=hp)
+            tap_r1 = (h, cur)
+        else:
+            h, hp = self._res_fwd_hp("mid_block.resnets.0", h, rows, cur, tb, full_of=full_of, stash=stash, xpart=hp, want_part=True)
+            tap_r0 = (h.hi, cur)
+            h, hp = self._tr_fwd_hp("mid_block.attentions.0", h, rows, cur, cfg.num_heads[-1], stash=stash, xpart=hp, want_part=True)
+            tap_at = (h.hi, cur)
+            ct0 = cats[0].shape[1] // 2
+            h, _ = self._res_fwd_hp("mid_block.resnets.1", h, rows, cur, tb, out=P(cats[0][:, :ch_h[0]], cats[0][:, ct0:ct0 + ch_h[0]]),
+                                    stash=stash, xpart=hp)
+            tap_r1 = (h.hi, cur)
         hp = None
         taps_up = []
         rev_heads = tuple(reversed(cfg.num_heads))
@@ -1240,9 +1304,22 @@ class HipUNet:
                 break
             for j in range(lpb1):
                 u = i * lpb1 + j
+                sp = skip_parts.pop() if skip_parts else None
+                rp, ap = f"up_blocks.{i}.resnets.{j}", f"up_blocks.{i}.attentions.{j}"
+                if plain_up(i):        # forward()'s form
+                    cat = cats[u]
+                    cpart = None
+                    if _GN_CONCAT and hp is not None and sp is not None and ops.gn_concat_ok(ch_h[u], cat.shape[1] - ch_h[u], G, hp.groups, sp.groups):
+                        cpart = (hp, ch_h[u], sp)
+                    nxt = cats[u + 1][:, :ch_h[u + 1]] if j < lpb1 - 1 else None
+                    if i > 0:
+                        h, hp = self._res_fwd(rp, cat, rows, cur, tb, stash, xpart=cpart, want_part=True)
+                        h, hp = self._tr_fwd(ap, h, rows, cur, rev_heads[i], stash, out=nxt, xpart=hp, want_part=j < lpb1 - 1)
+                    else:
+                        h, hp = self._res_fwd(rp, cat, rows, cur, tb, stash, out=nxt, xpart=cpart, want_part=j < lpb1 - 1)
+                    continue
                 ct = cats[u].shape[1] // 2
                 cat = P(cats[u][:, :ct], cats[u][:, ct:], cats[u])
-                sp = skip_parts.pop() if skip_parts else None
                 cpart = None
                 if _GN_CONCAT and hp is not None and sp is not None and ops.gn_concat_ok(ch_h[u], ct - ch_h[u], G, hp.groups, sp.groups):
                     cpart = (hp, ch_h[u], sp)
@@ -1251,36 +1328,44 @@ class HipUNet:
                     ctn = cats[u + 1].shape[1] // 2
                     nxt = P(cats[u + 1][:, :ch_h[u + 1]], cats[u + 1][:, ctn:ctn + ch_h[u + 1]])
                 if i > 0:
-                    h, hp = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, stash=stash, xpart=cpart, want_part=True)
+                    h, hp = self._res_fwd_hp(rp, cat, rows, cur, tb, stash=stash, xpart=cpart, want_part=True)
                     keepp = (want_eps and i == nb - 1 and j == lpb1 - 1) or j < lpb1 - 1
-                    h, hp = self._tr_fwd_hp(f"up_blocks.{i}.attentions.{j}", h, rows, cur, rev_heads[i], out=nxt, stash=stash,
-                                            xpart=hp, want_part=keepp)
+                    h, hp = self._tr_fwd_hp(ap, h, rows, cur, rev_heads[i], out=nxt, stash=stash, xpart=hp, want_part=keepp)
                 else:
-                    h, hp = self._res_fwd_hp(f"up_blocks.{i}.resnets.{j}", cat, rows, cur, tb, out=nxt, stash=stash, xpart=cpart,
-                                             want_part=j < lpb1 - 1)
+                    h, hp = self._res_fwd_hp(rp, cat, rows, cur, tb, out=nxt, stash=stash, xpart=cpart, want_part=j < lpb1 - 1)
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 u = (i + 1) * lpb1
-                ctn = cats[u].shape[1] // 2
-                o = P(cats[u][:, :ch_h[u]], cats[u][:, ctn:ctn + ch_h[u]])
-                if not HP_UP_TRIPLE and (p + ".weight:pp") in W and (p + ".weight:pp3") not in W:
-                    try:
-                        ops.conv_up2_pairout(h.hi, W[p + ".weight:pp"], rows, cur, cur, o, bias=W[p + ".bias"])
-                    except ops.SkgError as e:      # declined (an operand >= 2 GiB): the 9-tap gather form on the SAME hi-only operand
-                        if e.rc != -2:               # (both routes of the mode must see the same operand; pair output either way)
-                            raise
-                        ops.conv3x3(h.hi, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo, bias=W[p + ".bias"])
-                elif (p + ".weight:pp3") in W:      # polyphase, K axis [x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo]: 12 instead of 18 tap-products
-                    ops.conv_up2_hilo(full_of(h, h.hi.shape[1]), W[p + ".weight:pp3"], rows, cur, cur, o, bias=W[p + ".bias"],
-                                      W9x2=lambda p=p: self._w9x2(p + ".weight"))
+                if plain_up(i + 1):    # inside the plain zone: forward()'s form
+                    o = cats[u][:, :ch_h[u]]
+                    if (p + ".weight:pp") in W and (UP2_SMALL_MAPS or (rows * cur * cur // 128) * (h.shape[1] // 160) >= 200):
+                        ops.conv_up2(h, W[p + ".weight:pp"], rows, cur, cur, out=o, bias=W[p + ".bias"], W9=W[p + ".weight"])
+                    else:
+                        ops.conv3x3(h, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=o, bias=W[p + ".bias"])
                 else:
-                    ops.conv3x3(full_of(h, h.hi.shape[1]), W[p + ".weight:2"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo,
-                                bias=W[p + ".bias"])
+                    ctn = cats[u].shape[1] // 2
+                    o = P(cats[u][:, :ch_h[u]], cats[u][:, ctn:ctn + ch_h[u]])
+                    hin = hi_of(h)                            # (leaving the plain zone: h is fp16 and the hi-only launch is the natural one)
+                    if (plain_up(i) or not HP_UP_TRIPLE) and (p + ".weight:pp") in W and (p + ".weight:pp3") not in W:
+                        try:
+                            ops.conv_up2_pairout(hin, W[p + ".weight:pp"], rows, cur, cur, o, bias=W[p + ".bias"])
+                        except ops.SkgError as e:      # declined (an operand >= 2 GiB): the 9-tap gather form on the SAME hi-only operand
+                            if e.rc != -2:               # (both routes of the mode must see the same operand; pair output either way)
+                                raise
+                            ops.conv3x3(hin, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo, bias=W[p + ".bias"])
+                    elif plain_up(i):
+                        ops.conv3x3(hin, W[p + ".weight"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo, bias=W[p + ".bias"])
+                    elif (p + ".weight:pp3") in W:      # polyphase, K axis [x_hi | x_lo | x_hi] . [W_hi | W_hi | W_lo]: 12 instead of 18 tap-products
+                        ops.conv_up2_hilo(full_of(h, h.hi.shape[1]), W[p + ".weight:pp3"], rows, cur, cur, o, bias=W[p + ".bias"],
+                                          W9x2=lambda p=p: self._w9x2(p + ".weight"))
+                    else:
+                        ops.conv3x3(full_of(h, h.hi.shape[1]), W[p + ".weight:2"], rows, cur, cur, ops.CONV_UP2, out=o.hi, out_lo=o.lo,
+                                    bias=W[p + ".bias"])
                 h = o
                 hp = None
                 cur *= 2
             if i < 3:
-                taps_up.append((h.hi, cur))
+                taps_up.append((hi_of(h), cur))
                 if i == 2 and on_taps is not None:
                     on_taps(taps_down + [tap_at, tap_r0, tap_r1] + taps_up)
         eps = None

@@ -436,7 +436,7 @@ def test_sd15_config1_real_batch_16_rows_vs_oracle(residual_fp32):
         cos = float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm()))
         dl = abs(float(aux[si, 3]) - float(ao["loss"])) / float(ao["loss"])
         print(f"[parity] sd15 16 rows, residual_fp32={residual_fp32}: guided step, sample {si}: |hip|/|oracle| = {nr:.5f}, cos = {cos:.5f}, "
-              f"loss hip {float(aux[si, 3]):.4e} oracle {float(ao['loss']):.4e}, alpha hip {float(aux[si, 0]):.4f} oracle {float(ao['alpha']):.4f}")
+              f"loss hip {float(aux[si, 3]):.4e} oracle {float(ao['loss']):.4e}")
         # free-running within the step (the HIP update starts from the HIP x_{t-1}): the scheduler step's own eps error enters `upd`
         assert abs(nr - 1) < 2e-2 and cos > 0.9965 and dl < 2e-3
 

@@ -623,7 +623,8 @@ def test_declined_conv_shortcut_fold_falls_back_to_two_launches(monkeypatch, res
     if residual_fp32:
         monkeypatch.setattr(ops, "conv_up2_pairout", declined)
     e1, t1 = run()
-    assert len(calls) >= 4 and not any(k.endswith(".conv2.weight") for k in net.W.lazy)
+    # (the fall-back built its packs on first use; the norm-pair sites of the accuracy mode slice conv2's taps out of their own folded pack)
+    assert len(calls) >= 4 and len(net.W.lazy) < len(lazy_before)
     r, _ = report(f"eps, declined conv3x3_sc vs fused (residual_fp32={residual_fp32})", e1, e0)
     assert r < (2e-4 if residual_fp32 else 1.5e-3)
     for i, (a, b) in enumerate(zip(t1, t0)):

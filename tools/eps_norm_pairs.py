@@ -22,15 +22,19 @@ NEV = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 cfg = ounet.SD15
 W = ounet.init_weights(cfg)
 L = "up_blocks.3"
-VARIANTS = [
-    ("none (round 5)", ()),
-    ("attn.2 GN", (f"{L}.attentions.2.norm",)),
-    ("res.2 norm2 + attn.2 GN (default)", (f"{L}.resnets.2.norm2", f"{L}.attentions.2.norm")),
-    ("res.2 norm1 + norm2 + attn.2 GN", (f"{L}.resnets.2.norm1", f"{L}.resnets.2.norm2", f"{L}.attentions.2.norm")),
-    ("the three attention GNs", tuple(f"{L}.attentions.{j}.norm" for j in range(3))),
-    ("res.2 norm2 + the three attention GNs", (f"{L}.resnets.2.norm2",) + tuple(f"{L}.attentions.{j}.norm" for j in range(3))),
-    ("res.{1,2} norm2 + the three attention GNs", (f"{L}.resnets.1.norm2", f"{L}.resnets.2.norm2") + tuple(f"{L}.attentions.{j}.norm" for j in range(3))),
-    ("all nine of the last up block", tuple(f"{L}.resnets.{j}.{n}" for j in range(3) for n in ("norm1", "norm2")) + tuple(f"{L}.attentions.{j}.norm" for j in range(3))),
+N5 = (f"{L}.resnets.1.norm2", f"{L}.resnets.2.norm2") + tuple(f"{L}.attentions.{j}.norm" for j in range(3))
+N9 = tuple(f"{L}.resnets.{j}.{n}" for j in range(3) for n in ("norm1", "norm2")) + tuple(f"{L}.attentions.{j}.norm" for j in range(3))
+VARIANTS = [      # (name, deepest levels on the default fp16 kernels, norm outputs kept as pairs)
+    ("round 5: pairs everywhere, no norm pairs", 0, ()),
+    ("pairs everywhere + 5 norm sites", 0, N5),
+    ("8x8 plain + 5 norm sites", 1, N5),
+    ("8x8, 16x16 plain + 5 norm sites", 2, N5),
+    ("8x8, 16x16 plain + 5 + res.2 norm1", 2, N5 + (f"{L}.resnets.2.norm1",)),
+    ("8x8, 16x16 plain + 5 + res.{1,2} norm1", 2, N5 + (f"{L}.resnets.1.norm1", f"{L}.resnets.2.norm1")),
+    ("8x8, 16x16 plain + all nine", 2, N9),
+    ("8x8, 16x16, 32x32 plain + all nine", 3, N9),
+    ("8x8, 16x16 plain, no norm pairs", 2, ()),
+    ("DEFAULT mode (every stored tensor fp16)", -1, ()),
 ]
 cases = []
 ts = (981, 661, 341, 21)
@@ -48,10 +52,10 @@ for i in range(NEV):
 S = 8
 x16 = ops.nchw_to_nhwc(torch.cat([synthetic.initial_latents(0, S, 64)] * 2).to(DEV), CIN_PAD)
 ehs16 = synthetic.text_embeddings(S)
-print(f"\n{'norm outputs kept as pairs':44s} {'rel mean':>9s} {'rel max':>9s} {'max mean':>9s} {'max worst':>9s} {'rms':>9s} {'ms / 16-row eval':>17s}")
-for name, pairs in VARIANTS:
-    hunet.HP_NORM_PAIRS = pairs
-    net = HipUNet(SD15, W, DEV, need_backward=False, residual_fp32=True)
+print(f"\n{'accuracy-mode variant':44s} {'rel mean':>9s} {'rel max':>9s} {'max mean':>9s} {'max worst':>9s} {'rms':>9s} {'ms / 16-row eval':>17s}")
+for name, plv, pairs in VARIANTS:
+    hunet.HP_NORM_PAIRS, hunet.HP_PLAIN_LEVELS = pairs, max(plv, 0)
+    net = HipUNet(SD15, W, DEV, need_backward=False, residual_fp32=plv >= 0)
     rels, maxs, sq, n = [], [], 0.0, 0
     for xx, ehs, t, C in cases:
         net.prepare_context(ehs)
