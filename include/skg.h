@@ -170,6 +170,20 @@ int skg_conv3x3_up2_f16_pairout(const void* X, int ldx, const void* Wpp, void* Y
 int skg_conv3x3_sc_f16(const void* X, int ldx, const void* X2, int ldx2, int K2, const void* Wcat, void* Y, void* Y_lo, int ldy,
                        int rows, int IH, int IW, int Cin, int Cout, const void* bias, unsigned flags, float* gn_partial, int groups,
                        void* stream);
+/* 3x3 stride-1 convolution (padding 1) by Winograd F(2x2, 3x3) - the 16 x 16-level ResnetBlock convolutions of the UNet evaluated at
+ * modules/pipeline.py:96 and their data gradients inside torch.autograd.grad at modules/pipeline.py:159 (diffusers ResnetBlock2D conv1 /
+ * conv2 -> cuDNN).  2.25 x fewer MFMA flops and 4 x more workgroups than the implicit GEMM on maps that under-fill the chip:
+ *   V = B^T d B per 4 x 4 input tile (stride 2)  ->  16 GEMMs V_c [Mt][Cin] . U_c^T, Mt = rows * IH/2 * IW/2 (ONE split launch of the
+ *   GEMM kernel, fp32 slabs in the stream's workspace)  ->  Y = A^T M A + bias (+ residual) per 2 x 2 output tile.
+ * X [rows*IH*IW][ldx >= Cin] fp16; U [Cout][16 * Cin] fp16 = G g G^T per (cout, cin), component c = 4 i + j at columns [c Cin, (c + 1) Cin)
+ * (unet.pack_conv_wino); V: caller-owned scratch of skg_conv3x3_wino_v_bytes() bytes; Y [rows*IH*IW][ldy] (+ Y_lo: pair output);
+ * flags: SKG_EPI_RELU only.  Needs IH, IW even, Cin % 64 == 0, Cout % 8 == 0 and a registered workspace of >= 64 * Mt * Cout bytes
+ * (skg_set_workspace); otherwise SKG_E_UNSUPPORTED (nothing launched: run skg_conv3x3_f16).  U and V carry one more fp16 rounding than
+ * the implicit GEMM's operands (tools/eps_winograd.py prices it: default-mode eps rel 1.07e-3 -> 1.09e-3). */
+size_t skg_conv3x3_wino_v_bytes(int rows, int IH, int IW, int Cin);
+int skg_conv3x3_wino_f16(const void* X, int ldx, const void* U, void* V, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW,
+                         int Cin, int Cout, const void* bias, const void* residual, const void* residual_lo, int ldr, unsigned flags,
+                         void* stream);
 /* Data gradient of the polyphase upsample + convolution above (the autograd backward of diffusers Upsample2D inside
  * torch.autograd.grad at modules/pipeline.py:159): ONE 4 x 4 stride-2 convolution, padding 1, over the gradient at the upsampled
  * size.  X [rows*IH*IW, Cin] (ldx; IH, IW even), Y [rows*(IH/2)*(IW/2), Cout] (ldy), W16 [Cout][16 taps ky*4+kx][Cin]

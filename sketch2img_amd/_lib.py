@@ -37,6 +37,8 @@ SIGNATURES = {
     "skg_conv3x3_up2_f16_pairout": ("i", "pipppiiiiiipp"),
     "skg_conv3x3_sc_f16": ("i", "pipiipppiiiiiipupip"),
     "skg_conv4x4s2_f16": ("i", "pippiiiiiipp"),
+    "skg_conv3x3_wino_v_bytes": ("z", "iiii"),
+    "skg_conv3x3_wino_f16": ("i", "pippppiiiiiipppiup"),
     "skg_gemm_f16_rows": ("i", "pipipiiiipiip"),
     "skg_gemm_f16_hilo": ("i", "pipippiiiipppifup".replace(" ", "")),
     "skg_conv3x3_f16_hilo": ("i", "pipppiiiiiiipppifup"),

@@ -489,6 +489,48 @@ static int conv_up2_impl(const void* X, int ldx, const void* Wpp, void* Y, void*
   return SKG_OK;
 }
 
+// ---- 3x3 stride-1 convolution by Winograd F(2x2, 3x3) (include/skg.h, wino.hip) ---------------------------------------------
+extern "C" size_t skg_conv3x3_wino_v_bytes(int rows, int IH, int IW, int Cin) {
+  if (rows <= 0 || IH <= 0 || IW <= 0 || Cin <= 0) return 0;
+  return (size_t)rows * (IH / 2) * (IW / 2) * 16 * Cin * 2;
+}
+
+extern "C" int skg_conv3x3_wino_f16(const void* X, int ldx, const void* U, void* V, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW,
+                                    int Cin, int Cout, const void* bias, const void* residual, const void* residual_lo, int ldr,
+                                    unsigned flags, void* stream) {
+  SKG_REQUIRE(X && U && V && Y && rows > 0 && IH > 0 && IW > 0 && Cin > 0 && Cout > 0);
+  SKG_REQUIRE(ldx % 8 == 0 && ldx >= Cin && ldy % 4 == 0 && ldy >= Cout && skg_aligned(X, 16) && skg_aligned(U, 16) && skg_aligned(V, 16) &&
+              skg_aligned(Y, 8) && (!Y_lo || skg_aligned(Y_lo, 8)) && (!bias || skg_aligned(bias, 8)));
+  SKG_REQUIRE((!residual && !residual_lo) || (ldr % 4 == 0 && ldr >= Cout && (!residual || skg_aligned(residual, 8)) &&
+                                              (!residual_lo || skg_aligned(residual_lo, 8))));
+  SKG_REQUIRE(!(flags & ~SKG_EPI_RELU));
+  // shapes this path takes (everything else: SKG_E_UNSUPPORTED, nothing launched - run skg_conv3x3_f16): even maps, whole 64-deep K
+  // tiles per transform component, four output columns per thread of the output transform
+  if ((IH & 1) || (IW & 1) || Cin % 64 != 0 || Cout % 8 != 0) return SKG_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  GemmParams p{};
+  p.A = (const half_t*)V; p.lda = 16 * Cin; p.B = (const half_t*)U; p.ldb = 16 * Cin; p.C = Y; p.ldc = ldy;
+  p.bias = (const half_t*)bias; p.res = (const half_t*)residual; p.res_lo = (const half_t*)residual_lo; p.ldr = ldr;
+  p.c_lo = (half_t*)Y_lo;
+  p.M = rows * (IH / 2) * (IW / 2); p.N = Cout; p.K = 16 * Cin; p.alpha = 1.f; p.flags = flags;
+  p.wino = 16;
+  ws_attach(p, st);
+  if (!p.ws || (size_t)16 * p.M * p.N * 4 > p.ws_bytes) return SKG_E_UNSUPPORTED;      // the 16 fp32 slabs live in the stream's workspace
+  {   // (the launcher only reads the shapes and pointers of the GEMM proper: the epilogue fields belong to the output transform)
+    unsigned long long vb = (unsigned long long)p.M * p.lda * 2ull, ub = (unsigned long long)p.N * p.ldb * 2ull;
+    if (vb >= 0x7fffffffull || ub >= 0x7fffffffull) return SKG_E_UNSUPPORTED;
+  }
+  skg_wino_in_launch((const half_t*)X, ldx, (half_t*)V, rows, IH, IW, Cin, st);
+  SKG_CHECK_LAUNCH("skg_conv3x3_wino_f16 (input transform)");
+  GemmParams g = p;      // the GEMM step: raw slabs only
+  g.bias = nullptr; g.res = nullptr; g.res_lo = nullptr; g.c_lo = nullptr; g.flags = 0;
+  if (!skg_gemm2_try_launch(g, MODE_DIRECT, st)) return SKG_E_UNSUPPORTED;
+  SKG_CHECK_LAUNCH("skg_conv3x3_wino_f16 (GEMM)");
+  skg_wino_out_launch(p, p.ws, IH, IW, st);
+  SKG_CHECK_LAUNCH("skg_conv3x3_wino_f16 (output transform)");
+  return SKG_OK;
+}
+
 extern "C" int skg_conv3x3_up2_f16(const void* X, int ldx, const void* Wpp, void* Y, int ldy, int rows, int IH, int IW,
                                    int Cin, int Cout, const void* bias, void* stream) {
   return conv_up2_impl(X, ldx, Wpp, Y, nullptr, ldy, rows, IH, IW, Cin, Cout, 0, bias, stream);

@@ -1228,6 +1228,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
   const int KT = p.K / BK;
   // (the split-K reduce kernel has the plain epilogue only: fused-GEGLU launches never split)
   int splits = (BM == 128 && !(p.flags & SKG_EPI_GEGLU) && !p.up2 && !p.seg_rows) ? pick_splits(ntiles, KT, (size_t)p.M * p.N * 4, p.ws, p.ws_bytes) : 1;
+  if (p.wino) splits = p.wino;      // Winograd GEMM step: one K slice per transform component (skg_gemm2_try_launch checked the preconditions)
   constexpr int NTHR = WGM * WGN * 64;
   if (BM == 128 && BN == 160 && splits == 1 && gn_fusable(p, MODE)) p.flags |= SKG_FLAG_GN_STATS;
   if (direct_ok && splits == 1) p.flags |= 0x10000u;
@@ -1283,6 +1284,7 @@ void launch_cfg(const GemmParams& p_in, hipStream_t st) {
     if (!deep)
       hipLaunchKernelGGL((gemm2_kernel<BM, BN, WGM, WGN, MODE>), dim3(persistent_grid(ntiles * ns, NTHR)), dim3(NTHR),
                          0, st, p, tiles_n, ntiles * ns, (unsigned)a, (unsigned)b, (unsigned)s, per, p.ws);
+    if (p.wino) return;      // (the slabs are transform components, not partial sums: the caller's output transform follows)
     size_t blocks = ((size_t)p.M * (p.N / 4) + 255) / 256;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(blocks > 2048 ? 2048 : blocks)), dim3(256), 0, st, p,
                        (const float*)p.ws, ns);
@@ -1351,6 +1353,7 @@ template <int MODE>
 void launch_mode(const GemmParams& p, hipStream_t st) {
   TileCfg t = pick_tile(p.M, p.N, p.K);
   if (t.bm == 256 && (p.c_lo || p.res_lo || p.up2 || p.seg_rows)) t = TileCfg{128, 160};      // (hi / lo epilogue, polyphase row map: 128-row tiles)
+  if (p.wino) t = p.N % 160 == 0 ? TileCfg{128, 160} : p.N % 128 == 0 ? TileCfg{128, 128} : TileCfg{128, 64};      // 16 slices of 128-row tiles
   if (t.bm == 256) launch_cfg<256, 320, 2, 4, MODE>(p, st);
   else if (t.bn == 160) {
     launch_cfg<128, 160, 2, 2, MODE>(p, st);
@@ -1387,6 +1390,10 @@ void skg_splitk_reduce_launch(const GemmParams& p, const float* ws, int splits, 
 
 bool skg_gemm2_try_launch(const GemmParams& p, int mode, hipStream_t st) {
   if (!eligible(p, mode)) return false;
+  if (p.wino &&      // Winograd GEMM step: whole K tiles per component, its slabs fit the stream's workspace, plain launch otherwise
+      (mode != MODE_DIRECT || p.wino != 16 || (p.K / BK) % 16 != 0 || !p.ws || (size_t)16 * p.M * p.N * 4 > p.ws_bytes || p.gn_partial ||
+       p.seg_rows || p.up2 || p.aux || (p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32))))
+    return false;
   if (p.seg_rows &&               // segmented output rows: the plain fp16-staged epilogue, no split-K slabs
       (mode != MODE_DIRECT || p.res || p.gn_partial || p.c_lo || p.res_lo || p.aux || (p.flags & (SKG_EPI_GEGLU | SKG_EPI_OUT_F32)) ||
        p.ldc % 8 != 0 || (reinterpret_cast<uintptr_t>(p.C) & 15) != 0))

@@ -35,6 +35,10 @@ struct GemmParams {
   // walk read a SECOND row-major operand A2 [M][lda2 >= K2] (the ResnetBlock's input x: the 1x1 shortcut as a tenth "tap"
   // without halo) against columns [9 * Cin, 9 * Cin + K2) of the weight rows; K = 9 * Cin + K2 (0 = off)
   const half_t* A2; int lda2, K2;
+  // Winograd F(2x2, 3x3) GEMM step (wino.hip, round 6): a MODE_DIRECT launch on V [Mt][16 Cin] x U [N][16 Cin] whose K range is cut into
+  // exactly `wino` (= 16) slices, slab c = transform component c; the launcher writes the raw fp32 slabs to p.ws and launches NO
+  // reduce (the caller's output transform reads them) (0 = off)
+  int wino;
   // split-K workspace of the launch stream (host side: filled by the entry points from the per-stream registry of
   // skg_set_workspace; the kernels get the slab pointer as an argument)
   float* ws; size_t ws_bytes;
@@ -69,6 +73,9 @@ void skg_splitk_reduce_launch(const GemmParams& p, const float* ws, int splits, 
 // true when the kernel that skg_gemm8 / skg_gemm2 would run for this launch writes p.gn_partial itself
 bool skg_gemm8_fuses_gn(const GemmParams& p, int mode);
 bool skg_gemm2_fuses_gn(const GemmParams& p, int mode);
+// wino.hip: input / output transforms of the Winograd F(2x2, 3x3) convolution (the GEMM between them is a gemm2.hip split launch)
+void skg_wino_in_launch(const half_t* X, int ldx, half_t* V, int rows, int IH, int IW, int Cin, hipStream_t st);
+void skg_wino_out_launch(const GemmParams& p, const float* slabs, int IH, int IW, hipStream_t st);
 // norms.hip: the stand-alone statistics pass in the same partial format (nch chunks per sample)
 void skg_gn_partial_launch(const half_t* X, int ldx, int rows, int HW, int C, int groups, int nch, float* partial,
                            hipStream_t st);

@@ -397,6 +397,27 @@ def conv3x3_sc(X: torch.Tensor, X2: torch.Tensor, Wcat: torch.Tensor, rows: int,
     return (out, part) if part is not None else out
 
 
+def conv3x3_wino(X: torch.Tensor, U: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None,
+                 residual=None, relu: bool = False, out_lo=None, residual_lo=None):
+    """3x3 stride-1 convolution by Winograd F(2x2, 3x3) (skg_conv3x3_wino_f16): X [rows*IH*IW, Cin] (view), U [Cout, 16*Cin] =
+    unet.pack_conv_wino(weight).  Returns [rows*IH*IW, Cout].  Raises SkgError(rc = -2) when declined (odd map, Cin % 64, no room for the
+    16 fp32 slabs in the stream's workspace): the caller runs conv3x3."""
+    _f16(X, U, bias, residual, out_lo, residual_lo)
+    Cin, Cout = X.shape[1], U.shape[0]
+    assert U.shape[1] == 16 * Cin and U.is_contiguous() and X.shape[0] == rows * IH * IW
+    if out is None:
+        out = torch.empty(rows * IH * IW, Cout, device=X.device, dtype=torch.float16)
+    assert out_lo is None or _ld(out_lo) == _ld(out)
+    assert residual_lo is None or residual is None or _ld(residual_lo) == _ld(residual)
+    r_any = residual if residual is not None else residual_lo
+    st = _stream()
+    V = torch.empty(rows * (IH // 2) * (IW // 2), 16 * Cin, device=X.device, dtype=torch.float16)
+    check(lib.skg_conv3x3_wino_f16(_p(X), _ld(X), _p(U), _p(V), _p(out), _p(out_lo), _ld(out), rows, IH, IW, Cin, Cout, _p(bias),
+                                   _p(residual), _p(residual_lo), _ld(r_any) if r_any is not None else 0, EPI_RELU if relu else 0, st),
+          "skg_conv3x3_wino_f16")
+    return out
+
+
 def conv_up2(X: torch.Tensor, Wpp: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None, W9=None):
     """Nearest-2x upsample + 3x3 conv, polyphase (four 4-tap convs over the low-res input).  X [rows*IH*IW, Cin] (view),
     Wpp [4, Cout, 4*Cin] (unet.pack_conv_up2).  Returns [rows*2IH*2IW, Cout].  W9: the layer's ordinary 9-tap pack - the

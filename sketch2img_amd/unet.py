@@ -42,6 +42,13 @@ _FF_PROJ = os.environ.get("SKG_FF_PROJ", "1") != "0"                # proj_out +
 _FF_PROJ_HP = os.environ.get("SKG_FF_PROJ_HP", "1") != "0"          # ... in the accuracy mode too (skg_ff_block_proj_f16_hilo, round 5)
 _ATTN_DQ_DELTA = os.environ.get("SKG_ATTN_DQ_DELTA", "1") != "0"    # attention backward: delta inside the dQ launch (round 5)
 _RES_SC = os.environ.get("SKG_RES_SC", "1") != "0"                  # conv2 + conv_shortcut of a ResnetBlock as one implicit GEMM (round 5)
+# round 6: the ResnetBlock convolutions of the two deepest levels (16 x 16 / 8 x 8 at 64 x 64 latents) by Winograd F(2x2, 3x3) (csrc/wino.hip):
+# 0 = off, 1 = conv1, conv2 without a shortcut and the data gradients, 2 (default) = also conv2 of the channel-changing blocks of the
+# second-deepest level (shortcut GEMM + Winograd with a residual instead of the folded launch: 0.79-0.87 of its time at 16 x 16, 1.17 at
+# 8 x 8 - profiles/r06_wino_bench.txt).  A launch takes the path with >= _WINO_MIN_TILES tile positions (output pixels / 4): at 128 - the
+# cond-only backward of the 8 x 8 level - the 16 component GEMMs are 128 rows each and the implicit GEMM is as fast.
+_WINO = int(os.environ.get("SKG_WINO", "2"))
+_WINO_MIN_TILES = int(os.environ.get("SKG_WINO_MIN_TILES", "256"))  # tile positions (output pixels / 4) a launch needs to take the path
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -61,6 +68,20 @@ def pack_conv(w: torch.Tensor, dev, cin_pad: int = 0, cout_pad: int = 0) -> torc
     if cout_pad > co:
         p = torch.nn.functional.pad(p, (0, 0, 0, 0, 0, 0, 0, cout_pad - co))
     return _h(p.reshape(p.shape[0], -1), dev)
+
+
+_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
+
+
+def pack_conv_wino(w: torch.Tensor, dev, dgrad: bool = False) -> torch.Tensor:
+    """Winograd F(2x2, 3x3) weight pack of a 3x3 convolution [Cout, Cin, 3, 3] -> U [Cout, 16 * Cin] fp16: U = G g G^T per (cout, cin),
+    formed in fp32 and rounded once; component c = 4 i + j at columns [c Cin, (c + 1) Cin) (ops.conv3x3_wino, csrc/wino.hip).
+    dgrad: the pack of the convolution's DATA GRADIENT - itself a 3x3 convolution with the taps flipped and in / out swapped."""
+    g = w.detach().float().cpu()
+    if dgrad:
+        g = g.flip(2, 3).transpose(0, 1)
+    U = torch.einsum("ij,ocjk,lk->oilc", _WINO_G, g, _WINO_G)          # [Cout, 4, 4, Cin]
+    return _h(U.reshape(U.shape[0], -1), dev)
 
 
 def pack_conv_dgrad(w: torch.Tensor, dev, cin_pad: int = 0, cout_pad: int = 0) -> torch.Tensor:
@@ -388,6 +409,17 @@ class HipUNet:
             else:
                 W[k] = _h(_pad_vec(v, COUT_PAD) if k == "conv_out.bias" else v, dev)
         # conv2 + conv_shortcut as ONE implicit GEMM (ops.conv3x3_sc): [conv2 tap-major pack | W_sc] along K, biases summed
+        if _WINO and len(self.cfg.block_out_channels) >= 3:
+            nb = len(self.cfg.block_out_channels)
+            for blk, deepest in ((f"down_blocks.{nb - 2}.", False), ("up_blocks.1.", False), (f"down_blocks.{nb - 1}.", True),
+                                 ("mid_block.", True), ("up_blocks.0.", True)):
+                for k, v in sd.items():
+                    if k.startswith(blk) and ".resnets." in k and (k.endswith(".conv1.weight") or k.endswith(".conv2.weight")) and v.shape[1] % 64 == 0:
+                        if deepest and k.endswith(".conv2.weight") and (k[: -len(".conv2.weight")] + ".conv_shortcut.weight") in sd:
+                            continue      # (8 x 8: the folded shortcut launch stays ahead of shortcut GEMM + Winograd)
+                        W[k + ":wino"] = pack_conv_wino(v, dev)
+                        if bw and v.shape[0] % 64 == 0 and not deepest:      # (the deepest level's cond-only backward stays on the implicit GEMM)
+                            W[k + ":winoT"] = pack_conv_wino(v, dev, dgrad=True)
         for r in sorted(folded):
             w2, wsc = sd[r + ".conv2.weight"], sd[r + ".conv_shortcut.weight"]
             wsc = wsc.reshape(wsc.shape[0], wsc.shape[1])
@@ -554,6 +586,18 @@ class HipUNet:
         a 10-40 MB tensor - disappears.  Smaller maps keep the one-launch GroupNorm that holds a slice in registers."""
         return _GN_FROM_PRODUCER and HW >= 1024 and ops.gn_fusable(rows * HW, C, HW, self.cfg.norm_groups)
 
+    def _conv_wino(self, key: str, x, rows: int, H: int, **kw):
+        """The 3x3 convolution `key` (a weight name + ':wino' / ':winoT') by Winograd F(2x2, 3x3) when the pack exists and the launch is
+        large enough; None when the path does not take it (the caller runs the implicit GEMM)."""
+        if key not in self.W or rows * H * H // 4 < _WINO_MIN_TILES or (H & 1):
+            return None
+        try:
+            return ops.conv3x3_wino(x, self.W[key], rows, H, H, **kw)
+        except ops.SkgError as e:      # declined (no room for the slabs in the stream's workspace)
+            if e.rc != -2:
+                raise
+            return None
+
     def _res_fwd(self, p, x, rows, H, tb, stash: Optional[Stash], out=None, xpart=None, want_part=False, half=False):
         """xpart: GroupNorm partial sums of x from its producer (or None).  Returns (out, partial sums of out or None):
         they are produced when want_part is set and the level takes its statistics from the producers.
@@ -563,14 +607,25 @@ class HipUNet:
         n1, st1 = ops.groupnorm(x, rows, HW, G, 1e-5, W[p + ".norm1.weight"], W[p + ".norm1.bias"], True, partial=xpart)
         Cout = W[p + ".conv1.weight"].shape[0]
         fuse = self._gn_from_producer(rows, HW, Cout)
-        if fuse:
+        h1 = None if fuse else self._conv_wino(p + ".conv1.weight:wino", n1, rows, H, bias=tb[p])
+        if h1 is not None:
+            part1 = None
+        elif fuse:
             h1, part1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, bias=tb[p], gn_groups=G)
         else:
             h1, part1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, bias=tb[p]), None
         n2, st2 = ops.groupnorm(h1, rows, HW, G, 1e-5, W[p + ".norm2.weight"], W[p + ".norm2.bias"], True, partial=part1)
         opart = None
         done = False
-        if (p + ".conv2.weight:sc") in W:
+        has_sc = (p + ".conv_shortcut.weight") in W
+        if ((p + ".conv2.weight:wino") in W and not (want_part and fuse) and rows * HW // 4 >= _WINO_MIN_TILES and not (H & 1)
+                and (not has_sc or _WINO >= 2)):
+            # Winograd conv2 with the block input - or the shortcut GEMM's output - as its residual
+            sc = ops.gemm(x, W[p + ".conv_shortcut.weight"], bias=W[p + ".conv_shortcut.bias"]) if has_sc else x
+            o = self._conv_wino(p + ".conv2.weight:wino", n2, rows, H, out=out, bias=W[p + ".conv2.bias"], residual=sc)
+            if o is not None:
+                out, done = o, True
+        if not done and (p + ".conv2.weight:sc") in W:
             # the 1x1 shortcut as K tiles behind conv2's 3x3 walk: one launch, no [M, Cout] round trip of the shortcut output
             try:
                 if want_part and fuse:
@@ -1393,9 +1448,13 @@ class HipUNet:
         else:
             x, h1 = st["x"][S * HW:], st["h1"][S * HW:]
             st1, st2 = st["st1"][S:], st["st2"][S:]
-        dn2 = ops.conv3x3(dout, W[p + ".conv2.weight:T"], S, H, H)
+        dn2 = self._conv_wino(p + ".conv2.weight:winoT", dout, S, H)
+        if dn2 is None:
+            dn2 = ops.conv3x3(dout, W[p + ".conv2.weight:T"], S, H, H)
         dh1 = ops.groupnorm_bwd(h1, dn2, S, HW, G, st2, W[p + ".norm2.weight"], W[p + ".norm2.bias"], True)
-        dn1 = ops.conv3x3(dh1, W[p + ".conv1.weight:T"], S, H, H)
+        dn1 = self._conv_wino(p + ".conv1.weight:winoT", dh1, S, H)
+        if dn1 is None:
+            dn1 = ops.conv3x3(dh1, W[p + ".conv1.weight:T"], S, H, H)
         if (p + ".conv_shortcut.weight") in W:
             sc = ops.gemm(dout, W[p + ".conv_shortcut.weight:T"])
         else:

@@ -1241,6 +1241,61 @@ def test_conv3x3_with_folded_shortcut(ops, rows, hw, cin, cout, cx, gn):
     assert rp < 1e-4 and torch.equal(hi, y)
 
 
+# ------------------------------------------------------------------------------- Winograd F(2x2, 3x3), 16 x 16-level convolutions
+@pytest.mark.parametrize("rows,hw,cin,cout", [(16, 16, 1280, 1280), (16, 16, 2560, 1280), (8, 16, 1280, 2560), (16, 16, 640, 1280),
+                                              (2, 16, 1920, 1280), (8, 24, 640, 640), (3, 8, 64, 160), (1, 4, 128, 64)])
+def test_conv3x3_winograd(ops, rows, hw, cin, cout):
+    """skg_conv3x3_wino_f16 (round 6): input transform -> the GEMM kernel's split launch with one K slice per transform component ->
+    output transform + epilogue, against (a) fp32 torch, (b) the implicit-GEMM convolution it replaces (the transformed operands carry
+    one more fp16 rounding: rel <= 6e-4 of each other), with bias + residual, with a pair output, as the DATA GRADIENT through the dgrad
+    pack (vs autograd), bit-repeatable; declined (-2) on an odd map."""
+    from sketch2img_amd._lib import SkgError
+    from sketch2img_amd.unet import pack_conv, pack_conv_dgrad, pack_conv_wino
+    d = dev()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(rows, cin, hw, hw, generator=g).half()
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (9 * cin) ** -0.5).half()
+    b = (torch.randn(cout, generator=g) * 0.1).half()
+    res = torch.randn(rows * hw * hw, cout, generator=g).half()
+    xn = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(d)
+    U = pack_conv_wino(w, d)
+    y = ops.conv3x3_wino(xn, U, rows, hw, hw, bias=b.to(d), residual=res.to(d))
+    torch.cuda.synchronize()
+    nr = min(rows, 2)
+    ref = F.conv2d(x[:nr].float().to(d), w.float().to(d), b.float().to(d), padding=1).permute(0, 2, 3, 1).reshape(-1, cout) \
+        + res[:nr * hw * hw].float().to(d)
+    r, _ = report(f"winograd conv rows{rows} {cin}->{cout} @{hw} vs fp32", y[:nr * hw * hw].float().cpu(), ref.cpu())
+    assert r < 6e-4
+    y2 = ops.conv3x3(xn, pack_conv(w, d), rows, hw, hw, 0, bias=b.to(d), residual=res.to(d))
+    assert report("winograd vs the implicit GEMM", y.float().cpu(), y2.float().cpu())[0] < 6e-4
+    assert torch.equal(ops.conv3x3_wino(xn, U, rows, hw, hw, bias=b.to(d), residual=res.to(d)), y)
+    # no bias / residual, ReLU, pair output: hi + lo carries the fp32 result of the same arithmetic
+    hi, lo = torch.empty_like(y), torch.empty_like(y)
+    ops.conv3x3_wino(xn, U, rows, hw, hw, out=hi, out_lo=lo)
+    y3 = ops.conv3x3_wino(xn, U, rows, hw, hw, relu=True)
+    ref0 = F.conv2d(x[:nr].float().to(d), w.float().to(d), padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert torch.equal(y3, torch.relu(hi)) and report("winograd pair output vs fp32", (hi.float() + lo.float())[:nr * hw * hw].cpu(), ref0.cpu())[0] < 5e-4
+    # the data gradient: dX = conv3x3(dY, flipped / transposed weights) = autograd of the forward
+    dy = torch.randn(rows, cout, hw, hw, generator=g).half()
+    dyn = dy.permute(0, 2, 3, 1).reshape(-1, cout).contiguous().to(d)
+    if 64 * (rows * hw * hw // 4) * cin > ops.WORKSPACE_BYTES:      # the 16 fp32 slabs of the gradient would not fit the stream's workspace:
+        with pytest.raises(SkgError) as e:                            # declined, nothing launched (HipUNet then runs the implicit GEMM)
+            ops.conv3x3_wino(dyn, pack_conv_wino(w, d, dgrad=True), rows, hw, hw)
+        assert e.value.rc == -2
+        return
+    dx = ops.conv3x3_wino(dyn, pack_conv_wino(w, d, dgrad=True), rows, hw, hw)
+    xr = x[:nr].float().to(d).requires_grad_(True)
+    F.conv2d(xr, w.float().to(d), padding=1).backward(dy[:nr].float().to(d))
+    gref = xr.grad.permute(0, 2, 3, 1).reshape(-1, cin)
+    assert report("winograd dgrad vs autograd", dx[:nr * hw * hw].float().cpu(), gref.cpu())[0] < 6e-4
+    dx2 = ops.conv3x3(dyn, pack_conv_dgrad(w, d), rows, hw, hw)
+    assert report("winograd dgrad vs the implicit-GEMM dgrad", dx.float().cpu(), dx2.float().cpu())[0] < 6e-4
+    if hw % 2 == 0 and rows == 1:
+        with pytest.raises(SkgError) as e:      # odd map: declined, nothing launched
+            ops.conv3x3_wino(xn[: 3 * 3 * 1].contiguous(), U, 1, 3, 3)
+        assert e.value.rc == -2
+
+
 # ---------------------------------------------------------------------------------------------- sampler pointwise
 def test_cfg_ddim_and_guidance_update(ops):
     from sketch2img_amd.sampler import DDIMTables

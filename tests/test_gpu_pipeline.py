@@ -626,9 +626,10 @@ def test_declined_conv_shortcut_fold_falls_back_to_two_launches(monkeypatch, res
     # (the fall-back built its packs on first use; the norm-pair sites of the accuracy mode slice conv2's taps out of their own folded pack)
     assert len(calls) >= 4 and len(net.W.lazy) < len(lazy_before)
     r, _ = report(f"eps, declined conv3x3_sc vs fused (residual_fp32={residual_fp32})", e1, e0)
-    assert r < (2e-4 if residual_fp32 else 1.5e-3)
+    # (accuracy mode: only the blocks of the plain zone - the two deepest levels - round the shortcut output on the fall-back route)
+    assert r < (6e-4 if residual_fp32 else 1.5e-3)
     for i, (a, b) in enumerate(zip(t1, t0)):
-        assert report(f"tap{i}, declined vs fused", a, b)[0] < (1e-3 if residual_fp32 else 2e-3)
+        assert report(f"tap{i}, declined vs fused", a, b)[0] < 2e-3      # (fp16 taps; the deep ones come from the plain zone in either mode)
     with torch.no_grad():
         C, _ = ounet.unet_forward(ocfg, W, x, 500, ehs)
     assert report("eps, declined path vs fp32 oracle", e1, C)[0] < (8e-4 if residual_fp32 else 2.5e-3)
