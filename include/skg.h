@@ -179,11 +179,19 @@ int skg_conv3x3_sc_f16(const void* X, int ldx, const void* X2, int ldx2, int K2,
  * (unet.pack_conv_wino); V: caller-owned scratch of skg_conv3x3_wino_v_bytes() bytes; Y [rows*IH*IW][ldy] (+ Y_lo: pair output);
  * flags: SKG_EPI_RELU only.  Needs IH, IW even, Cin % 64 == 0, Cout % 8 == 0 and a registered workspace of >= 64 * Mt * Cout bytes
  * (skg_set_workspace); otherwise SKG_E_UNSUPPORTED (nothing launched: run skg_conv3x3_f16).  U and V carry one more fp16 rounding than
- * the implicit GEMM's operands (tools/eps_winograd.py prices it: default-mode eps rel 1.07e-3 -> 1.09e-3). */
+ * the implicit GEMM's operands (tools/eps_winograd.py prices it: default-mode eps rel 1.07e-3 -> 1.09e-3).
+ * X == NULL: V already holds the input transform (skg_groupnorm_wino_fwd wrote it). */
 size_t skg_conv3x3_wino_v_bytes(int rows, int IH, int IW, int Cin);
 int skg_conv3x3_wino_f16(const void* X, int ldx, const void* U, void* V, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW,
                          int Cin, int Cout, const void* bias, const void* residual, const void* residual_lo, int ldr, unsigned flags,
                          void* stream);
+/* GroupNorm(+SiLU) of a small map whose consumer is skg_conv3x3_wino_f16: statistics published to `stats` as skg_groupnorm_fwd does,
+ * and instead of the normalised tensor its Winograd input transform V [rows*IH/2*IW/2][16*C] (the fp16-rounded activations transformed:
+ * bit-identical to skg_groupnorm_fwd + the convolution's own input transform; one launch and one [M, C] round trip less).  One workgroup
+ * per (row, group) holds the slice in registers / LDS: C / groups a multiple of 8, IH * IW * C / groups / 8 <= 2560, even maps - else
+ * SKG_E_UNSUPPORTED (nothing launched).  Same replaced reference calls as skg_groupnorm_fwd (ResnetBlock2D.norm1 / norm2). */
+int skg_groupnorm_wino_fwd(const void* X, int ldx, void* V, int rows, int IH, int IW, int C, int groups, float eps,
+                           const void* gamma, const void* beta, int silu, float* stats, void* stream);
 /* Data gradient of the polyphase upsample + convolution above (the autograd backward of diffusers Upsample2D inside
  * torch.autograd.grad at modules/pipeline.py:159): ONE 4 x 4 stride-2 convolution, padding 1, over the gradient at the upsampled
  * size.  X [rows*IH*IW, Cin] (ldx; IH, IW even), Y [rows*(IH/2)*(IW/2), Cout] (ldy), W16 [Cout][16 taps ky*4+kx][Cin]

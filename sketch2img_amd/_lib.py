@@ -39,6 +39,7 @@ SIGNATURES = {
     "skg_conv4x4s2_f16": ("i", "pippiiiiiipp"),
     "skg_conv3x3_wino_v_bytes": ("z", "iiii"),
     "skg_conv3x3_wino_f16": ("i", "pippppiiiiiipppiup"),
+    "skg_groupnorm_wino_fwd": ("i", "pipiiiiifppipp"),
     "skg_gemm_f16_rows": ("i", "pipipiiiipiip"),
     "skg_gemm_f16_hilo": ("i", "pipippiiiipppifup".replace(" ", "")),
     "skg_conv3x3_f16_hilo": ("i", "pipppiiiiiiipppifup"),

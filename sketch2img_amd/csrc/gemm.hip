@@ -498,8 +498,8 @@ extern "C" size_t skg_conv3x3_wino_v_bytes(int rows, int IH, int IW, int Cin) {
 extern "C" int skg_conv3x3_wino_f16(const void* X, int ldx, const void* U, void* V, void* Y, void* Y_lo, int ldy, int rows, int IH, int IW,
                                     int Cin, int Cout, const void* bias, const void* residual, const void* residual_lo, int ldr,
                                     unsigned flags, void* stream) {
-  SKG_REQUIRE(X && U && V && Y && rows > 0 && IH > 0 && IW > 0 && Cin > 0 && Cout > 0);
-  SKG_REQUIRE(ldx % 8 == 0 && ldx >= Cin && ldy % 4 == 0 && ldy >= Cout && skg_aligned(X, 16) && skg_aligned(U, 16) && skg_aligned(V, 16) &&
+  SKG_REQUIRE(U && V && Y && rows > 0 && IH > 0 && IW > 0 && Cin > 0 && Cout > 0);
+  SKG_REQUIRE((!X || (ldx % 8 == 0 && ldx >= Cin)) && ldy % 4 == 0 && ldy >= Cout && skg_aligned(X, 16) && skg_aligned(U, 16) && skg_aligned(V, 16) &&
               skg_aligned(Y, 8) && (!Y_lo || skg_aligned(Y_lo, 8)) && (!bias || skg_aligned(bias, 8)));
   SKG_REQUIRE((!residual && !residual_lo) || (ldr % 4 == 0 && ldr >= Cout && (!residual || skg_aligned(residual, 8)) &&
                                               (!residual_lo || skg_aligned(residual_lo, 8))));
@@ -520,8 +520,10 @@ extern "C" int skg_conv3x3_wino_f16(const void* X, int ldx, const void* U, void*
     unsigned long long vb = (unsigned long long)p.M * p.lda * 2ull, ub = (unsigned long long)p.N * p.ldb * 2ull;
     if (vb >= 0x7fffffffull || ub >= 0x7fffffffull) return SKG_E_UNSUPPORTED;
   }
-  skg_wino_in_launch((const half_t*)X, ldx, (half_t*)V, rows, IH, IW, Cin, st);
-  SKG_CHECK_LAUNCH("skg_conv3x3_wino_f16 (input transform)");
+  if (X) {      // (X == NULL: V already holds the input transform - skg_groupnorm_wino_fwd wrote it)
+    skg_wino_in_launch((const half_t*)X, ldx, (half_t*)V, rows, IH, IW, Cin, st);
+    SKG_CHECK_LAUNCH("skg_conv3x3_wino_f16 (input transform)");
+  }
   GemmParams g = p;      // the GEMM step: raw slabs only
   g.bias = nullptr; g.res = nullptr; g.res_lo = nullptr; g.c_lo = nullptr; g.flags = 0;
   if (!skg_gemm2_try_launch(g, MODE_DIRECT, st)) return SKG_E_UNSUPPORTED;

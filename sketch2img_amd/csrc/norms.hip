@@ -574,6 +574,102 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const half_t* __restrict_
   }
 }
 
+// The same for a GroupNorm whose consumer is a Winograd F(2x2, 3x3) convolution (wino.hip, round 6): the normalised fp16 slice goes to
+// LDS instead of memory and the workgroup writes its INPUT TRANSFORM V = B^T n B - per 4 x 4 tile (stride 2, zero halo) and 8-channel
+// piece: the adds in fp32 on the fp16-rounded activations, one rounding, component c = 4 i + j at columns [c C, (c + 1) C) of
+// V [rows * IH/2 * IW/2][16 C] - bit-identical to gn_small_kernel followed by wino_in_kernel, one launch and one [M, C] round trip less.
+template <int NP>
+__global__ __launch_bounds__(256) void gn_small_wino_kernel(const half_t* __restrict__ X, int ldx, half_t* __restrict__ V, int IH, int IW, int C,
+                                                            int groups, const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                            int silu, float eps, float* __restrict__ stats) {
+  extern __shared__ __attribute__((aligned(16))) half_t gsl[];      // [HW][cpg]
+  __shared__ float red[8];
+  const int g = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+  const int HW = IH * IW;
+  const int cpg = C / groups, ppp = cpg >> 3;
+  const int npieces = HW * ppp;
+  const half_t* xb = X + (size_t)row * HW * ldx + g * cpg;
+  half8_t v[NP];
+  int off[NP];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int pi = tid + k * 256;
+    const int px = pi / ppp, pc = pi - px * ppp;
+    off[k] = pi < npieces ? (px << 8) | pc : -1;
+    v[k] = pi < npieces ? ld_half8(xb + (size_t)px * ldx + pc * 8) : zero_half8();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)v[k][j];
+  }
+  const float inv_n = 1.f / ((float)HW * cpg);
+  const float mean = block_sum<256>(s, red) * inv_n;
+  float s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NP; ++k)
+    if (off[k] >= 0)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)v[k][j] - mean; s2 += d * d; }
+  const float rstd = rsqrtf(block_sum<256>(s2, red) * inv_n + eps);
+  if (tid == 0) { stats[((size_t)row * groups + g) * 2] = mean; stats[((size_t)row * groups + g) * 2 + 1] = rstd; }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    if (off[k] < 0) continue;
+    const int px = off[k] >> 8, pc = off[k] & 255;
+    const half8_t gv = ld_half8(gamma + g * cpg + pc * 8), bv = ld_half8(beta + g * cpg + pc * 8);
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = ((float)v[k][j] - mean) * rstd * (float)gv[j] + (float)bv[j];
+      if (silu) y = silu_f(y);
+      o[j] = (half_t)y;
+    }
+    st_half8(gsl + (size_t)px * cpg + pc * 8, o);
+  }
+  __syncthreads();
+  const int TW = IW >> 1, tiles = (IH >> 1) * TW;
+  for (int it = tid; it < tiles * ppp; it += 256) {
+    const int tile = it / ppp, pc = it - tile * ppp;
+    const int ti = tile / TW, tj = tile - ti * TW;
+    float t[4][4][8];      // B^T d (rows transformed), per column
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int x = 2 * tj - 1 + b;
+      float d[4][8];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int y = 2 * ti - 1 + a;
+        half8_t q = zero_half8();
+        if (x >= 0 && x < IW && y >= 0 && y < IH) q = ld_half8(gsl + (size_t)(y * IW + x) * cpg + pc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[a][e] = (float)q[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        t[0][b][e] = d[0][e] - d[2][e];
+        t[1][b][e] = d[1][e] + d[2][e];
+        t[2][b][e] = d[2][e] - d[1][e];
+        t[3][b][e] = d[1][e] - d[3][e];
+      }
+    }
+    half_t* out = V + ((size_t)row * tiles + tile) * (16 * (size_t)C) + g * cpg + pc * 8;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      half8_t v0, v1, v2, v3;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v0[e] = (half_t)(t[a][0][e] - t[a][2][e]);
+        v1[e] = (half_t)(t[a][1][e] + t[a][2][e]);
+        v2[e] = (half_t)(t[a][2][e] - t[a][1][e]);
+        v3[e] = (half_t)(t[a][1][e] - t[a][3][e]);
+      }
+      st_half8(out + (size_t)(4 * a + 0) * C, v0);
+      st_half8(out + (size_t)(4 * a + 1) * C, v1);
+      st_half8(out + (size_t)(4 * a + 2) * C, v2);
+      st_half8(out + (size_t)(4 * a + 3) * C, v3);
+    }
+  }
+}
+
 // backward of the same: dx = rstd * (d - mean(d) - xhat * mean(d * xhat)) + residual,  d = dy * silu'(.) * gamma
 template <int NP>
 __global__ __launch_bounds__(256) void gn_bwd_small_kernel(
@@ -666,6 +762,31 @@ static int gn_fwd_impl(const void* X, const void* Xl, int ldx, void* Y, void* Yl
   if (Xl) SKG_GN_FOLD(true); else SKG_GN_FOLD(false);
 #undef SKG_GN_FOLD
   SKG_CHECK_LAUNCH("skg_groupnorm_fwd");
+  return SKG_OK;
+}
+
+extern "C" int skg_groupnorm_wino_fwd(const void* X, int ldx, void* V, int rows, int IH, int IW, int C, int groups, float eps,
+                                      const void* gamma, const void* beta, int silu, float* stats, void* stream) {
+  SKG_REQUIRE(X && V && stats && gamma && beta && rows > 0 && IH > 0 && IW > 0 && groups > 0 && groups <= 64);
+  SKG_REQUIRE(C % 8 == 0 && C % groups == 0 && ldx % 8 == 0 && ldx >= C);
+  SKG_REQUIRE(skg_aligned(X, 16) && skg_aligned(V, 16) && skg_aligned(gamma, 16) && skg_aligned(beta, 16));
+  const int cpg = C / groups, HW = IH * IW;
+  // one workgroup holds the (row, group) slice in registers, then in LDS: the shapes gn_small_kernel takes, on even maps
+  if ((IH & 1) || (IW & 1) || cpg % 8 != 0 || (cpg >> 3) > 255 || (long)HW * (cpg >> 3) > 2560 || (size_t)HW * cpg * 2 > 64 * 1024)
+    return SKG_E_UNSUPPORTED;
+  const int np = skg_cdiv(HW * (cpg >> 3), 256);
+  const dim3 grid(groups, rows);
+  const size_t lds = (size_t)HW * cpg * 2;
+  hipStream_t st = (hipStream_t)stream;
+#define SKG_GN_WINO(NP)                                                                                                          \
+  hipLaunchKernelGGL((gn_small_wino_kernel<NP>), grid, dim3(256), lds, st, (const half_t*)X, ldx, (half_t*)V, IH, IW, C, groups, \
+                     (const half_t*)gamma, (const half_t*)beta, silu, eps, stats)
+  if (np <= 2) SKG_GN_WINO(2);
+  else if (np <= 3) SKG_GN_WINO(3);
+  else if (np <= 5) SKG_GN_WINO(5);
+  else SKG_GN_WINO(10);
+#undef SKG_GN_WINO
+  SKG_CHECK_LAUNCH("skg_groupnorm_wino_fwd");
   return SKG_OK;
 }
 

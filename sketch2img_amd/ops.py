@@ -397,22 +397,42 @@ def conv3x3_sc(X: torch.Tensor, X2: torch.Tensor, Wcat: torch.Tensor, rows: int,
     return (out, part) if part is not None else out
 
 
-def conv3x3_wino(X: torch.Tensor, U: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None,
-                 residual=None, relu: bool = False, out_lo=None, residual_lo=None):
+def groupnorm_wino(X: torch.Tensor, rows: int, IH: int, IW: int, groups: int, eps: float, gamma, beta, silu: bool):
+    """GroupNorm(+SiLU) of a small map straight into the Winograd input transform of its consumer (skg_groupnorm_wino_fwd):
+    -> (V [rows*IH/2*IW/2, 16*C] for conv3x3_wino(None, ..., V=V), statistics [rows, groups, 2]).  Raises SkgError(rc = -2) when the
+    (row, group) slice does not fit one workgroup (run groupnorm + conv3x3_wino on its output)."""
+    _f16(X, gamma, beta)
+    C = X.shape[1]
+    V = torch.empty(rows * (IH // 2) * (IW // 2), 16 * C, device=X.device, dtype=torch.float16)
+    st = torch.empty(rows, groups, 2, device=X.device, dtype=torch.float32)
+    check(lib.skg_groupnorm_wino_fwd(_p(X), _ld(X), _p(V), rows, IH, IW, C, groups, eps, _p(gamma), _p(beta), int(silu), _p(st), _stream()),
+          "skg_groupnorm_wino_fwd")
+    return V, st
+
+
+def conv3x3_wino(X: Optional[torch.Tensor], U: torch.Tensor, rows: int, IH: int, IW: int, out: Optional[torch.Tensor] = None, *, bias=None,
+                 residual=None, relu: bool = False, out_lo=None, residual_lo=None, V: Optional[torch.Tensor] = None):
     """3x3 stride-1 convolution by Winograd F(2x2, 3x3) (skg_conv3x3_wino_f16): X [rows*IH*IW, Cin] (view), U [Cout, 16*Cin] =
     unet.pack_conv_wino(weight).  Returns [rows*IH*IW, Cout].  Raises SkgError(rc = -2) when declined (odd map, Cin % 64, no room for the
-    16 fp32 slabs in the stream's workspace): the caller runs conv3x3."""
-    _f16(X, U, bias, residual, out_lo, residual_lo)
-    Cin, Cout = X.shape[1], U.shape[0]
-    assert U.shape[1] == 16 * Cin and U.is_contiguous() and X.shape[0] == rows * IH * IW
+    16 fp32 slabs in the stream's workspace): the caller runs conv3x3.  X = None, V = groupnorm_wino(...)[0]: the input transform exists."""
+    _f16(X, U, bias, residual, out_lo, residual_lo, V)
+    Cout = U.shape[0]
+    Cin = U.shape[1] // 16
+    Mt = rows * (IH // 2) * (IW // 2)
+    if X is None:
+        assert V is not None and V.shape == (Mt, 16 * Cin) and V.is_contiguous() and U.is_contiguous()
+        dev_ = V.device
+    else:
+        assert X.shape[1] == Cin and U.is_contiguous() and X.shape[0] == rows * IH * IW
+        dev_ = X.device
+        V = torch.empty(Mt, 16 * Cin, device=dev_, dtype=torch.float16)
     if out is None:
-        out = torch.empty(rows * IH * IW, Cout, device=X.device, dtype=torch.float16)
+        out = torch.empty(rows * IH * IW, Cout, device=dev_, dtype=torch.float16)
     assert out_lo is None or _ld(out_lo) == _ld(out)
     assert residual_lo is None or residual is None or _ld(residual_lo) == _ld(residual)
     r_any = residual if residual is not None else residual_lo
     st = _stream()
-    V = torch.empty(rows * (IH // 2) * (IW // 2), 16 * Cin, device=X.device, dtype=torch.float16)
-    check(lib.skg_conv3x3_wino_f16(_p(X), _ld(X), _p(U), _p(V), _p(out), _p(out_lo), _ld(out), rows, IH, IW, Cin, Cout, _p(bias),
+    check(lib.skg_conv3x3_wino_f16(_p(X), _ld(X) if X is not None else 0, _p(U), _p(V), _p(out), _p(out_lo), _ld(out), rows, IH, IW, Cin, Cout, _p(bias),
                                    _p(residual), _p(residual_lo), _ld(r_any) if r_any is not None else 0, EPI_RELU if relu else 0, st),
           "skg_conv3x3_wino_f16")
     return out

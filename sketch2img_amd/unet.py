@@ -49,6 +49,7 @@ _RES_SC = os.environ.get("SKG_RES_SC", "1") != "0"                  # conv2 + co
 # cond-only backward of the 8 x 8 level - the 16 component GEMMs are 128 rows each and the implicit GEMM is as fast.
 _WINO = int(os.environ.get("SKG_WINO", "2"))
 _WINO_MIN_TILES = int(os.environ.get("SKG_WINO_MIN_TILES", "256"))  # tile positions (output pixels / 4) a launch needs to take the path
+_WINO_GN = os.environ.get("SKG_WINO_GN", "1") != "0"                # the GroupNorm in front writes the Winograd input transform itself
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -158,17 +159,21 @@ HP_UP_TRIPLE = os.environ.get("SKG_HP_UP_TRIPLE", "0") != "0"
 # consumes them - at the sites whose fp16 rounding carries the most of the mode's remaining eps distance (tools/eps_decompose_sites.py:
 # the norm outputs of the LAST up block are 66 % of its variance; conv_norm_out, 18 %, has been a pair since round 4).  Comma-separated
 # norm names of the last up block ("<resnet>.norm1" / ".norm2" -> conv1 / conv2, "<attention>.norm" -> proj_in); "" = none (round 5).
-# Default = norm2 of the last two ResnetBlocks, norm1 of the last one and the three attention GroupNorms, chosen together with
-# HP_PLAIN_LEVELS = 2 on one box (profiles/r06_eps_variants.txt, 16 rows, ms per 16-row evaluation): round 5's mode 4.83e-4 rel / 8.7e-4
-# worst max / 19.34 ms; this default 4.11e-4 / 7.2e-4 / 19.42 ms; all nine sites 3.75e-4 / 6.8e-4 / 19.95 ms; the default mode 17.29 ms.
+# Default = eight of the nine sites (all but norm1 of the first ResnetBlock: the widest operand, 960 channels, for the smallest share),
+# chosen together with HP_PLAIN_LEVELS = 1 AT THE REAL BATCH (profiles/r06_eps_real_batch.txt: configs[1]'s 8 samples x 3 timesteps = 48
+# rows, ms per 16-row evaluation on one box): round 5's mode rel 5.41e-4 / worst max 1.03e-3 / 18.89 ms; plain 2 + 6 sites + Winograd
+# 5.08e-4 / 9.8e-4 / 18.18; plain 1 + 6 sites 4.50e-4 / 8.4e-4 / 19.16; plain 1 + 9 sites 4.18e-4 / 8.1e-4 / 19.66; plain 0 + 9 sites
+# 4.14e-4 / 7.7e-4 / 19.88: accuracy costs ~0.5 % of time per 1 % of rel along the whole front - the setting is where the worst row keeps
+# ~15 % of north_star's bound (the throughput target has 60 % of headroom, the bound had 2 %).
 HP_NORM_PAIRS = tuple(n for n in os.environ.get(
-    "SKG_HP_NORM_PAIRS", "up_blocks.3.resnets.1.norm2,up_blocks.3.resnets.2.norm1,up_blocks.3.resnets.2.norm2,up_blocks.3.attentions.0.norm,"
-                         "up_blocks.3.attentions.1.norm,up_blocks.3.attentions.2.norm").split(",") if n)
+    "SKG_HP_NORM_PAIRS", "up_blocks.3.resnets.0.norm2,up_blocks.3.resnets.1.norm1,up_blocks.3.resnets.1.norm2,up_blocks.3.resnets.2.norm1,"
+                         "up_blocks.3.resnets.2.norm2,up_blocks.3.attentions.0.norm,up_blocks.3.attentions.1.norm,"
+                         "up_blocks.3.attentions.2.norm").split(",") if n)
 # accuracy mode (round 6): the DEEPEST resolution levels run the default fp16 kernels - tools/eps_decompose_stream.py: of what the pairs
 # (residual stream, conv outputs that feed a norm, stream-as-operand) buy, 60 % is bought in the last up block, 25 % in the first down block
 # (its skips feed the last up block), 15 % at the 32 x 32 level, ~4 % at the 16 x 16 level and nothing at 8 x 8.  n = number of deepest
 # levels (8 x 8, 16 x 16, ...) whose blocks run plain fp16: down_blocks[nb - n ..], mid_block, up_blocks[.. n - 1]; 0 = pairs everywhere.
-HP_PLAIN_LEVELS = int(os.environ.get("SKG_HP_PLAIN_LEVELS", "2"))
+HP_PLAIN_LEVELS = int(os.environ.get("SKG_HP_PLAIN_LEVELS", "1"))
 UP2_SMALL_MAPS = os.environ.get("SKG_UP2_SMALL", "1") != "0"    # A/B: polyphase also where one phase does not fill the chip
 UP2_DGRAD = os.environ.get("SKG_UP2_DGRAD", "1") != "0"         # A/B: the upsampler's backward as one 4 x 4 stride-2 convolution
 
@@ -586,14 +591,32 @@ class HipUNet:
         a 10-40 MB tensor - disappears.  Smaller maps keep the one-launch GroupNorm that holds a slice in registers."""
         return _GN_FROM_PRODUCER and HW >= 1024 and ops.gn_fusable(rows * HW, C, HW, self.cfg.norm_groups)
 
+    def _wino_ok(self, key: str, rows: int, H: int) -> bool:
+        return key in self.W and rows * H * H // 4 >= _WINO_MIN_TILES and not (H & 1)
+
     def _conv_wino(self, key: str, x, rows: int, H: int, **kw):
         """The 3x3 convolution `key` (a weight name + ':wino' / ':winoT') by Winograd F(2x2, 3x3) when the pack exists and the launch is
         large enough; None when the path does not take it (the caller runs the implicit GEMM)."""
-        if key not in self.W or rows * H * H // 4 < _WINO_MIN_TILES or (H & 1):
+        if not self._wino_ok(key, rows, H):
             return None
         try:
             return ops.conv3x3_wino(x, self.W[key], rows, H, H, **kw)
         except ops.SkgError as e:      # declined (no room for the slabs in the stream's workspace)
+            if e.rc != -2:
+                raise
+            return None
+
+    def _gn_conv_wino(self, nkey: str, wkey: str, x, rows: int, H: int, eps: float, **kw):
+        """GroupNorm + SiLU `nkey` and the Winograd convolution `wkey` behind it with the norm writing the convolution's input transform
+        (ops.groupnorm_wino: no normalised tensor in memory).  -> (conv output, statistics), or None when either step declines (nothing
+        was consumed: the caller runs groupnorm and the convolution as before)."""
+        if not _WINO_GN or not self._wino_ok(wkey, rows, H):
+            return None
+        W = self.W
+        try:
+            V, st = ops.groupnorm_wino(x, rows, H, H, self.cfg.norm_groups, eps, W[nkey + ".weight"], W[nkey + ".bias"], True)
+            return ops.conv3x3_wino(None, W[wkey], rows, H, H, V=V, **kw), st
+        except ops.SkgError as e:
             if e.rc != -2:
                 raise
             return None
@@ -604,24 +627,37 @@ class HipUNet:
         half: `rows` are the COND rows only (the shared CFG prefix, see forward): the stash says so."""
         cfg, W = self.cfg, self.W
         G, HW = cfg.norm_groups, H * H
-        n1, st1 = ops.groupnorm(x, rows, HW, G, 1e-5, W[p + ".norm1.weight"], W[p + ".norm1.bias"], True, partial=xpart)
         Cout = W[p + ".conv1.weight"].shape[0]
         fuse = self._gn_from_producer(rows, HW, Cout)
-        h1 = None if fuse else self._conv_wino(p + ".conv1.weight:wino", n1, rows, H, bias=tb[p])
+        # small maps: conv1 / conv2 by Winograd F(2x2, 3x3), the GroupNorm in front writing the input transform where its slice fits a workgroup
+        h1 = st1 = None
+        if not fuse and xpart is None:
+            got = self._gn_conv_wino(p + ".norm1", p + ".conv1.weight:wino", x, rows, H, 1e-5, bias=tb[p])
+            if got is not None:
+                h1, st1 = got
+        if h1 is None:
+            n1, st1 = ops.groupnorm(x, rows, HW, G, 1e-5, W[p + ".norm1.weight"], W[p + ".norm1.bias"], True, partial=xpart)
+            h1 = None if fuse else self._conv_wino(p + ".conv1.weight:wino", n1, rows, H, bias=tb[p])
         if h1 is not None:
             part1 = None
         elif fuse:
             h1, part1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, bias=tb[p], gn_groups=G)
         else:
             h1, part1 = ops.conv3x3(n1, W[p + ".conv1.weight"], rows, H, H, bias=tb[p]), None
-        n2, st2 = ops.groupnorm(h1, rows, HW, G, 1e-5, W[p + ".norm2.weight"], W[p + ".norm2.bias"], True, partial=part1)
         opart = None
         done = False
         has_sc = (p + ".conv_shortcut.weight") in W
-        if ((p + ".conv2.weight:wino") in W and not (want_part and fuse) and rows * HW // 4 >= _WINO_MIN_TILES and not (H & 1)
-                and (not has_sc or _WINO >= 2)):
+        wino2 = (self._wino_ok(p + ".conv2.weight:wino", rows, H) and not (want_part and fuse) and (not has_sc or _WINO >= 2))
+        n2 = st2 = None
+        if wino2:
             # Winograd conv2 with the block input - or the shortcut GEMM's output - as its residual
             sc = ops.gemm(x, W[p + ".conv_shortcut.weight"], bias=W[p + ".conv_shortcut.bias"]) if has_sc else x
+            got = self._gn_conv_wino(p + ".norm2", p + ".conv2.weight:wino", h1, rows, H, 1e-5, out=out, bias=W[p + ".conv2.bias"], residual=sc)
+            if got is not None:
+                (out, st2), done = got, True
+        if not done:
+            n2, st2 = ops.groupnorm(h1, rows, HW, G, 1e-5, W[p + ".norm2.weight"], W[p + ".norm2.bias"], True, partial=part1)
+        if wino2 and not done:
             o = self._conv_wino(p + ".conv2.weight:wino", n2, rows, H, out=out, bias=W[p + ".conv2.bias"], residual=sc)
             if o is not None:
                 out, done = o, True

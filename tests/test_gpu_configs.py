@@ -94,50 +94,61 @@ def test_sd15_accuracy_mode_meets_north_star_eps_bound():
     outputs that feed a norm / the residual sum as (hi, lo) fp16 pairs (~22 mantissa bits; the pair is the K-doubled operand
     where the stream itself enters a matmul) and - round 6 - the GroupNorm outputs of the last up block whose rounding carries
     the most of what is left (unet.HP_NORM_PAIRS, tools/eps_decompose_sites.py).
-    Round 6: 32 rows - four timesteps across the 50-step schedule x four pairs of latent seeds (two
-    independent rows per evaluation, each with its own text row), full-size SD1.5 evaluations (64 x 64 latents).  The maximum
-    of |eps - eps_fp32| over a row is an extreme value of 16 384 nearly Gaussian errors (it sits at ~4.2 sigma, the worst of 32
-    rows at ~4.9 sigma), so the test prints the DISTRIBUTION - per-row maxima, pooled percentiles, sigma - and asserts the
-    north_star number on every row, a margin on the pooled p99.99 and the scale-free relative distance.  One evaluation is
-    also checked against the oracle's emulation of the mode, and one is repeated with conv_out scaled by 2 (exact in fp16):
-    the error scales with the output, so the figure for a UNIT-VARIANCE eps is max / std - printed, with the relative bound
-    asserted (DESIGN.md 5 states the absolute one honestly)."""
+    Round 6: 32 rows AT configs[1]'s REAL BATCH - four timesteps across the 50-step schedule, each ONE
+    evaluation of all 8 samples (16 rows, the sampler's call form: the instantiations, split factors and the Winograd path of
+    the small maps that the timed region of bench.py runs; a 2-row evaluation takes other kernels), samples {0, 2, 5, 7} of each
+    against the oracle's evaluation of that sample alone.  The maximum of |eps - eps_fp32| over a row is an extreme value of
+    16 384 errors (~4.2 sigma; the worst of 32 rows ~5 sigma, with a tail heavier than Gaussian), so the test prints the
+    DISTRIBUTION - per-row maxima, pooled percentiles, sigma - and asserts the north_star number on every row, a margin on the
+    pooled percentiles and the scale-free relative distance.  One evaluation is also checked against the oracle's emulation of
+    round 5's form of the mode, and one is repeated with conv_out scaled by 2 (exact in fp16): the error scales with the
+    output, so the figure for a UNIT-VARIANCE eps is max / std - printed, with the relative bound asserted (DESIGN.md 5
+    states the absolute one honestly)."""
     from oracle import unet as ounet
+    from sketch2img_amd import ops, synthetic
     from sketch2img_amd.config import SD15
-    from sketch2img_amd.unet import HipUNet
+    from sketch2img_amd.unet import CIN_PAD, HipUNet
     _threads()
     cfg = ounet.SD15
-    W = ounet.init_weights(cfg)
+    W = synthetic.unet_state_dict(SD15)
+    S, h = 8, 64
+    lat = synthetic.initial_latents(0, S, h)
+    ehs1 = synthetic.text_embeddings(1)
     net = HipUNet(SD15, W, DEV, need_backward=False, residual_fp32=True)
+    net.prepare_context(synthetic.text_embeddings(S))
+    x16 = ops.nchw_to_nhwc(torch.cat([lat, lat]).to(DEV), CIN_PAD)
+
+    def hip16(t):
+        e, _ = net.forward(x16, t, 2 * S, h, want_taps=False, shared_input=True)
+        return ops.nhwc_to_nchw(e, 2 * S, 4, h, h).cpu()
+
     row_max, row_rel, pooled, stds = [], [], [], []
     first = None
     for t in (981, 661, 341, 21):
-        for seeds in ((7, 11), (23, 101), (3, 5), (13, 17)):
-            g = torch.Generator().manual_seed(seeds[0] * 1000 + t)
-            xx = torch.cat([torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(sd_)) for sd_ in seeds]).half().float()
-            ehs = torch.randn(2, 77, 768, generator=g).half().float()
-            net.prepare_context(ehs)
-            A, _ = _hip_eps(net, xx, t, 2, 64)
+        g16 = hip16(t)
+        for si in (0, 2, 5, 7):
+            xx = torch.cat([lat[si:si + 1]] * 2)
             with torch.no_grad():
-                C, _ = ounet.unet_forward(cfg, W, xx, t, ehs)
+                C, _ = ounet.unet_forward(cfg, W, xx, t, ehs1)
+            A = torch.stack([g16[si], g16[S + si]])
             for row in range(2):
-                rAC, mAC = report(f"sd15 eps  HIP accuracy mode vs fp32 oracle, t = {t}, seed {seeds[row]}", A[row], C[row])
+                rAC, mAC = report(f"sd15 eps  HIP accuracy mode (16-row evaluation) vs fp32 oracle, t = {t}, sample {si}, {'cond' if row else 'uncond'} row", A[row], C[row])
                 row_max.append(mAC); row_rel.append(rAC); stds.append(float(C[row].std()))
                 pooled.append((A[row] - C[row]).abs().flatten())
             if first is None:
-                first = (xx, ehs, t, A, C)
+                first = (t, si, A, C)
                 with torch.no_grad(), ounet.fp16_storage(skip=("res", "lin_n", "rop")):
-                    B, _ = ounet.unet_forward(cfg, W, xx, t, ehs)
+                    B, _ = ounet.unet_forward(cfg, W, xx, t, ehs1)
                 rAC, mAC = report("sd15 eps  HIP accuracy mode vs fp32 oracle", A, C)
                 rBC, mBC = report("sd15 eps  oracle emulation of round 5's form of the accuracy mode vs fp32 oracle", B, C)
                 report("sd15 eps  HIP accuracy mode vs that emulation", A, B)
-                assert mAC < 1.35 * mBC and rAC < 1.25 * rBC + 5e-5          # (round 6's norm pairs only move the HIP side down)
+                assert mAC < 1.35 * mBC and rAC < 1.25 * rBC + 5e-5
     err = torch.cat(pooled)
     q = lambda f: float(torch.quantile(err[:: max(1, err.numel() // 400000)], f))      # (torch.quantile's input limit)
     sigma = float(err.pow(2).mean().sqrt())
     rm = sorted(row_max)
     worst, worst_rel = rm[-1], max(row_rel)
-    print(f"[parity] accuracy mode, 4 timesteps x 8 seeds = {len(rm)} rows: per-row max |eps - eps_fp32|: min {rm[0]:.2e} median {rm[len(rm) // 2]:.2e} "
+    print(f"[parity] accuracy mode at the real batch, 4 timesteps x 4 samples x 2 = {len(rm)} rows: per-row max |eps - eps_fp32|: min {rm[0]:.2e} median {rm[len(rm) // 2]:.2e} "
           f"second worst {rm[-2]:.2e} WORST {worst:.2e} (north_star bound 1e-3: margin {100 * (1 - worst / 1e-3):.0f} %); pooled |err|: rms {sigma:.2e} "
           f"p99 {q(0.99):.2e} p99.9 {q(0.999):.2e} max / rms {worst / sigma:.2f}; rel: worst {worst_rel:.2e} mean {sum(row_rel) / len(row_rel):.2e}; "
           f"eps std {min(stds):.3f}-{max(stds):.3f}")
@@ -145,20 +156,20 @@ def test_sd15_accuracy_mode_meets_north_star_eps_bound():
     assert q(0.99) <= 5.5e-4 and rm[len(rm) // 2] <= 8e-4
     # unit-variance report: conv_out x 2 (a power of two: exact) -> every eps and every error doubles; absolute errors for a
     # unit-variance eps are therefore max / std of this model's
-    xx, ehs, t, A, C = first
+    t, si, A, C = first
     saved = {k: net.W[k].clone() for k in ("conv_out.weight:2", "conv_out.bias")}
     for k in saved:
         net.W[k].mul_(2.0)
-    net.prepare_context(ehs)
-    A2, _ = _hip_eps(net, xx, t, 2, 64)
+    g2 = hip16(t)
     for k, v in saved.items():
         net.W[k].copy_(v)
+    A2 = torch.stack([g2[si], g2[S + si]])
     lin = float((A2 - 2.0 * A).abs().max())
     r2, m2 = report("sd15 eps  accuracy mode, conv_out x 2 vs 2 x fp32 oracle (linearity of the error in the output scale)", A2, 2.0 * C)
     std = float(C.std())
     print(f"[parity] accuracy mode: conv_out x 2 reproduces 2 x eps to {lin:.1e}; at eps std {2 * std:.2f} the max error reads {m2:.2e}; for a UNIT-VARIANCE "
           f"eps: worst max {worst / min(stds):.2e}, rms {sigma / (sum(stds) / len(stds)):.2e} (absolute), relative {worst_rel:.2e} (scale-free)")
-    assert lin <= 2e-6 * 2 and abs(m2 / (2.0 * float((A - C).abs().max())) - 1) < 1e-3 and r2 <= 6.2e-4
+    assert lin <= 4e-6 and abs(m2 / (2.0 * float((A - C).abs().max())) - 1) < 1e-3 and r2 <= 6.2e-4
 
 
 def test_sd15_accuracy_mode_heavy_tailed_weights():
@@ -427,7 +438,7 @@ def test_sd15_config1_real_batch_16_rows_vs_oracle(residual_fp32):
                 assert r < 2e-3 and m < 3e-3                # the default mode's 2-row bounds
             for k, ((th, s_), tor) in enumerate(zip(taps_hip, to)):
                 rt = float((th[row] - tor.detach()[orow]).norm() / tor.detach()[orow].norm())
-                assert rt < (1.5e-3 if residual_fp32 else 2.5e-3), (k, row, rt)
+                assert rt < 2.5e-3, (k, row, rt)      # (fp16 taps; the deep ones come from plain-fp16 blocks in either mode)
         rc, _ = report(f"sd15 16 rows, residual_fp32={residual_fp32}: CFG eps of the guided step, sample {si}", eps_cfg[si], e_cfg[0])
         assert rc < (7e-3 if residual_fp32 else 1.4e-2)
         upd_ref = float(ao["alpha"]) * ao["cond_grad"]
