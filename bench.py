@@ -209,14 +209,14 @@ class LaunchTimer:
             return out
 
         def conv_wino(X, U, rows, IH, IW, *a, **k):      # Winograd F(2x2, 3x3): input transform + split GEMM + output transform (three launches)
-            Cin, Cout = X.shape[1], U.shape[0]
+            Cin, Cout = U.shape[1] // 16, U.shape[0]      # (X is None when the GroupNorm in front wrote the input transform: V=)
             M = rows * IH * IW
             e0, e1 = ev()
             e0.record()
             out = self._wino(X, U, rows, IH, IW, *a, **k)
             e1.record()
             # ALGORITHMIC flops of the convolution (the path executes 16 / 36 of them) and bytes (X, U, Y; V and the fp32 slabs are the path's own traffic)
-            self.rec.append(("wino_conv3x3 (wino_in + gemm2 split x16 + wino_out)", 2.0 * M * Cout * 9 * Cin, e0, e1,
+            self.rec.append(("wino_conv3x3 (wino_in | gn_small_wino + gemm2 split x16 + wino_out)", 2.0 * M * Cout * 9 * Cin, e0, e1,
                              2.0 * (M * Cin + Cout * 16 * Cin + M * Cout + (M * Cout if k.get("residual") is not None else 0)),
                              f"conv S1 Winograd M{M} Cin{Cin} Cout{Cout}" + "+res" * (k.get("residual") is not None), 3))
             return out
@@ -397,9 +397,17 @@ def by_operator(agg):
 
 
 # ------------------------------------------------------------------------------- committed rocprofv3 evidence
+_PROFILE_TAG = ""        # "fast" when `value` is timed in the all-fp16 mode (profiles/r<NN>fast_cfg<C>_*: tools/collect_profiles.sh)
+
+
 def _latest_profile(config: int, suffix: str):
-    """profiles/r<NN>_cfg<config>_<suffix> of the latest round that has one (round-1 files carry no cfg tag)."""
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_cfg{config}_{suffix}")))
+    """profiles/r<NN>[fast]_cfg<config>_<suffix> of the latest round that has one (round-1 files carry no cfg tag).  Rounds 1-5 profiled the
+    all-fp16 mode under the plain tag; from round 6 on the plain tag is the accuracy mode (the headline) and `fast` the all-fp16 one."""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]{_PROFILE_TAG}_cfg{config}_{suffix}")))
+    if _PROFILE_TAG == "fast":      # (rounds <= 5: the plain tag WAS the all-fp16 mode)
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0[1-5]_cfg{config}_{suffix}"))) + cands
+    else:
+        cands = [c for c in cands if os.path.basename(c) >= "r06"] or sorted(glob.glob(os.path.join(ROOT, "profiles", f"r0[3-5]acc_cfg{config}_{suffix}")))
     if not cands and config == 2:
         legacy = {"hbm_counters.json": "r01_hbm_counters.json", "kernel_stats.csv": "r01_kernel_stats_final.csv"}
         p = os.path.join(ROOT, "profiles", legacy.get(suffix, "-"))
@@ -743,6 +751,8 @@ def main():
     from sketch2img_amd import ops
 
     tol = args.mode == "tolerance"
+    global _PROFILE_TAG
+    _PROFILE_TAG = "" if tol else "fast"
     box = {}
     if rank == 0 and not args.no_box_probe:
         box = box_probe(dev)

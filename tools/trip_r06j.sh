@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-6 measurement trip: bench lines of configs 2 / 4 / 5 (config 2 with roofline, cpu_baseline, the second mode), per-shape tables of both
+# modes, the rocprofv3 evidence of config 2 (headline = accuracy mode: r06; all-fp16: r06fast) and of configs 4 / 5, the parity printouts.
+#   /usr/local/graft/bin/gpurun --timeout 3500 -- 'bash tools/trip_r06j.sh'
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+T=gpurun_out/r06final; mkdir -p $T
+timeout 500 bash tools/collect_profiles.sh r06 2 > $T/collect_c2.log 2>&1; echo "collect c2 rc=$?"; tail -8 $T/collect_c2.log
+mkdir -p profiles; cp gpurun_out/profiles_out/r06_cfg2_* profiles/ 2>/dev/null
+timeout 700 python bench.py --steps 5 --warmup 2 --shape-report $T/shapes_c2.txt > $T/bench_c2.json 2> $T/bench_c2.err; echo "bench c2 rc=$? $(grep -o '"value": [0-9.]*' $T/bench_c2.json | head -1)"; tail -2 $T/bench_c2.err
+timeout 300 python bench.py --fast-fp16 --steps 3 --shape-report $T/shapes_c2_fast.txt --no-cpu-baseline --no-second-mode > $T/bench_c2_fast.json 2>/dev/null; echo "bench c2 fast rc=$? $(grep -o '"value": [0-9.]*' $T/bench_c2_fast.json | head -1)"
+timeout 400 python bench.py --config 4 --steps 3 --no-cpu-baseline > $T/bench_c4.json 2> $T/bench_c4.err; echo "bench c4 rc=$? $(grep -o '"value": [0-9.]*' $T/bench_c4.json | head -1)"
+timeout 400 python bench.py --config 5 --steps 3 --no-cpu-baseline > $T/bench_c5.json 2> $T/bench_c5.err; echo "bench c5 rc=$? $(grep -o '"value": [0-9.]*' $T/bench_c5.json | head -1)"
+timeout 500 bash tools/collect_profiles.sh r06fast 2 --fast-fp16 > $T/collect_fast.log 2>&1; echo "collect fast rc=$?"; tail -4 $T/collect_fast.log
+timeout 500 bash tools/collect_profiles.sh r06 4 > $T/collect_c4.log 2>&1; echo "collect c4 rc=$?"; tail -3 $T/collect_c4.log
+timeout 500 bash tools/collect_profiles.sh r06 5 > $T/collect_c5.log 2>&1; echo "collect c5 rc=$?"; tail -3 $T/collect_c5.log
+timeout 900 python -m pytest tests/test_gpu_configs.py -q -m gpu -s -k "north_star or 16_rows or heavy_tailed" > $T/parity.log 2>&1; echo "parity rc=$?"; grep "parity\] accuracy mode\|16 rows.*guided step\|16 rows.*eps row" $T/parity.log | cut -c1-700
