@@ -422,7 +422,8 @@ class HipUNet:
                     if k.startswith(blk) and ".resnets." in k and (k.endswith(".conv1.weight") or k.endswith(".conv2.weight")) and v.shape[1] % 64 == 0:
                         if deepest and k.endswith(".conv2.weight") and (k[: -len(".conv2.weight")] + ".conv_shortcut.weight") in sd:
                             continue      # (8 x 8: the folded shortcut launch stays ahead of shortcut GEMM + Winograd)
-                        W[k + ":wino"] = pack_conv_wino(v, dev)
+                        if self._hp_plain(k):      # (accuracy mode: the forward of a pair-zone block runs _res_fwd_hp, which has no Winograd form)
+                            W[k + ":wino"] = pack_conv_wino(v, dev)
                         if bw and v.shape[0] % 64 == 0 and not deepest:      # (the deepest level's cond-only backward stays on the implicit GEMM)
                             W[k + ":winoT"] = pack_conv_wino(v, dev, dgrad=True)
         for r in sorted(folded):

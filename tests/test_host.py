@@ -448,6 +448,36 @@ def test_polyphase_packs_reproduce_upsample_conv_and_its_gradient():
 
 
 
+def test_winograd_pack_reproduces_conv_and_its_data_gradient():
+    """unet.pack_conv_wino (U = G g G^T, component c = 4 i + j at columns [c Cin, (c + 1) Cin)) with the transforms csrc/wino.hip applies -
+    V = B^T d B per 4 x 4 tile (stride 2, zero halo), M_c = V_c U_c^T, Y = A^T M A - reproduces F.conv2d(padding=1) and, with dgrad=True,
+    its data gradient (autograd), to the fp16 rounding of U."""
+    import torch.nn.functional as F
+    from sketch2img_amd.unet import pack_conv_wino
+    g = torch.Generator().manual_seed(0)
+    rows, H, Cin, Cout = 2, 8, 64, 128
+    x = torch.randn(rows, Cin, H, H, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 24).half().float()
+    BT = torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32)
+    AT = torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32)
+
+    def wino(inp, U):                                   # inp [rows, C, H, H], U [O, 16 * C]
+        C, O = inp.shape[1], U.shape[0]
+        d = F.pad(inp, (1, 1, 1, 1)).unfold(2, 4, 2).unfold(3, 4, 2)                    # [rows, C, H/2, H/2, 4, 4]
+        V = torch.einsum("ij,bcthjk,lk->bthilc", BT, d, BT).reshape(-1, 16, C)        # [Mt, 16, C]: the kernel's K order
+        M = torch.einsum("mkc,okc->kmo", V, U.float().reshape(O, 16, C)).reshape(4, 4, rows, H // 2, H // 2, O)
+        return torch.einsum("ai,ijrtso,bj->rtasbo", AT, M, AT).reshape(rows, H, H, O).permute(0, 3, 1, 2)
+
+    ref = F.conv2d(x, w, padding=1)
+    assert float((wino(x, pack_conv_wino(w, "cpu")) - ref).norm() / ref.norm()) < 6e-4
+    dy = torch.randn(rows, Cout, H, H, generator=g)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w, padding=1).backward(dy)
+    Ud = pack_conv_wino(w, "cpu", dgrad=True)
+    assert Ud.shape == (Cin, 16 * Cout)
+    assert float((wino(dy, Ud) - xr.grad).norm() / xr.grad.norm()) < 6e-4
+
+
 def test_ff_block_pack_reproduces_the_geglu_feed_forward():
     """unet.pack_ff_block (what skg_ff_block_f16 consumes), emulated on the CPU with the kernel's own index arithmetic
     (csrc/ffblock.hip): a 1 KB piece is an MFMA A operand, lane 16 g + l holds A[l][8 g + i]; the accumulator lane (l, g) holds
