@@ -525,6 +525,34 @@ def test_sd15_config0_trajectories_vs_oracle():
     print(f"[parity] sd15 config[0] guided, worst over 2 samples x 10 steps: eps rel {worst['eps']:.2e}, | |upd| ratio - 1 | {worst['nr']:.2e}, "
           f"cos {worst['cos']:.5f} (mean 1 - cos {mean_omc:.2e} over {len(omc)} guided steps), loss rel {worst['loss']:.2e}")
     assert mean_omc < 1.1e-3
+    # (c) round 6: the same two checks in the ACCURACY mode - the mode bench.py's `value` is timed in.  Unguided free running: the end latents
+    # follow the oracle's 3-4 x closer than the all-fp16 mode's; guided, teacher-forced, the last sample's trace: CFG eps, update norm / direction / loss
+    del net, sampler
+    torch.cuda.empty_cache()
+    acc = HipUNet(SD15, W, DEV, residual_fp32=True)
+    acc.prepare_context(ehs)
+    out_a = HipSampler(acc, None).sample(synthetic.initial_latents(0, 1, h), None, T, tables=tab).cpu()
+    ra, _ = report("sd15 config[0] unguided 10-step end latents, free running, ACCURACY mode", out_a, ref_u)
+    assert torch.isfinite(out_a).all() and ra < 8e-4 and ra < 0.6 * ru
+    smp = HipSampler(acc, HipLGP(sd, tap_channels(SD15), DEV))
+    acc.prepare_timesteps(tab.timesteps.tolist())
+    noise = x0.to(DEV)
+    w_eps, w_cos, w_nr = 0.0, 1.0, 0.0
+    for i in range(T):
+        x_i = x0 if i == 0 else tr[i - 1]["latents"]
+        xp, eps, aux = smp.step(x_i.to(DEV).contiguous(), noise, tgt.to(DEV), tab, i, 7.5, 1.6, want_eps=True)
+        e, _ = report(f"sd15 config[0] ACCURACY mode sample 1 step{i} CFG eps (teacher-forced)", eps.cpu(), tr[i]["eps"])
+        w_eps = max(w_eps, e)
+        if tr[i]["aux"] is None:
+            assert report(f"sd15 config[0] ACCURACY mode step{i} x_prev", xp.cpu(), tr[i]["latents"])[0] < 8e-4
+            continue
+        upd_ref = float(tr[i]["aux"]["alpha"]) * tr[i]["aux"]["cond_grad"]
+        upd = xp.cpu() - (tr[i]["latents"] - upd_ref)
+        w_nr = max(w_nr, abs(float(upd.norm() / upd_ref.norm()) - 1))
+        w_cos = min(w_cos, float((upd * upd_ref).sum() / (upd.norm() * upd_ref.norm())))
+    print(f"[parity] sd15 config[0] ACCURACY mode: unguided end latents rel {ra:.2e} (all-fp16: {ru:.2e}); guided, teacher-forced, 10 steps: worst CFG eps rel {w_eps:.2e}, "
+          f"| |upd| ratio - 1 | {w_nr:.2e}, cos {w_cos:.5f}")
+    assert w_eps < 7e-3 and w_nr < 1e-3 and w_cos > 0.9965
 
 
 @pytest.mark.parametrize("case", ["dpm", "sketch", "clip"])
@@ -607,6 +635,36 @@ def test_graph_replay_is_bit_identical_to_eager(sched):
         assert (x is None) == (y is None) and (x is None or torch.equal(x, y))
     # BatchNorm side effects match the eager run's after the same number of trajectories (2 here vs 1 eager -> compare counts)
     assert lg.num_batches_tracked == [2 * n for n in eager.lgp.num_batches_tracked]
+
+
+@pytest.mark.parametrize("residual_fp32", [False, True])
+def test_graph_replay_full_size_with_winograd_is_bit_identical(residual_fp32):
+    """Round 6: the Winograd path (three launches per convolution, 16 fp32 slabs in the stream's workspace, the GroupNorm that writes the
+    input transform) and the accuracy mode's mixed zones under hipGraph capture, at configs[1]'s real size - full SD1.5, 8 samples, 64 x 64
+    latents, 3 DDIM steps of which 2 are guided (the cond-only backward through the Winograd data gradients): replay == eager, bit for bit,
+    and a second replay reproduces it."""
+    from sketch2img_amd import synthetic
+    from sketch2img_amd.config import SD15, tap_channels
+    from sketch2img_amd.lgp import HipLGP
+    from sketch2img_amd.sampler import DDIMTables, HipSampler
+    from sketch2img_amd.unet import HipUNet
+    S, h, T = 8, 64, 3
+    W = synthetic.unet_state_dict(SD15)
+    sd = synthetic.lgp_state_dict(synthetic.lgp_input_dim(SD15))
+    x0, tgt = synthetic.initial_latents(0, S, h), synthetic.sketch_targets(0, S, h)
+    net = HipUNet(SD15, W, DEV, residual_fp32=residual_fp32)
+    assert any(k.endswith(":wino") for k in net.W) and any(k.endswith(":winoT") for k in net.W)
+    net.prepare_context(synthetic.text_embeddings(S))
+    tab = DDIMTables.make(T)
+    eager = HipSampler(net, HipLGP(sd, tap_channels(SD15), DEV))
+    a = eager.sample(x0, tgt, T, tables=tab).clone()
+    graphed = HipSampler(net, HipLGP(sd, tap_channels(SD15), DEV), use_graphs=True)
+    b = graphed.sample(x0, tgt, T, tables=tab).clone()        # capture + first replay
+    c = graphed.sample(x0, tgt, T, tables=tab).clone()        # replay only
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
+    assert [x is not None for x in eager.last_aux] == [True, True, False]
+    for x, y in zip(eager.last_aux, graphed.last_aux):
+        assert (x is None) == (y is None) and (x is None or torch.equal(x, y))
 
 
 @pytest.mark.parametrize("variant", ["clip", "sketch"])
