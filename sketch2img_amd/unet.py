@@ -71,17 +71,19 @@ def pack_conv(w: torch.Tensor, dev, cin_pad: int = 0, cout_pad: int = 0) -> torc
     return _h(p.reshape(p.shape[0], -1), dev)
 
 
-_WINO_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]])
-
-
 def pack_conv_wino(w: torch.Tensor, dev, dgrad: bool = False) -> torch.Tensor:
     """Winograd F(2x2, 3x3) weight pack of a 3x3 convolution [Cout, Cin, 3, 3] -> U [Cout, 16 * Cin] fp16: U = G g G^T per (cout, cin),
     formed in fp32 and rounded once; component c = 4 i + j at columns [c Cin, (c + 1) Cin) (ops.conv3x3_wino, csrc/wino.hip).
     dgrad: the pack of the convolution's DATA GRADIENT - itself a 3x3 convolution with the taps flipped and in / out swapped."""
-    g = w.detach().float().cpu()
+    g = w.detach().to(device=dev, dtype=torch.float32)                   # (formed on the target device, elementwise: no BLAS call at pack time)
     if dgrad:
         g = g.flip(2, 3).transpose(0, 1)
-    U = torch.einsum("ij,ocjk,lk->oilc", _WINO_G, g, _WINO_G)          # [Cout, 4, 4, Cin]
+
+    def G3(a, b, c):                                                     # G = [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]] applied along one axis
+        return a, 0.5 * (a + b + c), 0.5 * (a - b + c), c
+
+    rows = G3(g[:, :, 0, :], g[:, :, 1, :], g[:, :, 2, :])               # G g: 4 x [Cout, Cin, 3]
+    U = torch.stack([torch.stack(G3(r[:, :, 0], r[:, :, 1], r[:, :, 2]), 1) for r in rows], 1)      # (G g) G^T: [Cout, 4 (i), 4 (j), Cin]
     return _h(U.reshape(U.shape[0], -1), dev)
 
 
