@@ -152,8 +152,10 @@ def test_sd15_accuracy_mode_meets_north_star_eps_bound():
           f"second worst {rm[-2]:.2e} WORST {worst:.2e} (north_star bound 1e-3: margin {100 * (1 - worst / 1e-3):.0f} %); pooled |err|: rms {sigma:.2e} "
           f"p99 {q(0.99):.2e} p99.9 {q(0.999):.2e} max / rms {worst / sigma:.2f}; rel: worst {worst_rel:.2e} mean {sum(row_rel) / len(row_rel):.2e}; "
           f"eps std {min(stds):.3f}-{max(stds):.3f}")
-    assert worst <= 1e-3 and worst_rel <= 6.2e-4
-    assert q(0.99) <= 5.5e-4 and rm[len(rm) // 2] <= 8e-4
+    # measured (round 6, deterministic - fixed reduction orders): worst 7.52e-4, median 6.6e-4, p99 3.8e-4, rel 4.29e-4 mean / 4.43e-4 worst.
+    # The bound itself on every row, VERDICT r5's margin line (worst <= 8.5e-4) and the scale-free figure with ~10 % of slack
+    assert worst <= 1e-3 and worst <= 8.5e-4 and worst_rel <= 5.0e-4
+    assert q(0.99) <= 4.5e-4 and rm[len(rm) // 2] <= 7.5e-4
     # unit-variance report: conv_out x 2 (a power of two: exact) -> every eps and every error doubles; absolute errors for a
     # unit-variance eps are therefore max / std of this model's
     t, si, A, C = first
