@@ -50,6 +50,9 @@ _RES_SC = os.environ.get("SKG_RES_SC", "1") != "0"                  # conv2 + co
 _WINO = int(os.environ.get("SKG_WINO", "2"))
 _WINO_MIN_TILES = int(os.environ.get("SKG_WINO_MIN_TILES", "256"))  # tile positions (output pixels / 4) a launch needs to take the path
 _WINO_GN = os.environ.get("SKG_WINO_GN", "1") != "0"                # the GroupNorm in front writes the Winograd input transform itself
+# accuracy mode: Winograd also for the ResnetBlock convolutions of the PAIR zone's small maps (the 16 x 16 level with HP_PLAIN_LEVELS = 1):
+# pair output through the output transform, the K-doubled shortcut as a pair GEMM whose result is the residual
+_HP_WINO = os.environ.get("SKG_HP_WINO", "0") != "0"
 
 CIN_PAD = 64      # latent channels padded to one 64-deep K tile of the LDS-DMA implicit-GEMM conv
 COUT_PAD = 8      # conv_out / conv_in-dgrad output channels padded to the 8-channel store granule
@@ -424,7 +427,7 @@ class HipUNet:
                     if k.startswith(blk) and ".resnets." in k and (k.endswith(".conv1.weight") or k.endswith(".conv2.weight")) and v.shape[1] % 64 == 0:
                         if deepest and k.endswith(".conv2.weight") and (k[: -len(".conv2.weight")] + ".conv_shortcut.weight") in sd:
                             continue      # (8 x 8: the folded shortcut launch stays ahead of shortcut GEMM + Winograd)
-                        if self._hp_plain(k):      # (accuracy mode: the forward of a pair-zone block runs _res_fwd_hp, which has no Winograd form)
+                        if self._hp_plain(k) or _HP_WINO:      # (accuracy mode: the forward of a pair-zone block takes Winograd only with SKG_HP_WINO)
                             W[k + ":wino"] = pack_conv_wino(v, dev)
                         if bw and v.shape[0] % 64 == 0 and not deepest:      # (the deepest level's cond-only backward stays on the implicit GEMM)
                             W[k + ":winoT"] = pack_conv_wino(v, dev, dgrad=True)
@@ -1068,7 +1071,10 @@ class HipUNet:
         fuse = self._gn_from_producer(rows, HW, Cout)
         part1 = None
         a1, w1 = (n1.full, W[p + ".conv1.weight:n2"]) if isinstance(n1, ops.Pair) else (n1, W[p + ".conv1.weight"])
-        if fuse:
+        wino = _HP_WINO and not fuse      # (small maps only: the levels whose GroupNorm statistics do not come from the producers)
+        if wino and not isinstance(n1, ops.Pair) and self._conv_wino(p + ".conv1.weight:wino", n1, rows, H, out=h1.hi, out_lo=h1.lo, bias=tb[p]) is not None:
+            pass
+        elif fuse:
             _, part1 = ops.conv3x3(a1, w1, rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p], gn_groups=G)
         else:
             ops.conv3x3(a1, w1, rows, H, H, out=h1.hi, out_lo=h1.lo, bias=tb[p])
@@ -1081,6 +1087,17 @@ class HipUNet:
             stash.res[p] = dict(x=x.hi, st1=st1, h1=h1.hi, st2=st2, H=H, half=half)
         out = out or self._pair(M, Cout)
         opart = None
+        if wino and not n2_pair and self._wino_ok(p + ".conv2.weight:wino", rows, H):
+            # Winograd conv2, pair output; its residual is the block input pair or the K-doubled shortcut GEMM's pair output
+            if (p + ".conv_shortcut.weight") in W:
+                sc = self._pair(M, Cout)
+                xf = x.full if x.full is not None else full_of(x, x.hi.shape[1])
+                ops.gemm(xf, W[p + ".conv_shortcut.weight:2"], out=sc.hi, out_lo=sc.lo, bias=W[p + ".conv_shortcut.bias"])
+            else:
+                sc = x
+            if self._conv_wino(p + ".conv2.weight:wino", n2, rows, H, out=out.hi, out_lo=out.lo, bias=W[p + ".conv2.bias"],
+                               residual=sc.hi, residual_lo=sc.lo) is not None:
+                return out, None
         if (p + ".conv2.weight:sc2") in W:
             # conv2 + the K-doubled shortcut [x_hi | x_lo] . [W_sc | W_sc] in one launch, pair output
             xf = x.full if x.full is not None else full_of(x, x.hi.shape[1])

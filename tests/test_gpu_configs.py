@@ -454,6 +454,40 @@ def test_sd15_config1_real_batch_16_rows_vs_oracle(residual_fp32):
         assert abs(nr - 1) < 2e-2 and cos > 0.9965 and dl < 2e-3
 
 
+def test_accuracy_mode_pair_zone_winograd_option(monkeypatch):
+    """unet._HP_WINO (SKG_HP_WINO=1, off by default): Winograd also for the ResnetBlock convolutions of the accuracy mode's PAIR zone at the
+    16 x 16 level - pair output through the output transform, the K-doubled shortcut as a pair GEMM whose result is the residual.  One 16-row
+    evaluation at the real batch: close to the shipped form (two fp16 realisations of the 16 x 16 convolutions) and, sample 0 against the fp32
+    oracle, inside the mode's bound; measured trade (profiles/r06_eps_real_batch_hp_wino.txt): rel 4.27e-4 -> 4.56e-4, worst row of 48
+    7.9e-4 -> 8.8e-4, - 2.2 % per evaluation, + 1.5 % end to end - on the accuracy / time line, past the margin line, hence an option."""
+    from oracle import unet as ounet
+    from sketch2img_amd import ops, synthetic, unet as hunet
+    from sketch2img_amd.config import SD15
+    from sketch2img_amd.unet import CIN_PAD, HipUNet
+    _threads()
+    S, h, t = 8, 64, 981
+    W = synthetic.unet_state_dict(SD15)
+    lat = synthetic.initial_latents(0, S, h)
+    x16 = ops.nchw_to_nhwc(torch.cat([lat, lat]).to(DEV), CIN_PAD)
+    outs = []
+    for on in (False, True):
+        monkeypatch.setattr(hunet, "_HP_WINO", on)
+        net = HipUNet(SD15, W, DEV, need_backward=False, residual_fp32=True)
+        assert any(k.startswith("down_blocks.2.") and k.endswith(":wino") for k in net.W) == on
+        net.prepare_context(synthetic.text_embeddings(S))
+        e, _ = net.forward(x16, t, 2 * S, h, want_taps=False, shared_input=True)
+        outs.append(ops.nhwc_to_nchw(e, 2 * S, 4, h, h).cpu())
+        del net
+        torch.cuda.empty_cache()
+    r, _ = report("sd15 accuracy mode, 16 rows: Winograd in the pair zone vs the shipped form", outs[1], outs[0])
+    assert torch.isfinite(outs[1]).all() and 1e-5 < r < 6e-4
+    with torch.no_grad():
+        C, _ = ounet.unet_forward(ounet.SD15, W, torch.cat([lat[:1]] * 2), t, synthetic.text_embeddings(1))
+    A = torch.stack([outs[1][0], outs[1][S]])
+    ra, ma = report("sd15 accuracy mode, Winograd in the pair zone, sample 0 vs fp32 oracle", A, C)
+    assert ra < 5.5e-4 and ma < 1e-3
+
+
 # ------------------------------------------------------------------ full architecture, config[0]'s trajectory shape
 def test_sd15_config0_trajectories_vs_oracle():
     """VERDICT r2 missing #4: trajectory-level parity on the REAL architecture.  BASELINE configs[0]'s shape - full SD1.5

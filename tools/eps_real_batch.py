@@ -28,15 +28,17 @@ with torch.no_grad():
 L = "up_blocks.3"
 N6 = (f"{L}.resnets.1.norm2", f"{L}.resnets.2.norm1", f"{L}.resnets.2.norm2") + tuple(f"{L}.attentions.{j}.norm" for j in range(3))
 N9 = tuple(f"{L}.resnets.{j}.{n}" for j in range(3) for n in ("norm1", "norm2")) + tuple(f"{L}.attentions.{j}.norm" for j in range(3))
-N8 = tuple(n for n in N9 if n != f"{L}.resnets.0.norm2")
-VARIANTS = [("plain 2, 6 sites, Winograd (current)", 2, 2, N6), ("plain 2, 8 sites, Winograd", 2, 2, N8), ("plain 2, 9 sites, Winograd", 2, 2, N9),
-            ("plain 2, 6 sites, no Winograd", 2, 0, N6), ("plain 2, 9 sites, no Winograd", 2, 0, N9), ("plain 1, 6 sites, Winograd (8x8 only)", 1, 2, N6),
-            ("plain 1, 9 sites, Winograd (8x8 only)", 1, 2, N9), ("plain 0, 6 sites", 0, 0, N6), ("plain 0, 9 sites", 0, 0, N9),
-            ("round 5 (plain 0, no sites, no Winograd)", 0, 0, ())]
+N8 = tuple(n for n in N9 if n != f"{L}.resnets.0.norm1")
+VARIANTS = [("plain 1, 8 sites, Winograd at 8x8 (shipped)", 1, 2, N8, False), ("... + Winograd in the pair zone (16x16)", 1, 2, N8, True),
+            ("plain 1, 9 sites + Winograd in the pair zone", 1, 2, N9, True), ("plain 0, 8 sites + Winograd in the pair zone (16x16, 8x8)", 0, 2, N8, True),
+            ("plain 2, 6 sites, Winograd", 2, 2, N6, False), ("round 5 (plain 0, no sites, no Winograd)", 0, 0, (), False)]
+if "--all" in sys.argv:
+    VARIANTS += [("plain 2, 9 sites, Winograd", 2, 2, N9, False), ("plain 2, 6 sites, no Winograd", 2, 0, N6, False), ("plain 1, 6 sites, Winograd at 8x8", 1, 2, N6, False),
+                 ("plain 1, 9 sites, Winograd at 8x8", 1, 2, N9, False), ("plain 0, 6 sites", 0, 0, N6, False), ("plain 0, 9 sites", 0, 0, N9, False)]
 x16 = ops.nchw_to_nhwc(torch.cat([lat, lat]).to(DEV), CIN_PAD)
-print(f"\n{'variant':44s} {'rel mean':>9s} {'rel max':>9s} {'rms abs':>9s} {'max: median':>11s} {'p90 row':>9s} {'WORST':>9s} {'p99.99 |err|':>12s} {'ms / 16-row eval':>17s}")
-for name, pl, wino, pairs in VARIANTS:
-    hunet.HP_PLAIN_LEVELS, hunet._WINO, hunet.HP_NORM_PAIRS = pl, wino, pairs
+print(f"\n{'variant':58s} {'rel mean':>9s} {'rel max':>9s} {'rms abs':>9s} {'max: median':>11s} {'p90 row':>9s} {'WORST':>9s} {'p99.99 |err|':>12s} {'ms / 16-row eval':>17s}")
+for name, pl, wino, pairs, hpw in VARIANTS:
+    hunet.HP_PLAIN_LEVELS, hunet._WINO, hunet.HP_NORM_PAIRS, hunet._HP_WINO = pl, wino, pairs, hpw
     net = HipUNet(SD15, W, DEV, need_backward=False, residual_fp32=True)
     net.prepare_context(ehsS)
     rels, maxs, errs = [], [], []
@@ -59,7 +61,7 @@ for name, pl, wino, pairs in VARIANTS:
         net.forward(x16, 981, 2 * S, h, want_taps=False, shared_input=True)
     e1.record()
     torch.cuda.synchronize()
-    print(f"{name:44s} {sum(rels) / len(rels):9.3e} {max(rels):9.3e} {float(err.pow(2).mean().sqrt()):9.3e} {srt[len(srt) // 2]:11.3e} {srt[int(0.9 * len(srt))]:9.3e} "
+    print(f"{name:58s} {sum(rels) / len(rels):9.3e} {max(rels):9.3e} {float(err.pow(2).mean().sqrt()):9.3e} {srt[len(srt) // 2]:11.3e} {srt[int(0.9 * len(srt))]:9.3e} "
           f"{srt[-1]:9.3e} {p9999:12.3e} {e0.elapsed_time(e1) / 6:17.3f}", flush=True)
     del net
     torch.cuda.empty_cache()
