@@ -376,6 +376,57 @@ def test_tiny_50_step_trajectories_unguided_bounded_guided_reported():
     assert abs(l_hip - l_ref) < 0.25 * l_ref
 
 
+# ------------------------------------------------------------------ configs[3] / configs[4] at their REAL batch vs the oracle
+@pytest.mark.parametrize("config", [4, 5])
+def test_configs_4_and_5_real_batch_vs_oracle(config):
+    """The injected-attention configs at the batch bench.py times them at - config 4: SD1.5, 8 samples (16 rows) at 64 x 64 with
+    sketch_guided_attn; config 5: SD2.1, 4 samples (8 rows) at 96 x 96 with clip_guided_attn on [zeros; h] - one evaluation in the
+    sampler's call form (shared CFG prefix, batched injection K / V, the Winograd path of the 16 x 16 / 8 x 8 resp. 24 x 24 / 12 x 12
+    levels), the LAST sample's two rows against the oracle's evaluation of that sample alone; accuracy mode (what `value` is timed in)
+    and all-fp16 mode against the same reference."""
+    from oracle import attn_inject, unet as ounet
+    from sketch2img_amd import ops, synthetic
+    from sketch2img_amd.config import SD15, SD21
+    from sketch2img_amd.inject import HipInjector
+    from sketch2img_amd.unet import CIN_PAD, HipUNet
+    _threads()
+    c, oc, S, h, dim, variant = (SD15, ounet.SD15, 8, 64, 768, "sketch") if config == 4 else (SD21, ounet.SD21, 4, 96, 1024, "clip")
+    W = synthetic.unet_state_dict(c)
+    sd = synthetic.satmixin_state_dict(c, variant)
+    lat = synthetic.initial_latents(0, S, h)
+    si, t = S - 1, 981
+    ehs1 = synthetic.text_embeddings(1, dim=dim)
+    xx = torch.cat([lat[si:si + 1]] * 2)
+    with torch.no_grad():
+        if config == 4:
+            inj1 = attn_inject.make_sketch_inject(oc, sd, synthetic.res_samples(c, si, 1, h), 1.0)
+        else:
+            inj1 = attn_inject.make_clip_inject(sd, synthetic.sketch_state(si, 1), 1.0)
+        ref, _ = ounet.unet_forward(oc, W, xx, t, ehs1, inject=inj1)
+    x32 = ops.nchw_to_nhwc(torch.cat([lat, lat]).to(DEV), CIN_PAD)
+    for residual_fp32 in (True, False):
+        net = HipUNet(c, W, DEV, need_backward=False, residual_fp32=residual_fp32)
+        net.prepare_context(synthetic.text_embeddings(S, dim=dim))
+        inj = HipInjector(c, sd, variant, DEV)
+        inj.set_scale(1.0)
+        if config == 4:
+            inj.set_res_samples(synthetic.res_samples(c, 0, S, h))
+        else:
+            inj.set_state(synthetic.sketch_state(0, S))
+        net.inject = inj
+        e, _ = net.forward(x32, t, 2 * S, h, want_taps=False, shared_input=True)
+        g = ops.nhwc_to_nchw(e, 2 * S, 4, h, h).cpu()
+        got = torch.stack([g[si], g[S + si]])
+        r, m = report(f"config {config}, {2 * S} rows, residual_fp32={residual_fp32}: eps of sample {si} vs fp32 oracle", got, ref)
+        assert torch.isfinite(g).all()
+        if residual_fp32:
+            assert m <= 1e-3 and r <= 7e-4
+        else:
+            assert r < 2.5e-3 and m < 4e-3
+        del net, inj
+        torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------ configs[1] at its REAL batch: 16 rows vs the oracle
 @pytest.mark.parametrize("residual_fp32", [False, True])
 def test_sd15_config1_real_batch_16_rows_vs_oracle(residual_fp32):
