@@ -1,12 +1,12 @@
 #!/bin/bash
 # Package power and clocks while the config-2 / 4 / 5 benches run (rocm-smi samples every 0.25 s beside `bench.py --steps 4`): is the whole batch at the
-# power limit, or only its dense launches?   bash tools/bench_power.sh > gpurun_out/r05_bench_power.txt
+# power limit, or only its dense launches?   bash tools/bench_power.sh > gpurun_out/r06_bench_power.txt
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 for C in 2 4 5; do
   ( while true; do rocm-smi --showpower --showclocks 2>/dev/null | grep -E "Power|sclk" | tr '\n' ' '; echo; sleep 0.25; done ) > gpurun_out/bp_smi_c$C.txt &
   SMI=$!
-  python bench.py --config $C --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --fast-fp16 --no-second-mode 2>/dev/null > gpurun_out/bp_bench_c$C.json
+  python bench.py --config $C --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-second-mode --no-box-probe 2>/dev/null > gpurun_out/bp_bench_c$C.json
   kill $SMI; wait $SMI 2>/dev/null
   python - <<PY
 import json, re, statistics as st
