@@ -170,10 +170,11 @@ HP_UP_TRIPLE = os.environ.get("SKG_HP_UP_TRIPLE", "0") != "0"
 # 5.08e-4 / 9.8e-4 / 18.18; plain 1 + 6 sites 4.50e-4 / 8.4e-4 / 19.16; plain 1 + 9 sites 4.18e-4 / 8.1e-4 / 19.66; plain 0 + 9 sites
 # 4.14e-4 / 7.7e-4 / 19.88: accuracy costs ~0.5 % of time per 1 % of rel along the whole front - the setting is where the worst row keeps
 # ~15 % of north_star's bound (the throughput target has 60 % of headroom, the bound had 2 %).
+# ("{last}" = the index of the last up block of the UNet at hand: 3 for SD1.x / SD2.x.)
 HP_NORM_PAIRS = tuple(n for n in os.environ.get(
-    "SKG_HP_NORM_PAIRS", "up_blocks.3.resnets.0.norm2,up_blocks.3.resnets.1.norm1,up_blocks.3.resnets.1.norm2,up_blocks.3.resnets.2.norm1,"
-                         "up_blocks.3.resnets.2.norm2,up_blocks.3.attentions.0.norm,up_blocks.3.attentions.1.norm,"
-                         "up_blocks.3.attentions.2.norm").split(",") if n)
+    "SKG_HP_NORM_PAIRS", "up_blocks.{last}.resnets.0.norm2,up_blocks.{last}.resnets.1.norm1,up_blocks.{last}.resnets.1.norm2,"
+                         "up_blocks.{last}.resnets.2.norm1,up_blocks.{last}.resnets.2.norm2,up_blocks.{last}.attentions.0.norm,"
+                         "up_blocks.{last}.attentions.1.norm,up_blocks.{last}.attentions.2.norm").split(",") if n)
 # accuracy mode (round 6): the DEEPEST resolution levels run the default fp16 kernels - tools/eps_decompose_stream.py: of what the pairs
 # (residual stream, conv outputs that feed a norm, stream-as-operand) buy, 60 % is bought in the last up block, 25 % in the first down block
 # (its skips feed the last up block), 15 % at the 32 x 32 level, ~4 % at the 16 x 16 level and nothing at 8 x 8.  n = number of deepest
@@ -506,6 +507,7 @@ class HipUNet:
         # norm outputs as pairs (HP_NORM_PAIRS): the [W | W] pack of the matmul behind each listed norm
         self.hp_norm_pairs = set()
         for name in HP_NORM_PAIRS:
+            name = name.replace("{last}", str(len(self.cfg.block_out_channels) - 1))
             r, which = name.rsplit(".", 1)
             if which == "norm" and (r + ".proj_in.weight") in sd:
                 w = sd[r + ".proj_in.weight"]
@@ -522,8 +524,10 @@ class HipUNet:
                     W[r + ".conv2.weight:n2"] = _h(torch.cat([w2p, wsc, wsc], 1), dev)
                 else:
                     W[r + ".conv2.weight:n2"] = _h(w2p, dev)
-            else:
+            elif "SKG_HP_NORM_PAIRS" in os.environ:
                 raise ValueError(f"SKG_HP_NORM_PAIRS: {name!r} is not a GroupNorm of this UNet")
+            else:
+                continue                   # (a default site this architecture does not have: fewer layers per block)
             self.hp_norm_pairs.add(name)
 
     def _w9x2(self, k: str) -> torch.Tensor:
