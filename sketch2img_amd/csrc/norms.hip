@@ -286,9 +286,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const half_t* __restrict__ X, int ldx, const half_t* __restrict__ dY, int lddy, half_t* __restrict__ dX,
     int lddx, const half_t* __restrict__ R, int ldr, int HW, int C, int groups,
-    const float* __restrict__ stats, const float* __restrict__ sums, const half_t* __restrict__ gamma,
+    const float* __restrict__ stats, const float* __restrict__ partial, int pch, float inv_n, const half_t* __restrict__ gamma,
     const half_t* __restrict__ beta, int silu) {
   const int b = blockIdx.y, chunk = blockIdx.x, nch = gridDim.x;
+  // round 6: the fold of the stage-1 chunk partials (m1 = mean(d), m2 = mean(d * xhat) per group) happens here - every workgroup of a
+  // row repeats gn_finalize_kernel<1>'s fixed-order fold (16 lanes per group striding over the chunks, xor tree 8, 4, 2, 1: the same
+  // bits) into LDS; one launch per GroupNorm backward less (598 per config-2 batch)
+  __shared__ float sm_s[64][2];
+  for (int g0 = 0; g0 < groups; g0 += 16) {
+    const int grp = g0 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    float s1 = 0.f, s2 = 0.f;
+    if (grp < groups)
+      for (int c = sub; c < pch; c += 16) {
+        const float* q = partial + (((size_t)b * pch + c) * groups + grp) * 2;
+        s1 += q[0]; s2 += q[1];
+      }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    if (grp < groups && sub == 0) { sm_s[grp][0] = s1 * inv_n; sm_s[grp][1] = s2 * inv_n; }
+  }
+  __syncthreads();
   const int cpg = C / groups;
   const int per = (HW + nch - 1) / nch;
   const int p0 = chunk * per, p1 = min(HW, p0 + per);
@@ -305,10 +322,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(
     const int glo = c0 / cpg;
     const int nlo = min(8, (glo + 1) * cpg - c0);
     const float* st = stats + ((size_t)b * groups + glo) * 2;
-    const float* sm = sums + ((size_t)b * groups + glo) * 2;
     const bool two = nlo < 8;
-    const float mlo = st[0], rlo = st[1], m1lo = sm[0], m2lo = sm[1];
-    const float mhi = two ? st[2] : 0.f, rhi = two ? st[3] : 0.f, m1hi = two ? sm[2] : 0.f, m2hi = two ? sm[3] : 0.f;
+    const float mlo = st[0], rlo = st[1], m1lo = sm_s[glo][0], m2lo = sm_s[glo][1];
+    const float mhi = two ? st[2] : 0.f, rhi = two ? st[3] : 0.f, m1hi = two ? sm_s[glo + 1][0] : 0.f, m2hi = two ? sm_s[glo + 1][1] : 0.f;
     const half8_t gv = ld_half8(gamma + c0), bv = ld_half8(beta + c0);
     const size_t row0 = (size_t)b * HW;
     auto one = [&](const half8_t& xv, const half8_t& dv, const half8_t& rv, size_t m) {
@@ -901,16 +917,12 @@ extern "C" int skg_groupnorm_bwd(const void* X, int ldx, const void* dY, int ldd
     return SKG_OK;
   }
   const int nch = gn_chunks(HW);
-  float* sums = partial + (size_t)rows * GN_MAX_CHUNKS * groups * 2;
   hipLaunchKernelGGL((gn_partial_kernel<1>), dim3(nch, rows), dim3(256), 0, st, (const half_t*)X, ldx,
                      (const half_t*)dY, lddy, HW, C, groups, stats, (const half_t*)gamma, (const half_t*)beta,
                      silu, partial);
-  const int total = rows * groups;
-  hipLaunchKernelGGL((gn_finalize_kernel<1>), dim3(skg_cdiv(total * 16, 256)), dim3(256), 0, st, partial, nch,
-                     groups, 1.f / ((float)HW * (C / groups)), 0.f, sums, total);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gn_apply_chunks(HW, C), rows), dim3(256), 0, st, (const half_t*)X,
                      ldx, (const half_t*)dY, lddy, (half_t*)dX, lddx, (const half_t*)residual, ldr, HW, C, groups,
-                     stats, sums, (const half_t*)gamma, (const half_t*)beta, silu);
+                     stats, (const float*)partial, nch, 1.f / ((float)HW * (C / groups)), (const half_t*)gamma, (const half_t*)beta, silu);
   SKG_CHECK_LAUNCH("skg_groupnorm_bwd");
   return SKG_OK;
 }
